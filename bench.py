@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the hot path on MI355X.
+
+Metric (BASELINE.json): Poseidon-BLS12-381-Fr permutations/sec.  One "step" = one pass of the batched
+permutation kernel over `--log2-states` (default 2^20, BASELINE configs[1]) synthetic sponge states of
+t = 3 field elements (rate 2, alpha 17, R_F = 8, R_P = 31), inputs already resident in HBM.
+N > 1: one process per GPU (torchrun), every rank permutes its own 2^20 states (weak scaling, the batch
+shards with no data-path collective); `value` = states permuted by all ranks / max-over-ranks time.
+
+Extra objects on the same JSON line:
+  roofline      dominant kernel (poseidon_permute_kernel) -- algorithmic bytes (192 B / permutation,
+                SURVEY.md section 8d) / average launch duration measured with events on the launch stream,
+                against the 8 TB/s HBM peak; `valu` gives the integer-ALU view (the real bound).
+  cpu_baseline  oracle C restatement ("port") timed on this host on a bounded sample, rank 0 / N = 1 only.
+  merkle        MerkleTree::new over `--merkle-log2` Poseidon leaves (default 2^24 at N = 1... see below),
+                leaf shards per rank + one all-gather of sub-roots (RCCL); seconds and leaves/s.
+The oracle is used only as checker (a 256-state parity probe outside the timed region) and as the
+`cpu_baseline` leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (imported before the product so both share one HIP runtime)
+
+ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+MODMUL_PER_PERM_REF = 626        # reference-shaped count
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-states", type=int, default=20)
+    ap.add_argument("--merkle-log2", type=int, default=24, help="total leaves of the Merkle leg (0 disables)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import field
+    from crypto_primitives_amd._lib import lib, check, Context
+    from crypto_primitives_amd.distributed import GpuPoseidonBackend, build_sharded
+
+    ctx = cpa.default_context(local_rank)
+    cfg = cpa.get_default_poseidon_parameters(2, False)
+    ph = cfg.handle(ctx)
+    n = 1 << args.log2_states
+    t = cfg.t
+
+    # synthetic states (seed per BASELINE.md config 2), resident in HBM before the timed region
+    host_states = field.random_fr(n * t, seed=0xA5A50002 + rank).reshape(n, t, 4)
+    d_states = torch.from_numpy(host_states.view(np.int64)).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        check(lib.akp_poseidon_permute_batch_dev(ph.h, d_states.data_ptr(), n, stream))
+
+    # parity probe (checker only, outside the timed region)
+    parity = None
+    if rank == 0:
+        from oracle import cref
+        ora = cref.Poseidon(cfg.full_rounds, cfg.partial_rounds, cfg.alpha, cfg.rate, cfg.capacity, cfg.ark, cfg.mds)
+        probe = torch.from_numpy(host_states[:256].copy().view(np.int64)).to(dev)
+        check(lib.akp_poseidon_permute_batch_dev(ph.h, probe.data_ptr(), 256, stream))
+        torch.cuda.synchronize(dev)
+        parity = bool(np.array_equal(probe.cpu().numpy().view(np.uint64).reshape(256, t, 4),
+                                     ora.permute_batch(host_states[:256]).reshape(256, t, 4)))
+        if not parity:
+            raise SystemExit("parity probe FAILED: GPU permutation differs from the oracle")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_s = (sum(kern_ms) / len(kern_ms)) / 1e3
+
+    # ---- Merkle leg: sharded MerkleTree::new (strong scaling over the same total leaf count) ----
+    merkle = None
+    if args.merkle_log2:
+        total = 1 << args.merkle_log2
+        per = total // world
+        leaves = field.random_fr(per, seed=0xA5A50003 + rank).reshape(per, 1, 4)
+        d_leaves = torch.from_numpy(leaves.view(np.int64)).to(dev)
+        backend = GpuPoseidonBackend(cfg, cfg, leaf_len=1, device=dev)
+        build_sharded(backend, d_leaves[: max(per // 64, 2)], max(total // 64, 2 * world), dist)  # warm-up (allocations, RCCL)
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        m0 = time.perf_counter()
+        res = build_sharded(backend, d_leaves, total, dist)
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        msec = time.perf_counter() - m0
+        if dist:
+            tt = torch.tensor([msec], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            msec = float(tt.item())
+        merkle = {"leaves": total, "seconds": msec, "leaves_per_s": total / msec, "scaling": "strong",
+                  "permutations": 2 * total - 1, "root_limb0": int(np.asarray(res["root"]).reshape(-1)[0]),
+                  "algorithmic_GBps": 160.0 * total / msec / 1e9}
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    total_perms = n * world * args.steps
+    value = total_perms / elapsed
+    achieved = ALGO_BYTES_PER_PERM * n / kern_avg_s / 1e9
+    out = {
+        "metric": "poseidon_bls12_381_fr_permutations_per_sec",
+        "value": value,
+        "unit": "permutations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32x8 (255-bit Montgomery integers)",
+        "data": "synthetic",
+        "config": {"workload": "batched Poseidon permutation, BLS12-381 Fr, t=3 rate=2 alpha=17 RF=8 RP=31 "
+                               "(default Grain-LFSR parameters), 2^%d states per GPU, in place in HBM" % args.log2_states,
+                   "states_per_gpu": n, "parallelism": "shard%d (no collective)" % world},
+        "parity_probe_bit_exact": parity,
+        "roofline": {"bound": "hbm", "kernel": "poseidon_permute_kernel<256>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PERM * n,
+                     "valu": {"note": "integer-ALU bound: ~%d Montgomery products per 192 B" % MODMUL_PER_PERM_REF,
+                              "modmul_per_s_per_gpu": MODMUL_PER_PERM_REF * n / kern_avg_s}},
+    }
+    if merkle:
+        out["merkle"] = merkle
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import cref
+        threads = cref.hardware_threads()
+        ora = cref.Poseidon(cfg.full_rounds, cfg.partial_rounds, cfg.alpha, cfg.rate, cfg.capacity, cfg.ark, cfg.mds)
+        # calibrate on 2^12 states, then size the sample for ~cpu_seconds
+        cal = host_states[:4096]
+        c0 = time.perf_counter()
+        ora.permute_batch(cal, threads=threads)
+        rate = 4096 / (time.perf_counter() - c0)
+        sample = int(min(n, max(4096, rate * args.cpu_seconds)))
+        c0 = time.perf_counter()
+        ora.permute_batch(host_states[:sample], threads=threads)
+        cpu_s = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": sample / cpu_s, "unit": "permutations/s", "cores": threads, "kind": "port",
+                               "sample": "%d of the same 2^%d states, reference-shaped C restatement "
+                                         "(oracle/c/akp_oracle.c), %d pthreads" % (sample, args.log2_states, threads)}
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+"""ctypes binding of the product library (include/akp.h -> crypto_primitives_amd/lib/libakp.so).
+
+There is no fallback of any kind: if the shared library is missing this module raises at
+import, and every compute call fails loudly (AkpError) when no HIP device is usable.
+"""
+import ctypes as C
+import importlib.util
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("AKP_LIB", os.path.join(_HERE, "lib", "libakp.so"))
+
+AKP_OK, AKP_ERR_BAD_LENGTH, AKP_ERR_BAD_PARAMS, AKP_ERR_HIP, AKP_ERR_RCCL, AKP_ERR_NOT_POW2 = 0, 1, 2, 3, 4, 5
+TE_PEDERSEN, TE_BOWE_HOPWOOD = 0, 1
+
+
+class AkpError(RuntimeError):
+    """lib.rs:47-52 `Error` analogue carrying the C-ABI status code."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"akp error {code}: {msg}")
+        self.code = code
+
+
+class IncorrectInputLength(AkpError):
+    """Error::IncorrectInputLength / the reference's input-length panics."""
+
+
+class NotPowerOfTwo(AkpError):
+    """merkle_tree/mod.rs:430-433 assertion."""
+
+
+def _preload_torch_hip_runtime():
+    # torch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If torch is used
+    # in this process both must resolve to ONE runtime instance, or device pointers cannot be
+    # shared; load torch's copy first so libakp.so binds to it.
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C crypto_primitives_amd/csrc` (there is no CPU fallback)")
+    _preload_torch_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    vp, u64p, u8p, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t
+    i32, u32, u64 = C.c_int32, C.c_uint32, C.c_uint64
+    pp = C.POINTER(C.c_void_p)
+    sig = {
+        "akp_abi_version": (i32, []),
+        "akp_last_error": (C.c_char_p, []),
+        "akp_device_count": (i32, []),
+        "akp_ctx_create": (i32, [i32, pp]),
+        "akp_ctx_destroy": (None, [vp]),
+        "akp_ctx_synchronize": (i32, [vp]),
+        "akp_fr_to_mont": (i32, [u64p, u64p, sz]),
+        "akp_fr_from_mont": (i32, [u64p, u64p, sz]),
+        "akp_poseidon_params_create": (i32, [vp, u32, u32, u64, u32, u32, u64p, u64p, pp]),
+        "akp_poseidon_default_params": (i32, [vp, u32, i32, pp]),
+        "akp_poseidon_params_destroy": (None, [vp]),
+        "akp_poseidon_params_dims": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]),
+        "akp_poseidon_params_export": (i32, [vp, u64p, u64p]),
+        "akp_poseidon_permute_batch": (i32, [vp, u64p, sz]),
+        "akp_poseidon_permute_batch_dev": (i32, [vp, u64p, sz, vp]),
+        "akp_poseidon_crh_batch": (i32, [vp, u64p, sz, sz, u64p]),
+        "akp_poseidon_crh_batch_dev": (i32, [vp, u64p, sz, sz, u64p, vp]),
+        "akp_poseidon_two_to_one_batch": (i32, [vp, u64p, u64p, sz, u64p]),
+        "akp_poseidon_two_to_one_batch_dev": (i32, [vp, u64p, u64p, sz, u64p, vp]),
+        "akp_sponge_create": (i32, [vp, sz, pp]),
+        "akp_sponge_destroy": (None, [vp]),
+        "akp_sponge_absorb": (i32, [vp, u64p, sz]),
+        "akp_sponge_squeeze": (i32, [vp, u64p, sz]),
+        "akp_sponge_get_state": (i32, [vp, u64p, C.POINTER(i32), C.POINTER(u32)]),
+        "akp_sponge_set_state": (i32, [vp, u64p, i32, u32]),
+        "akp_te_params_create": (i32, [vp, i32, u32, u32, u64p, pp]),
+        "akp_te_params_destroy": (None, [vp]),
+        "akp_te_crh_batch": (i32, [vp, u8p, sz, sz, u64p]),
+        "akp_te_crh_batch_dev": (i32, [vp, u8p, sz, sz, u64p, vp]),
+        "akp_te_two_to_one_batch": (i32, [vp, u8p, u8p, sz, sz, u64p]),
+        "akp_te_compress_batch": (i32, [vp, u64p, u64p, sz, u64p]),
+        "akp_merkle_build_poseidon": (i32, [vp, vp, u64p, sz, sz, u64p, u64p, u64p]),
+        "akp_merkle_build_poseidon_dev": (i32, [vp, vp, u64p, sz, sz, u64p, u64p, vp]),
+        "akp_merkle_inner_poseidon_dev": (i32, [vp, u64p, sz, u64p, vp]),
+        "akp_merkle_build_te": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, u64p]),
+        "akp_merkle_build_te_dev": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return L, sorted(sig)
+
+
+lib, DECLARED_SYMBOLS = _load()
+
+
+def check(rc):
+    if rc == AKP_OK:
+        return
+    msg = lib.akp_last_error().decode("utf-8", "replace")
+    if rc == AKP_ERR_BAD_LENGTH:
+        raise IncorrectInputLength(rc, msg)
+    if rc == AKP_ERR_NOT_POW2:
+        raise NotPowerOfTwo(rc, msg)
+    raise AkpError(rc, msg)
+
+
+class Context:
+    """akp_ctx wrapper (one per device)."""
+
+    def __init__(self, device_id=0):
+        h = C.c_void_p()
+        check(lib.akp_ctx_create(device_id, C.byref(h)))
+        self.h = h
+        self.device_id = device_id
+
+    def synchronize(self):
+        check(lib.akp_ctx_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.akp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        # handles that depend on the context hold a reference to it, so it is destroyed last
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=None):
+    """process-wide context for `device_id` (default: LOCAL_RANK or 0)."""
+    if device_id is None:
+        device_id = int(os.environ.get("AKP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        if lib.akp_device_count() == 1:
+            device_id = 0
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = Context(device_id)
+    return _default_ctx[device_id]

@@ -1,0 +1,145 @@
+"""pedersen::{Window, Parameters, CRH, TwoToOneCRH} over Jubjub (crh/pedersen/mod.rs) on the GPU.
+
+Digests are affine points: wire-format arrays [..., 2, 4] (x, y).  Messages are bytes / uint8 arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .._lib import lib, check, default_context, TE_PEDERSEN, TE_BOWE_HOPWOOD
+
+
+class Window:
+    """pedersen::Window (crh/pedersen/mod.rs:23-26): subclass and set the two constants."""
+    WINDOW_SIZE = 0
+    NUM_WINDOWS = 0
+
+
+class Parameters:
+    """pedersen::Parameters<C> / bowe_hopwood::Parameters<P> { generators } (pedersen/mod.rs:28-31).
+    generators: wire-format affine points [NUM_WINDOWS, WINDOW_SIZE, 2, 4], used verbatim."""
+
+    _KIND = TE_PEDERSEN
+
+    def __init__(self, generators, window_size=None, num_windows=None):
+        g = np.ascontiguousarray(generators, dtype=np.uint64)
+        if g.ndim == 4:
+            num_windows, window_size = g.shape[0], g.shape[1]
+        self.generators = g.reshape(num_windows, window_size, 2, 4)
+        self.window_size, self.num_windows = window_size, num_windows
+        self._handles = {}
+
+    def handle(self, ctx=None):
+        ctx = ctx or default_context()
+        key = id(ctx)
+        if key not in self._handles:
+            h = C.c_void_p()
+            check(lib.akp_te_params_create(ctx.h, self._KIND, self.window_size, self.num_windows,
+                                           self.generators.ctypes.data, C.byref(h)))
+            self._handles[key] = _TeHandle(h, ctx)
+        return self._handles[key]
+
+
+class _TeHandle:
+    def __init__(self, h, ctx):
+        self.h, self.ctx = h, ctx
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib.akp_te_params_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _as_msgs(msgs, n=None, msg_len=None):
+    if isinstance(msgs, (bytes, bytearray)):
+        m = np.frombuffer(bytes(msgs), dtype=np.uint8)
+        return m, 1, len(m)
+    if isinstance(msgs, (list, tuple)) and msgs and isinstance(msgs[0], (bytes, bytearray)):
+        L = len(msgs[0])
+        assert all(len(x) == L for x in msgs), "batch forms take equal-length inputs"
+        return np.frombuffer(b"".join(bytes(x) for x in msgs), dtype=np.uint8), len(msgs), L
+    m = np.ascontiguousarray(msgs, dtype=np.uint8)
+    if m.ndim == 1:
+        return m, 1, m.shape[0]
+    return m, m.shape[0], m.shape[1]
+
+
+class _TeCRH:
+    _FE = 2  # field elements per digest
+
+    @classmethod
+    def _check_window(cls, W, parameters):
+        if W is not None:
+            # crh/pedersen/mod.rs:101-109 assert_eq!(parameters.generators.len(), W::NUM_WINDOWS)
+            assert parameters.num_windows == W.NUM_WINDOWS and parameters.window_size == W.WINDOW_SIZE, \
+                "Incorrect pp size for window params"
+
+    @classmethod
+    def evaluate(cls, parameters, input_, window=None):
+        """CRH::evaluate (crh/pedersen/mod.rs:76-129 / crh/bowe_hopwood/mod.rs:114-186) for one byte string."""
+        return cls.evaluate_batch(parameters, [bytes(input_)], window)[0]
+
+    @classmethod
+    def evaluate_batch(cls, parameters, msgs, window=None):
+        cls._check_window(window, parameters)
+        m, n, L = _as_msgs(msgs)
+        out = np.empty((n, cls._FE, 4), dtype=np.uint64)
+        check(lib.akp_te_crh_batch(parameters.handle().h, m.ctypes.data if m.size else None, n, L, out.ctypes.data))
+        return out if cls._FE == 2 else out.reshape(n, 4)
+
+
+class CRH(_TeCRH):
+    """pedersen::CRH<JubJub, W>: Input = [u8], Output = affine point."""
+
+    @staticmethod
+    def setup(window, seed=0):
+        """CRHScheme::setup (crh/pedersen/mod.rs:64-74).  The reference draws `C::rand(rng)` bases and
+        their doublings (:40-56); its rng stream is not reproducible outside ark-std, so the bases here
+        come from a seeded procedure of our own (host big-int, see params.py)."""
+        from ..params import pedersen_generators
+        return Parameters(pedersen_generators(seed, window.WINDOW_SIZE, window.NUM_WINDOWS))
+
+
+class TwoToOneCRH:
+    """pedersen::TwoToOneCRH<JubJub, W> (crh/pedersen/mod.rs:149-198)."""
+    _crh = CRH
+
+    @classmethod
+    def setup(cls, window, seed=0):
+        return cls._crh.setup(window, seed)
+
+    @classmethod
+    def evaluate(cls, parameters, left_input, right_input):
+        return cls.evaluate_batch(parameters, [bytes(left_input)], [bytes(right_input)])[0]
+
+    @classmethod
+    def evaluate_batch(cls, parameters, left, right):
+        """:158-182: left/right equal-length byte strings -> buffer of W*N/8 bytes -> CRH::evaluate."""
+        l, n, L = _as_msgs(left)
+        r, n2, L2 = _as_msgs(right)
+        assert (n, L) == (n2, L2), "left and right input should be of equal length"
+        fe = cls._crh._FE
+        out = np.empty((n, fe, 4), dtype=np.uint64)
+        check(lib.akp_te_two_to_one_batch(parameters.handle().h, l.ctypes.data if l.size else None,
+                                          r.ctypes.data if r.size else None, n, L, out.ctypes.data))
+        return out if fe == 2 else out.reshape(n, 4)
+
+    @classmethod
+    def compress(cls, parameters, left_input, right_input):
+        fe = cls._crh._FE
+        l = np.ascontiguousarray(left_input, dtype=np.uint64).reshape(1, fe, 4)
+        r = np.ascontiguousarray(right_input, dtype=np.uint64).reshape(1, fe, 4)
+        return cls.compress_batch(parameters, l, r)[0]
+
+    @classmethod
+    def compress_batch(cls, parameters, left, right):
+        """:187-197 / bowe_hopwood :229-239: digests are serialised uncompressed first (on the GPU)."""
+        fe = cls._crh._FE
+        l = np.ascontiguousarray(left, dtype=np.uint64).reshape(-1, fe, 4)
+        r = np.ascontiguousarray(right, dtype=np.uint64).reshape(-1, fe, 4)
+        out = np.empty_like(l)
+        check(lib.akp_te_compress_batch(parameters.handle().h, l.ctypes.data, r.ctypes.data, l.shape[0], out.ctypes.data))
+        return out if fe == 2 else out.reshape(-1, 4)

@@ -1,0 +1,866 @@
+// capi.hip -- implementation of include/akp.h: host-side C++ over the gfx950 kernels.
+// Product code.  Never includes, links or calls anything under oracle/; there is no CPU
+// fallback for any compute entry point (a missing device is AKP_ERR_HIP).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/akp.h"
+#include "fr.hpp"
+#include "poseidon_kernels.hpp"
+#include "te_kernels.hpp"
+
+using namespace akp;
+
+// ------------------------------------------------------------------------------------------
+// errors
+static thread_local std::string g_last_error;
+static int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(AKP_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* akp_last_error(void) { return g_last_error.c_str(); }
+extern "C" int32_t akp_abi_version(void) { return AKP_ABI_VERSION; }
+extern "C" int32_t akp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// context: device, stream, grow-only scratch slots
+enum { SCR_A = 0, SCR_B, SCR_C, SCR_D, SCR_E, SCR_F, SCR_COUNT };
+struct akp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* scratch[SCR_COUNT] = {};
+    size_t scratch_bytes[SCR_COUNT] = {};
+};
+static int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (c->scratch_bytes[slot] < bytes) {
+        if (c->scratch[slot]) {
+            HIP_TRY(hipDeviceSynchronize());  // work enqueued on other streams may still read it
+            HIP_TRY(hipFree(c->scratch[slot]));
+            c->scratch[slot] = nullptr;
+            c->scratch_bytes[slot] = 0;
+        }
+        HIP_TRY(hipMalloc(&c->scratch[slot], bytes));
+        c->scratch_bytes[slot] = bytes;
+    }
+    *out = c->scratch[slot];
+    return AKP_OK;
+}
+extern "C" int32_t akp_ctx_create(int32_t device_id, akp_ctx** out) {
+    if (!out) return fail(AKP_ERR_BAD_PARAMS, "akp_ctx_create: out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(AKP_ERR_HIP, "akp_ctx_create: device %d not present (%d visible)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    akp_ctx* c = new akp_ctx();
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(AKP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return AKP_OK;
+}
+extern "C" void akp_ctx_destroy(akp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < SCR_COUNT; ++i)
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int32_t akp_ctx_synchronize(akp_ctx* c) {
+    if (!c) return fail(AKP_ERR_BAD_PARAMS, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return AKP_OK;
+}
+static inline hipStream_t pick_stream(akp_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+
+// ------------------------------------------------------------------------------------------
+// host field helpers
+static inline Fr fr_from_words(const uint64_t* w) {
+    Fr f;
+    for (int i = 0; i < 4; ++i) {
+        f.l[2 * i] = (u32)w[i];
+        f.l[2 * i + 1] = (u32)(w[i] >> 32);
+    }
+    return f;
+}
+static inline void fr_to_words(const Fr& f, uint64_t* w) {
+    for (int i = 0; i < 4; ++i) w[i] = (uint64_t)f.l[2 * i] | ((uint64_t)f.l[2 * i + 1] << 32);
+}
+static bool fr_words_reduced(const uint64_t* w) {
+    const uint64_t P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    for (int i = 3; i >= 0; --i) {
+        if (w[i] < P[i]) return true;
+        if (w[i] > P[i]) return false;
+    }
+    return false;
+}
+extern "C" int32_t akp_fr_to_mont(const uint64_t* canonical, uint64_t* mont, size_t n) {
+    if ((!canonical || !mont) && n) return fail(AKP_ERR_BAD_PARAMS, "akp_fr_to_mont: NULL buffer");
+    for (size_t i = 0; i < n; ++i) {
+        if (!fr_words_reduced(canonical + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "akp_fr_to_mont: element %zu is not < p", i);
+        fr_to_words(fr_to_mont(fr_from_words(canonical + 4 * i)), mont + 4 * i);
+    }
+    return AKP_OK;
+}
+extern "C" int32_t akp_fr_from_mont(const uint64_t* mont, uint64_t* canonical, size_t n) {
+    if ((!canonical || !mont) && n) return fail(AKP_ERR_BAD_PARAMS, "akp_fr_from_mont: NULL buffer");
+    for (size_t i = 0; i < n; ++i) fr_to_words(fr_from_mont(fr_from_words(mont + 4 * i)), canonical + 4 * i);
+    return AKP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Poseidon parameters
+#define AKP_MAX_T 16u
+struct akp_poseidon {
+    akp_ctx* ctx = nullptr;
+    PoseidonDims dims{};
+    std::vector<Fr> ark, mds;         // host copies, wire format
+    Fr* d_ark = nullptr;
+    Fr* d_mds = nullptr;
+};
+
+extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds, uint32_t partial_rounds, uint64_t alpha,
+                                              uint32_t rate, uint32_t capacity, const uint64_t* ark, const uint64_t* mds,
+                                              akp_poseidon** out) {
+    if (!out || !ark || !mds) return fail(AKP_ERR_BAD_PARAMS, "akp_poseidon_params_create: NULL argument");
+    const uint32_t t = rate + capacity;
+    if (rate == 0 || t > AKP_MAX_T) return fail(AKP_ERR_BAD_PARAMS, "rate + capacity = %u unsupported (1 <= rate, t <= %u)", t, AKP_MAX_T);
+    if (alpha == 0) return fail(AKP_ERR_BAD_PARAMS, "alpha must be >= 1");
+    if (full_rounds % 2u) return fail(AKP_ERR_BAD_PARAMS, "full_rounds must be even");
+    const size_t na = (size_t)(full_rounds + partial_rounds) * t, nm = (size_t)t * t;
+    for (size_t i = 0; i < na; ++i)
+        if (!fr_words_reduced(ark + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "ark[%zu] not reduced", i);
+    for (size_t i = 0; i < nm; ++i)
+        if (!fr_words_reduced(mds + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "mds[%zu] not reduced", i);
+    akp_poseidon* p = new akp_poseidon();
+    p->ctx = ctx;
+    p->dims = PoseidonDims{t, rate, capacity, full_rounds, partial_rounds, alpha};
+    p->ark.resize(na);
+    p->mds.resize(nm);
+    for (size_t i = 0; i < na; ++i) p->ark[i] = fr_from_words(ark + 4 * i);
+    for (size_t i = 0; i < nm; ++i) p->mds[i] = fr_from_words(mds + 4 * i);
+    if (ctx) {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipMalloc(&p->d_ark, std::max<size_t>(na, 1) * sizeof(Fr));
+        if (e == hipSuccess) e = hipMalloc(&p->d_mds, nm * sizeof(Fr));
+        if (e == hipSuccess && na) e = hipMemcpy(p->d_ark, p->ark.data(), na * sizeof(Fr), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_mds, p->mds.data(), nm * sizeof(Fr), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (p->d_ark) (void)hipFree(p->d_ark);
+            if (p->d_mds) (void)hipFree(p->d_mds);
+            delete p;
+            return fail(AKP_ERR_HIP, "uploading Poseidon parameters: %s", hipGetErrorString(e));
+        }
+    }
+    *out = p;
+    return AKP_OK;
+}
+extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
+    if (!p) return;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    if (p->d_ark) (void)hipFree(p->d_ark);
+    if (p->d_mds) (void)hipFree(p->d_mds);
+    delete p;
+}
+extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
+                                            uint64_t* alpha, uint32_t* rate, uint32_t* capacity) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "params is NULL");
+    if (full_rounds) *full_rounds = p->dims.full_rounds;
+    if (partial_rounds) *partial_rounds = p->dims.partial_rounds;
+    if (alpha) *alpha = p->dims.alpha;
+    if (rate) *rate = p->dims.rate;
+    if (capacity) *capacity = p->dims.capacity;
+    return AKP_OK;
+}
+extern "C" int32_t akp_poseidon_params_export(const akp_poseidon* p, uint64_t* ark, uint64_t* mds) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "params is NULL");
+    if (ark)
+        for (size_t i = 0; i < p->ark.size(); ++i) fr_to_words(p->ark[i], ark + 4 * i);
+    if (mds)
+        for (size_t i = 0; i < p->mds.size(); ++i) fr_to_words(p->mds[i], mds + 4 * i);
+    return AKP_OK;
+}
+
+// ---- default parameters: Grain LFSR (sponge/poseidon/grain_lfsr.rs:16-181) + Cauchy MDS
+//      (sponge/poseidon/traits.rs:105-146), BLS12-381 Fr table (sponge/test.rs:13-31) -----------
+namespace {
+struct GrainLFSR {
+    bool st[80];
+    unsigned head = 0;
+    unsigned prime_bits;
+    GrainLFSR(bool sbox_inverse, unsigned prime_num_bits, unsigned state_len, unsigned rf, unsigned rp) : prime_bits(prime_num_bits) {
+        memset(st, 0, sizeof st);
+        st[1] = true;
+        st[5] = sbox_inverse;
+        auto put = [&](int lo, int hi, unsigned v) {
+            for (int i = hi; i >= lo; --i) { st[i] = v & 1u; v >>= 1; }
+        };
+        put(6, 17, prime_num_bits);
+        put(18, 29, state_len);
+        put(30, 39, rf);
+        put(40, 49, rp);
+        for (int i = 50; i < 80; ++i) st[i] = true;
+        for (int i = 0; i < 160; ++i) update();
+    }
+    bool update() {
+        bool nb = st[(head + 62) % 80] ^ st[(head + 51) % 80] ^ st[(head + 38) % 80] ^ st[(head + 23) % 80] ^ st[(head + 13) % 80] ^ st[head];
+        st[head] = nb;
+        head = (head + 1) % 80;
+        return nb;
+    }
+    bool next_bit() {  // get_bits :87-107: keep the second bit of a pair iff the first is 1
+        bool b = update();
+        while (!b) { update(); b = update(); }
+        return update();
+    }
+    // prime_bits bits, most significant first -> canonical 256-bit integer (8 x u32 LE)
+    void next_int(u32 (&v)[8]) {
+        for (int i = 0; i < 8; ++i) v[i] = 0;
+        for (unsigned i = 0; i < prime_bits; ++i) {
+            const unsigned pos = prime_bits - 1 - i;
+            if (next_bit()) v[pos >> 5] |= 1u << (pos & 31);
+        }
+    }
+};
+bool geq_p(const u32 (&v)[8]) {
+    for (int i = 7; i >= 0; --i) {
+        if (v[i] > fr_p_limb(i)) return true;
+        if (v[i] < fr_p_limb(i)) return false;
+    }
+    return true;
+}
+void sub_p(u32 (&v)[8]) {
+    u64 bw = 0;
+    for (int i = 0; i < 8; ++i) {
+        u64 d = (u64)v[i] - fr_p_limb(i) - bw;
+        v[i] = (u32)d;
+        bw = (d >> 32) & 1;
+    }
+}
+Fr lfsr_rejection(GrainLFSR& g) {  // :109-134
+    u32 v[8];
+    do g.next_int(v); while (geq_p(v));
+    Fr c;
+    for (int i = 0; i < 8; ++i) c.l[i] = v[i];
+    return fr_to_mont(c);
+}
+Fr lfsr_mod_p(GrainLFSR& g) {  // :136-160 (from_le_bytes_mod_order of a 255-bit value: < 3p)
+    u32 v[8];
+    g.next_int(v);
+    while (geq_p(v)) sub_p(v);
+    Fr c;
+    for (int i = 0; i < 8; ++i) c.l[i] = v[i];
+    return fr_to_mont(c);
+}
+struct DefaultEntry { unsigned rate, alpha, rf, rp, skip; };
+const DefaultEntry kConstraints[7] = {{2, 17, 8, 31, 0}, {3, 5, 8, 56, 0}, {4, 5, 8, 56, 0}, {5, 5, 8, 57, 0},
+                                      {6, 5, 8, 57, 0}, {7, 5, 8, 57, 0}, {8, 5, 8, 57, 0}};
+const DefaultEntry kWeights[7] = {{2, 257, 8, 13, 0}, {3, 257, 8, 13, 0}, {4, 257, 8, 13, 0}, {5, 257, 8, 13, 0},
+                                  {6, 257, 8, 13, 0}, {7, 257, 8, 13, 0}, {8, 257, 8, 13, 0}};
+}  // namespace
+
+extern "C" int32_t akp_poseidon_default_params(akp_ctx* ctx, uint32_t rate, int32_t optimized_for_weights, akp_poseidon** out) {
+    const DefaultEntry* tab = optimized_for_weights ? kWeights : kConstraints;
+    const DefaultEntry* e = nullptr;
+    for (int i = 0; i < 7; ++i)
+        if (tab[i].rate == rate) e = &tab[i];
+    if (!e) return fail(AKP_ERR_BAD_PARAMS, "no default Poseidon parameters for rate %u (reference returns None)", rate);
+    const unsigned t = rate + 1;
+    GrainLFSR g(false, 255, t, e->rf, e->rp);
+    std::vector<Fr> ark((size_t)(e->rf + e->rp) * t), mds((size_t)t * t), xs(t), ys(t);
+    for (auto& a : ark) a = lfsr_rejection(g);
+    for (unsigned s = 0; s < e->skip; ++s)
+        for (unsigned i = 0; i < 2 * t; ++i) (void)lfsr_mod_p(g);
+    for (auto& x : xs) x = lfsr_mod_p(g);
+    for (auto& y : ys) y = lfsr_mod_p(g);
+    for (unsigned i = 0; i < t; ++i)
+        for (unsigned j = 0; j < t; ++j) mds[(size_t)i * t + j] = fr_inv(fr_add(xs[i], ys[j]));
+    std::vector<uint64_t> aw(ark.size() * 4), mw(mds.size() * 4);
+    for (size_t i = 0; i < ark.size(); ++i) fr_to_words(ark[i], &aw[4 * i]);
+    for (size_t i = 0; i < mds.size(); ++i) fr_to_words(mds[i], &mw[4 * i]);
+    return akp_poseidon_params_create(ctx, e->rf, e->rp, e->alpha, rate, 1, aw.data(), mw.data(), out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Poseidon launches
+static inline unsigned poseidon_block(u32 t) { return t <= 4 ? 256u : (t <= 8 ? 128u : 64u); }
+
+static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
+    if (n == 0) return AKP_OK;
+    const unsigned B = poseidon_block(p->dims.t);
+    const size_t lds = (size_t)2 * p->dims.t * 32 * B;
+    const unsigned grid = (unsigned)((n + B - 1) / B);
+    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, d_states, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, d_states, n);
+    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, d_states, n);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
+static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
+    if (n == 0) return AKP_OK;
+    const unsigned B = poseidon_block(p->dims.t);
+    const size_t lds = (size_t)2 * p->dims.t * 32 * B;
+    const unsigned grid = (unsigned)((n + B - 1) / B);
+    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, in0, in1, k, d_out, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, in0, in1, k, d_out, n);
+    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, in0, in1, k, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
+#define NEED_DEV(p, what)                                                                                  \
+    do {                                                                                                   \
+        if (!(p)) return fail(AKP_ERR_BAD_PARAMS, what ": params is NULL");                                \
+        if (!(p)->ctx) return fail(AKP_ERR_HIP, what ": parameter handle has no device context (no CPU fallback)"); \
+        HIP_TRY(hipSetDevice((p)->ctx->device));                                                           \
+    } while (0)
+
+extern "C" int32_t akp_poseidon_permute_batch_dev(akp_poseidon* p, uint64_t* d_states, size_t n, void* stream) {
+    NEED_DEV(p, "akp_poseidon_permute_batch_dev");
+    return launch_permute(p, reinterpret_cast<Fr*>(d_states), n, pick_stream(p->ctx, stream));
+}
+extern "C" int32_t akp_poseidon_permute_batch(akp_poseidon* p, uint64_t* states, size_t n) {
+    NEED_DEV(p, "akp_poseidon_permute_batch");
+    if (n == 0) return AKP_OK;
+    if (!states) return fail(AKP_ERR_BAD_PARAMS, "states is NULL");
+    const size_t bytes = n * p->dims.t * sizeof(Fr);
+    void* d = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, bytes, &d)) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, s));
+    if (int32_t rc = launch_permute(p, (Fr*)d, n, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+extern "C" int32_t akp_poseidon_crh_batch_dev(akp_poseidon* p, const uint64_t* d_inputs, size_t n, size_t k, uint64_t* d_out, void* stream) {
+    NEED_DEV(p, "akp_poseidon_crh_batch_dev");
+    return launch_crh(p, (const Fr*)d_inputs, nullptr, k, (Fr*)d_out, n, pick_stream(p->ctx, stream));
+}
+extern "C" int32_t akp_poseidon_crh_batch(akp_poseidon* p, const uint64_t* inputs, size_t n, size_t k, uint64_t* out) {
+    NEED_DEV(p, "akp_poseidon_crh_batch");
+    if (n == 0) return AKP_OK;
+    if (!out || (!inputs && k)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    void *din = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * k * sizeof(Fr), &din)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * sizeof(Fr), &dout)) return rc;
+    hipStream_t s = p->ctx->stream;
+    if (k) HIP_TRY(hipMemcpyAsync(din, inputs, n * k * sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (int32_t rc = launch_crh(p, (const Fr*)din, nullptr, k, (Fr*)dout, n, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+extern "C" int32_t akp_poseidon_two_to_one_batch_dev(akp_poseidon* p, const uint64_t* d_left, const uint64_t* d_right, size_t n,
+                                                     uint64_t* d_out, void* stream) {
+    NEED_DEV(p, "akp_poseidon_two_to_one_batch_dev");
+    return launch_crh(p, (const Fr*)d_left, (const Fr*)d_right, 2, (Fr*)d_out, n, pick_stream(p->ctx, stream));
+}
+extern "C" int32_t akp_poseidon_two_to_one_batch(akp_poseidon* p, const uint64_t* left, const uint64_t* right, size_t n, uint64_t* out) {
+    NEED_DEV(p, "akp_poseidon_two_to_one_batch");
+    if (n == 0) return AKP_OK;
+    if (!left || !right || !out) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    void *dl = nullptr, *dr = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * sizeof(Fr), &dl)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * sizeof(Fr), &dr)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * sizeof(Fr), &dout)) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dl, left, n * sizeof(Fr), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dr, right, n * sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (int32_t rc = launch_crh(p, (const Fr*)dl, (const Fr*)dr, 2, (Fr*)dout, n, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// batched duplex sponge: device state, host-side DuplexSpongeMode bookkeeping
+__global__ void sponge_add_kernel(Fr* state, u32 t, u32 lane0, const Fr* elems, size_t k, size_t e0, u32 count, size_t batch) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * count) return;
+    const size_t b = i / count, j = i % count;
+    Fr* dst = state + b * t + lane0 + j;
+    store_fr_global(dst, fr_add(load_fr_global(dst), load_fr_global(elems + b * k + e0 + j)));
+}
+__global__ void sponge_copy_out_kernel(const Fr* state, u32 t, u32 lane0, Fr* out, size_t n_out, size_t o0, u32 count, size_t batch) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * count) return;
+    const size_t b = i / count, j = i % count;
+    store_fr_global(out + b * n_out + o0 + j, load_fr_global(state + b * t + lane0 + j));
+}
+struct akp_sponge {
+    akp_poseidon* p = nullptr;
+    size_t batch = 0;
+    Fr* d_state = nullptr;
+    Fr* d_io = nullptr;
+    size_t io_elems = 0;
+    int mode = 0;      // 0 absorbing, 1 squeezing (sponge/mod.rs:195-206)
+    u32 index = 0;
+};
+extern "C" int32_t akp_sponge_create(akp_poseidon* p, size_t batch, akp_sponge** out) {
+    NEED_DEV(p, "akp_sponge_create");
+    if (!out || batch == 0) return fail(AKP_ERR_BAD_PARAMS, "akp_sponge_create: bad argument");
+    akp_sponge* s = new akp_sponge();
+    s->p = p;
+    s->batch = batch;
+    hipError_t e = hipMalloc(&s->d_state, batch * p->dims.t * sizeof(Fr));
+    if (e == hipSuccess) e = hipMemset(s->d_state, 0, batch * p->dims.t * sizeof(Fr));  // new(): all-zero state :223-234
+    if (e != hipSuccess) {
+        if (s->d_state) (void)hipFree(s->d_state);
+        delete s;
+        return fail(AKP_ERR_HIP, "akp_sponge_create: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return AKP_OK;
+}
+extern "C" void akp_sponge_destroy(akp_sponge* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->p->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (s->d_state) (void)hipFree(s->d_state);
+    if (s->d_io) (void)hipFree(s->d_io);
+    delete s;
+}
+static int32_t sponge_io(akp_sponge* s, size_t elems) {
+    if (s->io_elems < elems) {
+        if (s->d_io) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(s->d_io));
+            s->d_io = nullptr;
+        }
+        HIP_TRY(hipMalloc(&s->d_io, elems * sizeof(Fr)));
+        s->io_elems = elems;
+    }
+    return AKP_OK;
+}
+static int32_t sponge_permute(akp_sponge* s) { return launch_permute(s->p, s->d_state, s->batch, s->p->ctx->stream); }
+// absorb_internal (sponge/poseidon/mod.rs:124-153)
+static int32_t sponge_absorb_internal(akp_sponge* s, u32 idx, size_t k) {
+    const PoseidonDims& D = s->p->dims;
+    hipStream_t st = s->p->ctx->stream;
+    size_t e0 = 0, remaining = k;
+    for (;;) {
+        const bool last = idx + remaining <= D.rate;
+        const u32 count = last ? (u32)remaining : D.rate - idx;
+        if (count) {
+            const size_t work = s->batch * count;
+            hipLaunchKernelGGL(sponge_add_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, s->d_state, D.t,
+                               D.capacity + idx, s->d_io, k, e0, count, s->batch);
+            HIP_TRY(hipGetLastError());
+        }
+        if (last) {
+            s->mode = 0;
+            s->index = idx + (u32)remaining;
+            return AKP_OK;
+        }
+        if (int32_t rc = sponge_permute(s)) return rc;
+        e0 += count;
+        remaining -= count;
+        idx = 0;
+    }
+}
+extern "C" int32_t akp_sponge_absorb(akp_sponge* s, const uint64_t* elems, size_t k) {
+    if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");
+    if (k == 0) return AKP_OK;  // :238-240
+    if (!elems) return fail(AKP_ERR_BAD_PARAMS, "elems is NULL");
+    HIP_TRY(hipSetDevice(s->p->ctx->device));
+    if (int32_t rc = sponge_io(s, s->batch * k)) return rc;
+    hipStream_t st = s->p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(s->d_io, elems, s->batch * k * sizeof(Fr), hipMemcpyHostToDevice, st));
+    int32_t rc;
+    if (s->mode == 0) {  // :243-250
+        u32 idx = s->index;
+        if (idx == s->p->dims.rate) {
+            if ((rc = sponge_permute(s))) return rc;
+            idx = 0;
+        }
+        rc = sponge_absorb_internal(s, idx, k);
+    } else {  // :251-255 no permutation between squeeze and absorb
+        rc = sponge_absorb_internal(s, 0, k);
+    }
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return AKP_OK;
+}
+// squeeze_internal (sponge/poseidon/mod.rs:156-186)
+static int32_t sponge_squeeze_internal(akp_sponge* s, u32 idx, size_t n_out) {
+    const PoseidonDims& D = s->p->dims;
+    hipStream_t st = s->p->ctx->stream;
+    size_t o0 = 0, remaining = n_out;
+    for (;;) {
+        const bool last = idx + remaining <= D.rate;
+        const u32 count = last ? (u32)remaining : D.rate - idx;
+        if (count) {
+            const size_t work = s->batch * count;
+            hipLaunchKernelGGL(sponge_copy_out_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, s->d_state, D.t,
+                               D.capacity + idx, s->d_io, n_out, o0, count, s->batch);
+            HIP_TRY(hipGetLastError());
+        }
+        if (last) {
+            s->mode = 1;
+            s->index = idx + (u32)remaining;
+            return AKP_OK;
+        }
+        o0 += count;
+        remaining -= count;
+        if (remaining != 0)
+            if (int32_t rc = sponge_permute(s)) return rc;
+        idx = 0;
+    }
+}
+extern "C" int32_t akp_sponge_squeeze(akp_sponge* s, uint64_t* out, size_t n_out) {
+    if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");
+    if (!out && n_out) return fail(AKP_ERR_BAD_PARAMS, "out is NULL");
+    HIP_TRY(hipSetDevice(s->p->ctx->device));
+    if (int32_t rc = sponge_io(s, s->batch * std::max<size_t>(n_out, 1))) return rc;
+    hipStream_t st = s->p->ctx->stream;
+    int32_t rc;
+    if (s->mode == 0) {  // :331-334 (permutes even when n_out == 0)
+        if ((rc = sponge_permute(s))) return rc;
+        rc = sponge_squeeze_internal(s, 0, n_out);
+    } else {  // :335-341
+        u32 idx = s->index;
+        if (idx == s->p->dims.rate) {
+            if ((rc = sponge_permute(s))) return rc;
+            idx = 0;
+        }
+        rc = sponge_squeeze_internal(s, idx, n_out);
+    }
+    if (rc) return rc;
+    if (n_out) HIP_TRY(hipMemcpyAsync(out, s->d_io, s->batch * n_out * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return AKP_OK;
+}
+extern "C" int32_t akp_sponge_get_state(akp_sponge* s, uint64_t* state, int32_t* mode, uint32_t* index) {
+    if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");
+    HIP_TRY(hipSetDevice(s->p->ctx->device));
+    if (state) {
+        HIP_TRY(hipStreamSynchronize(s->p->ctx->stream));
+        HIP_TRY(hipMemcpy(state, s->d_state, s->batch * s->p->dims.t * sizeof(Fr), hipMemcpyDeviceToHost));
+    }
+    if (mode) *mode = s->mode;
+    if (index) *index = s->index;
+    return AKP_OK;
+}
+extern "C" int32_t akp_sponge_set_state(akp_sponge* s, const uint64_t* state, int32_t mode, uint32_t index) {
+    if (!s || !state) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
+    if ((mode != 0 && mode != 1) || index > s->p->dims.rate) return fail(AKP_ERR_BAD_PARAMS, "bad duplex mode");
+    HIP_TRY(hipSetDevice(s->p->ctx->device));
+    HIP_TRY(hipStreamSynchronize(s->p->ctx->stream));
+    HIP_TRY(hipMemcpy(s->d_state, state, s->batch * s->p->dims.t * sizeof(Fr), hipMemcpyHostToDevice));
+    s->mode = mode;
+    s->index = index;
+    return AKP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pedersen / Bowe-Hopwood
+struct akp_te_params {
+    akp_ctx* ctx = nullptr;
+    int kind = 0;
+    u32 W = 0, N = 0;
+    u32 subs_per_window = 0;  // Pedersen: ceil(W / 4)
+    u32 n_units = 0;          // Pedersen: N * subs_per_window sub-windows; BH: N * W chunks
+    Niels* d_lut = nullptr;
+};
+static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN ? 2u : 1u; }
+static inline size_t te_input_bits(const akp_te_params* p) {  // max message bits before the reference panics
+    return p->kind == AKP_TE_PEDERSEN ? (size_t)p->W * p->N : (size_t)p->W * p->N * 3;
+}
+
+extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
+    if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
+    if (!out || !gens) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
+    if (kind != AKP_TE_PEDERSEN && kind != AKP_TE_BOWE_HOPWOOD) return fail(AKP_ERR_BAD_PARAMS, "unknown kind %d", kind);
+    if (W == 0 || N == 0) return fail(AKP_ERR_BAD_PARAMS, "empty window");
+    if (kind == AKP_TE_BOWE_HOPWOOD && W > 63) return fail(AKP_ERR_BAD_PARAMS, "Bowe-Hopwood window size %u > 63 (bowe_hopwood/mod.rs:81-101)", W);
+    const size_t n_gen = (size_t)W * N;
+    for (size_t i = 0; i < 2 * n_gen; ++i)
+        if (!fr_words_reduced(gens + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "generator coordinate %zu not reduced", i);
+    HIP_TRY(hipSetDevice(ctx->device));
+    akp_te_params* p = new akp_te_params();
+    p->ctx = ctx; p->kind = kind; p->W = W; p->N = N;
+    Fr* d_g = nullptr;
+    hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
+    if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
+    size_t entries = 0;
+    if (kind == AKP_TE_PEDERSEN) {
+        p->subs_per_window = (W + 3) / 4;
+        p->n_units = N * p->subs_per_window;
+        entries = (size_t)p->n_units * 16;
+    } else {
+        p->subs_per_window = 1;
+        p->n_units = (u32)n_gen;
+        entries = n_gen * 4;
+    }
+    if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(Niels));
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)((entries + 63) / 64);
+        if (kind == AKP_TE_PEDERSEN)
+            hipLaunchKernelGGL(te_build_pedersen_lut, dim3(grid), dim3(64), 0, ctx->stream, d_g, W, p->subs_per_window, p->n_units, p->d_lut);
+        else
+            hipLaunchKernelGGL(te_build_bh_lut, dim3(grid), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, p->d_lut);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_g) (void)hipFree(d_g);
+    if (e != hipSuccess) {
+        if (p->d_lut) (void)hipFree(p->d_lut);
+        delete p;
+        return fail(AKP_ERR_HIP, "akp_te_params_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return AKP_OK;
+}
+extern "C" void akp_te_params_destroy(akp_te_params* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (p->d_lut) (void)hipFree(p->d_lut);
+    delete p;
+}
+
+// number of table steps a message of msg_len bytes touches (later digits are zero / absent):
+// Pedersen pads with zero bytes (contribute the identity); Bowe-Hopwood stops at ceil(bits/3) chunks.
+static u32 te_steps(const akp_te_params* p, size_t msg_len) {
+    const size_t bits = msg_len * 8;
+    if (p->kind == AKP_TE_PEDERSEN) {
+        const size_t windows = std::min<size_t>((bits + p->W - 1) / p->W, p->N);
+        return (u32)(windows * p->subs_per_window);
+    }
+    return (u32)std::min<size_t>((bits + 2) / 3, (size_t)p->n_units);
+}
+// accumulate + finalize on device buffers.  scratch: SCR_E (xyz), SCR_F (prefix)
+static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s) {
+    if (msg_len * 8 > te_input_bits(p))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
+    if (n == 0) return AKP_OK;
+    void *xyz = nullptr, *prefix = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(Fr), &xyz)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(Fr), &prefix)) return rc;
+    const u32 steps = te_steps(p, msg_len);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (p->kind == AKP_TE_PEDERSEN)
+        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (Fr*)xyz, n);
+    else
+        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (Fr*)xyz, n);
+    HIP_TRY(hipGetLastError());
+    // share one inversion among up to 64 messages per lane, but keep >= 64K lanes busy when n allows
+    size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / 65536));
+    size_t lanes = (n + chain - 1) / chain;
+    const unsigned fgrid = (unsigned)((lanes + 255) / 256);
+    if (p->kind == AKP_TE_PEDERSEN)
+        hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, s, (const Fr*)xyz, (Fr*)prefix, d_out, n, lanes);
+    else
+        hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, s, (const Fr*)xyz, (Fr*)prefix, d_out, n, lanes);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
+#define NEED_TE(p, what)                                                    \
+    do {                                                                    \
+        if (!(p)) return fail(AKP_ERR_BAD_PARAMS, what ": params is NULL"); \
+        HIP_TRY(hipSetDevice((p)->ctx->device));                            \
+    } while (0)
+
+extern "C" int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out, void* stream) {
+    NEED_TE(p, "akp_te_crh_batch_dev");
+    return te_crh_dev(p, d_msgs, n, msg_len, (Fr*)d_out, pick_stream(p->ctx, stream));
+}
+extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_t n, size_t msg_len, uint64_t* out) {
+    NEED_TE(p, "akp_te_crh_batch");
+    if (msg_len * 8 > te_input_bits(p))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
+    if (n == 0) return AKP_OK;
+    if (!out || (!msgs && msg_len)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    const size_t fe = te_fe_per_digest(p);
+    void *dm = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * msg_len, &dm)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dout)) return rc;
+    hipStream_t s = p->ctx->stream;
+    if (msg_len) HIP_TRY(hipMemcpyAsync(dm, msgs, n * msg_len, hipMemcpyHostToDevice, s));
+    if (int32_t rc = te_crh_dev(p, (const uint8_t*)dm, n, msg_len, (Fr*)dout, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+extern "C" int32_t akp_te_two_to_one_batch(akp_te_params* p, const uint8_t* left, const uint8_t* right, size_t n, size_t half_len, uint64_t* out) {
+    NEED_TE(p, "akp_te_two_to_one_batch");
+    if (n == 0) return AKP_OK;
+    if (!out || ((!left || !right) && half_len)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    const size_t buflen = ((size_t)p->W * p->N) / 8;  // both schemes size the buffer from pedersen's INPUT_SIZE_BITS
+    const size_t fe = te_fe_per_digest(p);
+    void *dl = nullptr, *dr = nullptr, *dbuf = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * half_len, &dl)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * half_len, &dr)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * buflen, &dbuf)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * fe * sizeof(Fr), &dout)) return rc;
+    hipStream_t s = p->ctx->stream;
+    if (half_len) {
+        HIP_TRY(hipMemcpyAsync(dl, left, n * half_len, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dr, right, n * half_len, hipMemcpyHostToDevice, s));
+    }
+    if (buflen) {
+        const size_t work = n * buflen;
+        hipLaunchKernelGGL(te_concat_bytes_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (const uint8_t*)dl, (const uint8_t*)dr, half_len, buflen, (uint8_t*)dbuf, n);
+        HIP_TRY(hipGetLastError());
+    }
+    if (int32_t rc = te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, (Fr*)dout, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+// one level of compress(): serialise digest pairs into per-node buffers (SCR_D), hash into d_out
+static int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_right, size_t n, Fr* d_out, hipStream_t s) {
+    if (n == 0) return AKP_OK;
+    const size_t buflen = ((size_t)p->W * p->N) / 8;
+    const u32 fe = te_fe_per_digest(p);
+    const size_t used = std::min<size_t>(buflen, (size_t)2 * fe * 32);
+    void* dbuf = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * buflen, &dbuf)) return rc;
+    const size_t work = n * 2 * fe;
+    hipLaunchKernelGGL(te_serialize_pairs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, d_left, d_right, fe, buflen, (uint8_t*)dbuf, n);
+    HIP_TRY(hipGetLastError());
+    if (used < buflen) {
+        const size_t tw = n * (buflen - used);
+        hipLaunchKernelGGL(te_zero_tail_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, s, (uint8_t*)dbuf, buflen, used, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, d_out, s);
+}
+extern "C" int32_t akp_te_compress_batch(akp_te_params* p, const uint64_t* left, const uint64_t* right, size_t n, uint64_t* out) {
+    NEED_TE(p, "akp_te_compress_batch");
+    if (n == 0) return AKP_OK;
+    if (!left || !right || !out) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    const size_t fe = te_fe_per_digest(p);
+    void *dl = nullptr, *dr = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * fe * sizeof(Fr), &dl)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dr)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * fe * sizeof(Fr), &dout)) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dl, left, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dr, right, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (int32_t rc = te_compress_dev(p, (const Fr*)dl, (const Fr*)dr, n, (Fr*)dout, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Merkle tree (merkle_tree/mod.rs:411-523): one launch per level, bottom-up; level l of the
+// heap-ordered non_leaf array starts at 2^l - 1.
+static inline bool pow2_gt1(size_t n) { return n > 1 && (n & (n - 1)) == 0; }
+
+extern "C" int32_t akp_merkle_inner_poseidon_dev(akp_poseidon* two, const uint64_t* d_leaf_nodes, size_t n, uint64_t* d_non_leaf, void* stream) {
+    NEED_DEV(two, "akp_merkle_inner_poseidon_dev");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    hipStream_t s = pick_stream(two->ctx, stream);
+    Fr* nl = (Fr*)d_non_leaf;
+    const Fr* child = (const Fr*)d_leaf_nodes;
+    for (size_t width = n / 2; width >= 1; width /= 2) {
+        const size_t first = width - 1;
+        if (int32_t rc = launch_crh(two, child, nullptr, 2, nl + first, width, s)) return rc;
+        child = nl + first;
+    }
+    return AKP_OK;
+}
+extern "C" int32_t akp_merkle_build_poseidon_dev(akp_poseidon* leafp, akp_poseidon* two, const uint64_t* d_leaves, size_t n, size_t leaf_len,
+                                                 uint64_t* d_leaf_nodes, uint64_t* d_non_leaf, void* stream) {
+    NEED_DEV(leafp, "akp_merkle_build_poseidon_dev");
+    NEED_DEV(two, "akp_merkle_build_poseidon_dev");
+    if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "leaf and two-to-one parameters belong to different contexts");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    hipStream_t s = pick_stream(leafp->ctx, stream);
+    if (int32_t rc = launch_crh(leafp, (const Fr*)d_leaves, nullptr, leaf_len, (Fr*)d_leaf_nodes, n, s)) return rc;  // :417-419
+    return akp_merkle_inner_poseidon_dev(two, d_leaf_nodes, n, d_non_leaf, (void*)s);
+}
+extern "C" int32_t akp_merkle_build_poseidon(akp_poseidon* leafp, akp_poseidon* two, const uint64_t* leaves, size_t n, size_t leaf_len,
+                                             uint64_t* leaf_nodes, uint64_t* non_leaf, uint64_t* root_out) {
+    NEED_DEV(leafp, "akp_merkle_build_poseidon");
+    NEED_DEV(two, "akp_merkle_build_poseidon");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    if (!leaves && leaf_len) return fail(AKP_ERR_BAD_PARAMS, "leaves is NULL");
+    akp_ctx* c = leafp->ctx;
+    void *dl = nullptr, *dln = nullptr, *dnl = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len * sizeof(Fr), &dl)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dln)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * sizeof(Fr), &dnl)) return rc;
+    hipStream_t s = c->stream;
+    if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, n * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (int32_t rc = akp_merkle_build_poseidon_dev(leafp, two, (const uint64_t*)dl, n, leaf_len, (uint64_t*)dln, (uint64_t*)dnl, (void*)s)) return rc;
+    if (leaf_nodes) HIP_TRY(hipMemcpyAsync(leaf_nodes, dln, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    if (non_leaf) HIP_TRY(hipMemcpyAsync(non_leaf, dnl, (n - 1) * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, dnl, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+
+extern "C" int32_t akp_merkle_build_te_dev(akp_te_params* leafp, akp_te_params* two, const uint8_t* d_leaves, size_t n, size_t leaf_len,
+                                           uint64_t* d_leaf_nodes, uint64_t* d_non_leaf, void* stream) {
+    NEED_TE(leafp, "akp_merkle_build_te_dev");
+    NEED_TE(two, "akp_merkle_build_te_dev");
+    if (leafp->kind != two->kind) return fail(AKP_ERR_BAD_PARAMS, "leaf and two-to-one hashes must be of the same kind");
+    if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "parameters belong to different contexts");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    hipStream_t s = pick_stream(leafp->ctx, stream);
+    const u32 fe = te_fe_per_digest(two);
+    if (int32_t rc = te_crh_dev(leafp, d_leaves, n, leaf_len, (Fr*)d_leaf_nodes, s)) return rc;
+    Fr* nl = (Fr*)d_non_leaf;
+    const Fr* child = (const Fr*)d_leaf_nodes;
+    // bottom level: TwoToOneHash::evaluate(convert(l), convert(r)) with ByteDigestConverter (:454-483);
+    // upper levels: compress(l, r) (:486-515) -- both serialise the digests uncompressed first.
+    for (size_t width = n / 2; width >= 1; width /= 2) {
+        const size_t first = width - 1;
+        if (int32_t rc = te_compress_dev(two, child, nullptr, width, nl + first * fe, s)) return rc;
+        child = nl + first * fe;
+    }
+    return AKP_OK;
+}
+extern "C" int32_t akp_merkle_build_te(akp_te_params* leafp, akp_te_params* two, const uint8_t* leaves, size_t n, size_t leaf_len,
+                                       uint64_t* leaf_nodes, uint64_t* non_leaf, uint64_t* root_out) {
+    NEED_TE(leafp, "akp_merkle_build_te");
+    NEED_TE(two, "akp_merkle_build_te");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    if (leaf_len * 8 > te_input_bits(leafp))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", leaf_len, leafp->W, leafp->N);
+    if (!leaves && leaf_len) return fail(AKP_ERR_BAD_PARAMS, "leaves is NULL");
+    akp_ctx* c = leafp->ctx;
+    const size_t fe = te_fe_per_digest(two);
+    void *dl = nullptr, *dln = nullptr, *dnl = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len, &dl)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl)) return rc;
+    hipStream_t s = c->stream;
+    if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, n * leaf_len, hipMemcpyHostToDevice, s));
+    if (int32_t rc = akp_merkle_build_te_dev(leafp, two, (const uint8_t*)dl, n, leaf_len, (uint64_t*)dln, (uint64_t*)dnl, (void*)s)) return rc;
+    if (leaf_nodes) HIP_TRY(hipMemcpyAsync(leaf_nodes, dln, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    if (non_leaf) HIP_TRY(hipMemcpyAsync(non_leaf, dnl, (n - 1) * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, dnl, fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}

@@ -1,0 +1,107 @@
+"""Leaf-range sharding of MerkleTree::new across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI, "gloo" in CPU tests).
+Rank r of G owns leaves [r*n/G, (r+1)*n/G) and builds the height-log2(n/G)+1 sub-tree locally; its
+sub-root is global heap node (G-1)+r.  The only exchange is ONE all-gather of the G sub-roots
+(32 B each for Poseidon / Bowe-Hopwood digests, 64 B for Pedersen points -- latency-bound, link
+bandwidth irrelevant); every rank then computes the top G-1 nodes redundantly.  There is no
+data-path collective besides that, so the permutation / CRH batches shard with none at all.
+
+The hashing backend is injected so the control flow can be exercised on CPU (gloo) in tests with a
+test double; the product backend is `GpuPoseidonBackend` below (device pointers, no host copies).
+"""
+import numpy as np
+
+
+def shard_range(n_leaves: int, rank: int, world: int):
+    assert n_leaves % world == 0 and world & (world - 1) == 0, "world size must be a power of two dividing n"
+    per = n_leaves // world
+    assert per >= 2, "each rank needs at least two leaves (sub-tree of height >= 2)"
+    return rank * per, (rank + 1) * per
+
+
+def global_node_slices(n_leaves: int, rank: int, world: int):
+    """[(level, global_start, count, local_start)] mapping this rank's local non_leaf heap array onto
+    the global heap array: at global level l >= log2(world) the rank owns the contiguous slice
+    [2^l - 1 + r*2^l/G, 2^l - 1 + (r+1)*2^l/G)."""
+    out = []
+    g = world.bit_length() - 1
+    levels = (n_leaves.bit_length() - 1)  # non-leaf levels 0 .. log2(n)-1
+    for l in range(g, levels):
+        cnt = (1 << l) // world
+        local_level = l - g
+        out.append((l, (1 << l) - 1 + rank * cnt, cnt, (1 << local_level) - 1))
+    return out
+
+
+def combine_top(two_to_one_compress, sub_roots):
+    """top log2(G) levels from the G gathered sub-roots; returns heap-ordered array of the top G-1
+    nodes (root first).  `two_to_one_compress(left[m], right[m]) -> [m]`."""
+    level = np.asarray(sub_roots)
+    levels = []
+    while level.shape[0] > 1:
+        level = np.asarray(two_to_one_compress(level[0::2], level[1::2]))
+        levels.append(level)
+    if not levels:
+        return level[:0]
+    return np.concatenate(list(reversed(levels)), axis=0)
+
+
+def build_sharded(backend, local_leaves, n_leaves_global: int, dist=None):
+    """Sharded MerkleTree::new.  `backend` provides
+         build_subtree(local_leaves) -> (leaf_nodes, non_leaf_nodes, sub_root as numpy [digest...])
+         two_to_one_compress(left, right) -> numpy
+       `dist` is torch.distributed (initialised) or None for a single process.
+       Returns dict(root, top_nodes (G-1 heap-ordered), leaf_nodes, non_leaf_nodes (local))."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        leaf_nodes, non_leaf, root = backend.build_subtree(local_leaves)
+        return {"root": root, "top_nodes": np.asarray(root)[None][:0], "leaf_nodes": leaf_nodes, "non_leaf_nodes": non_leaf}
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    shard_range(n_leaves_global, rank, world)  # validates the partition
+    leaf_nodes, non_leaf, sub_root = backend.build_subtree(local_leaves)
+    sub_root = np.ascontiguousarray(sub_root, dtype=np.uint64)
+    dev = backend.comm_device()
+    mine = torch.from_numpy(sub_root.view(np.int64).reshape(-1)).to(dev)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)  # the one collective of the tree build
+    subs = np.stack([g.cpu().numpy().view(np.uint64).reshape(sub_root.shape) for g in gathered])
+    top = combine_top(backend.two_to_one_compress, subs)
+    root = top[0] if len(top) else subs[0]
+    return {"root": root, "top_nodes": top, "leaf_nodes": leaf_nodes, "non_leaf_nodes": non_leaf}
+
+
+class GpuPoseidonBackend:
+    """Poseidon leaf CRH + Poseidon two-to-one on this rank's GPU; leaves/nodes stay in HBM as torch
+    int64 tensors viewed as Fr wire format (4 x u64 per element)."""
+
+    def __init__(self, leaf_params, two_params, leaf_len=1, device=None):
+        import torch
+        from ._lib import default_context
+        self.torch = torch
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.ctx = default_context(self.device.index or 0)
+        self.leaf_h = leaf_params.handle(self.ctx)
+        self.two_h = two_params.handle(self.ctx)
+        self.two_params = two_params
+        self.leaf_len = leaf_len
+
+    def comm_device(self):
+        return self.device
+
+    def build_subtree(self, d_leaves):
+        """d_leaves: int64 cuda tensor [n_local, leaf_len, 4]."""
+        from ._lib import lib, check
+        torch = self.torch
+        n = d_leaves.shape[0]
+        leaf_nodes = torch.empty((n, 4), dtype=torch.int64, device=self.device)
+        non_leaf = torch.empty((n - 1, 4), dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.akp_merkle_build_poseidon_dev(self.leaf_h.h, self.two_h.h, d_leaves.data_ptr(), n, self.leaf_len,
+                                                leaf_nodes.data_ptr(), non_leaf.data_ptr(), stream))
+        root = non_leaf[0].cpu().numpy().view(np.uint64)
+        return leaf_nodes, non_leaf, root
+
+    def two_to_one_compress(self, left, right):
+        from .crh.poseidon import TwoToOneCRH
+        return TwoToOneCRH.compress_batch(self.two_params, np.ascontiguousarray(left), np.ascontiguousarray(right))

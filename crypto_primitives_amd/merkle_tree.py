@@ -1,0 +1,288 @@
+"""merkle_tree::{Config, MerkleTree, Path, MultiPath} (merkle_tree/mod.rs) with GPU level-wide hashing.
+
+The build (`MerkleTree.new`, :411-523) is the hot path: one leaf-hash launch and one two-to-one
+launch per level on the GPU, results landing in the reference's heap layout (`leaf_nodes[n]`,
+`non_leaf_nodes[n-1]`, root at 0).  Proof generation (:547-625) is index arithmetic over those
+arrays (host); verification (:172-212, :262-331) re-hashes through the same GPU batch entry points.
+
+Config objects bundle what the reference's `Config` trait (:83-122) fixes at type level.
+"""
+import numpy as np
+
+from ._lib import lib, check, NotPowerOfTwo
+from .crh import poseidon as _pos, pedersen as _ped, bowe_hopwood as _bh
+
+
+# ---- Config implementations ---------------------------------------------------------------------
+class PoseidonFieldConfig:
+    """Leaf = [Fr], LeafDigest = InnerDigest = Fr, IdentityDigestConverter, poseidon CRH / TwoToOneCRH
+    (the FieldMTConfig of merkle_tree/tests/mod.rs:198-206)."""
+    LeafHash = _pos.CRH
+    TwoToOneHash = _pos.TwoToOneCRH
+    digest_shape = (4,)
+
+    @staticmethod
+    def build(leaf_params, two_params, leaves):
+        x = np.ascontiguousarray(leaves, dtype=np.uint64)
+        n = x.shape[0]
+        k = x.size // (4 * n) if n else 0
+        leaf_nodes = np.empty((n, 4), dtype=np.uint64)
+        non_leaf = np.empty((max(n - 1, 0), 4), dtype=np.uint64)
+        check(lib.akp_merkle_build_poseidon(leaf_params.handle().h, two_params.handle().h, x.ctypes.data, n, k,
+                                            leaf_nodes.ctypes.data, non_leaf.ctypes.data, None))
+        return leaf_nodes, non_leaf
+
+    @staticmethod
+    def hash_leaves(leaf_params, leaves):
+        x = np.ascontiguousarray(leaves, dtype=np.uint64)
+        n = x.shape[0]
+        return _pos.CRH.evaluate_batch(leaf_params, x.reshape(n, -1, 4))
+
+    @staticmethod
+    def two_to_one_evaluate(two_params, left_digests, right_digests):  # IdentityDigestConverter (:53-63)
+        return _pos.TwoToOneCRH.evaluate_batch(two_params, left_digests, right_digests)
+
+    @staticmethod
+    def two_to_one_compress(two_params, left, right):
+        return _pos.TwoToOneCRH.compress_batch(two_params, left, right)
+
+
+class _ByteConfig:
+    """Leaf = [u8], ByteDigestConverter (:67-78): digests are serialised uncompressed before the
+    two-to-one hash (config shape merkle_tree/tests/mod.rs:24-33)."""
+
+    @classmethod
+    def build(cls, leaf_params, two_params, leaves):
+        m, n, L = _ped._as_msgs(leaves)
+        fe = cls.LeafHash._FE
+        leaf_nodes = np.empty((n, fe, 4), dtype=np.uint64)
+        non_leaf = np.empty((max(n - 1, 0), fe, 4), dtype=np.uint64)
+        check(lib.akp_merkle_build_te(leaf_params.handle().h, two_params.handle().h, m.ctypes.data if m.size else None,
+                                      n, L, leaf_nodes.ctypes.data, non_leaf.ctypes.data, None))
+        shp = cls.digest_shape
+        return leaf_nodes.reshape((n,) + shp), non_leaf.reshape((max(n - 1, 0),) + shp)
+
+    @classmethod
+    def hash_leaves(cls, leaf_params, leaves):
+        return cls.LeafHash.evaluate_batch(leaf_params, leaves)
+
+    @classmethod
+    def two_to_one_evaluate(cls, two_params, left_digests, right_digests):
+        # convert() = uncompressed bytes, then TwoToOneHash::evaluate == compress on the digests
+        return cls.TwoToOneHash.compress_batch(two_params, left_digests, right_digests)
+
+    @classmethod
+    def two_to_one_compress(cls, two_params, left, right):
+        return cls.TwoToOneHash.compress_batch(two_params, left, right)
+
+
+class PedersenByteConfig(_ByteConfig):
+    LeafHash = _ped.CRH
+    TwoToOneHash = _ped.TwoToOneCRH
+    digest_shape = (2, 4)
+
+
+class BoweHopwoodByteConfig(_ByteConfig):
+    LeafHash = _bh.CRH
+    TwoToOneHash = _bh.TwoToOneCRH
+    digest_shape = (4,)
+
+
+# ---- index helpers (:730-786) ---------------------------------------------------------------------
+def tree_height(num_leaves):
+    return 1 if num_leaves == 1 else (num_leaves.bit_length() - 1) + 1
+
+
+def left_child(i):
+    return 2 * i + 1
+
+
+def right_child(i):
+    return 2 * i + 2
+
+
+def parent(i):
+    return (i - 1) >> 1 if i > 0 else None
+
+
+def sibling(i):
+    if i == 0:
+        return None
+    return i + 1 if i % 2 == 1 else i - 1
+
+
+def is_left_child(i):
+    return i % 2 == 1
+
+
+def convert_index_to_last_level(index, height):
+    return index + (1 << (height - 1)) - 1
+
+
+def _eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+class Path:
+    """merkle_tree::Path (:146-213)."""
+
+    def __init__(self, config, leaf_sibling_hash, auth_path, leaf_index):
+        self.config = config
+        self.leaf_sibling_hash = leaf_sibling_hash
+        self.auth_path = auth_path  # root-side first, excludes the root
+        self.leaf_index = leaf_index
+
+    def verify(self, leaf_hash_params, two_to_one_params, root_hash, leaf) -> bool:
+        """:172-212."""
+        return verify_paths(self.config, leaf_hash_params, two_to_one_params, root_hash, [self], [leaf])[0]
+
+
+def verify_paths(config, leaf_params, two_params, root_hash, paths, leaves):
+    """Batched Path::verify: all paths advance one level per GPU launch."""
+    n = len(paths)
+    if n == 0:
+        return []
+    claimed = config.hash_leaves(leaf_params, leaves)
+    sib = np.stack([np.asarray(p.leaf_sibling_hash) for p in paths])
+    idx = np.array([p.leaf_index for p in paths], dtype=np.int64)
+    is_left = (idx & 1) == 0  # select_left_right_child (:367-381)
+    sel = is_left.reshape((n,) + (1,) * (claimed.ndim - 1))
+    left = np.where(sel, claimed, sib)
+    right = np.where(sel, sib, claimed)
+    cur = config.two_to_one_evaluate(two_params, left, right)
+    idx >>= 1
+    depth = len(paths[0].auth_path)
+    assert all(len(p.auth_path) == depth for p in paths)
+    for level in range(depth - 1, -1, -1):
+        sibs = np.stack([np.asarray(p.auth_path[level]) for p in paths])
+        is_left = (idx & 1) == 0
+        sel = is_left.reshape((n,) + (1,) * (cur.ndim - 1))
+        left = np.where(sel, cur, sibs)
+        right = np.where(sel, sibs, cur)
+        cur = config.two_to_one_compress(two_params, left, right)
+        idx >>= 1
+    root = np.asarray(root_hash)
+    return [bool(np.array_equal(cur[i], root)) for i in range(n)]
+
+
+class MultiPath:
+    """merkle_tree::MultiPath (:239-351): prefix-encoded authentication paths."""
+
+    def __init__(self, config, leaf_siblings_hashes, auth_paths_prefix_lenghts, auth_paths_suffixes, leaf_indexes):
+        self.config = config
+        self.leaf_siblings_hashes = leaf_siblings_hashes
+        self.auth_paths_prefix_lenghts = auth_paths_prefix_lenghts
+        self.auth_paths_suffixes = auth_paths_suffixes
+        self.leaf_indexes = leaf_indexes
+
+    def decode_paths(self):
+        """prefix_decode_path (:807-817) applied incrementally (:283-292)."""
+        paths = []
+        prev = list(self.auth_paths_suffixes[0])
+        for i, leaf_index in enumerate(self.leaf_indexes):
+            k = self.auth_paths_prefix_lenghts[i]
+            auth = (prev[:k] if k else []) + list(self.auth_paths_suffixes[i])
+            prev = auth
+            paths.append(Path(self.config, self.leaf_siblings_hashes[i], auth, leaf_index))
+        return paths
+
+    def verify(self, leaf_hash_params, two_to_one_params, root_hash, leaves) -> bool:
+        """:262-331.  The reference memoises shared nodes in a hash map; here every decoded path is
+        verified in one batched pass (same accept/reject result)."""
+        leaves = list(leaves)
+        return all(verify_paths(self.config, leaf_hash_params, two_to_one_params, root_hash, self.decode_paths(), leaves))
+
+
+class MerkleTree:
+    """merkle_tree::MerkleTree<P> (:383-726)."""
+
+    def __init__(self, config, leaf_hash_param, two_to_one_hash_param, leaf_nodes, non_leaf_nodes):
+        self.config = config
+        self.leaf_hash_param = leaf_hash_param
+        self.two_to_one_hash_param = two_to_one_hash_param
+        self.leaf_nodes = leaf_nodes
+        self.non_leaf_nodes = non_leaf_nodes
+        self._height = tree_height(len(leaf_nodes))
+
+    @classmethod
+    def new(cls, config, leaf_hash_param, two_to_one_hash_param, leaves):
+        """MerkleTree::new (:411-422): leaves.len() must be a power of two greater than one."""
+        n = len(leaves)
+        if n < 2 or n & (n - 1):
+            raise NotPowerOfTwo(5, "`leaves.len() should be power of two and greater than one")
+        leaf_nodes, non_leaf = config.build(leaf_hash_param, two_to_one_hash_param, leaves)
+        return cls(config, leaf_hash_param, two_to_one_hash_param, leaf_nodes, non_leaf)
+
+    def root(self):
+        return self.non_leaf_nodes[0].copy()
+
+    def height(self):
+        return self._height
+
+    def get_leaf_sibling_hash(self, index):  # :536-544
+        return self.leaf_nodes[index + 1 if index & 1 == 0 else index - 1].copy()
+
+    def compute_auth_path(self, index):  # :547-569
+        cur = parent(convert_index_to_last_level(index, self._height))
+        path = []
+        while cur != 0:
+            path.append(self.non_leaf_nodes[sibling(cur)].copy())
+            cur = parent(cur)
+        path.reverse()
+        return path
+
+    def generate_proof(self, index) -> Path:  # :572-579
+        return Path(self.config, self.get_leaf_sibling_hash(index), self.compute_auth_path(index), index)
+
+    def generate_multi_proof(self, indexes) -> MultiPath:  # :592-625
+        idxs = sorted(set(indexes))
+        prefix_lens, suffixes, sibs = [], [], []
+        prev = []
+        for i in idxs:
+            sibs.append(self.get_leaf_sibling_hash(i))
+            path = self.compute_auth_path(i)
+            k = 0
+            while k < min(len(prev), len(path)) and _eq(prev[k], path[k]):  # prefix_encode_path (:795-805)
+                k += 1
+            prefix_lens.append(k)
+            suffixes.append(path[k:])
+            prev = path
+        return MultiPath(self.config, sibs, prefix_lens, suffixes, idxs)
+
+    def _updated_path(self, index, new_leaf):  # :629-677
+        cfg = self.config
+        new_hash = cfg.hash_leaves(self.leaf_hash_param, [new_leaf])[0]
+        if index & 1 == 0:
+            l, r = new_hash, self.leaf_nodes[index + 1]
+        else:
+            l, r = self.leaf_nodes[index - 1], new_hash
+        cur = cfg.two_to_one_evaluate(self.two_to_one_hash_param, l[None], r[None])[0]
+        path = [cur]
+        prev_index = parent(convert_index_to_last_level(index, self._height))
+        while prev_index != 0:
+            sib = self.non_leaf_nodes[sibling(prev_index)]
+            l, r = (cur, sib) if is_left_child(prev_index) else (sib, cur)
+            cur = cfg.two_to_one_compress(self.two_to_one_hash_param, l[None], r[None])[0]
+            path.append(cur)
+            prev_index = parent(prev_index)
+        return new_hash, path  # bottom-to-top
+
+    def update(self, index, new_leaf):  # :692-702
+        assert index < len(self.leaf_nodes), "index out of range"
+        new_hash, path = self._updated_path(index, new_leaf)
+        self._apply(index, new_hash, path)
+
+    def check_update(self, index, new_leaf, asserted_new_root) -> bool:  # :707-725
+        assert index < len(self.leaf_nodes), "index out of range"
+        new_hash, path = self._updated_path(index, new_leaf)
+        if not _eq(path[-1], asserted_new_root):
+            return False
+        self._apply(index, new_hash, path)
+        return True
+
+    def _apply(self, index, new_hash, path_bottom_to_top):
+        self.leaf_nodes[index] = new_hash
+        cur = convert_index_to_last_level(index, self._height)
+        for node in path_bottom_to_top:
+            cur = parent(cur)
+            self.non_leaf_nodes[cur] = node

@@ -1,0 +1,174 @@
+/*
+ * akp.h -- C ABI of the MI355X-native CRH / sponge / Merkle hot path
+ *          (drop-in for the native, non-R1CS path of ark-crypto-primitives).
+ *
+ * The reference has no FFI: its "operator API" is three Rust traits with per-item static
+ * functions.  This header is the boundary a Rust shim binds to implement
+ * those traits level-wide on the GPU.  Each entry point cites the reference item it replaces
+ * (paths relative to /root/reference/crypto-primitives/src).
+ *
+ * Conventions
+ *   - Every call returns int32_t status (AKP_OK == 0).  No exceptions cross the boundary.
+ *     akp_last_error() returns a thread-local message for the last failure.
+ *   - Field element wire format ("Fr"): 32 bytes = 4 x u64 little-endian limbs, MONTGOMERY form
+ *     (x * 2^256 mod p), fully reduced -- byte-identical to ark-ff's in-memory Fp256
+ *     (`Fp(BigInt([u64; 4]))`) for BLS12-381 Fr (= Jubjub base field Fq), so a Rust caller
+ *     passes `&[Fr]` memory unchanged.  akp_fr_to_mont / akp_fr_from_mont convert canonical
+ *     little-endian integers for non-Rust callers.
+ *   - Arrays are AoS at the ABI: n x t x 32 B states, n x k x 32 B CRH inputs, n x len byte
+ *     messages.  Affine points are x || y (2 x Fr).
+ *   - Functions without suffix take HOST pointers (they stage through device scratch owned by
+ *     the context and synchronise before returning).  Functions ending in `_dev` take DEVICE
+ *     pointers plus a hipStream_t (passed as void*; NULL = the context's stream); they only
+ *     enqueue work and never synchronise -- this is the zero-copy path used when inputs are
+ *     already resident in HBM (bench.py, torch tensors' data_ptr()).
+ *   - Ownership: the caller owns every buffer it passes; the library owns parameter handles and
+ *     its scratch.  A context is not thread-safe; distinct contexts are independent.
+ *   - Errors mirror the reference: a length the reference would panic on
+ *     (crh/pedersen/mod.rs:82-89, crh/bowe_hopwood/mod.rs:121-129) returns AKP_ERR_BAD_LENGTH;
+ *     a leaf count that is not a power of two > 1 (merkle_tree/mod.rs:430-433) returns
+ *     AKP_ERR_NOT_POW2.  There is NO CPU fallback: without a HIP device every compute call
+ *     returns AKP_ERR_HIP.
+ */
+#ifndef AKP_H
+#define AKP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AKP_OK 0
+#define AKP_ERR_BAD_LENGTH 1 /* lib.rs:47-52 Error::IncorrectInputLength / length panics */
+#define AKP_ERR_BAD_PARAMS 2
+#define AKP_ERR_HIP 3
+#define AKP_ERR_RCCL 4 /* reserved: collectives are driven by the host layer (torch.distributed / RCCL) */
+#define AKP_ERR_NOT_POW2 5
+
+#define AKP_ABI_VERSION 1
+
+typedef struct akp_ctx akp_ctx;
+typedef struct akp_poseidon akp_poseidon; /* PoseidonConfig<Fr>, sponge/poseidon/mod.rs:27-45 */
+typedef struct akp_te_params akp_te_params; /* pedersen::Parameters / bowe_hopwood::Parameters */
+typedef struct akp_sponge akp_sponge;     /* batch of PoseidonSponge<Fr>, sponge/poseidon/mod.rs:54-63 */
+
+int32_t akp_abi_version(void);
+const char* akp_last_error(void);
+/* number of visible HIP devices (0 when there is none or the runtime is unusable) */
+int32_t akp_device_count(void);
+
+/* ---- context ---------------------------------------------------------------------------- */
+int32_t akp_ctx_create(int32_t device_id, akp_ctx** out);
+void akp_ctx_destroy(akp_ctx* ctx);
+int32_t akp_ctx_synchronize(akp_ctx* ctx);
+
+/* ---- field helpers (host side, no device needed) ------------------------------------------ */
+/* canonical little-endian integers (must be < p) <-> Montgomery wire format; n elements */
+int32_t akp_fr_to_mont(const uint64_t* canonical, uint64_t* mont, size_t n);
+int32_t akp_fr_from_mont(const uint64_t* mont, uint64_t* canonical, size_t n);
+
+/* ---- Poseidon parameters ------------------------------------------------------------------ */
+/* PoseidonConfig::new (sponge/poseidon/mod.rs:191-217): ark is [full+partial][t], mds is [t][t],
+ * t = rate + capacity, all Fr wire format.  ctx may be NULL for a host-only handle (parameter
+ * generation / inspection without a GPU); compute calls on such a handle return AKP_ERR_HIP. */
+int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds, uint32_t partial_rounds, uint64_t alpha,
+                                   uint32_t rate, uint32_t capacity, const uint64_t* ark, const uint64_t* mds,
+                                   akp_poseidon** out);
+/* PoseidonDefaultConfigField::get_default_poseidon_parameters for BLS12-381 Fr
+ * (sponge/poseidon/traits.rs:69-155: Grain LFSR + Cauchy MDS; per-field table sponge/test.rs:13-31).
+ * rate in 2..8.  Returns AKP_ERR_BAD_PARAMS where the reference returns None. */
+int32_t akp_poseidon_default_params(akp_ctx* ctx, uint32_t rate, int32_t optimized_for_weights, akp_poseidon** out);
+void akp_poseidon_params_destroy(akp_poseidon* p);
+/* read back the dimensions; any out pointer may be NULL */
+int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
+                                 uint64_t* alpha, uint32_t* rate, uint32_t* capacity);
+/* copy out ark ([full+partial][t]) and mds ([t][t]) in wire format; either may be NULL */
+int32_t akp_poseidon_params_export(const akp_poseidon* p, uint64_t* ark, uint64_t* mds);
+
+/* ---- Poseidon batches ----------------------------------------------------------------------- */
+/* PoseidonSponge::permute (sponge/poseidon/mod.rs:98-121) on n states of t Fr each, in place. */
+int32_t akp_poseidon_permute_batch(akp_poseidon* p, uint64_t* states, size_t n);
+int32_t akp_poseidon_permute_batch_dev(akp_poseidon* p, uint64_t* d_states, size_t n, void* stream);
+/* poseidon::CRH::evaluate (crh/poseidon/mod.rs:30-40): n inputs of elems_per_input Fr -> n Fr.
+ * elems_per_input may be 0 (hash of the empty slice). */
+int32_t akp_poseidon_crh_batch(akp_poseidon* p, const uint64_t* inputs, size_t n, size_t elems_per_input,
+                               uint64_t* out);
+int32_t akp_poseidon_crh_batch_dev(akp_poseidon* p, const uint64_t* d_inputs, size_t n, size_t elems_per_input,
+                                   uint64_t* d_out, void* stream);
+/* poseidon::TwoToOneCRH::{evaluate,compress} (crh/poseidon/mod.rs:58-79): out[i] = H(left[i], right[i]). */
+int32_t akp_poseidon_two_to_one_batch(akp_poseidon* p, const uint64_t* left, const uint64_t* right, size_t n,
+                                      uint64_t* out);
+int32_t akp_poseidon_two_to_one_batch_dev(akp_poseidon* p, const uint64_t* d_left, const uint64_t* d_right, size_t n,
+                                          uint64_t* d_out, void* stream);
+
+/* ---- batched duplex sponge (CryptographicSponge / FieldBasedCryptographicSponge) ------------ */
+/* `batch` independent PoseidonSponge<Fr> instances that follow the same absorb/squeeze schedule
+ * (sponge/poseidon/mod.rs:223-257, 324-344; state machine sponge/mod.rs:195-206).  State lives
+ * on the device; the duplex mode bookkeeping is host-side and shared by the batch. */
+int32_t akp_sponge_create(akp_poseidon* p, size_t batch, akp_sponge** out);
+void akp_sponge_destroy(akp_sponge* s);
+/* absorb: elems is [batch][elems_per_instance] Fr (host).  elems_per_instance == 0 is a no-op. */
+int32_t akp_sponge_absorb(akp_sponge* s, const uint64_t* elems, size_t elems_per_instance);
+/* squeeze_native_field_elements(n): out is [batch][n] Fr (host) */
+int32_t akp_sponge_squeeze(akp_sponge* s, uint64_t* out, size_t n_per_instance);
+/* SpongeExt::{into_state,from_state} (sponge/mod.rs:184-191): state is [batch][t] Fr;
+ * mode 0 = Absorbing{index}, 1 = Squeezing{index}. */
+int32_t akp_sponge_get_state(akp_sponge* s, uint64_t* state, int32_t* mode, uint32_t* index);
+int32_t akp_sponge_set_state(akp_sponge* s, const uint64_t* state, int32_t mode, uint32_t index);
+
+/* ---- Pedersen / Bowe-Hopwood over Jubjub (ark_ed_on_bls12_381) -------------------------------- */
+#define AKP_TE_PEDERSEN 0     /* crh/pedersen/mod.rs: digest = affine point x||y (2 Fr) */
+#define AKP_TE_BOWE_HOPWOOD 1 /* crh/bowe_hopwood/mod.rs: digest = x coordinate (1 Fr) */
+/* Parameters { generators } (crh/pedersen/mod.rs:28-31, crh/bowe_hopwood/mod.rs:33-37):
+ * generators is [num_windows][window_size] affine points (x||y, Fr wire format), used verbatim
+ * (no assumption that generators[i][j] is a multiple of generators[i][0]).
+ * For AKP_TE_BOWE_HOPWOOD window_size must be <= 63 (setup bound, bowe_hopwood/mod.rs:81-101). */
+int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
+                             const uint64_t* generators_affine, akp_te_params** out);
+void akp_te_params_destroy(akp_te_params* p);
+/* pedersen::CRH::evaluate (crh/pedersen/mod.rs:76-129) / bowe_hopwood::CRH::evaluate
+ * (crh/bowe_hopwood/mod.rs:114-186): n messages of msg_len bytes each ->
+ * n digests (2 Fr for Pedersen, 1 Fr for Bowe-Hopwood). */
+int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_t n, size_t msg_len, uint64_t* out);
+int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out,
+                             void* stream);
+/* TwoToOneCRH::evaluate (crh/pedersen/mod.rs:158-182, crh/bowe_hopwood/mod.rs:202-227):
+ * left/right are n x half_len bytes; buffer = (W*N)/8 zero bytes overwritten by left||right
+ * (zip-truncated), then CRH::evaluate. */
+int32_t akp_te_two_to_one_batch(akp_te_params* p, const uint8_t* left, const uint8_t* right, size_t n,
+                                size_t half_len, uint64_t* out);
+/* TwoToOneCRH::compress (crh/pedersen/mod.rs:187-197, crh/bowe_hopwood/mod.rs:229-239): inputs are
+ * digests (wire format); they are serialised uncompressed (canonical LE) on the device first. */
+int32_t akp_te_compress_batch(akp_te_params* p, const uint64_t* left, const uint64_t* right, size_t n, uint64_t* out);
+
+/* ---- Merkle tree ---------------------------------------------------------------------------- */
+/* MerkleTree::new (merkle_tree/mod.rs:411-523) with Poseidon leaf CRH + Poseidon TwoToOneCRH and
+ * IdentityDigestConverter (config shape merkle_tree/tests/mod.rs:198-206).
+ * leaves: n_leaves x leaf_len Fr.  leaf_nodes: n_leaves Fr.  non_leaf_nodes: n_leaves-1 Fr in the
+ * reference's heap order (root at 0; level l occupies [2^l - 1, 2^(l+1) - 1)).
+ * Either output may be NULL in the host variant (skips that copy); root_out (1 Fr) may be NULL. */
+int32_t akp_merkle_build_poseidon(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* leaves,
+                                  size_t n_leaves, size_t leaf_len, uint64_t* leaf_nodes, uint64_t* non_leaf_nodes,
+                                  uint64_t* root_out);
+int32_t akp_merkle_build_poseidon_dev(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params,
+                                      const uint64_t* d_leaves, size_t n_leaves, size_t leaf_len, uint64_t* d_leaf_nodes,
+                                      uint64_t* d_non_leaf_nodes, void* stream);
+/* MerkleTree::new_with_leaf_digest (merkle_tree/mod.rs:424-523): inner levels only. */
+int32_t akp_merkle_inner_poseidon_dev(akp_poseidon* two_to_one_params, const uint64_t* d_leaf_nodes, size_t n_leaves,
+                                      uint64_t* d_non_leaf_nodes, void* stream);
+/* MerkleTree::new over byte leaves with Pedersen or Bowe-Hopwood hashes and ByteDigestConverter
+ * (merkle_tree/mod.rs:67-78; config shape merkle_tree/tests/mod.rs:13-33).  Both parameter sets
+ * must have the same kind.  Digest = 2 Fr (Pedersen) / 1 Fr (Bowe-Hopwood) per node. */
+int32_t akp_merkle_build_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* leaves,
+                            size_t n_leaves, size_t leaf_len, uint64_t* leaf_nodes, uint64_t* non_leaf_nodes,
+                            uint64_t* root_out);
+int32_t akp_merkle_build_te_dev(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* d_leaves,
+                                size_t n_leaves, size_t leaf_len, uint64_t* d_leaf_nodes, uint64_t* d_non_leaf_nodes,
+                                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKP_H */

@@ -1,0 +1,120 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/akp.h declares,
+host-side parameter generation reproduces the reference KATs, and compute calls fail loudly
+(no CPU fallback) when no device context exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "akp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(akp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import crypto_primitives_amd as cpa
+    L = C.CDLL(cpa.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/akp.h but not exported"
+    # and the python binding declares prototypes for exactly that set
+    assert sorted(cpa._lib.DECLARED_SYMBOLS) == syms
+    assert cpa.lib.akp_abi_version() == 1
+
+
+def test_product_never_imports_oracle():
+    """the product package must not reference oracle/ (a CPU fallback would void parity claims)"""
+    pkg = os.path.join(ROOT, "crypto_primitives_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+                assert not re.search(r"#\s*include\s*[\"<][^\">]*oracle", txt), f
+                assert "akp_oracle" not in txt and "libakp_oracle" not in txt, f
+
+
+def test_default_parameters_match_reference_kats(kats):
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import field
+    for e in kats["default_params"]:
+        c = cpa.get_default_poseidon_parameters(e["rate"], e["optimized_for_weights"])
+        assert field.to_ints(c.ark[0][0])[0] == int(e["ark00"])
+        assert field.to_ints(c.mds[0][0])[0] == int(e["mds00"])
+    assert cpa.get_default_poseidon_parameters(9) is None  # reference returns None
+    assert cpa.get_default_poseidon_parameters(1) is None
+
+
+def test_default_parameters_equal_oracle_everywhere():
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import field
+    from oracle import poseidon as po
+    for rate, w in ((2, False), (4, False), (8, True)):
+        c = cpa.get_default_poseidon_parameters(rate, w)
+        o = po.get_default_poseidon_parameters(rate, w)
+        assert (c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity) == (o.full_rounds, o.partial_rounds, o.alpha, o.rate, o.capacity)
+        assert field.to_ints(c.ark.reshape(-1, 4)) == [x for r in o.ark for x in r]
+        assert field.to_ints(c.mds.reshape(-1, 4)) == [x for r in o.mds for x in r]
+
+
+def test_field_conversion_roundtrip():
+    from crypto_primitives_amd import field
+    from oracle import fr as ofr
+    vals = [0, 1, 2, field.MODULUS - 1, 12345678901234567890123456789]
+    m = field.fr(vals)
+    assert np.array_equal(m, ofr.ints_to_mont_array(vals))
+    assert field.to_ints(m) == vals
+    import crypto_primitives_amd as cpa
+    bad = field.ints_to_canonical([0])
+    bad[0] = [0xFFFFFFFFFFFFFFFF] * 4  # >= p
+    out = np.empty_like(bad)
+    assert cpa.lib.akp_fr_to_mont(bad.ctypes.data, out.ctypes.data, 1) == 2  # AKP_ERR_BAD_PARAMS
+
+
+def test_params_validation_without_device():
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import field
+    h = C.c_void_p()
+    ark = field.fr(range(3 * 4)); mds = field.fr(range(9))
+    # odd full_rounds, t too large, alpha 0
+    assert cpa.lib.akp_poseidon_params_create(None, 3, 1, 5, 2, 1, ark.ctypes.data, mds.ctypes.data, C.byref(h)) == 2
+    assert cpa.lib.akp_poseidon_params_create(None, 2, 2, 0, 2, 1, ark.ctypes.data, mds.ctypes.data, C.byref(h)) == 2
+    assert cpa.lib.akp_poseidon_params_create(None, 2, 2, 5, 30, 1, ark.ctypes.data, mds.ctypes.data, C.byref(h)) == 2
+    assert cpa.lib.akp_poseidon_params_create(None, 2, 2, 5, 2, 1, ark.ctypes.data, mds.ctypes.data, C.byref(h)) == 0
+    # host-only handle: compute must fail loudly, never fall back to the CPU
+    st = field.fr([0, 1, 2])
+    assert cpa.lib.akp_poseidon_permute_batch(h, st.ctypes.data, 1) == 3  # AKP_ERR_HIP
+    assert b"no CPU fallback" in cpa.lib.akp_last_error()
+    cpa.lib.akp_poseidon_params_destroy(h)
+
+
+def test_no_device_means_loud_failure():
+    import crypto_primitives_amd as cpa
+    if cpa.lib.akp_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(cpa.AkpError):
+        cpa.Context(0)
+    cfg = cpa.get_default_poseidon_parameters(2)
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    from crypto_primitives_amd import field
+    with pytest.raises(cpa.AkpError):
+        pcrh.CRH.evaluate(cfg, field.fr([1, 2]))
+
+
+def test_seeded_generators_equal_oracle(derived):
+    from crypto_primitives_amd import params, field
+    from oracle import jubjub as jj
+    g = params.pedersen_generators(0xA5A50004, 4, 2)
+    go = jj.pedersen_generators(0xA5A50004, 4, 2)
+    assert field.to_ints(g) == [v for row in go for pt in row for v in pt]
+    assert [str(v) for v in field.to_ints(g[0][0])] == derived["pedersen_4x256"]["g00"]
+    gb = params.bowe_hopwood_generators(0xA5A50005, 3, 2)
+    gbo = jj.bowe_hopwood_generators(0xA5A50005, 3, 2)
+    assert field.to_ints(gb) == [v for row in gbo for pt in row for v in pt]

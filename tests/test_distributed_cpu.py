@@ -1,0 +1,82 @@
+"""N > 1 control flow of the sharded tree build on CPU: two processes, gloo backend, the hashing backend
+replaced by a test double over the oracle (the product backend needs a GPU).  Checks partition, the single
+all-gather of sub-roots, the redundant top-level combine and the mapping of local heap slices onto the
+reference's global heap layout."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from crypto_primitives_amd.distributed import build_sharded, shard_range, global_node_slices
+from oracle import poseidon as po
+from helpers import cref_poseidon, rand_fr_array
+
+class OracleBackend:  # test double: same interface as GpuPoseidonBackend, CPU hashing via the oracle
+    def __init__(self): self.ora = cref_poseidon(po.get_default_poseidon_parameters(2, False))
+    def comm_device(self): return torch.device("cpu")
+    def build_subtree(self, leaves):
+        ln, nl = self.ora.merkle_build(self.ora, leaves, 1)
+        return ln, nl, nl[0].copy()
+    def two_to_one_compress(self, l, r): return self.ora.two_to_one_batch(np.ascontiguousarray(l), np.ascontiguousarray(r))
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 64
+leaves = rand_fr_array(n, 1234).reshape(n, 1, 4)
+lo, hi = shard_range(n, rank, world)
+b = OracleBackend()
+res = build_sharded(b, leaves[lo:hi], n, dist)
+# full tree on every rank for comparison
+ln, nl = b.ora.merkle_build(b.ora, leaves, 1)
+assert np.array_equal(res["root"], nl[0]), "root mismatch"
+assert np.array_equal(res["top_nodes"], nl[: world - 1]), "top nodes mismatch"
+for (lvl, gstart, cnt, lstart) in global_node_slices(n, rank, world):
+    assert np.array_equal(res["non_leaf_nodes"][lstart:lstart + cnt], nl[gstart:gstart + cnt]), ("slice", lvl)
+assert np.array_equal(res["leaf_nodes"], ln[lo:hi])
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_world(world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+
+
+def test_sharded_tree_world2_gloo():
+    _run_world(2)
+
+
+def test_sharded_tree_world4_gloo():
+    _run_world(4)
+
+
+def test_partition_helpers():
+    from crypto_primitives_amd.distributed import shard_range, global_node_slices, combine_top
+    assert shard_range(16, 1, 4) == (4, 8)
+    # n = 16, G = 4: rank 1 owns global level 2 node 3+1, level 3 nodes 7+2..7+4
+    assert global_node_slices(16, 1, 4) == [(2, 4, 1, 0), (3, 9, 2, 1)]
+    top = combine_top(lambda l, r: l + r, np.arange(1, 9, dtype=np.int64).reshape(8, 1))
+    assert top.reshape(-1).tolist() == [36, 10, 26, 3, 7, 11, 15]
+    import pytest
+    with pytest.raises(AssertionError):
+        shard_range(16, 0, 3)

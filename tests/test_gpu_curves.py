@@ -1,0 +1,166 @@
+"""GPU parity: Pedersen / Bowe-Hopwood CRH over Jubjub through the C ABI vs the oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import jubjub as jj, pedersen as opd, bowe_hopwood as obh, fr as ofr, cref  # noqa: E402
+from helpers import ints, gens_array  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import crypto_primitives_amd as m
+    assert m.lib.akp_device_count() >= 1
+    return m
+
+
+@pytest.fixture(scope="module")
+def ped(cpa):
+    from crypto_primitives_amd.crh import pedersen
+    g = jj.pedersen_generators(0xA5A50004, 4, 256)
+    return pedersen.Parameters(gens_array(g)), g, cref.CurveParams(4, 256, gens_array(g))
+
+
+@pytest.fixture(scope="module")
+def bhp(cpa):
+    from crypto_primitives_amd.crh import bowe_hopwood
+    g = jj.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    return bowe_hopwood.Parameters(gens_array(g)), g, cref.CurveParams(63, 9, gens_array(g))
+
+
+def _msgs(n, L, seed):
+    return np.frombuffer(ofr.SplitMix64(seed).bytes(max(n * L, 1)), dtype=np.uint8)[: n * L].reshape(n, L).copy()
+
+
+def test_pedersen_golden_and_known_answers(cpa, ped, derived):
+    from crypto_primitives_amd.crh import pedersen
+    from crypto_primitives_amd import field
+    P, g, _ = ped
+    d = derived["pedersen_4x256"]
+    msg = bytes.fromhex(d["msg"])
+    assert [str(v) for v in field.to_ints(pedersen.CRH.evaluate(P, msg))] == d["digest"]
+    assert [str(v) for v in field.to_ints(pedersen.CRH.evaluate(P, msg[:32]))] == d["digest_first32"]
+    ident = field.to_ints(pedersen.CRH.evaluate(P, b""))
+    assert ident == [0, 1] == field.to_ints(pedersen.CRH.evaluate(P, bytes(128)))  # identity (pedersen/mod.rs:116-122)
+    h, h32 = pedersen.CRH.evaluate(P, msg), pedersen.CRH.evaluate(P, msg[:32])
+    assert [str(v) for v in field.to_ints(pedersen.TwoToOneCRH.compress(P, h, h32))] == d["compress_h_h32"]
+    assert np.array_equal(pedersen.TwoToOneCRH.evaluate(P, msg[:64], msg[64:]), h)
+    with pytest.raises(cpa.IncorrectInputLength):  # reference panics (pedersen/mod.rs:82-89)
+        pedersen.CRH.evaluate(P, bytes(129))
+
+    class W4x256(pedersen.Window):
+        WINDOW_SIZE, NUM_WINDOWS = 4, 256
+
+    class W4x128(pedersen.Window):
+        WINDOW_SIZE, NUM_WINDOWS = 4, 128
+    pedersen.CRH.evaluate(P, msg, window=W4x256)
+    with pytest.raises(AssertionError):
+        pedersen.CRH.evaluate(P, msg[:8], window=W4x128)
+
+
+@pytest.mark.parametrize("L", [128, 32, 1, 77])
+def test_pedersen_batch_vs_oracle(cpa, ped, L):
+    from crypto_primitives_amd.crh import pedersen
+    P, g, C = ped
+    n = 2051
+    m = _msgs(n, L, 0xA5A50004 + L)
+    got = pedersen.CRH.evaluate_batch(P, m)
+    exp = C.pedersen_crh_batch(m, n, L, threads=8)
+    assert np.array_equal(got, exp)
+    # python big-int oracle on a few
+    for i in (0, n - 1):
+        assert tuple(ints(got[i])) == opd.evaluate(g, 4, 256, bytes(m[i]))
+
+
+def test_pedersen_other_windows(cpa):
+    from crypto_primitives_amd.crh import pedersen
+    for W, N in ((8, 20), (6, 10), (3, 7), (1, 16)):
+        g = jj.pedersen_generators(31 + W, W, N)
+        P = pedersen.Parameters(gens_array(g))
+        for L in {W * N // 8, 1, 0}:
+            m = _msgs(5, L, W * 100 + L)
+            got = pedersen.CRH.evaluate_batch(P, m if L else [b""] * 5)
+            for i in range(5):
+                assert tuple(ints(got[i])) == opd.evaluate(g, W, N, bytes(m[i]) if L else b""), (W, N, L)
+
+
+def test_bowe_hopwood_golden_and_known_answers(cpa, bhp, derived):
+    from crypto_primitives_amd.crh import bowe_hopwood
+    from crypto_primitives_amd import field
+    P, g, _ = bhp
+    d = derived["bowe_hopwood_63x9"]
+    x32 = bowe_hopwood.CRH.evaluate(P, bytes.fromhex(d["msg32"]))
+    x70 = bowe_hopwood.CRH.evaluate(P, bytes.fromhex(d["msg70"]))
+    assert str(field.to_ints(x32)[0]) == d["digest32"] and str(field.to_ints(x70)[0]) == d["digest70"]
+    assert str(field.to_ints(bowe_hopwood.TwoToOneCRH.compress(P, x32, x70))[0]) == d["compress"]
+    assert str(field.to_ints(bowe_hopwood.CRH.evaluate(P, bytes(3)))[0]) == d["zero_3bytes"]
+    assert field.to_ints(bowe_hopwood.CRH.evaluate(P, b""))[0] == 0            # identity -> x = 0
+    with pytest.raises(cpa.IncorrectInputLength):                               # 213 B > 63*9*3 bits
+        bowe_hopwood.CRH.evaluate(P, bytes(213))
+    # test_simple_bh (crh/bowe_hopwood/mod.rs:258-271): 63x8 window, input [1,2,3]
+    g8 = jj.bowe_hopwood_generators(3, 63, 8)
+    P8 = bowe_hopwood.Parameters(gens_array(g8))
+    assert field.to_ints(bowe_hopwood.CRH.evaluate(P8, bytes([1, 2, 3])))[0] == obh.evaluate(g8, 63, 8, bytes([1, 2, 3]))
+
+    class Big(bowe_hopwood._ped.Window):
+        WINDOW_SIZE, NUM_WINDOWS = 64, 2
+    with pytest.raises(ValueError):
+        bowe_hopwood.CRH.setup(Big)
+
+
+@pytest.mark.parametrize("L", [32, 70, 3, 212])
+def test_bowe_hopwood_batch_vs_oracle(cpa, bhp, L):
+    from crypto_primitives_amd.crh import bowe_hopwood
+    P, g, C = bhp
+    n = 1500
+    m = _msgs(n, L, 0xA5A50005 + L)
+    got = bowe_hopwood.CRH.evaluate_batch(P, m)
+    assert np.array_equal(got, C.bh_crh_batch(m, n, L, threads=8))
+    assert ints(got[7])[0] == obh.evaluate(g, 63, 9, bytes(m[7]))
+
+
+def test_two_to_one_batches(cpa, ped, bhp):
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    P, g, _ = ped
+    l, r = _msgs(9, 64, 1), _msgs(9, 64, 2)
+    got = pedersen.TwoToOneCRH.evaluate_batch(P, l, r)
+    for i in range(9):
+        assert tuple(ints(got[i])) == opd.two_to_one_evaluate(g, 4, 256, bytes(l[i]), bytes(r[i]))
+    l, r = _msgs(9, 20, 3), _msgs(9, 20, 4)  # shorter halves: zero tail
+    got = pedersen.TwoToOneCRH.evaluate_batch(P, l, r)
+    for i in range(9):
+        assert tuple(ints(got[i])) == opd.two_to_one_evaluate(g, 4, 256, bytes(l[i]), bytes(r[i]))
+    B, gb, _ = bhp
+    l, r = _msgs(9, 32, 5), _msgs(9, 32, 6)
+    got = bowe_hopwood.TwoToOneCRH.evaluate_batch(B, l, r)
+    for i in range(9):
+        assert ints(got[i])[0] == obh.two_to_one_evaluate(gb, 63, 9, bytes(l[i]), bytes(r[i]))
+    l, r = _msgs(4, 40, 7), _msgs(4, 40, 8)  # 80 bytes > 70-byte buffer: zip truncation (:219-224)
+    got = bowe_hopwood.TwoToOneCRH.evaluate_batch(B, l, r)
+    for i in range(4):
+        assert ints(got[i])[0] == obh.two_to_one_evaluate(gb, 63, 9, bytes(l[i]), bytes(r[i]))
+
+
+def test_digests_on_curve_and_in_subgroup(cpa, ped):
+    from crypto_primitives_amd.crh import pedersen
+    P, g, _ = ped
+    got = pedersen.CRH.evaluate_batch(P, _msgs(4, 128, 99))
+    for i in range(4):
+        pt = tuple(ints(got[i]))
+        assert jj.is_on_curve(pt) and jj.mul(pt, jj.SUBGROUP_ORDER) == jj.IDENTITY
+
+
+def test_setup_generators(cpa):
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    from crypto_primitives_amd import field
+
+    class W(pedersen.Window):
+        WINDOW_SIZE, NUM_WINDOWS = 4, 8
+    P = pedersen.CRH.setup(W, seed=5)
+    go = jj.pedersen_generators(5, 4, 8)
+    assert field.to_ints(P.generators) == [v for row in go for pt in row for v in pt]
+    assert tuple(field.to_ints(pedersen.CRH.evaluate(P, bytes([0xff, 1, 2, 3])))) == opd.evaluate(go, 4, 8, bytes([0xff, 1, 2, 3]))
+    B = bowe_hopwood.CRH.setup(W, seed=6)
+    gb = jj.bowe_hopwood_generators(6, 4, 8)
+    assert field.to_ints(bowe_hopwood.CRH.evaluate(B, bytes(range(12))))[0] == obh.evaluate(gb, 4, 8, bytes(range(12)))

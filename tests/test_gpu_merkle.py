@@ -1,0 +1,158 @@
+"""GPU parity: MerkleTree::new / proofs / update for the three tree configurations vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import jubjub as jj, pedersen as opd, bowe_hopwood as obh, poseidon as po, merkle as omk, fr as ofr, cref  # noqa: E402
+from helpers import ints, mont, rand_fr_array, gens_array, cref_poseidon  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import crypto_primitives_amd as m
+    assert m.lib.akp_device_count() >= 1
+    return m
+
+
+def test_poseidon_tree_golden(cpa, derived):
+    from crypto_primitives_amd import field
+    c = cpa.get_default_poseidon_parameters(2, False)
+    d = derived["poseidon_merkle_8"]
+    leaves = field.fr(range(1, 9)).reshape(8, 1, 4)
+    t = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
+    assert [str(x) for x in field.to_ints(t.non_leaf_nodes)] == d["non_leaf"]
+    assert [str(x) for x in field.to_ints(t.leaf_nodes)] == d["leaf_nodes"]
+    assert str(field.to_ints(t.root())[0]) == d["root"] and t.height() == 4
+
+
+@pytest.mark.parametrize("log2n,leaf_len", [(1, 1), (2, 3), (7, 3), (12, 1), (16, 1)])
+def test_poseidon_tree_vs_oracle(cpa, log2n, leaf_len):
+    c = cpa.get_default_poseidon_parameters(2, False)
+    ora = cref_poseidon(po.get_default_poseidon_parameters(2, False))
+    n = 1 << log2n
+    leaves = rand_fr_array(n * leaf_len, 0xA5A50003 + log2n).reshape(n, leaf_len, 4)
+    t = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
+    ln, nl = ora.merkle_build(ora, leaves, leaf_len, threads=8)
+    assert np.array_equal(t.leaf_nodes, ln) and np.array_equal(t.non_leaf_nodes, nl)
+    assert t.height() == log2n + 1
+
+
+def test_poseidon_tree_distinct_leaf_and_inner_params(cpa):
+    """leaf hash with rate-3 parameters, inner hash with rate-2 (Config allows different parameter sets)"""
+    cl, ci = cpa.get_default_poseidon_parameters(3, False), cpa.get_default_poseidon_parameters(2, False)
+    ol, oi = cref_poseidon(po.get_default_poseidon_parameters(3, False)), cref_poseidon(po.get_default_poseidon_parameters(2, False))
+    leaves = rand_fr_array(64 * 4, 5).reshape(64, 4, 4)
+    t = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, cl, ci, leaves)
+    ln, nl = ol.merkle_build(oi, leaves, 4, threads=4)
+    assert np.array_equal(t.non_leaf_nodes, nl)
+
+
+def test_not_power_of_two_rejected(cpa):
+    c = cpa.get_default_poseidon_parameters(2, False)
+    for n in (0, 1, 3, 12):
+        with pytest.raises(cpa.NotPowerOfTwo):  # merkle_tree/mod.rs:430-433 asserts
+            cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, rand_fr_array(max(n, 1), 1).reshape(-1, 1, 4)[:n])
+    import ctypes as C
+    buf = rand_fr_array(3, 1)
+    out = np.empty((3, 4), np.uint64)
+    assert cpa.lib.akp_merkle_build_poseidon(c.handle().h, c.handle().h, buf.ctypes.data, 3, 1, out.ctypes.data, out.ctypes.data, None) == 5
+
+
+def test_field_tree_proofs_and_update(cpa):
+    """merkle_tree/tests/mod.rs:208-309 (field_mt_tests::good_root_test shape: 128 leaves of 3 elements)."""
+    c = cpa.get_default_poseidon_parameters(2, False)
+    n = 128
+    leaves = rand_fr_array(n * 3, 42).reshape(n, 3, 4)
+    tree = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
+    root = tree.root()
+    paths = [tree.generate_proof(i) for i in range(n)]
+    assert all(cpa.merkle_tree.verify_paths(cpa.PoseidonFieldConfig, c, c, root, paths, leaves))
+    assert paths[5].verify(c, c, root, leaves[5])
+    wrong = root.copy(); wrong[0] ^= np.uint64(1)
+    assert not paths[0].verify(c, c, wrong, leaves[0])
+    assert not paths[0].verify(c, c, root, leaves[1])
+    mp = tree.generate_multi_proof(range(n))
+    assert mp.verify(c, c, root, leaves) and not mp.verify(c, c, wrong, leaves)
+    mp8 = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves[:8]).generate_multi_proof(range(8))
+    assert mp8.auth_paths_prefix_lenghts == [0, 2, 1, 2, 0, 2, 1, 2]  # merkle_tree/tests/mod.rs:166
+    new = rand_fr_array(5 * 3, 43).reshape(5, 3, 4)
+    for (i, v) in zip((2, 3, 5, 111, 127), new):
+        tree.update(i, v); leaves[i] = v
+    rebuilt = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
+    assert np.array_equal(tree.non_leaf_nodes, rebuilt.non_leaf_nodes) and np.array_equal(tree.leaf_nodes, rebuilt.leaf_nodes)
+    root = tree.root()
+    assert all(tree.generate_proof(i).verify(c, c, root, leaves[i]) for i in (0, 2, 3, 111, 127))
+    assert not tree.check_update(0, leaves[1], wrong)
+    assert tree.check_update(0, leaves[1], cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, np.concatenate([leaves[1:2], leaves[1:]])).root())
+
+
+def _byte_leaves(n, L, seed):
+    return np.frombuffer(ofr.SplitMix64(seed).bytes(n * L), dtype=np.uint8).reshape(n, L).copy()
+
+
+def test_bowe_hopwood_tree(cpa, derived):
+    from crypto_primitives_amd.crh import bowe_hopwood
+    from crypto_primitives_amd import field
+    g = jj.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    P = bowe_hopwood.Parameters(gens_array(g))
+    C = cref.CurveParams(63, 9, gens_array(g))
+    d = derived["bowe_hopwood_merkle_4"]
+    leaves = [bytes.fromhex(x) for x in d["leaves"]]
+    t = cpa.MerkleTree.new(cpa.BoweHopwoodByteConfig, P, P, leaves)
+    assert str(field.to_ints(t.root())[0]) == d["root"]
+    n = 512
+    lv = _byte_leaves(n, 32, 0xA5A50005)
+    t = cpa.MerkleTree.new(cpa.BoweHopwoodByteConfig, P, P, lv)
+    ln, nl = C.merkle_build(1, C, lv, n, 32, threads=8)
+    assert np.array_equal(t.leaf_nodes, ln.reshape(n, 4)) and np.array_equal(t.non_leaf_nodes, nl.reshape(n - 1, 4))
+    root = t.root()
+    for i in (0, 1, 255, 511):
+        assert t.generate_proof(i).verify(P, P, root, bytes(lv[i]))
+    assert not t.generate_proof(3).verify(P, P, root, bytes(lv[4]))
+    t.update(9, bytes(lv[10])); lv[9] = lv[10]
+    assert np.array_equal(t.non_leaf_nodes, cpa.MerkleTree.new(cpa.BoweHopwoodByteConfig, P, P, lv).non_leaf_nodes)
+
+
+def test_pedersen_tree(cpa, derived):
+    """bytes_mt_tests (merkle_tree/tests/mod.rs:5-131): Window4x256 on Jubjub, ByteDigestConverter."""
+    from crypto_primitives_amd.crh import pedersen
+    from crypto_primitives_amd import field
+    g = jj.pedersen_generators(0xA5A50004, 4, 256)
+    P = pedersen.Parameters(gens_array(g))
+    C = cref.CurveParams(4, 256, gens_array(g))
+    d = derived["pedersen_merkle_4"]
+    t = cpa.MerkleTree.new(cpa.PedersenByteConfig, P, P, [bytes.fromhex(x) for x in d["leaves"]])
+    assert [str(v) for v in field.to_ints(t.root())] == d["root"]
+    for n in (2, 4, 128):
+        lv = _byte_leaves(n, 32, 1000 + n)
+        t = cpa.MerkleTree.new(cpa.PedersenByteConfig, P, P, lv)
+        ln, nl = C.merkle_build(0, C, lv, n, 32, threads=8)
+        assert np.array_equal(t.leaf_nodes, ln) and np.array_equal(t.non_leaf_nodes, nl)
+        root = t.root()
+        assert all(t.generate_proof(i).verify(P, P, root, bytes(lv[i])) for i in range(0, n, max(1, n // 8)))
+        if n >= 4:
+            mp = t.generate_multi_proof(range(n))
+            assert mp.verify(P, P, root, [bytes(x) for x in lv])
+
+
+def test_poseidon_tree_2pow20_sampled(cpa):
+    """large tree: root + sampled nodes vs the oracle path recomputation; heap-layout property:
+    every sampled inner node equals compress(children)."""
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    c = cpa.get_default_poseidon_parameters(2, False)
+    ora = cref_poseidon(po.get_default_poseidon_parameters(2, False))
+    n = 1 << 20
+    leaves = rand_fr_array(n, 0xA5A50003).reshape(n, 1, 4)
+    t = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
+    idx = np.unique(np.concatenate([np.arange(0, 4096), np.random.default_rng(1).integers(0, n // 2 - 1, 4096)]))
+    l = np.where(2 * idx + 1 < n - 1, 0, 0)
+    left_is_inner = (2 * idx + 1) < (n - 1)
+    li = idx[left_is_inner]
+    exp = ora.two_to_one_batch(t.non_leaf_nodes[2 * li + 1], t.non_leaf_nodes[2 * li + 2], threads=8)
+    assert np.array_equal(t.non_leaf_nodes[li], exp)
+    bottom = np.arange(n // 2 - 1, n // 2 - 1 + 2048)
+    exp = ora.two_to_one_batch(t.leaf_nodes[2 * (bottom - (n // 2 - 1))], t.leaf_nodes[2 * (bottom - (n // 2 - 1)) + 1], threads=8)
+    assert np.array_equal(t.non_leaf_nodes[bottom], exp)
+    assert np.array_equal(t.leaf_nodes[:2048], ora.crh_batch(leaves[:2048], 1, threads=8))
+    assert t.generate_proof(123457).verify(c, c, t.root(), leaves[123457])

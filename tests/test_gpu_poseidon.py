@@ -1,0 +1,184 @@
+"""GPU parity: Poseidon permutation / CRH / two-to-one / duplex sponge through the C ABI vs the oracle.
+Bit-exact (integer arithmetic)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import poseidon as po, fr as ofr  # noqa: E402
+from helpers import mont, ints, rand_fr, rand_fr_array, cref_poseidon  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import crypto_primitives_amd as m
+    assert m.lib.akp_device_count() >= 1, "no HIP device: the product has no CPU path"
+    return m
+
+
+def _cfg_pair(cpa, rate, weights=False):
+    c = cpa.get_default_poseidon_parameters(rate, weights)
+    o = po.get_default_poseidon_parameters(rate, weights)
+    return c, o, cref_poseidon(o)
+
+
+def _permute(cpa, cfg, states):
+    st = np.ascontiguousarray(states, dtype=np.uint64).copy()
+    n = st.size // (4 * cfg.t)
+    cpa._lib.check(cpa.lib.akp_poseidon_permute_batch(cfg.handle().h, st.ctypes.data, n))
+    return st
+
+
+def test_permute_kat_vectors(cpa, derived):
+    c, o, _ = _cfg_pair(cpa, 2)
+    got = _permute(cpa, c, mont([0, 1, 2]))
+    assert [str(x) for x in ints(got)] == derived["poseidon_rate2"]["permute_0_1_2"]
+
+
+@pytest.mark.parametrize("log2n", [0, 6, 8, 14])
+def test_permute_batch_rate2_vs_oracle(cpa, log2n):
+    c, o, ora = _cfg_pair(cpa, 2)
+    n = 1 << log2n
+    n += 3 if log2n == 8 else 0  # ragged: not a multiple of the block size
+    st = rand_fr_array(n * 3, 0xA5A50002 + log2n).reshape(n, 3, 4)
+    got = _permute(cpa, c, st)
+    exp = ora.permute_batch(st, threads=8).reshape(n, 3, 4)
+    assert np.array_equal(got, exp)
+
+
+def test_permute_edge_values(cpa):
+    c, o, ora = _cfg_pair(cpa, 2)
+    P = ofr.P
+    vals = [0, 0, 0, P - 1, P - 1, P - 1, 1, P - 1, 0, 2 ** 254, 2 ** 128 - 1, 2 ** 64]
+    st = mont(vals).reshape(-1, 3, 4)
+    assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st).reshape(-1, 3, 4))
+    assert ints(_permute(cpa, c, st[:1])) == po.permute(o, vals[:3])
+    # empty batch is a no-op
+    assert cpa.lib.akp_poseidon_permute_batch(c.handle().h, None, 0) == 0
+
+
+@pytest.mark.parametrize("rate,weights", [(3, False), (4, False), (5, False), (6, False), (7, False), (8, False),
+                                          (2, True), (4, True), (8, True)])
+def test_permute_all_default_configs(cpa, rate, weights):
+    c, o, ora = _cfg_pair(cpa, rate, weights)
+    n, t = 257, rate + 1
+    st = rand_fr_array(n * t, 77 + rate).reshape(n, t, 4)
+    assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st, threads=8).reshape(n, t, 4))
+
+
+def test_full_size_batch_sampled_parity(cpa):
+    """BASELINE configs[1] size (2^20 states): compare a strided sample of 4096 states with the oracle and
+    check the size-independent property that permuting a batch equals permuting its two halves."""
+    c, o, ora = _cfg_pair(cpa, 2)
+    n = 1 << 20
+    st = rand_fr_array(n * 3, 0xA5A50002).reshape(n, 3, 4)
+    got = _permute(cpa, c, st)
+    idx = np.arange(0, n, n // 4096)
+    assert np.array_equal(got[idx], ora.permute_batch(st[idx], threads=8).reshape(-1, 3, 4))
+    halves = np.concatenate([_permute(cpa, c, st[: n // 2]), _permute(cpa, c, st[n // 2:])])
+    assert np.array_equal(got, halves)
+    assert np.array_equal(got[-1], ora.permute_batch(st[-1:]).reshape(3, 4))
+
+
+def test_crh_lengths_and_golden(cpa, derived):
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    from crypto_primitives_amd import field
+    c, o, ora = _cfg_pair(cpa, 2)
+    d = derived["poseidon_rate2"]
+    assert str(field.to_ints(pcrh.CRH.evaluate(c, field.fr([1])))[0]) == d["crh_1"]
+    assert str(field.to_ints(pcrh.CRH.evaluate(c, field.fr([1, 2])))[0]) == d["crh_1_2"]
+    assert str(field.to_ints(pcrh.CRH.evaluate(c, field.fr([1, 2, 3])))[0]) == d["crh_1_2_3"]
+    assert str(field.to_ints(pcrh.CRH.evaluate(c, np.zeros((0, 4), np.uint64)))[0]) == d["crh_empty"]
+    assert str(field.to_ints(pcrh.TwoToOneCRH.compress(c, field.fr([1]), field.fr([2])))[0]) == d["compress_1_2"]
+    assert np.array_equal(pcrh.TwoToOneCRH.evaluate(c, field.fr([1]), field.fr([2])), pcrh.TwoToOneCRH.compress(c, field.fr([1]), field.fr([2])))
+    for k in (1, 2, 3, 4, 7):
+        n = 1000 + k
+        x = rand_fr_array(n * k, 500 + k).reshape(n, k, 4)
+        assert np.array_equal(pcrh.CRH.evaluate_batch(c, x), ora.crh_batch(x, k, threads=8)), k
+    with pytest.raises(NotImplementedError):
+        pcrh.CRH.setup()
+
+
+def test_crh_config1_2pow16(cpa):
+    """BASELINE configs[0]: Poseidon sponge CRH over 2^16 inputs (2 Fr each)."""
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    c, o, ora = _cfg_pair(cpa, 2)
+    n = 1 << 16
+    x = rand_fr_array(n * 2, 0xA5A50001).reshape(n, 2, 4)
+    got = pcrh.CRH.evaluate_batch(c, x)
+    assert np.array_equal(got, ora.crh_batch(x, 2, threads=8))
+    # compress(l, r) == CRH([l, r]) (crh/poseidon/constraints.rs:84-92 relies on it)
+    assert np.array_equal(pcrh.TwoToOneCRH.compress_batch(c, x[:, 0], x[:, 1]), got)
+
+
+@pytest.mark.parametrize("rate", [3, 5, 8])
+def test_crh_other_rates(cpa, rate):
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    c, o, ora = _cfg_pair(cpa, rate)
+    for k in (0, 1, rate - 1, rate, rate + 1, 2 * rate + 3):
+        n = 130
+        x = rand_fr_array(n * max(k, 1), 900 + k).reshape(n, max(k, 1), 4)[:, :k]
+        got = pcrh.CRH.evaluate_batch(c, np.ascontiguousarray(x))
+        if k == 0:
+            assert np.array_equal(got, np.repeat(ora.crh_empty(), n, axis=0))
+        else:
+            assert np.array_equal(got, ora.crh_batch(np.ascontiguousarray(x), k, threads=4)), (rate, k)
+    l, r = rand_fr_array(64, 1), rand_fr_array(64, 2)
+    assert np.array_equal(pcrh.TwoToOneCRH.compress_batch(c, l, r), ora.two_to_one_batch(l, r))
+
+
+def test_sponge_consistency_kat_on_gpu(cpa, kats):  # sponge/poseidon/mod.rs:381-404
+    from crypto_primitives_amd import field
+    k = kats["sponge_consistency"]
+    c = cpa.get_default_poseidon_parameters(2, False)
+    sp = cpa.PoseidonSponge(c)
+    sp.absorb(field.fr([int(x) for x in k["absorb"]]))
+    assert [str(x) for x in field.to_ints(sp.squeeze_native_field_elements(3))] == k["squeeze"]
+
+
+def test_sponge_cross_fuzz(cpa):
+    """model-based fuzz of the duplex state machine (sponge/poseidon/tests.rs:68-240), batch of 3 sponges."""
+    from crypto_primitives_amd import field
+    r = random.Random(11)
+    for rate in (2, 3):
+        c = cpa.get_default_poseidon_parameters(rate, False)
+        o = po.get_default_poseidon_parameters(rate, False)
+        for trial in range(6):
+            B = 3
+            sp = cpa.PoseidonSponge(c, batch=B)
+            models = [po.PoseidonSponge(o) for _ in range(B)]
+            for _ in range(r.randint(2, 9)):
+                k = r.randint(0, 6)
+                if r.random() < 0.5:
+                    el = [rand_fr(k, r.randint(0, 1 << 30)) for _ in range(B)]
+                    for m, e in zip(models, el):
+                        m.absorb(e)
+                    sp.absorb(field.fr([x for e in el for x in e]).reshape(B, k, 4))
+                else:
+                    exp = [m.squeeze_native_field_elements(k) for m in models]
+                    got = sp.squeeze_native_field_elements(k).reshape(B, k, 4)
+                    assert [field.to_ints(got[b]) for b in range(B)] == exp
+            st, mode, idx = sp.into_state()
+            for b, m in enumerate(models):
+                assert field.to_ints(st[b]) == m.state
+            assert (mode, idx) == ((0 if models[0].mode[0] == po.ABSORBING else 1), models[0].mode[1])
+            sp2 = cpa.PoseidonSponge.from_state((st, mode, idx), c)
+            assert [field.to_ints(x) for x in sp2.squeeze_native_field_elements(2).reshape(B, 2, 4)] == \
+                   [m.squeeze_native_field_elements(2) for m in models]
+
+
+def test_sponge_bytes_bits_and_regression(cpa):
+    from crypto_primitives_amd import field
+    c = cpa.get_default_poseidon_parameters(2, False)
+    o = po.get_default_poseidon_parameters(2, False)
+    a, b = cpa.PoseidonSponge(c), po.PoseidonSponge(o)
+    a.absorb(field.fr([5, 6, 7])); b.absorb([5, 6, 7])
+    assert a.squeeze_bytes(70) == b.squeeze_bytes(70)
+    assert a.squeeze_bits(300) == b.squeeze_bits(300)
+    # demo_bug (sponge/poseidon/tests.rs:12-65)
+    x, y = cpa.PoseidonSponge(c), cpa.PoseidonSponge(c)
+    x.absorb(field.fr([1, 2, 3])); y.absorb(field.fr([1, 2, 3]))
+    part = np.concatenate([x.squeeze_native_field_elements(1), x.squeeze_native_field_elements(2)])
+    assert np.array_equal(part, y.squeeze_native_field_elements(3))

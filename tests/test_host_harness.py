@@ -1,0 +1,125 @@
+"""Runs the PRODUCT's per-item device logic (crypto_primitives_amd/csrc/*.hpp host+device functions) on the
+CPU through tests/host_harness and compares with the oracle: round loop, sponge collapse, LUT construction,
+digit accumulation, shared-inversion finalisation, digest serialisation.  The GPU kernels are thin wrappers
+around the same functions (the inline-asm multiplier itself is covered by the -m gpu tests)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fr as ofr, poseidon as po, jubjub as jj, pedersen as pd, bowe_hopwood as bh
+from helpers import mont, ints, rand_fr, gens_array
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+vp = C.c_void_p
+
+
+@pytest.fixture(scope="module")
+def H():
+    h = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "harness.so"))
+    h.hh_poseidon_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t]
+    h.hh_poseidon_crh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t]
+    h.hh_te_build_lut.restype = C.c_size_t
+    h.hh_te_build_lut.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, vp]
+    h.hh_te_crh.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
+    h.hh_te_serialize_pairs.argtypes = [vp, vp, C.c_uint32, C.c_size_t, vp, C.c_size_t]
+    h.hh_fr_pow.argtypes = [vp, C.c_uint64, vp]
+    return h
+
+
+def P(a):
+    return a.ctypes.data_as(vp)
+
+
+def test_field_ops(H):
+    rng = ofr.SplitMix64(3)
+    pairs = [(rng.fr(), rng.fr()) for _ in range(300)] + [(ofr.P - 1, ofr.P - 1), (0, 5), (1, 1), (ofr.P - 1, 1), (0, 0)]
+    for a, b in pairs:
+        A, B, O = mont([a]), mont([b]), np.zeros((1, 4), np.uint64)
+        H.hh_fr_mul(P(A), P(B), P(O)); assert ints(O)[0] == a * b % ofr.P
+        H.hh_fr_add(P(A), P(B), P(O)); assert ints(O)[0] == (a + b) % ofr.P
+        H.hh_fr_sub(P(A), P(B), P(O)); assert ints(O)[0] == (a - b) % ofr.P
+    for a in (3, ofr.P - 2, pairs[0][0]):
+        A, O = mont([a]), np.zeros((1, 4), np.uint64)
+        H.hh_fr_inv(P(A), P(O)); assert ints(O)[0] == pow(a, -1, ofr.P)
+        for e in (1, 5, 17, 257):
+            H.hh_fr_pow(P(A), e, P(O)); assert ints(O)[0] == pow(a, e, ofr.P)
+
+
+@pytest.mark.parametrize("rate,weights", [(2, False), (3, False), (8, False), (2, True), (5, True)])
+def test_poseidon_round_code(H, rate, weights):
+    c = po.get_default_poseidon_parameters(rate, weights)
+    ark, mds = mont([x for r in c.ark for x in r]), mont([x for r in c.mds for x in r])
+    t = rate + 1
+    sts = [rand_fr(t, 40 + i) for i in range(3)]
+    S = mont([x for s in sts for x in s])
+    H.hh_poseidon_permute(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(S), 3)
+    assert ints(S) == [x for s in sts for x in po.permute(c, s)]
+    for k in (0, 1, 2, 3, 5, 9):
+        ins = [rand_fr(k, 90 + k + i) for i in range(2)]
+        I = mont([x for s in ins for x in s]) if k else np.zeros((1, 4), np.uint64)
+        O = np.zeros((2, 4), np.uint64)
+        H.hh_poseidon_crh(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(I), None, k, P(O), 2)
+        assert ints(O) == [po.crh_evaluate(c, s) for s in ins], (rate, k)
+    L, R, O = mont([1, 2]), mont([3, 4]), np.zeros((2, 4), np.uint64)
+    H.hh_poseidon_crh(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(L), P(R), 2, P(O), 2)
+    assert ints(O) == [po.two_to_one_compress(c, 1, 3), po.two_to_one_compress(c, 2, 4)]
+
+
+def _steps(kind, W, N, L):
+    bits = 8 * L
+    if kind == 0:
+        return min((bits + W - 1) // W, N) * ((W + 3) // 4)
+    return min((bits + 2) // 3, W * N)
+
+
+@pytest.mark.parametrize("W,N", [(4, 256), (8, 20), (6, 10), (3, 7)])
+def test_pedersen_table_path(H, W, N):
+    g = jj.pedersen_generators(11, W, N)
+    G = gens_array(g)
+    subs = (W + 3) // 4
+    lut = np.zeros((N * subs * 16, 3, 4), np.uint64)
+    assert H.hh_te_build_lut(0, P(G), W, N, P(lut)) == N * subs * 16
+    for L in sorted({W * N // 8, 1, 0, max(W * N // 8 - 3, 0)}):
+        n = 5
+        m = np.frombuffer(ofr.SplitMix64(L + W).bytes(max(L, 1) * n), dtype=np.uint8).copy()
+        out = np.zeros((n, 2, 4), np.uint64)
+        H.hh_te_crh(0, P(lut), P(m), n, L, W, subs, _steps(0, W, N, L), 2, P(out))
+        for i in range(n):
+            assert tuple(ints(out[i])) == pd.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, L)
+
+
+@pytest.mark.parametrize("W,N", [(63, 9), (63, 8), (5, 3)])
+def test_bowe_hopwood_table_path(H, W, N):
+    g = jj.bowe_hopwood_generators(12, W, N)
+    G = gens_array(g)
+    lut = np.zeros((N * W * 4, 3, 4), np.uint64)
+    H.hh_te_build_lut(1, P(G), W, N, P(lut))
+    maxL = W * N * 3 // 8
+    for L in sorted({maxL, 32 if 32 <= maxL else 1, 1, 0, 3, min(70, maxL)}):
+        n = 4
+        m = np.frombuffer(ofr.SplitMix64(L + W).bytes(max(L, 1) * n), dtype=np.uint8).copy()
+        out = np.zeros((n, 4), np.uint64)
+        H.hh_te_crh(1, P(lut), P(m), n, L, W, 1, _steps(1, W, N, L), 3, P(out))
+        for i in range(n):
+            assert ints(out[i])[0] == bh.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, L)
+
+
+def test_digest_serialisation(H):
+    pts = [(rand_fr(1, i)[0], rand_fr(1, 50 + i)[0]) for i in range(4)]
+    left = mont([v for p in pts[:2] for v in p]); right = mont([v for p in pts[2:] for v in p])
+    buf = np.full((2, 128), 0xAA, np.uint8)
+    H.hh_te_serialize_pairs(P(left), P(right), 2, 128, P(buf), 2)
+    for i in range(2):
+        assert bytes(buf[i]) == jj.serialize_uncompressed(pts[i]) + jj.serialize_uncompressed(pts[2 + i])
+    # level form (right == NULL): pairs (d[2i], d[2i+1]); Bowe-Hopwood 70-byte buffer keeps its tail untouched
+    d = mont([p[0] for p in pts])
+    buf = np.full((2, 70), 0xAA, np.uint8)
+    H.hh_te_serialize_pairs(P(d), None, 1, 70, P(buf), 2)
+    for i in range(2):
+        assert bytes(buf[i][:64]) == jj.fq_serialize(pts[2 * i][0]) + jj.fq_serialize(pts[2 * i + 1][0])
+    # truncation when the buffer is shorter than the two digests (63x8 window: 63 bytes)
+    buf = np.zeros((2, 63), np.uint8)
+    H.hh_te_serialize_pairs(P(d), None, 1, 63, P(buf), 2)
+    assert bytes(buf[0]) == (jj.fq_serialize(pts[0][0]) + jj.fq_serialize(pts[1][0]))[:63]

@@ -1,0 +1,100 @@
+"""Pedersen / Bowe-Hopwood / Merkle oracle checks.  The reference holds no absolute vectors for these
+(PARITY UNPINNED at value level); the oracle is pinned structurally instead."""
+import numpy as np
+import pytest
+
+from oracle import jubjub as jj, pedersen as pd, bowe_hopwood as bh, merkle, fr as ofr, cref
+from helpers import mont, ints, gens_array
+
+
+def test_curve_constants():
+    assert jj.is_on_curve(jj.GENERATOR) and jj.is_on_curve(jj.IDENTITY)
+    assert jj.mul(jj.GENERATOR, jj.SUBGROUP_ORDER) == jj.IDENTITY
+    assert jj.mul(jj.GENERATOR, jj.SUBGROUP_ORDER * jj.COFACTOR) == jj.IDENTITY
+    assert jj.add(jj.GENERATOR, jj.neg(jj.GENERATOR)) == jj.IDENTITY
+    p3 = jj.mul(jj.GENERATOR, 3)
+    assert jj.add(jj.double(jj.GENERATOR), jj.GENERATOR) == p3 and jj.is_on_curve(p3)
+    assert bh.max_chunks_per_segment() == 63  # bowe_hopwood/mod.rs:82-101 for Jubjub's scalar field
+
+
+def test_pedersen_known_answers_and_scalar_form():
+    g = jj.pedersen_generators(1, 4, 256)
+    assert pd.evaluate(g, 4, 256, b"") == jj.IDENTITY            # nothing is added (pedersen/mod.rs:116-122)
+    assert pd.evaluate(g, 4, 256, bytes(128)) == jj.IDENTITY
+    msg = bytes(range(128))
+    h = pd.evaluate(g, 4, 256, msg)
+    nibs = []
+    for b in msg:
+        nibs += [b & 15, b >> 4]
+    assert h == jj.sum_points([jj.mul(g[i][0], nibs[i]) for i in range(256)])  # H(m) = sum nibble_i * G_i
+    assert jj.is_on_curve(h) and jj.mul(h, jj.SUBGROUP_ORDER) == jj.IDENTITY
+    assert pd.evaluate(g, 4, 256, msg[:40]) == pd.evaluate(g, 4, 256, msg[:40] + bytes(88))  # zero padding :91-99
+    with pytest.raises(pd.InputLengthPanic):
+        pd.evaluate(g, 4, 256, bytes(129))
+    # two-to-one: concatenation semantics :158-182
+    assert pd.two_to_one_evaluate(g, 4, 256, msg[:64], msg[64:]) == h
+
+
+def test_bowe_hopwood_known_answers():
+    g = jj.bowe_hopwood_generators(2, 63, 9)
+    assert bh.evaluate(g, 63, 9, b"") == 0                         # identity -> x = 0
+    flat = [p for row in g for p in row]
+    for L in (1, 3, 32):
+        n_chunks = (8 * L + 2) // 3
+        assert bh.evaluate(g, 63, 9, bytes(L)) == jj.sum_points(flat[:n_chunks])[0]  # zero chunk = +g (:167)
+    # signed-digit scalar form: digit = (1 + b0 + 2 b1) * (-1)^b2 times generators[s][0] * 16^j
+    msg = ofr.SplitMix64(5).bytes(32)
+    bits = pd.bytes_to_bits(msg)
+    bits += [False] * (-len(bits) % 3)
+    pts = []
+    for c in range(len(bits) // 3):
+        b0, b1, b2 = bits[3 * c:3 * c + 3]
+        d = (1 + b0 + 2 * b1) * (-1 if b2 else 1)
+        pts.append(jj.mul(g[c // 63][0], (d * 16 ** (c % 63)) % jj.SUBGROUP_ORDER))
+    assert bh.evaluate(g, 63, 9, msg) == jj.sum_points(pts)[0]
+    with pytest.raises(pd.InputLengthPanic):
+        bh.evaluate(g, 63, 9, bytes(213))
+
+
+def test_c_oracle_curves_equal_python(derived):
+    g = jj.pedersen_generators(0xA5A50004, 4, 256)
+    d = derived["pedersen_4x256"]
+    assert [str(g[0][0][0]), str(g[0][0][1])] == d["g00"]
+    CP = cref.CurveParams(4, 256, gens_array(g))
+    msg = bytes.fromhex(d["msg"])
+    o = CP.pedersen_crh_batch(np.frombuffer(msg, np.uint8), 1, 128)
+    assert [str(v) for v in ints(o[0])] == d["digest"]
+    o = CP.pedersen_crh_batch(np.frombuffer(msg[:32], np.uint8), 1, 32)
+    assert [str(v) for v in ints(o[0])] == d["digest_first32"]
+    gb = jj.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    db = derived["bowe_hopwood_63x9"]
+    BP = cref.CurveParams(63, 9, gens_array(gb))
+    assert str(ints(BP.bh_crh_batch(np.frombuffer(bytes.fromhex(db["msg32"]), np.uint8), 1, 32))[0]) == db["digest32"]
+    assert str(ints(BP.bh_crh_batch(np.frombuffer(bytes.fromhex(db["msg70"]), np.uint8), 1, 70))[0]) == db["digest70"]
+    assert str(ints(BP.bh_crh_batch(np.zeros(3, np.uint8), 1, 3))[0]) == db["zero_3bytes"]
+    leaves = b"".join(bytes.fromhex(x) for x in derived["bowe_hopwood_merkle_4"]["leaves"])
+    ln, nl = BP.merkle_build(1, BP, np.frombuffer(leaves, np.uint8), 4, 32, threads=2)
+    assert str(ints(nl[0])[0]) == derived["bowe_hopwood_merkle_4"]["root"]
+    ln, nl = CP.merkle_build(0, CP, np.frombuffer(leaves, np.uint8), 4, 32, threads=2)
+    assert [str(v) for v in ints(nl[0])] == derived["pedersen_merkle_4"]["root"]
+
+
+def test_merkle_structure_python_oracle():
+    """proof round trips + multi-proof prefix lengths [0,2,1,2,0,2,1,2] (merkle_tree/tests/mod.rs:95-182)."""
+    from oracle import poseidon as po
+    c = po.get_default_poseidon_parameters(2, False)
+    leaves = [[i, i + 1, i + 2] for i in range(8)]
+    t = merkle.MerkleTree(lambda l: po.crh_evaluate(c, l), lambda a, b: po.two_to_one_compress(c, a, b),
+                          lambda a, b: po.two_to_one_compress(c, a, b), lambda x: x, leaves=leaves)
+    assert t.height == 4
+    for i in range(8):
+        assert t.verify(t.generate_proof(i), t.root(), leaves[i])
+        assert not t.verify(t.generate_proof(i), (t.root() + 1) % ofr.P, leaves[i])
+    mp = t.generate_multi_proof(range(8))
+    assert mp["auth_paths_prefix_lenghts"] == [0, 2, 1, 2, 0, 2, 1, 2]
+    assert t.verify_multi(mp, t.root(), leaves)
+    t.update(3, [9, 9, 9]); leaves[3] = [9, 9, 9]
+    for i in range(8):
+        assert t.verify(t.generate_proof(i), t.root(), leaves[i])
+    with pytest.raises(AssertionError):
+        merkle.MerkleTree(t.leaf_hash, t.t_eval, t.t_comp, t.convert, leaves=leaves[:3])

@@ -1,0 +1,174 @@
+// microbench.hip -- measures the issue rate of the VALU instructions the Fr multiplier can be built
+// from on gfx950, and the throughput of the multiplier variants themselves.  Evidence for DESIGN.md
+// "Fr multiply".  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o tools/microbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../crypto_primitives_amd/csrc/fr.hpp"
+using namespace akp;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+#define REP8(X) X X X X X X X X
+#define REP64(X) REP8(REP8(X))
+
+// 8 independent chains x 8 = 64 instructions per loop iteration
+#define KERNEL_U64(name, INSTR)                                                             \
+__global__ void __launch_bounds__(256) name(u64* out, int iters, u32 x, u32 y) {              \
+    u64 a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    u32 vx = x + threadIdx.x, vy = y ^ threadIdx.x;                                            \
+    for (int i = 0; i < iters; ++i) {                                                        \
+        REP8(asm volatile(INSTR(%0) "\n\t" INSTR(%1) "\n\t" INSTR(%2) "\n\t" INSTR(%3) "\n\t" INSTR(%4) "\n\t" INSTR(%5) "\n\t" INSTR(%6) "\n\t" INSTR(%7) \
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vx), "v"(vy) : "vcc");) \
+    }                                                                                        \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;       \
+}
+#define KERNEL_U32(name, INSTR)                                                             \
+__global__ void __launch_bounds__(256) name(u64* out, int iters, u32 x, u32 y) {              \
+    u32 a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    u32 vx = x + threadIdx.x, vy = y ^ threadIdx.x;                                            \
+    for (int i = 0; i < iters; ++i) {                                                        \
+        REP8(asm volatile(INSTR(%0) "\n\t" INSTR(%1) "\n\t" INSTR(%2) "\n\t" INSTR(%3) "\n\t" INSTR(%4) "\n\t" INSTR(%5) "\n\t" INSTR(%6) "\n\t" INSTR(%7) \
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vx), "v"(vy) : "vcc");) \
+    }                                                                                        \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;       \
+}
+#define I_MAD64(r) "v_mad_u64_u32 " #r ", vcc, %8, %9, " #r
+#define I_MAD64_SGPRDST(r) "v_mad_u64_u32 " #r ", s[10:11], %8, %9, " #r
+#define I_LSHLADD64(r) "v_lshl_add_u64 " #r ", " #r ", 0, " #r
+#define I_FMA64(r) "v_fma_f64 " #r ", " #r ", " #r ", " #r
+#define I_MULLO(r) "v_mul_lo_u32 " #r ", " #r ", %8"
+#define I_MULHI(r) "v_mul_hi_u32 " #r ", " #r ", %8"
+#define I_ADD32(r) "v_add_u32_e32 " #r ", %8, " #r
+#define I_ADDCO(r) "v_add_co_u32_e32 " #r ", vcc, %8, " #r
+#define I_ADDC(r) "v_addc_co_u32_e32 " #r ", vcc, %8, " #r ", vcc"
+#define I_MAD24(r) "v_mad_u32_u24 " #r ", %8, %9, " #r
+#define I_FMA32(r) "v_fma_f32 " #r ", " #r ", " #r ", " #r
+#define I_ADD3(r) "v_add3_u32 " #r ", %8, %9, " #r
+#define I_CNDMASK(r) "v_cndmask_b32_e32 " #r ", %8, " #r ", vcc"
+#define I_ALIGNBIT(r) "v_alignbit_b32 " #r ", " #r ", %8, 7"
+#define I_PKFMA32(r) "v_pk_fma_f32 " #r ", " #r ", " #r ", " #r
+#define I_MULF64(r) "v_mul_f64 " #r ", " #r ", " #r
+#define I_ADDF64(r) "v_add_f64 " #r ", " #r ", " #r
+
+KERNEL_U64(k_mad64, I_MAD64)
+KERNEL_U64(k_lshladd64, I_LSHLADD64)
+KERNEL_U64(k_fma64, I_FMA64)
+KERNEL_U64(k_mulf64, I_MULF64)
+KERNEL_U64(k_addf64, I_ADDF64)
+KERNEL_U64(k_pkfma32, I_PKFMA32)
+KERNEL_U32(k_mullo, I_MULLO)
+KERNEL_U32(k_mulhi, I_MULHI)
+KERNEL_U32(k_add32, I_ADD32)
+KERNEL_U32(k_addco, I_ADDCO)
+KERNEL_U32(k_addc, I_ADDC)
+KERNEL_U32(k_mad24, I_MAD24)
+KERNEL_U32(k_fma32, I_FMA32)
+KERNEL_U32(k_add3, I_ADD3)
+KERNEL_U32(k_cndmask, I_CNDMASK)
+KERNEL_U32(k_alignbit, I_ALIGNBIT)
+
+// one dependent chain: latency of v_mad_u64_u32 -> v_mad_u64_u32
+__global__ void __launch_bounds__(256) k_mad64_dep(u64* out, int iters, u32 x, u32 y) {
+    u64 a0 = threadIdx.x;
+    u32 vx = x + threadIdx.x, vy = y ^ threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        REP64(asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a0) : "v"(vx), "v"(vy) : "vcc");)
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0;
+}
+// mad + addc pair as used by the multiplier (dependent through vcc, 4 independent accumulators)
+__global__ void __launch_bounds__(256) k_mac_pair(u64* out, int iters, u32 x, u32 y) {
+    u64 a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3;
+    u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    u32 vx = x + threadIdx.x, vy = y ^ threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        REP8(asm volatile(
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+            "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+            "v_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_addc_co_u32_e32 %7, vcc, 0, %7, vcc"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(vx), "v"(vy) : "vcc");)
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ c0 ^ c1 ^ c2 ^ c3;
+}
+
+// multiplier variants: chain of dependent Montgomery products
+__global__ void __launch_bounds__(256) k_frmul_asm(Fr* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr a = x[i], b = x[i ^ 1];
+    for (int k = 0; k < iters; ++k) a = fr_mul(a, b);
+    x[i] = a;
+}
+__global__ void __launch_bounds__(256) k_frmul_portable(Fr* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr a = x[i], b = x[i ^ 1];
+    for (int k = 0; k < iters; ++k) a = fr_mul_portable(a, b);
+    x[i] = a;
+}
+__global__ void __launch_bounds__(256) k_fradd(Fr* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr a = x[i], b = x[i ^ 1];
+    for (int k = 0; k < iters; ++k) { a = fr_add(a, b); b = fr_sub(b, a); }
+    x[i] = a;
+}
+
+template <class F>
+static float time_ms(F&& launch, int reps = 3) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    launch();
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0));
+        launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main() {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const double clk = prop.clockRate * 1e3;  // Hz
+    printf("device %s, %d CUs, clock %.0f MHz\n", prop.name, cus, clk / 1e6);
+    u64* d; CK(hipMalloc(&d, sizeof(u64) * cus * 8 * 256));
+    Fr* df; CK(hipMalloc(&df, sizeof(Fr) * cus * 8 * 256));
+    std::vector<Fr> h(cus * 8 * 256);
+    for (size_t i = 0; i < h.size(); ++i) for (int j = 0; j < 8; ++j) h[i].l[j] = (u32)(i * 2654435761u + j * 40503u) & (j == 7 ? 0x3fffffffu : 0xffffffffu);
+    CK(hipMemcpy(df, h.data(), sizeof(Fr) * h.size(), hipMemcpyHostToDevice));
+    const int iters = 2000;
+    printf("%-22s %6s %12s %14s\n", "instr", "w/SIMD", "ms", "cyc/wave-instr");
+    struct K { const char* name; void (*fn)(u64*, int, u32, u32); int per_iter; };
+    K ks[] = {{"v_mad_u64_u32", k_mad64, 64}, {"v_mad_u64_u32 dep", k_mad64_dep, 64}, {"mad+addc pair(x2)", k_mac_pair, 64},
+              {"v_mul_lo_u32", k_mullo, 64}, {"v_mul_hi_u32", k_mulhi, 64}, {"v_add_u32", k_add32, 64}, {"v_add_co_u32", k_addco, 64},
+              {"v_addc_co_u32", k_addc, 64}, {"v_add3_u32", k_add3, 64}, {"v_cndmask_b32", k_cndmask, 64}, {"v_alignbit_b32", k_alignbit, 64},
+              {"v_mad_u32_u24", k_mad24, 64}, {"v_lshl_add_u64", k_lshladd64, 64}, {"v_fma_f32", k_fma32, 64}, {"v_pk_fma_f32", k_pkfma32, 64},
+              {"v_fma_f64", k_fma64, 64}, {"v_mul_f64", k_mulf64, 64}, {"v_add_f64", k_addf64, 64}};
+    for (auto& k : ks) {
+        for (int wps : {1, 2, 4}) {  // waves per SIMD: blocks of 256 threads = 4 waves = 1 per SIMD
+            const int blocks = cus * wps;
+            float ms = time_ms([&] { hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d, iters, 12345u, 678u); });
+            double cyc = ms * 1e-3 * clk / ((double)iters * k.per_iter * wps);
+            printf("%-22s %6d %12.3f %14.2f\n", k.name, wps, ms, cyc);
+        }
+    }
+    struct M { const char* name; void (*fn)(Fr*, int); int mul_per_iter; };
+    M ms_[] = {{"fr_mul asm", k_frmul_asm, 1}, {"fr_mul portable", k_frmul_portable, 1}, {"fr_add+fr_sub", k_fradd, 2}};
+    const int miters = 2000;
+    printf("%-22s %6s %12s %14s %16s\n", "field op", "w/SIMD", "ms", "cyc/wave-op", "ops/s (chip)");
+    for (auto& k : ms_) {
+        for (int wps : {1, 2, 4, 8}) {
+            const int blocks = cus * wps;
+            float ms = time_ms([&] { hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, df, miters); });
+            double ops = (double)blocks * 256 * miters * k.mul_per_iter;
+            double cyc = ms * 1e-3 * clk / ((double)miters * k.mul_per_iter * wps);
+            printf("%-22s %6d %12.3f %14.1f %16.4g\n", k.name, wps, ms, cyc, ops / (ms * 1e-3));
+        }
+    }
+    return 0;
+}
