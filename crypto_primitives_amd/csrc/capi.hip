@@ -12,6 +12,7 @@
 
 #include "../../include/akp.h"
 #include "fr.hpp"
+#include "f29.hpp"
 #include "poseidon_kernels.hpp"
 #include "te_kernels.hpp"
 
@@ -98,7 +99,9 @@ extern "C" int32_t akp_ctx_synchronize(akp_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return AKP_OK;
 }
-static inline hipStream_t pick_stream(akp_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+// `_dev` entry points use the caller's stream verbatim (NULL = HIP's legacy default stream, which is what
+// torch's default stream is), so event timing and ordering follow the caller's stream semantics.
+static inline hipStream_t pick_stream(akp_ctx*, void* s) { return (hipStream_t)s; }
 
 // ------------------------------------------------------------------------------------------
 // host field helpers
@@ -142,8 +145,10 @@ struct akp_poseidon {
     akp_ctx* ctx = nullptr;
     PoseidonDims dims{};
     std::vector<Fr> ark, mds;         // host copies, wire format
-    Fr* d_ark = nullptr;
+    Fr* d_ark = nullptr;              // wire format (export / conversion source)
     Fr* d_mds = nullptr;
+    F29Pad* d_ark29 = nullptr;        // internal radix-2^29 form read by the kernels
+    F29Pad* d_mds29 = nullptr;
 };
 
 extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds, uint32_t partial_rounds, uint64_t alpha,
@@ -172,9 +177,19 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
         if (e == hipSuccess) e = hipMalloc(&p->d_mds, nm * sizeof(Fr));
         if (e == hipSuccess && na) e = hipMemcpy(p->d_ark, p->ark.data(), na * sizeof(Fr), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->d_mds, p->mds.data(), nm * sizeof(Fr), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(&p->d_ark29, std::max<size_t>(na, 1) * sizeof(F29Pad));
+        if (e == hipSuccess) e = hipMalloc(&p->d_mds29, nm * sizeof(F29Pad));
+        if (e == hipSuccess) {
+            if (na) hipLaunchKernelGGL(poseidon_convert_params_kernel, dim3((unsigned)((na + 63) / 64)), dim3(64), 0, ctx->stream, p->d_ark, p->d_ark29, na);
+            hipLaunchKernelGGL(poseidon_convert_params_kernel, dim3((unsigned)((nm + 63) / 64)), dim3(64), 0, ctx->stream, p->d_mds, p->d_mds29, nm);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
         if (e != hipSuccess) {
             if (p->d_ark) (void)hipFree(p->d_ark);
             if (p->d_mds) (void)hipFree(p->d_mds);
+            if (p->d_ark29) (void)hipFree(p->d_ark29);
+            if (p->d_mds29) (void)hipFree(p->d_mds29);
             delete p;
             return fail(AKP_ERR_HIP, "uploading Poseidon parameters: %s", hipGetErrorString(e));
         }
@@ -187,6 +202,8 @@ extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (p->ctx) (void)hipSetDevice(p->ctx->device);
     if (p->d_ark) (void)hipFree(p->d_ark);
     if (p->d_mds) (void)hipFree(p->d_mds);
+    if (p->d_ark29) (void)hipFree(p->d_ark29);
+    if (p->d_mds29) (void)hipFree(p->d_mds29);
     delete p;
 }
 extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
@@ -310,27 +327,40 @@ extern "C" int32_t akp_poseidon_default_params(akp_ctx* ctx, uint32_t rate, int3
 
 // ------------------------------------------------------------------------------------------
 // Poseidon launches
-static inline unsigned poseidon_block(u32 t) { return t <= 4 ? 256u : (t <= 8 ? 128u : 64u); }
+static inline unsigned poseidon_block(u32 t) { return t <= 3 ? 256u : (t <= 7 ? 128u : 64u); }  // 72*t*B bytes of LDS <= 64 KiB
+
+// LDS bytes of the generic kernel: two buffers of t elements, 9 dwords each, per lane
+static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)2 * t * 9 * 4 * B; }
 
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
+    if (p->dims.t == 3) {
+        hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
     const unsigned B = poseidon_block(p->dims.t);
-    const size_t lds = (size_t)2 * p->dims.t * 32 * B;
+    const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, d_states, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, d_states, n);
-    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, d_states, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
+    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
 static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
+    if (p->dims.t == 3) {
+        hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
     const unsigned B = poseidon_block(p->dims.t);
-    const size_t lds = (size_t)2 * p->dims.t * 32 * B;
+    const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, in0, in1, k, d_out, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, in0, in1, k, d_out, n);
-    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark, p->d_mds, in0, in1, k, d_out, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
+    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
@@ -587,7 +617,7 @@ struct akp_te_params {
     u32 W = 0, N = 0;
     u32 subs_per_window = 0;  // Pedersen: ceil(W / 4)
     u32 n_units = 0;          // Pedersen: N * subs_per_window sub-windows; BH: N * W chunks
-    Niels* d_lut = nullptr;
+    NielsPad* d_lut = nullptr;
 };
 static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN ? 2u : 1u; }
 static inline size_t te_input_bits(const akp_te_params* p) {  // max message bits before the reference panics
@@ -619,7 +649,7 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
         p->n_units = (u32)n_gen;
         entries = n_gen * 4;
     }
-    if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(Niels));
+    if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
     if (e == hipSuccess) {
         const unsigned grid = (unsigned)((entries + 63) / 64);
         if (kind == AKP_TE_PEDERSEN)
@@ -662,23 +692,23 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
     if (n == 0) return AKP_OK;
     void *xyz = nullptr, *prefix = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(Fr), &xyz)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(Fr), &prefix)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix)) return rc;
     const u32 steps = te_steps(p, msg_len);
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (p->kind == AKP_TE_PEDERSEN)
-        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (Fr*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (F29Pad*)xyz, n);
     else
-        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (Fr*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (F29Pad*)xyz, n);
     HIP_TRY(hipGetLastError());
     // share one inversion among up to 64 messages per lane, but keep >= 64K lanes busy when n allows
     size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / 65536));
     size_t lanes = (n + chain - 1) / chain;
     const unsigned fgrid = (unsigned)((lanes + 255) / 256);
     if (p->kind == AKP_TE_PEDERSEN)
-        hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, s, (const Fr*)xyz, (Fr*)prefix, d_out, n, lanes);
+        hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, s, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, lanes);
     else
-        hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, s, (const Fr*)xyz, (Fr*)prefix, d_out, n, lanes);
+        hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, s, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, lanes);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }

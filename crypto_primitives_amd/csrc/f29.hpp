@@ -1,0 +1,354 @@
+// f29.hpp -- the arithmetic core of the gfx950 kernels: BLS12-381 Fr in radix 2^29, 9 limbs, lazy reduction.
+//
+// Why this representation (measured on MI355X, profiles/r01_s1_microbench_instruction_rates.txt):
+// v_mad_u64_u32 / v_mad_i64_i32 issue at the SAME rate as v_addc_co_u32, v_lshl_add_u64 or v_fma_f64
+// (~4.4 cycles per wave64); only plain e32 adds/ands are cheaper (~2.6).  The cost of a field product is
+// therefore its instruction COUNT, and a saturated radix-2^32 multiplier spends more than half of its
+// ~324 instructions on carries (one v_addc per partial product) and on the conditional subtraction.
+// With 29-bit limbs a partial product is < 2^58 (< 2^60 for lazily added operands), so a whole column of a
+// 9x9 product -- and of a 3-term dot product -- accumulates in ONE 64-bit register with no carry handling:
+// one v_mad per partial product, two instructions per column for the carry (and + 64-bit shift).
+//   product:      81 + 81 mads + ~45 others  ~ 205 instructions   (was 324)
+//   square:       45 + 81 mads + ~55 others  ~ 180
+//   3-term dot:  243 + 81 mads + ~45 others  ~ 370                (was 3 x 324 + adds)
+//   add / sub:     9 plain adds, no reduction
+// No conditional subtraction is ever needed between operations: the Montgomery radix is R' = 2^261, so
+// p / R' = 2^-6 and every product lands in (-1.1p, 2.1p) for operands below 2^258 in magnitude.
+//
+// Internal form of a field element x:  any integer v == x * 2^261 (mod p), |v| < 2^258,
+//   v = sum l[i] * 2^(29 i).   "Normalised": l[0..7] in [0, 2^29), l[8] small (signed in the signed flavour).
+// Flavours:  FU (unsigned limbs, Poseidon: only + and *),  FS (signed limbs, Jubjub: also -).
+// Headroom rules (checked in DESIGN.md "F29 bounds"):
+//   FU: 9*A*B + 9*2^58 < 2^64 -> product operands may have limbs < 2^30 (one lazy add each); a 3-term dot
+//       may take state limbs < 2^30 against normalised constants (27 * 2^59 + 9 * 2^58 < 2^64).
+//   FS: 9*A*B + 9*2^58 < 2^63 -> A*B <= 2^59.4: one operand may be a lazy sum/difference (< 2^30), the
+//       other normalised; anything larger goes through f29_weak_norm first.
+// Wire format <-> internal: one Montgomery product with a constant each way (x*2^256 <-> x*2^261).
+#pragma once
+#include <stdint.h>
+
+#include "fr.hpp"
+
+namespace akp {
+
+#define AKP_MASK29 0x1fffffffu
+
+template <bool SIGNED>
+struct F29T;
+template <>
+struct F29T<false> {
+    typedef uint32_t L;
+    typedef uint64_t W;
+    L l[9];
+};
+template <>
+struct F29T<true> {
+    typedef int32_t L;
+    typedef int64_t W;
+    L l[9];
+};
+typedef F29T<false> FU;
+typedef F29T<true> FS;
+
+AKP_HD u32 p29(int i) {
+    constexpr u32 P[9] = {0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u};
+    return P[i];
+}
+#define AKP_F29_CONST(name, ...)                       \
+    template <bool S>                                  \
+    AKP_HD F29T<S> name() {                            \
+        constexpr u32 C[9] = {__VA_ARGS__};            \
+        F29T<S> r;                                     \
+        _Pragma("unroll") for (int i = 0; i < 9; ++i) r.l[i] = (typename F29T<S>::L)C[i]; \
+        return r;                                      \
+    }
+// R' mod p  (the field's one), 2^266 mod p (wire -> internal), 2^256 mod p (internal -> wire), d*R' (Jubjub d)
+AKP_F29_CONST(f29_one, 0x1fffffbau, 0x0000022fu, 0x1cb61180u, 0x0a4e5c00u, 0x0ee8b1a2u, 0x16e6aedfu, 0x1907f8bbu, 0x0853ddf7u, 0x004d043fu)
+AKP_F29_CONST(f29_k_in, 0x1ffff72bu, 0x000046a7u, 0x1f5f3540u, 0x0ce3021cu, 0x118f3661u, 0x008176cbu, 0x054e487cu, 0x102e8190u, 0x001e092eu)
+AKP_F29_CONST(f29_k_out, 0x1ffffffeu, 0x0000000fu, 0x00d20080u, 0x096ff400u, 0x04ff5588u, 0x07f7f65eu, 0x15be6631u, 0x0b3598a0u, 0x001824b1u)
+AKP_F29_CONST(f29_te_d, 0x0e9ed5e8u, 0x12245679u, 0x002d9f52u, 0x03bb3367u, 0x0d9bfb3du, 0x18ebb3ccu, 0x1c29ceccu, 0x0a7b6020u, 0x0020d725u)
+AKP_F29_CONST(f29_4p, 0x00000004u, 0x1fffffe0u, 0x1e5bfeffu, 0x0d2017ffu, 0x160154efu, 0x10101343u, 0x1483339du, 0x0994cebeu, 0x01cfb69du)
+AKP_F29_CONST(f29_2p, 0x00000002u, 0x1ffffff0u, 0x1f2dff7fu, 0x16900bffu, 0x1b00aa77u, 0x180809a1u, 0x0a4199ceu, 0x14ca675fu, 0x00e7db4eu)
+AKP_F29_CONST(f29_p, 0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u)
+
+template <bool S>
+AKP_HD F29T<S> f29_zero() {
+    F29T<S> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = 0;
+    return r;
+}
+template <bool S>
+AKP_HD F29T<S> f29_add(const F29T<S>& a, const F29T<S>& b) {
+    F29T<S> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+AKP_HD FS f29_sub(const FS& a, const FS& b) {
+    FS r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+AKP_HD FS f29_neg(const FS& a) {
+    FS r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = -a.l[i];
+    return r;
+}
+template <bool S>
+AKP_HD F29T<S> f29_dbl(const F29T<S>& a) {
+    return f29_add(a, a);
+}
+// one parallel carry step: limbs back to [0, 2^29 + small) (top limb absorbs the rest)
+template <bool S>
+AKP_HD F29T<S> f29_weak_norm(const F29T<S>& a) {
+    typedef typename F29T<S>::L L;
+    F29T<S> r;
+    r.l[0] = (L)((u32)a.l[0] & AKP_MASK29);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r.l[i] = (L)((u32)a.l[i] & AKP_MASK29) + (a.l[i - 1] >> 29);
+    r.l[8] = a.l[8] + (a.l[7] >> 29);
+    return r;
+}
+
+// ---- Montgomery reduction tail shared by mul / sqr / dot: columns 0..8 have been folded into m[] ----
+#define AKP_F29_MSTEP()                           \
+    m[k] = (0u - (u32)acc) & AKP_MASK29;          \
+    acc += (W)(L)m[k];                            \
+    acc >>= 29;
+
+// a * b / 2^261 (mod p).  Output normalised.
+template <bool S>
+AKP_HD F29T<S> f29_mul(const F29T<S>& a, const F29T<S>& b) {
+    typedef typename F29T<S>::L L;
+    typedef typename F29T<S>::W W;
+    W acc = 0;
+    u32 m[9];
+    F29T<S> t;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (W)a.l[i] * (W)b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        AKP_F29_MSTEP()
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (W)a.l[i] * (W)b.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
+        acc >>= 29;
+    }
+    t.l[8] = (L)acc;
+    return t;
+}
+
+// a^2 / 2^261: off-diagonal products use the doubled operand (45 products instead of 81)
+template <bool S>
+AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
+    typedef typename F29T<S>::L L;
+    typedef typename F29T<S>::W W;
+    L a2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a2[i] = a.l[i] + a.l[i];
+    W acc = 0;
+    u32 m[9];
+    F29T<S> t;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; ++i) acc += (W)a2[i] * (W)a.l[k - i];
+        if ((k & 1) == 0) acc += (W)a.l[k / 2] * (W)a.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        AKP_F29_MSTEP()
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; ++i) acc += (W)a2[i] * (W)a.l[k - i];
+        if ((k & 1) == 0) acc += (W)a.l[k / 2] * (W)a.l[k / 2];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
+        acc >>= 29;
+    }
+    t.l[8] = (L)acc;
+    return t;
+}
+
+// (a0*b0 + a1*b1 + a2*b2) / 2^261: one reduction for three products (the MDS row of a t = 3 state).
+// FU only: a limbs < 2^30, b limbs < 2^29  =>  27 * 2^59 + 9 * 2^58 + carry < 2^64.
+AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const FU& a2, const FU& b2) {
+    typedef u32 L;
+    typedef u64 W;
+    W acc = 0;
+    u32 m[9];
+    FU t;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) {
+            acc += (W)a0.l[i] * (W)b0.l[k - i];
+            acc += (W)a1.l[i] * (W)b1.l[k - i];
+            acc += (W)a2.l[i] * (W)b2.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (W)m[i] * (W)p29(k - i);
+        AKP_F29_MSTEP()
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) {
+            acc += (W)a0.l[i] * (W)b0.l[k - i];
+            acc += (W)a1.l[i] * (W)b1.l[k - i];
+            acc += (W)a2.l[i] * (W)b2.l[k - i];
+        }
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (W)m[i] * (W)p29(k - i);
+        t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
+        acc >>= 29;
+    }
+    t.l[8] = (L)acc;
+    return t;
+}
+
+// x^e, small public exponent (S-box).  MSB-first from x; equals ark-ff Field::pow for e >= 1.
+template <bool S>
+AKP_HD F29T<S> f29_pow_small(const F29T<S>& x, u64 e) {
+    if (e == 0) return f29_one<S>();
+    int top = 63 - __builtin_clzll(e);
+    F29T<S> r = x;
+#pragma unroll 1
+    for (int i = top - 1; i >= 0; --i) {
+        r = f29_sqr(r);
+        if ((e >> i) & 1) r = f29_mul(r, x);
+    }
+    return r;
+}
+// a^(p-2); a == 0 -> 0
+template <bool S>
+AKP_HD F29T<S> f29_inv(const F29T<S>& a) {
+    const u32 E[8] = {0xffffffffu, 0xfffffffeu, AKP_P2, AKP_P3, AKP_P4, AKP_P5, AKP_P6, AKP_P7};  // p - 2
+    F29T<S> r = a;  // bit 254 of p-2 is set
+#pragma unroll 1
+    for (int i = 253; i >= 0; --i) {
+        r = f29_sqr(r);
+        if ((E[i >> 5] >> (i & 31)) & 1) r = f29_mul(r, a);
+    }
+    return r;
+}
+
+// ---- wire format (8 x u32, x * 2^256 mod p, canonical) <-> internal ------------------------------------
+template <bool S>
+AKP_HD F29T<S> f29_unpack(const Fr& w) {  // plain re-limbing of a 256-bit integer
+    typedef typename F29T<S>::L L;
+    F29T<S> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        u32 v = w.l[wi] >> sh;
+        if (sh + 29 > 32 && wi + 1 < 8) v |= w.l[wi + 1] << (32 - sh);
+        r.l[i] = (L)(v & AKP_MASK29);
+    }
+    return r;
+}
+template <bool S>
+AKP_HD F29T<S> f29_from_wire(const Fr& w) {
+    return f29_mul(f29_unpack<S>(w), f29_k_in<S>());
+}
+// canonical representative in [0, p) of a value with |v| < 4p (FS) / 0 <= v < 8p (FU), as 8 x u32
+template <bool S>
+AKP_HD Fr f29_canonical_pack(const F29T<S>& a) {
+    // 1. make non-negative, 2. exact carry propagation, 3. subtract 4p, 2p, p where possible, 4. re-limb
+    int32_t v[9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int32_t x = (int32_t)a.l[i] + c;
+        if (S) x += (int32_t)f29_4p<false>().l[i];
+        if (i < 8) {
+            v[i] = (int32_t)((u32)x & AKP_MASK29);
+            c = x >> 29;
+        } else {
+            v[i] = x;
+        }
+    }
+#pragma unroll
+    for (int step = 0; step < 3; ++step) {
+        const FU sub = step == 0 ? f29_4p<false>() : (step == 1 ? f29_2p<false>() : f29_p<false>());
+        int32_t d[9];
+        int32_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int32_t x = v[i] - (int32_t)sub.l[i] + bw;
+            if (i < 8) {
+                d[i] = (int32_t)((u32)x & AKP_MASK29);
+                bw = x >> 29;
+            } else {
+                d[i] = x;
+            }
+        }
+        const bool ge = d[8] >= 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v[i] = ge ? d[i] : v[i];
+    }
+    Fr o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int bit = 32 * j, li = bit / 29, sh = bit % 29;
+        u32 x = (u32)v[li] >> sh;
+        if (li + 1 < 9) x |= (u32)v[li + 1] << (29 - sh);
+        if (58 - sh < 32 && li + 2 < 9) x |= (u32)v[li + 2] << (58 - sh);
+        o.l[j] = x;
+    }
+    return o;
+}
+template <bool S>
+AKP_HD Fr f29_to_wire(const F29T<S>& a) {
+    return f29_canonical_pack(f29_mul(a, f29_k_out<S>()));
+}
+// canonical little-endian integer of the field element (ark-serialize's encoding of Fq)
+template <bool S>
+AKP_HD Fr f29_to_canonical_int(const F29T<S>& a) {
+    F29T<S> one = f29_zero<S>();
+    one.l[0] = 1;
+    return f29_canonical_pack(f29_mul(a, one));  // a / R' = x
+}
+AKP_HD FS f29_to_signed(const FU& a) {
+    FS r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (int32_t)a.l[i];
+    return r;
+}
+
+// 12-dword padded storage (three 16-byte vectors) for tables / scratch in global memory
+struct F29Pad {
+    u32 w[12];
+};
+template <bool S>
+AKP_HD F29T<S> f29_load_pad(const F29Pad* p) {
+    typedef typename F29T<S>::L L;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    F29T<S> r;
+    r.l[0] = (L)a.x; r.l[1] = (L)a.y; r.l[2] = (L)a.z; r.l[3] = (L)a.w;
+    r.l[4] = (L)b.x; r.l[5] = (L)b.y; r.l[6] = (L)b.z; r.l[7] = (L)b.w;
+    r.l[8] = (L)c.x;
+    return r;
+}
+template <bool S>
+AKP_HD void f29_store_pad(F29Pad* p, const F29T<S>& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4((u32)v.l[0], (u32)v.l[1], (u32)v.l[2], (u32)v.l[3]);
+    q[1] = make_uint4((u32)v.l[4], (u32)v.l[5], (u32)v.l[6], (u32)v.l[7]);
+    q[2] = make_uint4((u32)v.l[8], 0u, 0u, 0u);
+}
+
+}  // namespace akp

@@ -6,39 +6,28 @@
 //   poseidon::TwoToOneCRH::compress    crh/poseidon/mod.rs:66-79
 //   MerkleTree level loops             merkle_tree/mod.rs:458-515 (one launch per level)
 //
-// Mapping: one sponge instance per lane (64 per wavefront).  The path is integer-ALU bound
-// (~626 Montgomery products per 192 algorithmic bytes), so the design goal is issue
-// efficiency of v_mad_u64_u32, a small instruction footprint (the whole round loop stays
-// inside the instruction cache) and >= 2 waves per SIMD -- not HBM bandwidth.
+// Mapping: one sponge instance per lane (64 per wavefront).  The path is integer-ALU bound (hundreds of
+// 255-bit modular products per 192 algorithmic bytes), so the design goal is a minimal VALU instruction
+// count per product (f29.hpp), a round body that stays inside the instruction cache and >= 2 waves per
+// SIMD to cover the dependent v_mad chains -- not HBM bandwidth.
 //
-// Generic kernel ("LDS register file"): the t-word sponge state of each lane lives in LDS in
-// a lane-interleaved layout (slot s, half h, lane l -> uint4 index (2s+h)*BLOCK + l, i.e.
-// conflict-free ds_read/write_b128), so loops over state elements are real loops (dynamic
-// slot index) and there is exactly one inlined multiplier body per use site.  Round keys and
-// the MDS matrix are wave-uniform: they are fetched through the scalar cache (s_load_dwordx8)
-// straight into SGPR operands of the multiplier.
+// Arithmetic runs in the lazy radix-2^29 form of f29.hpp (unsigned flavour: Poseidon only adds and
+// multiplies).  Round keys and the MDS matrix are converted to that form once per parameter set and are
+// wave-uniform: they come through the scalar cache (s_load) straight into SGPR operands of v_mad_u64_u32.
+//   t == 3 (the rate-2 headline instance): state in 27 VGPRs, S-box x^alpha by square-and-multiply,
+//          each MDS row as ONE 3-term dot product with a single Montgomery reduction.
+//   any other t <= 16: the state lives in an LDS "register file" (lane-interleaved dwords, conflict-free)
+//          so loops over state elements are real loops; MDS rows are chunks of 3-term dots.
+// Values cross HBM in the ABI's wire format (ark-ff Montgomery, R = 2^256); one product with a constant
+// converts on load / store.
 #pragma once
-#include "fr.hpp"
+#include "f29.hpp"
 
 namespace akp {
 
 struct PoseidonDims {
     u32 t, rate, capacity, full_rounds, partial_rounds;
     u64 alpha;
-};
-
-template <int BLOCK>
-struct LdsFile {
-    uint4* base;  // [slot][2][BLOCK]
-    AKP_D Fr load(u32 slot) const {
-        const uint4 lo = base[(2 * slot) * BLOCK + threadIdx.x];
-        const uint4 hi = base[(2 * slot + 1) * BLOCK + threadIdx.x];
-        return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
-    }
-    AKP_D void store(u32 slot, const Fr& v) const {
-        base[(2 * slot) * BLOCK + threadIdx.x] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-        base[(2 * slot + 1) * BLOCK + threadIdx.x] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-    }
 };
 
 AKP_HD Fr load_fr_global(const Fr* p) {
@@ -51,26 +40,111 @@ AKP_HD void store_fr_global(Fr* p, const Fr& v) {
     q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
+AKP_HD FU ldc(const F29Pad* p) { return f29_load_pad<false>(p); }  // wave-uniform address -> scalar loads
 
-// S-box x^alpha for a wave-uniform runtime alpha (sponge/poseidon/mod.rs:66-77)
-AKP_HD Fr sbox_runtime(const Fr& x, u64 alpha) {
-    if (alpha == 0) return fr_one();
-    int top = 63 - __builtin_clzll(alpha);
-    Fr r = x;
-#pragma unroll 1
-    for (int i = top - 1; i >= 0; --i) {
-        r = fr_sqr(r);
-        if ((alpha >> i) & 1) r = fr_mul(r, x);
-    }
-    return r;
+// wire-format parameter array -> internal form (run once per parameter set)
+__global__ void poseidon_convert_params_kernel(const Fr* __restrict__ in, F29Pad* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f29_store_pad(out + i, f29_from_wire<false>(load_fr_global(in + i)));
 }
 
-// One full permutation of the state held in buffer `cur` of the state file `f`
-// (slots [cur*t, cur*t + t)).  On return the state is in buffer `cur` (updated).
-// `File` is LdsFile<BLOCK> on the device; tests/host_harness instantiates it with a plain array
-// so the very same round code runs on the CPU against the oracle.
+// =============================== t == 3: register-resident state ===================================
+// One full permutation (sponge/poseidon/mod.rs:98-121): per round ARK (:79-83), S-box x^alpha on every
+// lane (full rounds) or lane 0 only (partial rounds) (:66-77), then state = MDS * state (:85-96).
+// Limb bounds: MDS outputs are normalised (< 2^29); + round key (< 2^29) -> < 2^30, which is what
+// f29_sqr / f29_mul / f29_dot3 admit.
+AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds, FU& s0,
+                                FU& s1, FU& s2) {
+    const u32 half = D.full_rounds / 2;
+    const u32 R = D.full_rounds + D.partial_rounds;
+#pragma unroll 1
+    for (u32 r = 0; r < R; ++r) {
+        const bool full = (r < half) || (r >= half + D.partial_rounds);
+        const F29Pad* a = ark + (size_t)r * 3;
+        s0 = f29_pow_small(f29_add(s0, ldc(a)), D.alpha);
+        s1 = f29_add(s1, ldc(a + 1));
+        s2 = f29_add(s2, ldc(a + 2));
+        if (full) {
+            s1 = f29_pow_small(s1, D.alpha);
+            s2 = f29_pow_small(s2, D.alpha);
+        }
+        const FU n0 = f29_dot3(s0, ldc(mds + 0), s1, ldc(mds + 1), s2, ldc(mds + 2));
+        const FU n1 = f29_dot3(s0, ldc(mds + 3), s1, ldc(mds + 4), s2, ldc(mds + 5));
+        const FU n2 = f29_dot3(s0, ldc(mds + 6), s1, ldc(mds + 7), s2, ldc(mds + 8));
+        s0 = n0;
+        s1 = n1;
+        s2 = n2;
+    }
+}
+// absorb: lane += input, renormalised so that the following ARK add stays below 2^30
+AKP_HD void t3_add_slot(FU& s0, FU& s1, FU& s2, u32 slot, const FU& v) {
+    if (slot == 0) s0 = f29_weak_norm(f29_add(s0, v));
+    else if (slot == 1) s1 = f29_weak_norm(f29_add(s1, v));
+    else s2 = f29_weak_norm(f29_add(s2, v));
+}
+// Fixed-length sponge CRH of item idx on a fresh sponge: squeeze1(absorb(in[0..k))).
+// Element e of item idx is in0[idx*k + e] (in1 == nullptr), or in0[idx] / in1[idx] for e = 0 / 1.
+// absorb_internal from index 0 (:124-153) + the squeeze permutation (:324-344): ceil(k/rate)
+// permutations, or one permutation of the zero state when k == 0 (:238-240).
+AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds,
+                               const Fr* __restrict__ in0, const Fr* __restrict__ in1, size_t k, size_t idx) {
+    FU s0 = f29_zero<false>(), s1 = s0, s2 = s0;  // PoseidonSponge::new :223-234
+    size_t done = 0;
+    do {
+        const size_t take = (k - done) < D.rate ? (k - done) : D.rate;
+#pragma unroll 1
+        for (size_t j = 0; j < take; ++j) {
+            const size_t e = done + j;
+            const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
+            t3_add_slot(s0, s1, s2, D.capacity + (u32)j, f29_from_wire<false>(load_fr_global(src)));
+        }
+        done += take;
+        poseidon_permute_t3(D, ark, mds, s0, s1, s2);
+    } while (done < k);
+    const FU out = D.capacity == 0 ? s0 : (D.capacity == 1 ? s1 : s2);  // squeeze_internal(0, 1) :156-186
+    return f29_to_wire(out);
+}
+
+__global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
+                                                                 const F29Pad* __restrict__ mds, Fr* states, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    Fr* st = states + idx * 3;
+    FU s0 = f29_from_wire<false>(load_fr_global(st)), s1 = f29_from_wire<false>(load_fr_global(st + 1)),
+       s2 = f29_from_wire<false>(load_fr_global(st + 2));
+    poseidon_permute_t3(D, ark, mds, s0, s1, s2);
+    store_fr_global(st, f29_to_wire(s0));
+    store_fr_global(st + 1, f29_to_wire(s1));
+    store_fr_global(st + 2, f29_to_wire(s2));
+}
+__global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
+                                                             const F29Pad* __restrict__ mds, const Fr* __restrict__ in0,
+                                                             const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    store_fr_global(out + idx, poseidon_crh_item_t3(D, ark, mds, in0, in1, k, idx));
+}
+
+// =============================== any t: LDS "register file" ========================================
+// slot s, limb i, lane l -> dword (s*9 + i)*BLOCK + l : consecutive lanes hit consecutive banks.
+template <int BLOCK>
+struct LdsFile29 {
+    u32* base;
+    AKP_D FU load(u32 slot) const {
+        FU r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = base[(slot * 9 + i) * BLOCK + threadIdx.x];
+        return r;
+    }
+    AKP_D void store(u32 slot, const FU& v) const {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) base[(slot * 9 + i) * BLOCK + threadIdx.x] = v.l[i];
+    }
+};
+// state in buffer `cur` of the file (slots [cur*t, cur*t + t)); on return the state is in the updated `cur`.
+// `File` is LdsFile29<BLOCK> on the device; tests/host_harness instantiates it with a plain array.
 template <class File>
-AKP_HD void poseidon_permute_file(const PoseidonDims& D, const Fr* __restrict__ ark, const Fr* __restrict__ mds,
+AKP_HD void poseidon_permute_file(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds,
                                   const File& f, u32& cur) {
     const u32 T = D.t;
     const u32 half = D.full_rounds / 2;
@@ -79,38 +153,36 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const Fr* __restrict__ 
     for (u32 r = 0; r < R; ++r) {
         const bool full = (r < half) || (r >= half + D.partial_rounds);
         const u32 nsbox = full ? T : 1u;
-        const Fr* arkr = ark + (size_t)r * T;
+        const F29Pad* arkr = ark + (size_t)r * T;
         const u32 src = cur * T, dst = (cur ^ 1u) * T;
-        // ARK (:79-83) fused with the S-box (:66-77)
 #pragma unroll 1
-        for (u32 e = 0; e < T; ++e) {
-            Fr x = fr_add(f.load(src + e), arkr[e]);
-            if (e < nsbox) x = sbox_runtime(x, D.alpha);
+        for (u32 e = 0; e < T; ++e) {  // ARK fused with the S-box
+            FU x = f29_add(f.load(src + e), ldc(arkr + e));
+            if (e < nsbox) x = f29_pow_small(x, D.alpha);
             f.store(src + e, x);
         }
-        // MDS (:85-96): new[i] = sum_j state[j] * mds[i][j]
 #pragma unroll 1
-        for (u32 i = 0; i < T; ++i) {
-            const Fr* row = mds + (size_t)i * T;
-            Fr acc = fr_mul(f.load(src), row[0]);
+        for (u32 i = 0; i < T; ++i) {  // new[i] = sum_j state[j] * mds[i][j], 3 terms per reduction
+            const F29Pad* row = mds + (size_t)i * T;
+            FU acc = f29_zero<false>();
+            u32 j = 0;
 #pragma unroll 1
-            for (u32 j = 1; j < T; ++j) acc = fr_add(acc, fr_mul(f.load(src + j), row[j]));
-            f.store(dst + i, acc);
+            for (; j + 3 <= T; j += 3)
+                acc = f29_add(acc, f29_dot3(f.load(src + j), ldc(row + j), f.load(src + j + 1), ldc(row + j + 1),
+                                            f.load(src + j + 2), ldc(row + j + 2)));
+#pragma unroll 1
+            for (; j < T; ++j) acc = f29_add(acc, f29_mul(f.load(src + j), ldc(row + j)));
+            f.store(dst + i, f29_weak_norm(acc));  // <= 6 normalised terms summed: back below 2^29 + 8
         }
         cur ^= 1u;
     }
 }
-
-// Fixed-length sponge CRH of item `idx`: squeeze1(absorb(in[0..k))) on a fresh sponge.
-// Element e of item idx is in0[idx*k + e] (in1 == nullptr), or in0[idx] / in1[idx] for e = 0 / 1.
 template <class File>
-AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const Fr* __restrict__ ark, const Fr* __restrict__ mds, const File& f,
+AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds, const File& f,
                             const Fr* __restrict__ in0, const Fr* __restrict__ in1, size_t k, size_t idx) {
     u32 cur = 0;
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) f.store(e, fr_zero());  // PoseidonSponge::new :223-234
-    // absorb_internal from index 0 (:124-153) followed by the squeeze permutation (:324-344):
-    // ceil(k/rate) permutations, or one permutation of the zero state when k == 0 (:238-240).
+    for (u32 e = 0; e < D.t; ++e) f.store(e, f29_zero<false>());
     size_t done = 0;
     do {
         const size_t take = (k - done) < D.rate ? (k - done) : D.rate;
@@ -119,43 +191,36 @@ AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const Fr* __restrict__ ark, c
             const size_t e = done + j;
             const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
             const u32 slot = cur * D.t + D.capacity + (u32)j;
-            f.store(slot, fr_add(f.load(slot), load_fr_global(src)));
+            // the rate lane holds a weakly normalised MDS output (or zero): keep it that way
+            f.store(slot, f29_weak_norm(f29_add(f.load(slot), f29_from_wire<false>(load_fr_global(src)))));
         }
         done += take;
         poseidon_permute_file(D, ark, mds, f, cur);
     } while (done < k);
-    return f.load(cur * D.t + D.capacity);  // squeeze_internal(0, 1) :156-186
+    return f29_to_wire(f.load(cur * D.t + D.capacity));
 }
 
-// ---- kernels --------------------------------------------------------------------------
-// states: [n][t] Fr, permuted in place.
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D, const Fr* __restrict__ ark,
-                                                               const Fr* __restrict__ mds, Fr* states, size_t n) {
+__global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
+                                                               const F29Pad* __restrict__ mds, Fr* states, size_t n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    LdsFile<BLOCK> f{reinterpret_cast<uint4*>(smem)};
+    LdsFile29<BLOCK> f{reinterpret_cast<u32*>(smem)};
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= n) return;  // lanes never exchange data: no barriers anywhere
     Fr* st = states + idx * D.t;
     u32 cur = 0;
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) f.store(e, load_fr_global(st + e));
+    for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(load_fr_global(st + e)));
     poseidon_permute_file(D, ark, mds, f, cur);
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, f.load(cur * D.t + e));
+    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, f29_to_wire(f.load(cur * D.t + e)));
 }
-
-// Fixed-length sponge CRH: out[i] = squeeze1(absorb(in_i[0..k))).
-// Element j of input i is  (j < split ? in0 : in1)[i * stride_j ...]:
-//   CRH batch / Merkle levels: in0 = inputs, k elements contiguous per item  (in1 = nullptr)
-//   two-to-one batch:          in0 = left, in1 = right, k = 2
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, const Fr* __restrict__ ark,
-                                                           const Fr* __restrict__ mds, const Fr* __restrict__ in0,
-                                                           const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out,
-                                                           size_t n) {
+__global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
+                                                           const F29Pad* __restrict__ mds, const Fr* __restrict__ in0,
+                                                           const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out, size_t n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    LdsFile<BLOCK> f{reinterpret_cast<uint4*>(smem)};
+    LdsFile29<BLOCK> f{reinterpret_cast<u32*>(smem)};
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= n) return;
     store_fr_global(out + idx, poseidon_crh_item(D, ark, mds, f, in0, in1, k, idx));

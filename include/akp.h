@@ -19,8 +19,8 @@
  *     messages.  Affine points are x || y (2 x Fr).
  *   - Functions without suffix take HOST pointers (they stage through device scratch owned by
  *     the context and synchronise before returning).  Functions ending in `_dev` take DEVICE
- *     pointers plus a hipStream_t (passed as void*; NULL = the context's stream); they only
- *     enqueue work and never synchronise -- this is the zero-copy path used when inputs are
+ *     pointers plus a hipStream_t (passed as void*; NULL = HIP's default stream, used verbatim); they
+ *     only enqueue work and never synchronise -- this is the zero-copy path used when inputs are
  *     already resident in HBM (bench.py, torch tensors' data_ptr()).
  *   - Ownership: the caller owns every buffer it passes; the library owns parameter handles and
  *     its scratch.  A context is not thread-safe; distinct contexts are independent.

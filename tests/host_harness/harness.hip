@@ -8,15 +8,22 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "../../crypto_primitives_amd/csrc/fr.hpp"
+#include "../../crypto_primitives_amd/csrc/f29.hpp"
 #include "../../crypto_primitives_amd/csrc/poseidon_kernels.hpp"
 #include "../../crypto_primitives_amd/csrc/te_kernels.hpp"
 using namespace akp;
 
 struct HostFile {
-    Fr* slots;
-    Fr load(u32 s) const { return slots[s]; }
-    void store(u32 s, const Fr& v) const { slots[s] = v; }
+    FU* slots;
+    FU load(u32 s) const { return slots[s]; }
+    void store(u32 s, const FU& v) const { slots[s] = v; }
 };
+// wire-format parameter arrays -> internal form (what poseidon_convert_params_kernel does on the device)
+static std::vector<F29Pad> to29(const Fr* in, size_t n) {
+    std::vector<F29Pad> out(n);
+    for (size_t i = 0; i < n; ++i) f29_store_pad(&out[i], f29_from_wire<false>(in[i]));
+    return out;
+}
 static PoseidonDims mk(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap) {
     return PoseidonDims{rate + cap, rate, cap, rf, rp, alpha};
 }
@@ -26,43 +33,78 @@ void hh_fr_add(const Fr* a, const Fr* b, Fr* o) { *o = fr_add(*a, *b); }
 void hh_fr_sub(const Fr* a, const Fr* b, Fr* o) { *o = fr_sub(*a, *b); }
 void hh_fr_inv(const Fr* a, Fr* o) { *o = fr_inv(*a); }
 void hh_fr_pow(const Fr* a, uint64_t e, Fr* o) { *o = fr_pow_small(*a, e); }
+// radix-2^29 core, both flavours: out = [a*b, a^2, (a+b)*(c+d) (FU), (a-b)*c (FS), (a-b)*weak_norm(c+d) (FS), a^-1, a^17,
+//                                       dot3(a+c, b, b+d, c, c, d), canonical integer of a]
+void hh_f29_ops(const Fr* a, const Fr* b, const Fr* c, const Fr* d, Fr* o) {
+    const FU ua = f29_from_wire<false>(*a), ub = f29_from_wire<false>(*b), uc = f29_from_wire<false>(*c), ud = f29_from_wire<false>(*d);
+    const FS sa = f29_from_wire<true>(*a), sb = f29_from_wire<true>(*b), sc = f29_from_wire<true>(*c), sd = f29_from_wire<true>(*d);
+    o[0] = f29_to_wire(f29_mul(ua, ub));
+    o[1] = f29_to_wire(f29_sqr(sa));
+    o[2] = f29_to_wire(f29_mul(f29_add(ua, ub), f29_add(uc, ud)));
+    o[3] = f29_to_wire(f29_mul(f29_sub(sa, sb), sc));
+    o[4] = f29_to_wire(f29_mul(f29_sub(sa, sb), f29_weak_norm(f29_add(sc, sd))));
+    o[5] = f29_to_wire(f29_inv(sa));
+    o[6] = f29_to_wire(f29_pow_small(ua, 17));
+    o[7] = f29_to_wire(f29_dot3(f29_add(ua, uc), ub, f29_add(ub, ud), uc, uc, ud));
+    o[8] = f29_to_canonical_int(sa);
+    o[9] = f29_to_wire(f29_sqr(f29_add(ua, ub)));
+    o[10] = f29_to_wire(f29_neg(f29_sub(sa, sb)));
+}
+// worst-case limb patterns fed straight into the multipliers (internal limbs, not via the wire):
+// returns a*b/2^261 mod p canonical for FU (limbs given), and for FS.
+void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int is_signed, Fr* o) {
+    if (is_signed) { FS x, y; for (int i = 0; i < 9; ++i) { x.l[i] = (int32_t)al[i]; y.l[i] = (int32_t)bl[i]; }
+        o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); }
+    else { FU x, y; for (int i = 0; i < 9; ++i) { x.l[i] = al[i]; y.l[i] = bl[i]; }
+        o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
+}
 
 void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
-                         Fr* states, size_t n) {
+                         Fr* states, size_t n, int force_generic) {
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
-    std::vector<Fr> buf(2 * D.t);
+    const std::vector<F29Pad> a29 = to29(ark, (size_t)(rf + rp) * D.t), m29 = to29(mds, (size_t)D.t * D.t);
+    std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
     for (size_t i = 0; i < n; ++i) {
+        if (D.t == 3 && !force_generic) {  // the register-resident fast path
+            FU s0 = f29_from_wire<false>(states[i * 3]), s1 = f29_from_wire<false>(states[i * 3 + 1]), s2 = f29_from_wire<false>(states[i * 3 + 2]);
+            poseidon_permute_t3(D, a29.data(), m29.data(), s0, s1, s2);
+            states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
+            continue;
+        }
         u32 cur = 0;
-        for (u32 e = 0; e < D.t; ++e) f.store(e, states[i * D.t + e]);
-        poseidon_permute_file(D, ark, mds, f, cur);
-        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f.load(cur * D.t + e);
+        for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(states[i * D.t + e]));
+        poseidon_permute_file(D, a29.data(), m29.data(), f, cur);
+        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(cur * D.t + e));
     }
 }
 void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
-                     const Fr* in0, const Fr* in1, size_t k, Fr* out, size_t n) {
+                     const Fr* in0, const Fr* in1, size_t k, Fr* out, size_t n, int force_generic) {
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
-    std::vector<Fr> buf(2 * D.t);
+    const std::vector<F29Pad> a29 = to29(ark, (size_t)(rf + rp) * D.t), m29 = to29(mds, (size_t)D.t * D.t);
+    std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
-    for (size_t i = 0; i < n; ++i) out[i] = poseidon_crh_item(D, ark, mds, f, in0, in1, k, i);
+    for (size_t i = 0; i < n; ++i)
+        out[i] = (D.t == 3 && !force_generic) ? poseidon_crh_item_t3(D, a29.data(), m29.data(), in0, in1, k, i)
+                                              : poseidon_crh_item(D, a29.data(), m29.data(), f, in0, in1, k, i);
 }
 // returns number of LUT entries written
-size_t hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, Niels* lut) {
+size_t hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, NielsPad* lut) {
     if (kind == 0) {
         const u32 subs = (W + 3) / 4, n_sub = N * subs;
-        for (u32 i = 0; i < n_sub * 16; ++i) lut[i] = te_pedersen_lut_entry(gens, W, subs, i);
+        for (u32 i = 0; i < n_sub * 16; ++i) store_niels(lut + i, te_pedersen_lut_entry(gens, W, subs, i));
         return (size_t)n_sub * 16;
     }
-    for (u32 i = 0; i < W * N * 4; ++i) lut[i] = te_bh_lut_entry(gens, i);
+    for (u32 i = 0; i < W * N * 4; ++i) store_niels(lut + i, te_bh_lut_entry(gens, i));
     return (size_t)W * N * 4;
 }
-void hh_te_crh(int kind, const Niels* lut, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t W, uint32_t subs,
+void hh_te_crh(int kind, const NielsPad* lut, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t W, uint32_t subs,
                uint32_t steps, size_t lanes, Fr* out) {
-    std::vector<Fr> xyz(n * 3), prefix(n);
+    std::vector<F29Pad> xyz(n * 3), prefix(n);
     for (size_t i = 0; i < n; ++i) {
         Ext a = kind == 0 ? te_accumulate_item<0>(lut, msgs + i * msg_len, msg_len, W, subs, steps)
                           : te_accumulate_item<1>(lut, msgs + i * msg_len, msg_len, W, subs, steps);
-        xyz[3 * i] = a.X; xyz[3 * i + 1] = a.Y; xyz[3 * i + 2] = a.Z;
+        f29_store_pad(&xyz[3 * i], a.X); f29_store_pad(&xyz[3 * i + 1], a.Y); f29_store_pad(&xyz[3 * i + 2], a.Z);
     }
     for (size_t l = 0; l < lanes && l < n; ++l) {
         if (kind == 0) te_finalize_lane<0>(xyz.data(), prefix.data(), out, n, lanes, l);

@@ -18,8 +18,9 @@ vp = C.c_void_p
 @pytest.fixture(scope="module")
 def H():
     h = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "harness.so"))
-    h.hh_poseidon_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t]
-    h.hh_poseidon_crh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t]
+    h.hh_poseidon_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t, C.c_int]
+    h.hh_poseidon_crh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int]
+    h.hh_f29_raw_mul.argtypes = [vp, vp, C.c_int, vp]
     h.hh_te_build_lut.restype = C.c_size_t
     h.hh_te_build_lut.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, vp]
     h.hh_te_crh.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
@@ -47,23 +48,75 @@ def test_field_ops(H):
             H.hh_fr_pow(P(A), e, P(O)); assert ints(O)[0] == pow(a, e, ofr.P)
 
 
+def test_f29_core_ops(H):
+    """radix-2^29 lazy arithmetic (f29.hpp), unsigned and signed flavours, against python big-int."""
+    p = ofr.P
+    rng = ofr.SplitMix64(17)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 2 ** 254, 2 ** 128, 2 ** 29 - 1, 2 ** 29, 2 ** 232]
+    quads = [[rng.fr() for _ in range(4)] for _ in range(150)]
+    quads += [[a, b, a, b] for a in edge for b in edge] + [[p - 1] * 4, [0, p - 1, p - 1, p - 1], [p - 1, 0, p - 1, p - 1]]
+    for a, b, c, d in quads:
+        O = np.zeros((11, 4), np.uint64)
+        H.hh_f29_ops(P(mont([a])), P(mont([b])), P(mont([c])), P(mont([d])), P(O))
+        got = ints(O[:8]) + ints(O[9:])
+        exp = [a * b % p, a * a % p, (a + b) * (c + d) % p, (a - b) * c % p, (a - b) * (c + d) % p,
+               pow(a, -1, p) if a else 0, pow(a, 17, p), ((a + c) * b + (b + d) * c + c * d) % p,
+               (a + b) ** 2 % p, (b - a) % p]
+        assert got == exp, (a, b, c, d)
+        assert ofr.canon_array_to_ints(O[8:9])[0] == a
+
+
+def test_f29_worst_case_limbs(H):
+    """limb patterns at the documented headroom limits, fed straight into the multipliers."""
+    p = ofr.P
+    Rinv = pow(1 << 261, -1, p)
+
+    def val(l, signed):
+        return sum((int(x) - (1 << 32) if signed and x >= (1 << 31) else int(x)) << (29 * i) for i, x in enumerate(l))
+    M30, M29 = (1 << 30) - 1, (1 << 29) - 1
+    T = 1 << 25  # |value| < 2^258 keeps the top limb below 2^26
+    cases_u = [([M30] * 8 + [T], [M30] * 8 + [T]), ([M29] * 8 + [T], [M30] * 8 + [T]), ([0] * 9, [M30] * 8 + [T]), ([M30 + 8] * 8 + [3], [M29] * 8 + [5])]
+    for a, b in cases_u:
+        A, B = np.array(a, np.uint32), np.array(b, np.uint32)
+        O = np.zeros((3, 4), np.uint64)
+        H.hh_f29_raw_mul(P(A), P(B), 0, P(O))
+        va, vb = val(a, False), val(b, False)
+        got = ofr.canon_array_to_ints(O)
+        assert got[0] == va * vb * Rinv % p and got[1] == va * va * Rinv % p
+        if max(b) <= M29:
+            assert got[2] == 3 * va * vb * Rinv % p
+    neg = lambda x: (1 << 32) - x
+    cases_s = [([neg(M29)] * 8 + [neg(7)], [M30] * 8 + [9]), ([M30] * 8 + [neg(3)], [neg(M29)] * 8 + [neg(T)]), ([M29] * 8 + [T], [neg(M30)] * 8 + [0]),
+               ([neg(M29)] * 8 + [neg(T)], [neg(M29)] * 8 + [neg(T)])]
+    for a, b in cases_s:
+        A, B = np.array(a, np.uint32), np.array(b, np.uint32)
+        O = np.zeros((3, 4), np.uint64)
+        H.hh_f29_raw_mul(P(A), P(B), 1, P(O))
+        va, vb = val(a, True), val(b, True)
+        got = ofr.canon_array_to_ints(O)
+        assert got[0] == va * vb * Rinv % p
+        if max(abs(val([x], True)) for x in a) <= M29 + 1:  # squares need |limb| <= 2^29.7
+            assert got[1] == va * va * Rinv % p
+
+
+@pytest.mark.parametrize("generic", [0, 1])
 @pytest.mark.parametrize("rate,weights", [(2, False), (3, False), (8, False), (2, True), (5, True)])
-def test_poseidon_round_code(H, rate, weights):
+def test_poseidon_round_code(H, rate, weights, generic):
     c = po.get_default_poseidon_parameters(rate, weights)
     ark, mds = mont([x for r in c.ark for x in r]), mont([x for r in c.mds for x in r])
     t = rate + 1
     sts = [rand_fr(t, 40 + i) for i in range(3)]
     S = mont([x for s in sts for x in s])
-    H.hh_poseidon_permute(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(S), 3)
+    H.hh_poseidon_permute(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(S), 3, generic)
     assert ints(S) == [x for s in sts for x in po.permute(c, s)]
     for k in (0, 1, 2, 3, 5, 9):
         ins = [rand_fr(k, 90 + k + i) for i in range(2)]
         I = mont([x for s in ins for x in s]) if k else np.zeros((1, 4), np.uint64)
         O = np.zeros((2, 4), np.uint64)
-        H.hh_poseidon_crh(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(I), None, k, P(O), 2)
+        H.hh_poseidon_crh(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(I), None, k, P(O), 2, generic)
         assert ints(O) == [po.crh_evaluate(c, s) for s in ins], (rate, k)
     L, R, O = mont([1, 2]), mont([3, 4]), np.zeros((2, 4), np.uint64)
-    H.hh_poseidon_crh(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(L), P(R), 2, P(O), 2)
+    H.hh_poseidon_crh(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds), P(L), P(R), 2, P(O), 2, generic)
     assert ints(O) == [po.two_to_one_compress(c, 1, 3), po.two_to_one_compress(c, 2, 4)]
 
 
@@ -79,7 +132,7 @@ def test_pedersen_table_path(H, W, N):
     g = jj.pedersen_generators(11, W, N)
     G = gens_array(g)
     subs = (W + 3) // 4
-    lut = np.zeros((N * subs * 16, 3, 4), np.uint64)
+    lut = np.zeros((N * subs * 16, 36), np.uint32)
     assert H.hh_te_build_lut(0, P(G), W, N, P(lut)) == N * subs * 16
     for L in sorted({W * N // 8, 1, 0, max(W * N // 8 - 3, 0)}):
         n = 5
@@ -94,7 +147,7 @@ def test_pedersen_table_path(H, W, N):
 def test_bowe_hopwood_table_path(H, W, N):
     g = jj.bowe_hopwood_generators(12, W, N)
     G = gens_array(g)
-    lut = np.zeros((N * W * 4, 3, 4), np.uint64)
+    lut = np.zeros((N * W * 4, 36), np.uint32)
     H.hh_te_build_lut(1, P(G), W, N, P(lut))
     maxL = W * N * 3 // 8
     for L in sorted({maxL, 32 if 32 <= maxL else 1, 1, 0, 3, min(70, maxL)}):

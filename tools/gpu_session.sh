@@ -12,7 +12,7 @@ echo "== microbench ==";  timeout 300 tools/microbench > $OUT/microbench.log 2>&
 echo "== smoke ==";       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log
 echo "== pytest gpu ==";  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -15 $OUT/pytest_gpu.log
 echo "== bench ==";       timeout 900 python bench.py > $OUT/bench.log 2>&1; tail -3 $OUT/bench.log
-echo "== rocprof ==";     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 1 --merkle-log2 20 --no-cpu-baseline > $OUT/rocprof.log 2>&1); tail -3 $OUT/rocprof.log
+echo "== rocprof ==";     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 1 --merkle-log2 20 --no-cpu-baseline > $OUT/rocprof.log 2>&1); tail -3 $OUT/rocprof.log
 ls -R $OUT/prof 2>/dev/null | head -20
 for f in $(find $OUT/prof -name "*kernel_stats.csv" 2>/dev/null); do echo "--- $f"; head -12 $f; done
 # keep only the small summaries (<= 64 MiB merge limit)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../crypto_primitives_amd/csrc/fr.hpp"
+#include "../crypto_primitives_amd/csrc/f29.hpp"
 using namespace akp;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -34,6 +35,9 @@ __global__ void __launch_bounds__(256) name(u64* out, int iters, u32 x, u32 y) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;       \
 }
 #define I_MAD64(r) "v_mad_u64_u32 " #r ", vcc, %8, %9, " #r
+#define I_MADI64(r) "v_mad_i64_i32 " #r ", vcc, %8, %9, " #r
+#define I_LSHR64(r) "v_lshrrev_b64 " #r ", 29, " #r
+#define I_AND32(r) "v_and_b32_e32 " #r ", %8, " #r
 #define I_MAD64_SGPRDST(r) "v_mad_u64_u32 " #r ", s[10:11], %8, %9, " #r
 #define I_LSHLADD64(r) "v_lshl_add_u64 " #r ", " #r ", 0, " #r
 #define I_FMA64(r) "v_fma_f64 " #r ", " #r ", " #r ", " #r
@@ -53,6 +57,9 @@ __global__ void __launch_bounds__(256) name(u64* out, int iters, u32 x, u32 y) {
 
 KERNEL_U64(k_mad64, I_MAD64)
 KERNEL_U64(k_lshladd64, I_LSHLADD64)
+KERNEL_U64(k_madi64, I_MADI64)
+KERNEL_U64(k_lshr64, I_LSHR64)
+KERNEL_U32(k_and32, I_AND32)
 KERNEL_U64(k_fma64, I_FMA64)
 KERNEL_U64(k_mulf64, I_MULF64)
 KERNEL_U64(k_addf64, I_ADDF64)
@@ -113,6 +120,28 @@ __global__ void __launch_bounds__(256) k_fradd(Fr* x, int iters) {
     x[i] = a;
 }
 
+// radix-2^29 core (f29.hpp)
+template <bool S>
+__global__ void __launch_bounds__(256) k_f29_mul(Fr* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    F29T<S> a = f29_from_wire<S>(x[i]), b = f29_from_wire<S>(x[i ^ 1]);
+    for (int k = 0; k < iters; ++k) a = f29_mul(a, b);
+    x[i] = f29_to_wire(a);
+}
+__global__ void __launch_bounds__(256) k_f29_sqr(Fr* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    FU a = f29_from_wire<false>(x[i]);
+    for (int k = 0; k < iters; ++k) a = f29_sqr(a);
+    x[i] = f29_to_wire(a);
+}
+__global__ void __launch_bounds__(256) k_f29_dot3(Fr* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    FU a = f29_from_wire<false>(x[i]), b = f29_from_wire<false>(x[i ^ 1]), c = f29_from_wire<false>(x[i ^ 2]);
+    const FU m0 = f29_one<false>(), m1 = f29_k_in<false>(), m2 = f29_k_out<false>();
+    for (int k = 0; k < iters; ++k) { FU r = f29_dot3(a, m0, b, m1, c, m2); c = b; b = a; a = r; }
+    x[i] = f29_to_wire(a);
+}
+
 template <class F>
 static float time_ms(F&& launch, int reps = 3) {
     hipEvent_t e0, e1;
@@ -145,7 +174,7 @@ int main() {
     printf("%-22s %6s %12s %14s\n", "instr", "w/SIMD", "ms", "cyc/wave-instr");
     struct K { const char* name; void (*fn)(u64*, int, u32, u32); int per_iter; };
     K ks[] = {{"v_mad_u64_u32", k_mad64, 64}, {"v_mad_u64_u32 dep", k_mad64_dep, 64}, {"mad+addc pair(x2)", k_mac_pair, 64},
-              {"v_mul_lo_u32", k_mullo, 64}, {"v_mul_hi_u32", k_mulhi, 64}, {"v_add_u32", k_add32, 64}, {"v_add_co_u32", k_addco, 64},
+              {"v_mad_i64_i32", k_madi64, 64}, {"v_lshrrev_b64", k_lshr64, 64}, {"v_and_b32", k_and32, 64}, {"v_mul_lo_u32", k_mullo, 64}, {"v_mul_hi_u32", k_mulhi, 64}, {"v_add_u32", k_add32, 64}, {"v_add_co_u32", k_addco, 64},
               {"v_addc_co_u32", k_addc, 64}, {"v_add3_u32", k_add3, 64}, {"v_cndmask_b32", k_cndmask, 64}, {"v_alignbit_b32", k_alignbit, 64},
               {"v_mad_u32_u24", k_mad24, 64}, {"v_lshl_add_u64", k_lshladd64, 64}, {"v_fma_f32", k_fma32, 64}, {"v_pk_fma_f32", k_pkfma32, 64},
               {"v_fma_f64", k_fma64, 64}, {"v_mul_f64", k_mulf64, 64}, {"v_add_f64", k_addf64, 64}};
@@ -158,7 +187,8 @@ int main() {
         }
     }
     struct M { const char* name; void (*fn)(Fr*, int); int mul_per_iter; };
-    M ms_[] = {{"fr_mul asm", k_frmul_asm, 1}, {"fr_mul portable", k_frmul_portable, 1}, {"fr_add+fr_sub", k_fradd, 2}};
+    M ms_[] = {{"f29_mul unsigned", k_f29_mul<false>, 1}, {"f29_mul signed", k_f29_mul<true>, 1}, {"f29_sqr", k_f29_sqr, 1}, {"f29_dot3 (3 products)", k_f29_dot3, 1},
+               {"fr_mul asm", k_frmul_asm, 1}, {"fr_mul portable", k_frmul_portable, 1}, {"fr_add+fr_sub", k_fradd, 2}};
     const int miters = 2000;
     printf("%-22s %6s %12s %14s %16s\n", "field op", "w/SIMD", "ms", "cyc/wave-op", "ops/s (chip)");
     for (auto& k : ms_) {
