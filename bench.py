@@ -32,6 +32,8 @@ import torch  # noqa: E402  (imported before the product so both share one HIP r
 ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODMUL_PER_PERM_REF = 626        # reference-shaped count
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # measured: one v_mad_u64_u32 (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
+MADS_PER_PERM = 8 * (3 * (4 * 126 + 162) + 3 * 324) + 31 * ((4 * 126 + 162) + 3 * 324)  # v_mad per permutation in the kernel (f29.hpp counts)
 
 
 def main():
@@ -159,17 +161,21 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32x8 (255-bit Montgomery integers)",
+        "dtype": "u32 limbs (255-bit Montgomery integers, radix 2^29 x 9, 64-bit v_mad accumulation)",
         "data": "synthetic",
         "config": {"workload": "batched Poseidon permutation, BLS12-381 Fr, t=3 rate=2 alpha=17 RF=8 RP=31 "
                                "(default Grain-LFSR parameters), 2^%d states per GPU, in place in HBM" % args.log2_states,
                    "states_per_gpu": n, "parallelism": "shard%d (no collective)" % world},
         "parity_probe_bit_exact": parity,
-        "roofline": {"bound": "hbm", "kernel": "poseidon_permute_kernel<256>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "poseidon_permute_t3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PERM * n,
-                     "valu": {"note": "integer-ALU bound: ~%d Montgomery products per 192 B" % MODMUL_PER_PERM_REF,
-                              "modmul_per_s_per_gpu": MODMUL_PER_PERM_REF * n / kern_avg_s}},
+                     "valu": {"note": "the path is integer-ALU bound (~%d reference-shaped Montgomery products per 192 B); "
+                                      "fraction of the measured v_mad_u64_u32 issue peak spent on multiplies" % MODMUL_PER_PERM_REF,
+                              "ref_modmul_per_s": MODMUL_PER_PERM_REF * n / kern_avg_s,
+                              "v_mad_per_s": MADS_PER_PERM * n / kern_avg_s,
+                              "v_mad_peak_per_s": VALU_PEAK_WAVE_INSTR * 64,
+                              "frac_of_mad_issue_peak": MADS_PER_PERM * n / kern_avg_s / (VALU_PEAK_WAVE_INSTR * 64)}},
     }
     if merkle:
         out["merkle"] = merkle
