@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "fr.hpp"
 #include "f29.hpp"
 #include "poseidon_kernels.hpp"
+#include "poseidon_opt.hpp"
 #include "te_kernels.hpp"
 
 using namespace akp;
@@ -149,8 +151,27 @@ struct akp_poseidon {
     Fr* d_mds = nullptr;
     F29Pad* d_ark29 = nullptr;        // internal radix-2^29 form read by the kernels
     F29Pad* d_mds29 = nullptr;
+    // t == 3: sparse-partial-round form (poseidon_opt.hpp); null when not applicable
+    F29Pad* d_arkmod29 = nullptr;
+    F29Pad* d_mpre29 = nullptr;
+    F29Pad* d_sparse29 = nullptr;
 };
+static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) {
+    Fr* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, v.size() * sizeof(Fr)));
+    hipError_t e = hipMemcpy(tmp, v.data(), v.size() * sizeof(Fr), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(out, v.size() * sizeof(F29Pad));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(poseidon_convert_params_kernel, dim3((unsigned)((v.size() + 63) / 64)), dim3(64), 0, ctx->stream, tmp, *out, v.size());
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(AKP_ERR_HIP, "uploading optimised Poseidon constants: %s", hipGetErrorString(e));
+    return AKP_OK;
+}
 
+extern "C" void akp_poseidon_params_destroy(akp_poseidon* p);
 extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds, uint32_t partial_rounds, uint64_t alpha,
                                               uint32_t rate, uint32_t capacity, const uint64_t* ark, const uint64_t* mds,
                                               akp_poseidon** out) {
@@ -193,6 +214,18 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
             delete p;
             return fail(AKP_ERR_HIP, "uploading Poseidon parameters: %s", hipGetErrorString(e));
         }
+        if (t == 3 && !getenv("AKP_POSEIDON_DENSE")) {
+            const PoseidonOpt opt = poseidon_optimize(t, full_rounds, partial_rounds, p->ark, p->mds);
+            if (opt.ok) {
+                int32_t rc = upload_f29(ctx, opt.ark_mod, &p->d_arkmod29);
+                if (!rc) rc = upload_f29(ctx, opt.mpre, &p->d_mpre29);
+                if (!rc) rc = upload_f29(ctx, opt.sparse, &p->d_sparse29);
+                if (rc) {
+                    akp_poseidon_params_destroy(p);
+                    return rc;
+                }
+            }
+        }
     }
     *out = p;
     return AKP_OK;
@@ -204,6 +237,9 @@ extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (p->d_mds) (void)hipFree(p->d_mds);
     if (p->d_ark29) (void)hipFree(p->d_ark29);
     if (p->d_mds29) (void)hipFree(p->d_mds29);
+    if (p->d_arkmod29) (void)hipFree(p->d_arkmod29);
+    if (p->d_mpre29) (void)hipFree(p->d_mpre29);
+    if (p->d_sparse29) (void)hipFree(p->d_sparse29);
     delete p;
 }
 extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
@@ -332,10 +368,14 @@ static inline unsigned poseidon_block(u32 t) { return t <= 3 ? 256u : (t <= 7 ? 
 // LDS bytes of the generic kernel: two buffers of t elements, 9 dwords each, per lane
 static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)2 * t * 9 * 4 * B; }
 
+static inline PoseidonT3Consts t3_consts(const akp_poseidon* p) {
+    if (p->d_sparse29) return PoseidonT3Consts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29};
+    return PoseidonT3Consts{p->d_ark29, p->d_mds29, nullptr, nullptr};
+}
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
     if (p->dims.t == 3) {
-        hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
+        hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), d_states, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -351,7 +391,7 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
 static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
     if (p->dims.t == 3) {
-        hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
+        hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }

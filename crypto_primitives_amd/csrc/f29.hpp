@@ -52,6 +52,15 @@ typedef F29T<true> FS;
 
 AKP_HD u32 p29(int i) {
     constexpr u32 P[9] = {0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u};
+#if defined(__HIP_DEVICE_COMPILE__)
+    // p[1] = 2^29 - 8: left visible, hipcc turns m * p[1] into two 64-bit shift/subtract instructions; one
+    // v_mad_u64_u32 with the constant in an SGPR is cheaper (same issue cost per instruction on gfx950).
+    if (i == 1) {
+        u32 c = P[1];
+        asm("" : "+s"(c));
+        return c;
+    }
+#endif
     return P[i];
 }
 #define AKP_F29_CONST(name, ...)                       \

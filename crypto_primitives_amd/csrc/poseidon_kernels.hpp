@@ -51,29 +51,53 @@ __global__ void poseidon_convert_params_kernel(const Fr* __restrict__ in, F29Pad
 // =============================== t == 3: register-resident state ===================================
 // One full permutation (sponge/poseidon/mod.rs:98-121): per round ARK (:79-83), S-box x^alpha on every
 // lane (full rounds) or lane 0 only (partial rounds) (:66-77), then state = MDS * state (:85-96).
-// Limb bounds: MDS outputs are normalised (< 2^29); + round key (< 2^29) -> < 2^30, which is what
-// f29_sqr / f29_mul / f29_dot3 admit.
-AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds, FU& s0,
-                                FU& s1, FU& s2) {
+// When `sparse` is given the partial rounds run in the algebraically identical sparse form derived on the
+// host (poseidon_opt.hpp): one key add, one S-box, row 0 as a 3-term dot, lanes 1,2 += w_i * s; the full
+// round before the block applies `mpre`, and `ark` already carries the folded key residue.
+// Limb bounds: dot3 / product outputs are normalised (< 2^29); + round key (< 2^29) -> < 2^30, which is what
+// f29_sqr / f29_mul / f29_dot3 admit.  In the sparse block lanes 1,2 grow by < 2^29 per round and are
+// renormalised every second round (dot3 admits lanes < 1.46 * 2^30 next to a normalised lane 0).
+struct PoseidonT3Consts {
+    const F29Pad* ark;     // [R][3] round keys (with the residue folded in when sparse != nullptr)
+    const F29Pad* mds;     // [3][3]
+    const F29Pad* mpre;    // [3][3] or nullptr
+    const F29Pad* sparse;  // [RP][6] = q0, a00, u1, u2, w1, w2  or nullptr (dense partial rounds)
+};
+AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2) {
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
+    const bool opt = C.sparse != nullptr;
 #pragma unroll 1
     for (u32 r = 0; r < R; ++r) {
         const bool full = (r < half) || (r >= half + D.partial_rounds);
-        const F29Pad* a = ark + (size_t)r * 3;
-        s0 = f29_pow_small(f29_add(s0, ldc(a)), D.alpha);
-        s1 = f29_add(s1, ldc(a + 1));
-        s2 = f29_add(s2, ldc(a + 2));
-        if (full) {
-            s1 = f29_pow_small(s1, D.alpha);
-            s2 = f29_pow_small(s2, D.alpha);
+        if (full || !opt) {
+            const F29Pad* a = C.ark + (size_t)r * 3;
+            s0 = f29_pow_small(f29_add(s0, ldc(a)), D.alpha);
+            s1 = f29_add(s1, ldc(a + 1));
+            s2 = f29_add(s2, ldc(a + 2));
+            if (full) {
+                s1 = f29_pow_small(s1, D.alpha);
+                s2 = f29_pow_small(s2, D.alpha);
+            }
+            const F29Pad* m = (opt && r + 1 == half) ? C.mpre : C.mds;
+            const FU n0 = f29_dot3(s0, ldc(m + 0), s1, ldc(m + 1), s2, ldc(m + 2));
+            const FU n1 = f29_dot3(s0, ldc(m + 3), s1, ldc(m + 4), s2, ldc(m + 5));
+            const FU n2 = f29_dot3(s0, ldc(m + 6), s1, ldc(m + 7), s2, ldc(m + 8));
+            s0 = n0;
+            s1 = n1;
+            s2 = n2;
+        } else {
+            const u32 j = r - half;
+            const F29Pad* sp = C.sparse + (size_t)j * 6;
+            const FU s = f29_pow_small(f29_add(s0, ldc(sp)), D.alpha);
+            s0 = f29_dot3(s, ldc(sp + 1), s1, ldc(sp + 2), s2, ldc(sp + 3));
+            s1 = f29_add(s1, f29_mul(s, ldc(sp + 4)));
+            s2 = f29_add(s2, f29_mul(s, ldc(sp + 5)));
+            if ((j & 1u) || j + 1 == D.partial_rounds) {
+                s1 = f29_weak_norm(s1);
+                s2 = f29_weak_norm(s2);
+            }
         }
-        const FU n0 = f29_dot3(s0, ldc(mds + 0), s1, ldc(mds + 1), s2, ldc(mds + 2));
-        const FU n1 = f29_dot3(s0, ldc(mds + 3), s1, ldc(mds + 4), s2, ldc(mds + 5));
-        const FU n2 = f29_dot3(s0, ldc(mds + 6), s1, ldc(mds + 7), s2, ldc(mds + 8));
-        s0 = n0;
-        s1 = n1;
-        s2 = n2;
     }
 }
 // absorb: lane += input, renormalised so that the following ARK add stays below 2^30
@@ -86,8 +110,8 @@ AKP_HD void t3_add_slot(FU& s0, FU& s1, FU& s2, u32 slot, const FU& v) {
 // Element e of item idx is in0[idx*k + e] (in1 == nullptr), or in0[idx] / in1[idx] for e = 0 / 1.
 // absorb_internal from index 0 (:124-153) + the squeeze permutation (:324-344): ceil(k/rate)
 // permutations, or one permutation of the zero state when k == 0 (:238-240).
-AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds,
-                               const Fr* __restrict__ in0, const Fr* __restrict__ in1, size_t k, size_t idx) {
+AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C, const Fr* __restrict__ in0,
+                               const Fr* __restrict__ in1, size_t k, size_t idx) {
     FU s0 = f29_zero<false>(), s1 = s0, s2 = s0;  // PoseidonSponge::new :223-234
     size_t done = 0;
     do {
@@ -99,30 +123,28 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const F29Pad* __restrict__
             t3_add_slot(s0, s1, s2, D.capacity + (u32)j, f29_from_wire<false>(load_fr_global(src)));
         }
         done += take;
-        poseidon_permute_t3(D, ark, mds, s0, s1, s2);
+        poseidon_permute_t3(D, C, s0, s1, s2);
     } while (done < k);
     const FU out = D.capacity == 0 ? s0 : (D.capacity == 1 ? s1 : s2);  // squeeze_internal(0, 1) :156-186
     return f29_to_wire(out);
 }
 
-__global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
-                                                                 const F29Pad* __restrict__ mds, Fr* states, size_t n) {
+__global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D, PoseidonT3Consts C, Fr* states, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     Fr* st = states + idx * 3;
     FU s0 = f29_from_wire<false>(load_fr_global(st)), s1 = f29_from_wire<false>(load_fr_global(st + 1)),
        s2 = f29_from_wire<false>(load_fr_global(st + 2));
-    poseidon_permute_t3(D, ark, mds, s0, s1, s2);
+    poseidon_permute_t3(D, C, s0, s1, s2);
     store_fr_global(st, f29_to_wire(s0));
     store_fr_global(st + 1, f29_to_wire(s1));
     store_fr_global(st + 2, f29_to_wire(s2));
 }
-__global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
-                                                             const F29Pad* __restrict__ mds, const Fr* __restrict__ in0,
+__global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, PoseidonT3Consts C, const Fr* __restrict__ in0,
                                                              const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    store_fr_global(out + idx, poseidon_crh_item_t3(D, ark, mds, in0, in1, k, idx));
+    store_fr_global(out + idx, poseidon_crh_item_t3(D, C, in0, in1, k, idx));
 }
 
 // =============================== any t: LDS "register file" ========================================

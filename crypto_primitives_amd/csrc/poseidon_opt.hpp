@@ -1,0 +1,147 @@
+// poseidon_opt.hpp -- host-side derivation of the "sparse partial rounds" form of a Poseidon instance.
+//
+// The reference applies the dense t x t MDS matrix in every round (sponge/poseidon/mod.rs:85-121).  In a partial
+// round only lane 0 passes through the S-box, so the linear layers of consecutive partial rounds can be
+// re-associated (Poseidon paper, appendix on optimised implementations).  The result is the SAME function on field
+// elements -- outputs are identical canonical integers -- with t + (t-1) instead of t^2 constant products per
+// partial round and one round-key addition instead of t.
+//
+// Derivation used here (x = state, M = MDS, S_0 = S-box on lane 0, c^(j) = round keys of partial round j = 1..RP):
+//   every matrix A with invertible lower-right block A^ factors as  A = A'' * A',
+//       A' = diag(1, A^),   A'' = [[a00, v^T A^-1], [w, I]]        (a00, v, w, A^ the blocks of A),
+//   and A' commutes with S_0.  Going backwards from A_RP = M:   A_j = A''_j A'_j,   A_{j-1} = A'_j M.
+//   With y_j = A'_j x_{j-1}:   y_{j+1} = A''_j S_0(y_j + A'_j c^(j)),  y_{RP+1} = x_RP, and the full round that
+//   precedes the partial block applies M_pre = A_0 = A'_1 M instead of M.
+//   Round keys of lanes 1.. are pushed forward through the (linear) lanes: only q_j[0] is added in round j and
+//   the residue d is folded into the keys of the first full round after the block.
+// Layout of `sparse` per partial round (2t entries): [ q0, a00, u_1..u_{t-1} (first row), w_1..w_{t-1} (first column) ].
+#pragma once
+#include <vector>
+
+#include "fr.hpp"
+
+namespace akp {
+
+struct PoseidonOpt {
+    bool ok = false;
+    std::vector<Fr> ark_mod;  // [R][t]: original keys; row (half + RP) has the residue folded in
+    std::vector<Fr> mpre;     // [t][t]
+    std::vector<Fr> sparse;   // [RP][2t]
+};
+
+namespace optdetail {
+typedef std::vector<Fr> Mat;  // row-major n x n
+inline Mat matmul(const Mat& a, const Mat& b, unsigned n) {
+    Mat r((size_t)n * n, fr_zero());
+    for (unsigned i = 0; i < n; ++i)
+        for (unsigned j = 0; j < n; ++j) {
+            Fr acc = fr_zero();
+            for (unsigned k = 0; k < n; ++k) acc = fr_add(acc, fr_mul(a[(size_t)i * n + k], b[(size_t)k * n + j]));
+            r[(size_t)i * n + j] = acc;
+        }
+    return r;
+}
+// Gauss-Jordan inverse; returns false if singular
+inline bool matinv(const Mat& a, unsigned n, Mat& out) {
+    Mat m = a;
+    out.assign((size_t)n * n, fr_zero());
+    for (unsigned i = 0; i < n; ++i) out[(size_t)i * n + i] = fr_one();
+    for (unsigned col = 0; col < n; ++col) {
+        unsigned piv = col;
+        while (piv < n && fr_is_zero(m[(size_t)piv * n + col])) ++piv;
+        if (piv == n) return false;
+        if (piv != col)
+            for (unsigned j = 0; j < n; ++j) {
+                std::swap(m[(size_t)piv * n + j], m[(size_t)col * n + j]);
+                std::swap(out[(size_t)piv * n + j], out[(size_t)col * n + j]);
+            }
+        const Fr inv = fr_inv(m[(size_t)col * n + col]);
+        for (unsigned j = 0; j < n; ++j) {
+            m[(size_t)col * n + j] = fr_mul(m[(size_t)col * n + j], inv);
+            out[(size_t)col * n + j] = fr_mul(out[(size_t)col * n + j], inv);
+        }
+        for (unsigned i = 0; i < n; ++i) {
+            if (i == col) continue;
+            const Fr f = m[(size_t)i * n + col];
+            if (fr_is_zero(f)) continue;
+            for (unsigned j = 0; j < n; ++j) {
+                m[(size_t)i * n + j] = fr_sub(m[(size_t)i * n + j], fr_mul(f, m[(size_t)col * n + j]));
+                out[(size_t)i * n + j] = fr_sub(out[(size_t)i * n + j], fr_mul(f, out[(size_t)col * n + j]));
+            }
+        }
+    }
+    return true;
+}
+}  // namespace optdetail
+
+inline PoseidonOpt poseidon_optimize(unsigned t, unsigned full_rounds, unsigned partial_rounds, const std::vector<Fr>& ark,
+                                     const std::vector<Fr>& mds) {
+    using namespace optdetail;
+    PoseidonOpt o;
+    const unsigned half = full_rounds / 2, RP = partial_rounds, n1 = t - 1;
+    if (t < 2 || half == 0 || RP == 0) return o;  // needs a full round on each side of the partial block
+    struct Fac { Fr a00; std::vector<Fr> u, w; Mat hat; };
+    std::vector<Fac> fac(RP + 1);  // 1-based
+    Mat A = mds;
+    for (unsigned j = RP; j >= 1; --j) {
+        Fac f;
+        f.a00 = A[0];
+        std::vector<Fr> v(n1);
+        f.w.resize(n1);
+        f.hat.assign((size_t)n1 * n1, fr_zero());
+        for (unsigned i = 0; i < n1; ++i) {
+            v[i] = A[1 + i];
+            f.w[i] = A[(size_t)(1 + i) * t];
+            for (unsigned k = 0; k < n1; ++k) f.hat[(size_t)i * n1 + k] = A[(size_t)(1 + i) * t + 1 + k];
+        }
+        Mat hinv;
+        if (!matinv(f.hat, n1, hinv)) return o;  // singular block: keep the dense form
+        f.u.assign(n1, fr_zero());               // u^T = v^T * hat^-1
+        for (unsigned k = 0; k < n1; ++k) {
+            Fr acc = fr_zero();
+            for (unsigned i = 0; i < n1; ++i) acc = fr_add(acc, fr_mul(v[i], hinv[(size_t)i * n1 + k]));
+            f.u[k] = acc;
+        }
+        // A_{j-1} = A'_j * M,  A'_j = diag(1, hat)
+        Mat Ap((size_t)t * t, fr_zero());
+        Ap[0] = fr_one();
+        for (unsigned i = 0; i < n1; ++i)
+            for (unsigned k = 0; k < n1; ++k) Ap[(size_t)(1 + i) * t + 1 + k] = f.hat[(size_t)i * n1 + k];
+        A = matmul(Ap, mds, t);
+        fac[j] = std::move(f);
+    }
+    o.mpre = A;
+    o.ark_mod = ark;
+    o.sparse.assign((size_t)RP * 2 * t, fr_zero());
+    std::vector<Fr> d(t, fr_zero());  // pending constant vector (d[0] is always folded immediately)
+    for (unsigned j = 1; j <= RP; ++j) {
+        const Fac& f = fac[j];
+        const Fr* c = &ark[(size_t)(half + j - 1) * t];
+        // k_j = A'_j c^(j):  k[0] = c[0],  k[1..] = hat * c[1..];   q = d + k
+        std::vector<Fr> q(t);
+        q[0] = fr_add(d[0], c[0]);
+        for (unsigned i = 0; i < n1; ++i) {
+            Fr acc = fr_zero();
+            for (unsigned k = 0; k < n1; ++k) acc = fr_add(acc, fr_mul(f.hat[(size_t)i * n1 + k], c[1 + k]));
+            q[1 + i] = fr_add(d[1 + i], acc);
+        }
+        Fr* s = &o.sparse[(size_t)(j - 1) * 2 * t];
+        s[0] = q[0];
+        s[1] = f.a00;
+        for (unsigned i = 0; i < n1; ++i) {
+            s[2 + i] = f.u[i];
+            s[2 + n1 + i] = f.w[i];
+        }
+        // d_{j+1} = A''_j [0; q_rest]:  d[0] = u . q_rest,  d[1..] = q_rest
+        Fr acc = fr_zero();
+        for (unsigned i = 0; i < n1; ++i) acc = fr_add(acc, fr_mul(f.u[i], q[1 + i]));
+        d[0] = acc;
+        for (unsigned i = 0; i < n1; ++i) d[1 + i] = q[1 + i];
+    }
+    Fr* nxt = &o.ark_mod[(size_t)(half + RP) * t];  // first full round after the block
+    for (unsigned i = 0; i < t; ++i) nxt[i] = fr_add(nxt[i], d[i]);
+    o.ok = true;
+    return o;
+}
+
+}  // namespace akp

@@ -10,6 +10,7 @@
 #include "../../crypto_primitives_amd/csrc/fr.hpp"
 #include "../../crypto_primitives_amd/csrc/f29.hpp"
 #include "../../crypto_primitives_amd/csrc/poseidon_kernels.hpp"
+#include "../../crypto_primitives_amd/csrc/poseidon_opt.hpp"
 #include "../../crypto_primitives_amd/csrc/te_kernels.hpp"
 using namespace akp;
 
@@ -24,6 +25,21 @@ static std::vector<F29Pad> to29(const Fr* in, size_t n) {
     for (size_t i = 0; i < n; ++i) f29_store_pad(&out[i], f29_from_wire<false>(in[i]));
     return out;
 }
+// force_generic: 0 = t3 register path with sparse partial rounds (product default), 1 = generic file path,
+//                2 = t3 register path with dense partial rounds
+struct T3Host {
+    std::vector<F29Pad> ark, mds, mpre, sparse;
+    PoseidonT3Consts c;
+    T3Host(uint32_t rf, uint32_t rp, const Fr* a, const Fr* m, bool sparse_form) {
+        std::vector<Fr> av(a, a + (size_t)(rf + rp) * 3), mv(m, m + 9);
+        PoseidonOpt o;
+        if (sparse_form) o = poseidon_optimize(3, rf, rp, av, mv);
+        mds = to29(mv.data(), 9);
+        if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), 9); sparse = to29(o.sparse.data(), o.sparse.size());
+                    c = PoseidonT3Consts{ark.data(), mds.data(), mpre.data(), sparse.data()}; }
+        else { ark = to29(av.data(), av.size()); c = PoseidonT3Consts{ark.data(), mds.data(), nullptr, nullptr}; }
+    }
+};
 static PoseidonDims mk(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap) {
     return PoseidonDims{rate + cap, rate, cap, rf, rp, alpha};
 }
@@ -65,10 +81,11 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
     const std::vector<F29Pad> a29 = to29(ark, (size_t)(rf + rp) * D.t), m29 = to29(mds, (size_t)D.t * D.t);
     std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
+    T3Host* th = (D.t == 3 && force_generic != 1) ? new T3Host(rf, rp, ark, mds, force_generic == 0) : nullptr;
     for (size_t i = 0; i < n; ++i) {
-        if (D.t == 3 && !force_generic) {  // the register-resident fast path
+        if (th) {  // the register-resident fast path
             FU s0 = f29_from_wire<false>(states[i * 3]), s1 = f29_from_wire<false>(states[i * 3 + 1]), s2 = f29_from_wire<false>(states[i * 3 + 2]);
-            poseidon_permute_t3(D, a29.data(), m29.data(), s0, s1, s2);
+            poseidon_permute_t3(D, th->c, s0, s1, s2);
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
             continue;
         }
@@ -77,6 +94,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
         poseidon_permute_file(D, a29.data(), m29.data(), f, cur);
         for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(cur * D.t + e));
     }
+    delete th;
 }
 void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
                      const Fr* in0, const Fr* in1, size_t k, Fr* out, size_t n, int force_generic) {
@@ -84,9 +102,10 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     const std::vector<F29Pad> a29 = to29(ark, (size_t)(rf + rp) * D.t), m29 = to29(mds, (size_t)D.t * D.t);
     std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
+    T3Host* th = (D.t == 3 && force_generic != 1) ? new T3Host(rf, rp, ark, mds, force_generic == 0) : nullptr;
     for (size_t i = 0; i < n; ++i)
-        out[i] = (D.t == 3 && !force_generic) ? poseidon_crh_item_t3(D, a29.data(), m29.data(), in0, in1, k, i)
-                                              : poseidon_crh_item(D, a29.data(), m29.data(), f, in0, in1, k, i);
+        out[i] = th ? poseidon_crh_item_t3(D, th->c, in0, in1, k, i) : poseidon_crh_item(D, a29.data(), m29.data(), f, in0, in1, k, i);
+    delete th;
 }
 // returns number of LUT entries written
 size_t hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, NielsPad* lut) {

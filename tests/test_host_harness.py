@@ -99,7 +99,7 @@ def test_f29_worst_case_limbs(H):
             assert got[1] == va * va * Rinv % p
 
 
-@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("generic", [0, 1, 2])  # 0 = t3 sparse (default), 1 = generic LDS-file path, 2 = t3 dense
 @pytest.mark.parametrize("rate,weights", [(2, False), (3, False), (8, False), (2, True), (5, True)])
 def test_poseidon_round_code(H, rate, weights, generic):
     c = po.get_default_poseidon_parameters(rate, weights)

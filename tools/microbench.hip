@@ -142,6 +142,39 @@ __global__ void __launch_bounds__(256) k_f29_dot3(Fr* x, int iters) {
     x[i] = f29_to_wire(a);
 }
 
+// experiment: empty-asm barriers after every partial product keep ONE accumulator chain (hipcc otherwise splits
+// the chain for ILP and pays 15 extra 64-bit adds per product); the price is one s_nop per barrier.
+template <int MODE>
+__device__ __forceinline__ FU mulv(const FU& a, const FU& b) {
+    typedef u32 L; typedef u64 W;
+    W acc = 0; u32 m[9]; FU t;
+#define BAR_P() if (MODE == 2) asm("" : "+v"(acc));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) { acc += (W)a.l[i] * (W)b.l[k - i]; BAR_P() }
+#pragma unroll
+        for (int i = 0; i < k; ++i) { acc += (W)(L)m[i] * (W)(L)p29(k - i); BAR_P() }
+        m[k] = (0u - (u32)acc) & AKP_MASK29; acc += (W)(L)m[k]; acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) { acc += (W)a.l[i] * (W)b.l[k - i]; BAR_P() }
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) { acc += (W)(L)m[i] * (W)(L)p29(k - i); BAR_P() }
+        t.l[k - 9] = (L)((u32)acc & AKP_MASK29); acc >>= 29;
+    }
+    t.l[8] = (L)acc; return t;
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_f29_mulv(Fr* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    FU a = f29_from_wire<false>(x[i]), b = f29_from_wire<false>(x[i ^ 1]);
+    for (int k = 0; k < iters; ++k) a = mulv<MODE>(a, b);
+    x[i] = f29_to_wire(a);
+}
+
 template <class F>
 static float time_ms(F&& launch, int reps = 3) {
     hipEvent_t e0, e1;
@@ -187,7 +220,7 @@ int main() {
         }
     }
     struct M { const char* name; void (*fn)(Fr*, int); int mul_per_iter; };
-    M ms_[] = {{"f29_mul unsigned", k_f29_mul<false>, 1}, {"f29_mul signed", k_f29_mul<true>, 1}, {"f29_sqr", k_f29_sqr, 1}, {"f29_dot3 (3 products)", k_f29_dot3, 1},
+    M ms_[] = {{"f29_mul chain-split (hipcc)", k_f29_mulv<0>, 1}, {"f29_mul single chain+nops", k_f29_mulv<2>, 1}, {"f29_mul unsigned", k_f29_mul<false>, 1}, {"f29_mul signed", k_f29_mul<true>, 1}, {"f29_sqr", k_f29_sqr, 1}, {"f29_dot3 (3 products)", k_f29_dot3, 1},
                {"fr_mul asm", k_frmul_asm, 1}, {"fr_mul portable", k_frmul_portable, 1}, {"fr_add+fr_sub", k_fradd, 2}};
     const int miters = 2000;
     printf("%-22s %6s %12s %14s %16s\n", "field op", "w/SIMD", "ms", "cyc/wave-op", "ops/s (chip)");
