@@ -32,8 +32,12 @@ import torch  # noqa: E402  (imported before the product so both share one HIP r
 ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODMUL_PER_PERM_REF = 626        # reference-shaped count
+# HBM bytes per 2^20-state launch from the PMC passes of profiles/r01_s3/pmc_{FETCH,WRITE}_SIZE_counter_collection.csv
+# (separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 reports half of a wide coalesced read):
+# (2 * 50 300 KB + 98 304 KB) * 1024 per 2^20 permutations = 194.3 B per permutation  (algorithmic: 192 B)
+PMC_TRAFFIC_BYTES_PER_PERM = (2 * 50300.0 + 98304.0) * 1024 / (1 << 20)
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # measured: one v_mad_u64_u32 (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
-MADS_PER_PERM = 8 * (3 * (4 * 126 + 162) + 3 * 324) + 31 * ((4 * 126 + 162) + 3 * 324)  # v_mad per permutation in the kernel (f29.hpp counts)
+MADS_PER_PERM = 8 * (3 * (4 * 118 + 154) + 3 * 316) + 31 * ((4 * 118 + 154) + 316 + 2 * 154)  # v_mad per permutation (ISA counts: sqr 118, mul 154, dot3 316; sparse partial rounds)
 
 
 def main():
@@ -168,7 +172,8 @@ def main():
                    "states_per_gpu": n, "parallelism": "shard%d (no collective)" % world},
         "parity_probe_bit_exact": parity,
         "roofline": {"bound": "hbm", "kernel": "poseidon_permute_t3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_PERM * n,
+                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction (profiles/r01_s3)",
                      "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PERM * n,
                      "valu": {"note": "the path is integer-ALU bound (~%d reference-shaped Montgomery products per 192 B); "
                                       "fraction of the measured v_mad_u64_u32 issue peak spent on multiplies" % MODMUL_PER_PERM_REF,

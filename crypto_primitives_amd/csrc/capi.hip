@@ -655,13 +655,21 @@ struct akp_te_params {
     akp_ctx* ctx = nullptr;
     int kind = 0;
     u32 W = 0, N = 0;
-    u32 subs_per_window = 0;  // Pedersen: ceil(W / 4)
-    u32 n_units = 0;          // Pedersen: N * subs_per_window sub-windows; BH: N * W chunks
-    NielsPad* d_lut = nullptr;
+    u32 n_gen = 0;             // W * N flat generators
+    u32 digit_bits = 0;        // Pedersen: table digit width D (1..8)
+    u32 group = 1;             // Bowe-Hopwood: chunks per table step (1 or 3)
+    NielsPad* d_lut = nullptr;   // Pedersen: [ceil(n_gen/D)][2^D]; BH: triples [n_gen/3][256] (group 3) or singles
+    NielsPad* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]
 };
 static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN ? 2u : 1u; }
 static inline size_t te_input_bits(const akp_te_params* p) {  // max message bits before the reference panics
     return p->kind == AKP_TE_PEDERSEN ? (size_t)p->W * p->N : (size_t)p->W * p->N * 3;
+}
+static u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
+    const char* e = getenv(name);
+    if (!e) return dflt;
+    long v = strtol(e, nullptr, 10);
+    return (v < (long)lo || v > (long)hi) ? dflt : (u32)v;
 }
 
 extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
@@ -671,37 +679,47 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     if (W == 0 || N == 0) return fail(AKP_ERR_BAD_PARAMS, "empty window");
     if (kind == AKP_TE_BOWE_HOPWOOD && W > 63) return fail(AKP_ERR_BAD_PARAMS, "Bowe-Hopwood window size %u > 63 (bowe_hopwood/mod.rs:81-101)", W);
     const size_t n_gen = (size_t)W * N;
+    if (n_gen > (1u << 22)) return fail(AKP_ERR_BAD_PARAMS, "window %ux%u too large", W, N);
     for (size_t i = 0; i < 2 * n_gen; ++i)
         if (!fr_words_reduced(gens + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "generator coordinate %zu not reduced", i);
     HIP_TRY(hipSetDevice(ctx->device));
     akp_te_params* p = new akp_te_params();
-    p->ctx = ctx; p->kind = kind; p->W = W; p->N = N;
+    p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
     Fr* d_g = nullptr;
     hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
-    size_t entries = 0;
     if (kind == AKP_TE_PEDERSEN) {
-        p->subs_per_window = (W + 3) / 4;
-        p->n_units = N * p->subs_per_window;
-        entries = (size_t)p->n_units * 16;
+        // digit width: 8 bits unless the table would exceed ~64 MB (AKP_PEDERSEN_DIGIT_BITS overrides)
+        u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 8, 1, 8);
+        while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > ((size_t)64 << 20)) --D;
+        p->digit_bits = D;
+        const size_t entries = ((n_gen + D - 1) / D) << D;
+        if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, D, (u32)entries, p->d_lut);
+            e = hipGetLastError();
+        }
     } else {
-        p->subs_per_window = 1;
-        p->n_units = (u32)n_gen;
-        entries = n_gen * 4;
+        p->group = env_u32("AKP_BH_GROUP", 3, 1, 3) == 3 && n_gen >= 3 ? 3 : 1;
+        if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(NielsPad));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, p->d_lut1);
+            e = hipGetLastError();
+        }
+        if (p->group == 3) {
+            const size_t triples = n_gen / 3;
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut, triples * 256 * sizeof(NielsPad));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_build_bh_lut3, dim3((unsigned)((triples * 256 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)triples, p->d_lut);
+                e = hipGetLastError();
+            }
+        }
     }
-    if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
-    if (e == hipSuccess) {
-        const unsigned grid = (unsigned)((entries + 63) / 64);
-        if (kind == AKP_TE_PEDERSEN)
-            hipLaunchKernelGGL(te_build_pedersen_lut, dim3(grid), dim3(64), 0, ctx->stream, d_g, W, p->subs_per_window, p->n_units, p->d_lut);
-        else
-            hipLaunchKernelGGL(te_build_bh_lut, dim3(grid), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, p->d_lut);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_g) (void)hipFree(d_g);
     if (e != hipSuccess) {
         if (p->d_lut) (void)hipFree(p->d_lut);
+        if (p->d_lut1) (void)hipFree(p->d_lut1);
         delete p;
         return fail(AKP_ERR_HIP, "akp_te_params_create: %s", hipGetErrorString(e));
     }
@@ -713,18 +731,29 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipDeviceSynchronize();
     if (p->d_lut) (void)hipFree(p->d_lut);
+    if (p->d_lut1) (void)hipFree(p->d_lut1);
     delete p;
 }
 
-// number of table steps a message of msg_len bytes touches (later digits are zero / absent):
-// Pedersen pads with zero bytes (contribute the identity); Bowe-Hopwood stops at ceil(bits/3) chunks.
-static u32 te_steps(const akp_te_params* p, size_t msg_len) {
+// table steps a message of msg_len bytes touches (later digits are zero / absent): Pedersen pads with zero
+// bytes (those digits select the identity); Bowe-Hopwood stops at ceil(bits/3) chunks = `groups` triples +
+// left-over singles.
+static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32* n_steps) {
     const size_t bits = msg_len * 8;
     if (p->kind == AKP_TE_PEDERSEN) {
-        const size_t windows = std::min<size_t>((bits + p->W - 1) / p->W, p->N);
-        return (u32)(windows * p->subs_per_window);
+        const size_t used = std::min<size_t>(bits, p->n_gen);
+        *n_groups = 0;
+        *n_steps = (u32)((used + p->digit_bits - 1) / p->digit_bits);
+        return;
     }
-    return (u32)std::min<size_t>((bits + 2) / 3, (size_t)p->n_units);
+    const size_t chunks = std::min<size_t>((bits + 2) / 3, (size_t)p->n_gen);
+    if (p->group == 3) {
+        *n_groups = (u32)(chunks / 3);
+        *n_steps = (u32)(chunks / 3 + chunks % 3);
+    } else {
+        *n_groups = 0;
+        *n_steps = (u32)chunks;
+    }
 }
 // accumulate + finalize on device buffers.  scratch: SCR_E (xyz), SCR_F (prefix)
 static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s) {
@@ -734,12 +763,13 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     void *xyz = nullptr, *prefix = nullptr;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz)) return rc;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix)) return rc;
-    const u32 steps = te_steps(p, msg_len);
+    u32 groups = 0, steps = 0;
+    te_steps(p, msg_len, &groups, &steps);
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (p->kind == AKP_TE_PEDERSEN)
-        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (F29Pad*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
     else
-        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, d_msgs, msg_len, p->W, p->subs_per_window, steps, (F29Pad*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
     HIP_TRY(hipGetLastError());
     // share one inversion among up to 64 messages per lane, but keep >= 64K lanes busy when n allows
     size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / 65536));

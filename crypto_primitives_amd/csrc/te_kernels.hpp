@@ -5,10 +5,14 @@
 //   bowe_hopwood::CRH::evaluate    crh/bowe_hopwood/mod.rs:114-186 (hot loop :161-181)
 // The reference walks the message bit by bit doing conditional projective additions of
 // `generators[i][j]`.  Here the hash is evaluated as a FIXED-BASE windowed multi-scalar sum:
-//   Pedersen:  H(m) = sum over sub-windows u of  LUT[u][digit_u],  digit = up to 4 message bits,
-//              LUT[u][v] = sum_j v_j * generators[i][4s + j]   (valid for arbitrary generators)
-//   Bowe-Hopwood: H(m) = x( sum over 3-bit chunks c of (-1)^b2 * LUT[c][b0 + 2 b1] ),
-//              LUT[c][k] = (k + 1) * generators[c / W][c % W]  (zero chunk contributes +g, :167)
+//   Pedersen:  message bit g selects generators[g / W][g % W], i.e. FLAT generator index g, so the window
+//              structure is irrelevant to evaluation and the digit width D is a free tuning parameter:
+//              H(m) = sum over digits u of LUT[u][digit_u],  digit_u = message bits [uD, uD + D),
+//              LUT[u][v] = sum_b v_b * G[uD + b]   (valid for arbitrary generators; D = 8 by default, so a
+//              4x256 hash is 128 mixed additions instead of the reference's ~512 conditional + 255 window adds)
+//   Bowe-Hopwood: chunk c (3 bits) uses flat generator G[c]; digit = (1 + b0 + 2 b1) * (-1)^b2 (zero chunk = +g, :167).
+//              Three chunks per step: sum_i (-1)^{s_i} (k_i+1) G[3u+i] = (-1)^{s_0} * LUT3[u][k0,k1,k2,s1^s0,s2^s0]
+//              (256 entries per triple); the <= 2 chunks left over at the end of a message use LUT1[c][k] = (k+1) G[c].
 // LUT entries are precomputed once per parameter set in halved "Niels" form ((y+x)/2, (y-x)/2, d*x*y),
 // so one step is a 7-product mixed addition (madd-2008-hwcd-3, a = -1, complete on Jubjub because d is a
 // non-square; every coordinate comes out scaled by 1/4, which the projective form absorbs and which
@@ -81,33 +85,31 @@ AKP_HD Niels niels_of_ext(const Ext& acc) {  // affine point of acc, as a table 
 }
 
 // ---- table construction (one-off per parameter set) ------------------------------------------
-// Pedersen: sub-window u = (window i, nibble s) covers generators[i][4s .. 4s+w), w = min(4, W-4s).
-// entry v in [0,16): sum of the generators selected by the bits of v (v = 0 -> identity).
-AKP_HD Niels te_pedersen_lut_entry(const Fr* __restrict__ gens_affine /*[N][W][2] wire*/, u32 W, u32 subs_per_window, u32 idx) {
-    const u32 u = idx >> 4, v = idx & 15u;
-    const u32 i = u / subs_per_window, s = u % subs_per_window;
-    const u32 w = (W - 4u * s) < 4u ? (W - 4u * s) : 4u;
+AKP_HD Niels te_niels_of_gen(const Fr* __restrict__ gens_affine, size_t g) {
+    return niels_from_affine(f29_from_wire<true>(load_fr_g(gens_affine + 2 * g)), f29_from_wire<true>(load_fr_g(gens_affine + 2 * g + 1)));
+}
+// Pedersen: digit u covers flat generators [uD, uD + D) (clipped to n_gen); entry v in [0, 2^D):
+// sum of the generators selected by the bits of v (v = 0 -> identity).
+AKP_HD Niels te_pedersen_lut_entry(const Fr* __restrict__ gens_affine /*[N*W][2] wire*/, u32 n_gen, u32 D, u32 idx) {
+    const u32 u = idx >> D, v = idx & ((1u << D) - 1u);
     Ext acc = ext_identity();
 #pragma unroll 1
-    for (u32 j = 0; j < w; ++j) {
-        if ((v >> j) & 1u) {
-            const Fr* g = gens_affine + ((size_t)i * W + 4u * s + j) * 2;
-            acc = te_madd(acc, niels_from_affine(f29_from_wire<true>(load_fr_g(g)), f29_from_wire<true>(load_fr_g(g + 1))));
-        }
+    for (u32 b = 0; b < D; ++b) {
+        const u32 g = u * D + b;
+        if (((v >> b) & 1u) && g < n_gen) acc = te_madd(acc, te_niels_of_gen(gens_affine, g));
     }
     return niels_of_ext(acc);
 }
-__global__ void te_build_pedersen_lut(const Fr* __restrict__ gens_affine, u32 W, u32 subs_per_window, u32 n_sub,
-                                      NielsPad* __restrict__ lut /*[n_sub][16]*/) {
+__global__ void te_build_pedersen_lut(const Fr* __restrict__ gens_affine, u32 n_gen, u32 D, u32 n_entries,
+                                      NielsPad* __restrict__ lut /*[n_digits][2^D]*/) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_sub * 16u) return;
-    store_niels(lut + idx, te_pedersen_lut_entry(gens_affine, W, subs_per_window, idx));
+    if (idx >= n_entries) return;
+    store_niels(lut + idx, te_pedersen_lut_entry(gens_affine, n_gen, D, idx));
 }
-// Bowe-Hopwood: chunk c uses generators flat index c; entry k in [0,4): (k+1) * g.
+// Bowe-Hopwood single-chunk table: entry k in [0,4): (k+1) * G[c].
 AKP_HD Niels te_bh_lut_entry(const Fr* __restrict__ gens_affine /*[N*W][2] wire*/, u32 idx) {
     const u32 c = idx >> 2, k = idx & 3u;
-    const Fr* g = gens_affine + (size_t)c * 2;
-    const Niels gn = niels_from_affine(f29_from_wire<true>(load_fr_g(g)), f29_from_wire<true>(load_fr_g(g + 1)));
+    const Niels gn = te_niels_of_gen(gens_affine, c);
     Ext acc = ext_identity();
 #pragma unroll 1
     for (u32 j = 0; j <= k; ++j) acc = te_madd(acc, gn);
@@ -118,50 +120,87 @@ __global__ void te_build_bh_lut(const Fr* __restrict__ gens_affine, u32 n_gen, N
     if (idx >= n_gen * 4u) return;
     store_niels(lut + idx, te_bh_lut_entry(gens_affine, idx));
 }
+// Bowe-Hopwood triple table: index = k0 | k1 << 2 | k2 << 4 | r1 << 6 | r2 << 7 with r_i = s_i ^ s_0:
+// (k0+1) G[3u] + (-1)^r1 (k1+1) G[3u+1] + (-1)^r2 (k2+1) G[3u+2].
+AKP_HD Niels te_bh_lut3_entry(const Fr* __restrict__ gens_affine, u32 idx) {
+    const u32 u = idx >> 8, v = idx & 255u;
+    Ext acc = ext_identity();
+#pragma unroll 1
+    for (u32 i = 0; i < 3; ++i) {
+        Niels gn = te_niels_of_gen(gens_affine, 3 * u + i);
+        if (i > 0 && ((v >> (5 + i)) & 1u)) gn = niels_neg(gn);
+        const u32 k = (v >> (2 * i)) & 3u;
+#pragma unroll 1
+        for (u32 j = 0; j <= k; ++j) acc = te_madd(acc, gn);
+    }
+    return niels_of_ext(acc);
+}
+__global__ void te_build_bh_lut3(const Fr* __restrict__ gens_affine, u32 n_triples, NielsPad* __restrict__ lut) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_triples * 256u) return;
+    store_niels(lut + idx, te_bh_lut3_entry(gens_affine, idx));
+}
 
 // ---- message bit access -----------------------------------------------------------------------
-// bits [o, o+w) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
+// bits [o, o+w) (w <= 9) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
 // bits past the end read as zero (Pedersen zero padding :91-99 / Bowe-Hopwood chunk padding :131-138).
 AKP_HD u32 msg_bits(const uint8_t* __restrict__ msg, size_t len, size_t o, u32 w) {
     const size_t byte = o >> 3;
     u32 v = 0;
     if (byte < len) v = msg[byte];
     if (byte + 1 < len) v |= (u32)msg[byte + 1] << 8;
+    if (byte + 2 < len) v |= (u32)msg[byte + 2] << 16;
     return (v >> (o & 7)) & ((1u << w) - 1u);
 }
 
 // ---- accumulate: one message per lane ------------------------------------------------------------
-// kind 0 (Pedersen): n_steps sub-windows, digit = msg_bits(i*W + 4s, w), entry lut[u*16 + digit].
-// kind 1 (Bowe-Hopwood): n_steps chunks, entry lut[c*4 + (b0 + 2 b1)], negated when b2.
+// Table entry of step u for this message.
+//  kind 0 (Pedersen): digit = msg_bits(u*D, D), entry lut[u << D | digit].
+//  kind 1 (Bowe-Hopwood): steps [0, n_groups) are chunk triples from lut (256 entries each), negated by s_0;
+//                         steps [n_groups, n_steps) are the left-over single chunks from lut1.
 template <int KIND>
-AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const uint8_t* __restrict__ msg, size_t msg_len, u32 W,
-                              u32 subs_per_window, u32 n_steps) {
+AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
+                           size_t msg_len, u32 D, u32 n_groups, u32 u) {
+    if (KIND == 0) {
+        const u32 digit = msg_bits(msg, msg_len, (size_t)u * D, D);
+        return load_niels(lut + (((size_t)u << D) | digit));
+    }
+    if (u < n_groups) {
+        const u32 b = msg_bits(msg, msg_len, (size_t)u * 9u, 9u);
+        const u32 s0 = (b >> 2) & 1u, s1 = (b >> 5) & 1u, s2 = (b >> 8) & 1u;
+        const u32 idx = (b & 3u) | (((b >> 3) & 3u) << 2) | (((b >> 6) & 3u) << 4) | ((s1 ^ s0) << 6) | ((s2 ^ s0) << 7);
+        const Niels q = load_niels(lut + (size_t)u * 256u + idx);
+        return s0 ? niels_neg(q) : q;
+    }
+    const u32 c = 3u * n_groups + (u - n_groups);
+    const u32 bits = msg_bits(msg, msg_len, (size_t)c * 3u, 3u);
+    const Niels q = load_niels(lut1 + (size_t)c * 4u + (bits & 3u));
+    return (bits & 4u) ? niels_neg(q) : q;
+}
+template <int KIND>
+AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
+                              size_t msg_len, u32 D, u32 n_groups, u32 n_steps) {
     Ext acc = ext_identity();
+    if (n_steps == 0) return acc;
+    Niels q = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 0);
 #pragma unroll 1
     for (u32 u = 0; u < n_steps; ++u) {
-        Niels q;
-        if (KIND == 0) {
-            const u32 i = u / subs_per_window, s = u % subs_per_window;
-            const u32 w = (W - 4u * s) < 4u ? (W - 4u * s) : 4u;
-            const u32 digit = msg_bits(msg, msg_len, (size_t)i * W + 4u * s, w);
-            q = load_niels(lut + (size_t)u * 16u + digit);
-        } else {
-            const u32 bits = msg_bits(msg, msg_len, (size_t)u * 3u, 3u);
-            q = load_niels(lut + (size_t)u * 4u + (bits & 3u));
-            if (bits & 4u) q = niels_neg(q);
-        }
+        // fetch the next entry before the ~2000-instruction addition that consumes the current one
+        const u32 un = (u + 1 < n_steps) ? u + 1 : u;
+        const Niels qn = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, un);
         acc = te_madd(acc, q);
+        q = qn;
     }
     return acc;
 }
 // writes the extended-coordinate sum (X, Y, Z), internal form, to xyz[idx*3 ..]
 template <int KIND>
-__global__ void __launch_bounds__(256) te_accumulate_kernel(const NielsPad* __restrict__ lut, const uint8_t* __restrict__ msgs,
-                                                           size_t msg_len, u32 W, u32 subs_per_window, u32 n_steps,
-                                                           F29Pad* __restrict__ xyz, size_t n) {
+__global__ void __launch_bounds__(256) te_accumulate_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
+                                                           const uint8_t* __restrict__ msgs, size_t msg_len, u32 D, u32 n_groups,
+                                                           u32 n_steps, F29Pad* __restrict__ xyz, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const Ext acc = te_accumulate_item<KIND>(lut, msgs + idx * msg_len, msg_len, W, subs_per_window, n_steps);
+    const Ext acc = te_accumulate_item<KIND>(lut, lut1, msgs + idx * msg_len, msg_len, D, n_groups, n_steps);
     f29_store_pad(xyz + idx * 3, acc.X);
     f29_store_pad(xyz + idx * 3 + 1, acc.Y);
     f29_store_pad(xyz + idx * 3 + 2, acc.Z);

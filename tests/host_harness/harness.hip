@@ -107,22 +107,25 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
         out[i] = th ? poseidon_crh_item_t3(D, th->c, in0, in1, k, i) : poseidon_crh_item(D, a29.data(), m29.data(), f, in0, in1, k, i);
     delete th;
 }
-// returns number of LUT entries written
-size_t hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, NielsPad* lut) {
+// LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
+// kind 1 -> Bowe-Hopwood single table lut1 [n_gen][4] and, when group == 3, triple table lut [n_gen/3][256].
+void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t D, uint32_t group, NielsPad* lut, NielsPad* lut1) {
+    const u32 n_gen = W * N;
     if (kind == 0) {
-        const u32 subs = (W + 3) / 4, n_sub = N * subs;
-        for (u32 i = 0; i < n_sub * 16; ++i) store_niels(lut + i, te_pedersen_lut_entry(gens, W, subs, i));
-        return (size_t)n_sub * 16;
+        const u32 entries = ((n_gen + D - 1) / D) << D;
+        for (u32 i = 0; i < entries; ++i) store_niels(lut + i, te_pedersen_lut_entry(gens, n_gen, D, i));
+        return;
     }
-    for (u32 i = 0; i < W * N * 4; ++i) store_niels(lut + i, te_bh_lut_entry(gens, i));
-    return (size_t)W * N * 4;
+    for (u32 i = 0; i < n_gen * 4; ++i) store_niels(lut1 + i, te_bh_lut_entry(gens, i));
+    if (group == 3)
+        for (u32 i = 0; i < (n_gen / 3) * 256; ++i) store_niels(lut + i, te_bh_lut3_entry(gens, i));
 }
-void hh_te_crh(int kind, const NielsPad* lut, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t W, uint32_t subs,
-               uint32_t steps, size_t lanes, Fr* out) {
+void hh_te_crh(int kind, const NielsPad* lut, const NielsPad* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
+               uint32_t groups, uint32_t steps, size_t lanes, Fr* out) {
     std::vector<F29Pad> xyz(n * 3), prefix(n);
     for (size_t i = 0; i < n; ++i) {
-        Ext a = kind == 0 ? te_accumulate_item<0>(lut, msgs + i * msg_len, msg_len, W, subs, steps)
-                          : te_accumulate_item<1>(lut, msgs + i * msg_len, msg_len, W, subs, steps);
+        Ext a = kind == 0 ? te_accumulate_item<0>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps)
+                          : te_accumulate_item<1>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps);
         f29_store_pad(&xyz[3 * i], a.X); f29_store_pad(&xyz[3 * i + 1], a.Y); f29_store_pad(&xyz[3 * i + 2], a.Z);
     }
     for (size_t l = 0; l < lanes && l < n; ++l) {

@@ -182,3 +182,54 @@ def test_sponge_bytes_bits_and_regression(cpa):
     x.absorb(field.fr([1, 2, 3])); y.absorb(field.fr([1, 2, 3]))
     part = np.concatenate([x.squeeze_native_field_elements(1), x.squeeze_native_field_elements(2)])
     assert np.array_equal(part, y.squeeze_native_field_elements(3))
+
+
+def _custom_cfg(cpa, rate, capacity, rf, rp, alpha, mds_ints, seed):
+    """a PoseidonConfig with caller-supplied parameters (PoseidonConfig::new, sponge/poseidon/mod.rs:191-217)"""
+    from crypto_primitives_amd import field
+    t = rate + capacity
+    ark_ints = rand_fr((rf + rp) * t, seed)
+    c = cpa.PoseidonConfig(rf, rp, alpha, field.fr(ark_ints).reshape(rf + rp, t, 4), field.fr([x for r in mds_ints for x in r]).reshape(t, t, 4), rate, capacity)
+    o = po.PoseidonConfig(rf, rp, alpha, [ark_ints[i * t:(i + 1) * t] for i in range(rf + rp)], mds_ints, rate, capacity)
+    return c, o
+
+
+@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5_random", "rp_even", "no_partial", "alpha3_t3"])
+def test_custom_t3_parameters(cpa, case):
+    """t = 3 instances other than the default one: exercises the sparse-partial-round derivation, its fallback to
+    dense rounds when a block is singular (the near-MDS matrix of merkle_tree/tests/test_utils.rs:643-653), other
+    capacities / exponents / round counts."""
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    near = [[1, 0, 1], [1, 1, 0], [0, 1, 1]]
+    rnd = [rand_fr(3, 70 + i) for i in range(3)]
+    c, o = {
+        "near_mds": lambda: _custom_cfg(cpa, 2, 1, 8, 29, 17, near, 1),
+        "rate1_cap2": lambda: _custom_cfg(cpa, 1, 2, 8, 31, 17, rnd, 2),
+        "alpha5_random": lambda: _custom_cfg(cpa, 2, 1, 8, 56, 5, rnd, 3),
+        "rp_even": lambda: _custom_cfg(cpa, 2, 1, 6, 10, 17, rnd, 4),
+        "no_partial": lambda: _custom_cfg(cpa, 2, 1, 8, 0, 5, rnd, 5),
+        "alpha3_t3": lambda: _custom_cfg(cpa, 2, 1, 2, 1, 3, rnd, 6),
+    }[case]()
+    ora = cref_poseidon(o)
+    n = 300
+    st = rand_fr_array(n * 3, 5).reshape(n, 3, 4)
+    assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st, threads=4).reshape(n, 3, 4))
+    assert ints(_permute(cpa, c, st[:1])) == po.permute(o, ints(st[0]))
+    for k in (0, 1, 2, 3, 5):
+        x = rand_fr_array(64 * max(k, 1), 50 + k).reshape(64, max(k, 1), 4)[:, :k]
+        got = pcrh.CRH.evaluate_batch(c, np.ascontiguousarray(x))
+        exp = np.repeat(ora.crh_empty(), 64, axis=0) if k == 0 else ora.crh_batch(np.ascontiguousarray(x), k)
+        assert np.array_equal(got, exp), (case, k)
+    l, r = rand_fr_array(32, 8), rand_fr_array(32, 9)
+    assert np.array_equal(pcrh.TwoToOneCRH.compress_batch(c, l, r), ora.two_to_one_batch(l, r))
+
+
+def test_generic_kernel_on_custom_t(cpa):
+    """t = 2 and t = 4 with non-default parameters (generic LDS-file kernel)"""
+    for rate, cap in ((1, 1), (2, 2), (3, 1)):
+        t = rate + cap
+        mds = [rand_fr(t, 200 + i + t) for i in range(t)]
+        c, o = _custom_cfg(cpa, rate, cap, 4, 7, 5, mds, 10 + t)
+        ora = cref_poseidon(o)
+        st = rand_fr_array(70 * t, 3).reshape(70, t, 4)
+        assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st).reshape(70, t, 4))

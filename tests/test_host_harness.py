@@ -21,9 +21,8 @@ def H():
     h.hh_poseidon_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t, C.c_int]
     h.hh_poseidon_crh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int]
     h.hh_f29_raw_mul.argtypes = [vp, vp, C.c_int, vp]
-    h.hh_te_build_lut.restype = C.c_size_t
-    h.hh_te_build_lut.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, vp]
-    h.hh_te_crh.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
+    h.hh_te_build_lut.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    h.hh_te_crh.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
     h.hh_te_serialize_pairs.argtypes = [vp, vp, C.c_uint32, C.c_size_t, vp, C.c_size_t]
     h.hh_fr_pow.argtypes = [vp, C.c_uint64, vp]
     return h
@@ -120,43 +119,48 @@ def test_poseidon_round_code(H, rate, weights, generic):
     assert ints(O) == [po.two_to_one_compress(c, 1, 3), po.two_to_one_compress(c, 2, 4)]
 
 
-def _steps(kind, W, N, L):
-    bits = 8 * L
-    if kind == 0:
-        return min((bits + W - 1) // W, N) * ((W + 3) // 4)
-    return min((bits + 2) // 3, W * N)
+def _pedersen_steps(n_gen, D, L):
+    return (min(8 * L, n_gen) + D - 1) // D
 
 
-@pytest.mark.parametrize("W,N", [(4, 256), (8, 20), (6, 10), (3, 7)])
-def test_pedersen_table_path(H, W, N):
+@pytest.mark.parametrize("W,N,D", [(4, 256, 8), (4, 256, 4), (8, 20, 8), (6, 10, 8), (6, 10, 5), (3, 7, 8), (3, 7, 1), (5, 13, 7)])
+def test_pedersen_table_path(H, W, N, D):
+    """digit width D is a free parameter of the table method (flat generator index == message bit index)"""
     g = jj.pedersen_generators(11, W, N)
     G = gens_array(g)
-    subs = (W + 3) // 4
-    lut = np.zeros((N * subs * 16, 36), np.uint32)
-    assert H.hh_te_build_lut(0, P(G), W, N, P(lut)) == N * subs * 16
+    n_gen = W * N
+    entries = ((n_gen + D - 1) // D) << D
+    if entries > 40000:  # the 4x256 / D=8 table is built on the GPU in the gpu tests; keep the CPU suite fast
+        pytest.skip("table too large for the CPU harness")
+    lut = np.zeros((entries, 36), np.uint32)
+    H.hh_te_build_lut(0, P(G), W, N, D, 1, P(lut), None)
     for L in sorted({W * N // 8, 1, 0, max(W * N // 8 - 3, 0)}):
         n = 5
         m = np.frombuffer(ofr.SplitMix64(L + W).bytes(max(L, 1) * n), dtype=np.uint8).copy()
         out = np.zeros((n, 2, 4), np.uint64)
-        H.hh_te_crh(0, P(lut), P(m), n, L, W, subs, _steps(0, W, N, L), 2, P(out))
+        H.hh_te_crh(0, P(lut), None, P(m), n, L, D, 0, _pedersen_steps(n_gen, D, L), 2, P(out))
         for i in range(n):
-            assert tuple(ints(out[i])) == pd.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, L)
+            assert tuple(ints(out[i])) == pd.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, D, L)
 
 
-@pytest.mark.parametrize("W,N", [(63, 9), (63, 8), (5, 3)])
-def test_bowe_hopwood_table_path(H, W, N):
+@pytest.mark.parametrize("W,N,group", [(63, 9, 1), (5, 3, 3), (5, 3, 1), (7, 2, 3), (63, 1, 3)])
+def test_bowe_hopwood_table_path(H, W, N, group):
     g = jj.bowe_hopwood_generators(12, W, N)
     G = gens_array(g)
-    lut = np.zeros((N * W * 4, 36), np.uint32)
-    H.hh_te_build_lut(1, P(G), W, N, P(lut))
+    n_gen = W * N
+    lut1 = np.zeros((n_gen * 4, 36), np.uint32)
+    lut3 = np.zeros((max(n_gen // 3, 1) * 256, 36), np.uint32)
+    H.hh_te_build_lut(1, P(G), W, N, 0, group, P(lut3), P(lut1))
     maxL = W * N * 3 // 8
-    for L in sorted({maxL, 32 if 32 <= maxL else 1, 1, 0, 3, min(70, maxL)}):
+    for L in sorted({maxL, 32 if 32 <= maxL else 1, 1, 0, 3, 2, 4, min(70, maxL), max(maxL - 1, 0)}):
         n = 4
         m = np.frombuffer(ofr.SplitMix64(L + W).bytes(max(L, 1) * n), dtype=np.uint8).copy()
         out = np.zeros((n, 4), np.uint64)
-        H.hh_te_crh(1, P(lut), P(m), n, L, W, 1, _steps(1, W, N, L), 3, P(out))
+        chunks = min((8 * L + 2) // 3, n_gen)
+        groups, steps = (chunks // 3, chunks // 3 + chunks % 3) if group == 3 else (0, chunks)
+        H.hh_te_crh(1, P(lut3), P(lut1), P(m), n, L, 0, groups, steps, 3, P(out))
         for i in range(n):
-            assert ints(out[i])[0] == bh.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, L)
+            assert ints(out[i])[0] == bh.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, group, L)
 
 
 def test_digest_serialisation(H):
@@ -176,3 +180,26 @@ def test_digest_serialisation(H):
     buf = np.zeros((2, 63), np.uint8)
     H.hh_te_serialize_pairs(P(d), None, 1, 63, P(buf), 2)
     assert bytes(buf[0]) == (jj.fq_serialize(pts[0][0]) + jj.fq_serialize(pts[1][0]))[:63]
+
+
+@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5", "rp_even", "no_partial"])
+def test_poseidon_t3_custom_parameters(H, case):
+    """sparse-partial-round derivation on non-default t = 3 instances, incl. the singular-block fallback"""
+    near = [[1, 0, 1], [1, 1, 0], [0, 1, 1]]
+    rnd = [rand_fr(3, 70 + i) for i in range(3)]
+    rate, cap, rf, rp, alpha, mdsi = {"near_mds": (2, 1, 8, 29, 17, near), "rate1_cap2": (1, 2, 8, 31, 17, rnd), "alpha5": (2, 1, 8, 56, 5, rnd),
+                                      "rp_even": (2, 1, 6, 10, 17, rnd), "no_partial": (2, 1, 8, 0, 5, rnd)}[case]
+    arki = rand_fr((rf + rp) * 3, 9)
+    c = po.PoseidonConfig(rf, rp, alpha, [arki[i * 3:(i + 1) * 3] for i in range(rf + rp)], mdsi, rate, cap)
+    ark, mds = mont(arki), mont([x for r in mdsi for x in r])
+    sts = [rand_fr(3, 40 + i) for i in range(2)]
+    for mode in (0, 2):
+        S = mont([x for s in sts for x in s])
+        H.hh_poseidon_permute(rf, rp, alpha, rate, cap, P(ark), P(mds), P(S), 2, mode)
+        assert ints(S) == [x for s in sts for x in po.permute(c, s)], (case, mode)
+        for k in (0, 1, 2, 3):
+            ins = [rand_fr(k, 90 + k)]
+            I = mont(ins[0]) if k else np.zeros((1, 4), np.uint64)
+            O = np.zeros((1, 4), np.uint64)
+            H.hh_poseidon_crh(rf, rp, alpha, rate, cap, P(ark), P(mds), P(I), None, k, P(O), 1, mode)
+            assert ints(O) == [po.crh_evaluate(c, ins[0])], (case, mode, k)
