@@ -53,7 +53,7 @@ def build_sharded(backend, local_leaves, n_leaves_global: int, dist=None):
          two_to_one_compress(left, right) -> numpy
        `dist` is torch.distributed (initialised) or None for a single process.
        Returns dict(root, top_nodes (G-1 heap-ordered), leaf_nodes, non_leaf_nodes (local))."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         leaf_nodes, non_leaf, root = backend.build_subtree(local_leaves)
         return {"root": root, "top_nodes": np.asarray(root)[None][:0], "leaf_nodes": leaf_nodes, "non_leaf_nodes": non_leaf}
     import torch

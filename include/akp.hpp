@@ -1,0 +1,286 @@
+// akp.hpp -- header-only C++17 mirror of the reference's operator surface over the C ABI (akp.h).
+//
+// The reference is Rust; its host-side API for this path is three traits with static functions.  This header
+// gives a C++ caller the same shapes (same names, argument meaning and error behaviour):
+//   CRHScheme            (crh/mod.rs:18-28)   -> struct with static setup / evaluate           (+ evaluate_batch)
+//   TwoToOneCRHScheme    (crh/mod.rs:31-51)   -> static evaluate / compress                      (+ *_batch)
+//   CryptographicSponge  (sponge/mod.rs:101-179) -> PoseidonSponge: absorb / squeeze_native_field_elements
+//   MerkleTree<P>        (merkle_tree/mod.rs:383-726) -> MerkleTree<Config>: new_ / root / height / generate_proof,
+//                                                  Path<Config>::verify
+// Errors: the reference returns Err(Error::...) or panics; here every failure throws akp::Error carrying the
+// ABI status (1 = IncorrectInputLength / length panic, 5 = leaf count not a power of two, 3 = no device...).
+// There is no CPU fallback behind any of these calls.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "akp.h"
+
+namespace akp {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error("akp error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int32_t rc) {
+    if (rc != AKP_OK) throw Error(rc, akp_last_error());
+}
+
+// ark-ff Fp256 memory image: 4 x u64 LE limbs, Montgomery form
+using FrWire = std::array<uint64_t, 4>;
+inline std::vector<FrWire> fr_from_canonical(const std::vector<FrWire>& c) {
+    std::vector<FrWire> m(c.size());
+    check(akp_fr_to_mont(c.empty() ? nullptr : c[0].data(), m.empty() ? nullptr : m[0].data(), c.size()));
+    return m;
+}
+inline FrWire fr_from_u64(uint64_t v) { return fr_from_canonical({FrWire{v, 0, 0, 0}})[0]; }
+inline std::vector<FrWire> fr_to_canonical(const std::vector<FrWire>& m) {
+    std::vector<FrWire> c(m.size());
+    check(akp_fr_from_mont(m.empty() ? nullptr : m[0].data(), c.empty() ? nullptr : c[0].data(), m.size()));
+    return c;
+}
+
+class Context {
+  public:
+    explicit Context(int device_id = 0) { check(akp_ctx_create(device_id, &h_)); }
+    ~Context() { akp_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    akp_ctx* get() const { return h_; }
+
+  private:
+    akp_ctx* h_ = nullptr;
+};
+
+// ---- PoseidonConfig<Fr> (sponge/poseidon/mod.rs:27-45) -----------------------------------------------------
+class PoseidonConfig {
+  public:
+    // PoseidonConfig::new (:191-217); ark is [full+partial][t], mds is [t][t], flattened
+    PoseidonConfig(const Context& ctx, uint32_t full_rounds, uint32_t partial_rounds, uint64_t alpha, const std::vector<FrWire>& mds,
+                   const std::vector<FrWire>& ark, uint32_t rate, uint32_t capacity) {
+        check(akp_poseidon_params_create(ctx.get(), full_rounds, partial_rounds, alpha, rate, capacity, ark[0].data(), mds[0].data(), &h_));
+        load_dims();
+    }
+    // Fr::get_default_poseidon_parameters(rate, optimized_for_weights) (traits.rs:148-155); throws where the
+    // reference returns None
+    static PoseidonConfig get_default_poseidon_parameters(const Context& ctx, uint32_t rate, bool optimized_for_weights) {
+        akp_poseidon* h = nullptr;
+        check(akp_poseidon_default_params(ctx.get(), rate, optimized_for_weights ? 1 : 0, &h));
+        return PoseidonConfig(h);
+    }
+    ~PoseidonConfig() { akp_poseidon_params_destroy(h_); }
+    PoseidonConfig(PoseidonConfig&& o) noexcept { *this = std::move(o); }
+    PoseidonConfig& operator=(PoseidonConfig&& o) noexcept {
+        std::swap(h_, o.h_);
+        full_rounds = o.full_rounds; partial_rounds = o.partial_rounds; alpha = o.alpha; rate = o.rate; capacity = o.capacity;
+        return *this;
+    }
+    PoseidonConfig(const PoseidonConfig&) = delete;
+    akp_poseidon* get() const { return h_; }
+    uint32_t full_rounds = 0, partial_rounds = 0, rate = 0, capacity = 0;
+    uint64_t alpha = 0;
+    std::vector<FrWire> ark() const { std::vector<FrWire> a((size_t)(full_rounds + partial_rounds) * (rate + capacity)); check(akp_poseidon_params_export(h_, a[0].data(), nullptr)); return a; }
+    std::vector<FrWire> mds() const { std::vector<FrWire> m((size_t)(rate + capacity) * (rate + capacity)); check(akp_poseidon_params_export(h_, nullptr, m[0].data())); return m; }
+
+  private:
+    explicit PoseidonConfig(akp_poseidon* h) : h_(h) { load_dims(); }
+    void load_dims() { check(akp_poseidon_params_dims(h_, &full_rounds, &partial_rounds, &alpha, &rate, &capacity)); }
+    akp_poseidon* h_ = nullptr;
+};
+
+// ---- PoseidonSponge<Fr> (batch of sponges sharing one schedule; sponge/poseidon/mod.rs:54-63,220-345) ------
+class PoseidonSponge {
+  public:
+    // CryptographicSponge::new(&config)
+    explicit PoseidonSponge(const PoseidonConfig& cfg, size_t batch = 1) : batch_(batch) { check(akp_sponge_create(cfg.get(), batch, &h_)); }
+    ~PoseidonSponge() { akp_sponge_destroy(h_); }
+    PoseidonSponge(const PoseidonSponge&) = delete;
+    // absorb(&[Fr]) for each sponge of the batch: input is [batch][k]
+    void absorb(const std::vector<FrWire>& input) { check(akp_sponge_absorb(h_, input.empty() ? nullptr : input[0].data(), input.size() / batch_)); }
+    // FieldBasedCryptographicSponge::squeeze_native_field_elements(n): [batch][n]
+    std::vector<FrWire> squeeze_native_field_elements(size_t n) {
+        std::vector<FrWire> out(batch_ * n);
+        check(akp_sponge_squeeze(h_, out.empty() ? nullptr : out[0].data(), n));
+        return out;
+    }
+
+  private:
+    akp_sponge* h_ = nullptr;
+    size_t batch_;
+};
+
+namespace poseidon {
+// poseidon::CRH<Fr> (crh/poseidon/mod.rs:15-41): Input = [Fr], Output = Fr, Parameters = PoseidonConfig<Fr>
+struct CRH {
+    using Parameters = PoseidonConfig;
+    using Output = FrWire;
+    [[noreturn]] static Parameters setup() { throw std::logic_error("not implemented in the reference either (crh/poseidon/mod.rs:24-28)"); }
+    static std::vector<Output> evaluate_batch(const Parameters& p, const std::vector<FrWire>& inputs, size_t elems_per_input) {
+        const size_t n = elems_per_input ? inputs.size() / elems_per_input : 1;
+        std::vector<Output> out(n);
+        check(akp_poseidon_crh_batch(p.get(), inputs.empty() ? nullptr : inputs[0].data(), n, elems_per_input, out[0].data()));
+        return out;
+    }
+    static Output evaluate(const Parameters& p, const std::vector<FrWire>& input) { return evaluate_batch(p, input, input.size())[0]; }
+};
+// poseidon::TwoToOneCRH<Fr> (crh/poseidon/mod.rs:43-80)
+struct TwoToOneCRH {
+    using Parameters = PoseidonConfig;
+    using Output = FrWire;
+    static std::vector<Output> compress_batch(const Parameters& p, const std::vector<FrWire>& left, const std::vector<FrWire>& right) {
+        if (left.size() != right.size()) throw Error(AKP_ERR_BAD_LENGTH, "left and right batches differ in length");
+        std::vector<Output> out(left.size());
+        if (!left.empty()) check(akp_poseidon_two_to_one_batch(p.get(), left[0].data(), right[0].data(), left.size(), out[0].data()));
+        return out;
+    }
+    static Output compress(const Parameters& p, const FrWire& l, const FrWire& r) { return compress_batch(p, {l}, {r})[0]; }
+    static Output evaluate(const Parameters& p, const FrWire& l, const FrWire& r) { return compress(p, l, r); }
+};
+}  // namespace poseidon
+
+// ---- Pedersen / Bowe-Hopwood over Jubjub -------------------------------------------------------------------
+struct AffineWire { FrWire x, y; };  // ark_ed_on_bls12_381::EdwardsAffine coordinates
+template <int KIND>
+class TeParameters {  // pedersen::Parameters / bowe_hopwood::Parameters { generators } as affine points [N][W]
+  public:
+    TeParameters(const Context& ctx, uint32_t window_size, uint32_t num_windows, const std::vector<AffineWire>& generators)
+        : window_size(window_size), num_windows(num_windows) {
+        if (generators.size() != (size_t)window_size * num_windows) throw Error(AKP_ERR_BAD_PARAMS, "Incorrect pp size for window params");
+        check(akp_te_params_create(ctx.get(), KIND, window_size, num_windows, generators[0].x.data(), &h_));
+    }
+    ~TeParameters() { akp_te_params_destroy(h_); }
+    TeParameters(const TeParameters&) = delete;
+    akp_te_params* get() const { return h_; }
+    uint32_t window_size, num_windows;
+
+  private:
+    akp_te_params* h_ = nullptr;
+};
+namespace pedersen {
+using Parameters = TeParameters<AKP_TE_PEDERSEN>;
+struct CRH {  // crh/pedersen/mod.rs:58-130: Input = [u8], Output = affine point
+    using Output = AffineWire;
+    static std::vector<Output> evaluate_batch(const Parameters& p, const std::vector<uint8_t>& msgs, size_t msg_len) {
+        const size_t n = msg_len ? msgs.size() / msg_len : 1;
+        std::vector<Output> out(n);
+        check(akp_te_crh_batch(p.get(), msgs.data(), n, msg_len, out[0].x.data()));
+        return out;
+    }
+    static Output evaluate(const Parameters& p, const std::vector<uint8_t>& input) { return evaluate_batch(p, input, input.size())[0]; }
+};
+struct TwoToOneCRH {  // :149-198
+    using Output = AffineWire;
+    static Output evaluate(const Parameters& p, const std::vector<uint8_t>& l, const std::vector<uint8_t>& r) {
+        if (l.size() != r.size()) throw Error(AKP_ERR_BAD_LENGTH, "left and right input should be of equal length");
+        Output out;
+        check(akp_te_two_to_one_batch(p.get(), l.data(), r.data(), 1, l.size(), out.x.data()));
+        return out;
+    }
+    static Output compress(const Parameters& p, const Output& l, const Output& r) {
+        Output out;
+        check(akp_te_compress_batch(p.get(), l.x.data(), r.x.data(), 1, out.x.data()));
+        return out;
+    }
+};
+}  // namespace pedersen
+namespace bowe_hopwood {
+using Parameters = TeParameters<AKP_TE_BOWE_HOPWOOD>;
+struct CRH {  // crh/bowe_hopwood/mod.rs:75-187: Output = Fq (x coordinate)
+    using Output = FrWire;
+    static std::vector<Output> evaluate_batch(const Parameters& p, const std::vector<uint8_t>& msgs, size_t msg_len) {
+        const size_t n = msg_len ? msgs.size() / msg_len : 1;
+        std::vector<Output> out(n);
+        check(akp_te_crh_batch(p.get(), msgs.data(), n, msg_len, out[0].data()));
+        return out;
+    }
+    static Output evaluate(const Parameters& p, const std::vector<uint8_t>& input) { return evaluate_batch(p, input, input.size())[0]; }
+};
+struct TwoToOneCRH {  // :189-240
+    using Output = FrWire;
+    static Output evaluate(const Parameters& p, const std::vector<uint8_t>& l, const std::vector<uint8_t>& r) {
+        if (l.size() != r.size()) throw Error(AKP_ERR_BAD_LENGTH, "left and right input should be of equal length");
+        Output out;
+        check(akp_te_two_to_one_batch(p.get(), l.data(), r.data(), 1, l.size(), out.data()));
+        return out;
+    }
+    static Output compress(const Parameters& p, const Output& l, const Output& r) {
+        Output out;
+        check(akp_te_compress_batch(p.get(), l.data(), r.data(), 1, out.data()));
+        return out;
+    }
+};
+}  // namespace bowe_hopwood
+
+// ---- MerkleTree (merkle_tree/mod.rs) -----------------------------------------------------------------------
+// Config for Leaf = [Fr], poseidon CRH + TwoToOneCRH, IdentityDigestConverter (merkle_tree/tests/mod.rs:198-206)
+struct PoseidonFieldConfig {
+    using LeafParam = PoseidonConfig;
+    using TwoToOneParam = PoseidonConfig;
+    using Digest = FrWire;
+};
+template <class P>
+struct Path {  // merkle_tree::Path (:146-213)
+    typename P::Digest leaf_sibling_hash;
+    std::vector<typename P::Digest> auth_path;  // root side first, root excluded
+    size_t leaf_index = 0;
+    // Path::verify (:172-212)
+    bool verify(const typename P::LeafParam& leaf_params, const typename P::TwoToOneParam& two_params, const typename P::Digest& root,
+                const std::vector<FrWire>& leaf) const {
+        const FrWire claimed = poseidon::CRH::evaluate(leaf_params, leaf);
+        FrWire cur = (leaf_index & 1) == 0 ? poseidon::TwoToOneCRH::evaluate(two_params, claimed, leaf_sibling_hash)
+                                           : poseidon::TwoToOneCRH::evaluate(two_params, leaf_sibling_hash, claimed);
+        size_t index = leaf_index >> 1;
+        for (size_t level = auth_path.size(); level-- > 0;) {
+            cur = (index & 1) == 0 ? poseidon::TwoToOneCRH::compress(two_params, cur, auth_path[level])
+                                   : poseidon::TwoToOneCRH::compress(two_params, auth_path[level], cur);
+            index >>= 1;
+        }
+        return cur == root;
+    }
+};
+template <class P>
+class MerkleTree {  // merkle_tree::MerkleTree<P> (:383-726)
+  public:
+    // MerkleTree::new (:411-422): leaves is [n][leaf_len]; n must be a power of two > 1 (else Error code 5)
+    static MerkleTree new_(const typename P::LeafParam& leaf_params, const typename P::TwoToOneParam& two_params,
+                           const std::vector<FrWire>& leaves, size_t leaf_len) {
+        MerkleTree t;
+        const size_t n = leaf_len ? leaves.size() / leaf_len : 0;
+        t.leaf_nodes_.resize(n);
+        t.non_leaf_nodes_.resize(n ? n - 1 : 0);
+        check(akp_merkle_build_poseidon(leaf_params.get(), two_params.get(), leaves.empty() ? nullptr : leaves[0].data(), n, leaf_len,
+                                        n ? t.leaf_nodes_[0].data() : nullptr, n > 1 ? t.non_leaf_nodes_[0].data() : nullptr, nullptr));
+        t.height_ = 1;
+        while (((size_t)1 << (t.height_ - 1)) < n) ++t.height_;
+        return t;
+    }
+    typename P::Digest root() const { return non_leaf_nodes_[0]; }  // :526-528
+    size_t height() const { return height_; }                       // :531-533
+    const std::vector<typename P::Digest>& leaf_nodes() const { return leaf_nodes_; }
+    const std::vector<typename P::Digest>& non_leaf_nodes() const { return non_leaf_nodes_; }  // heap order, root first
+    // generate_proof (:572-579) / compute_auth_path (:547-569)
+    Path<P> generate_proof(size_t index) const {
+        Path<P> p;
+        p.leaf_index = index;
+        p.leaf_sibling_hash = leaf_nodes_[(index & 1) == 0 ? index + 1 : index - 1];
+        size_t cur = (index + ((size_t)1 << (height_ - 1)) - 1 - 1) >> 1;  // parent of the leaf's tree index
+        while (cur != 0) {
+            const size_t sib = (cur % 2 == 1) ? cur + 1 : cur - 1;
+            p.auth_path.push_back(non_leaf_nodes_[sib]);
+            cur = (cur - 1) >> 1;
+        }
+        std::vector<typename P::Digest> rev(p.auth_path.rbegin(), p.auth_path.rend());
+        p.auth_path.swap(rev);
+        return p;
+    }
+
+  private:
+    std::vector<typename P::Digest> leaf_nodes_, non_leaf_nodes_;
+    size_t height_ = 0;
+};
+
+}  // namespace akp

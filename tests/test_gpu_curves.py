@@ -164,3 +164,29 @@ def test_setup_generators(cpa):
     B = bowe_hopwood.CRH.setup(W, seed=6)
     gb = jj.bowe_hopwood_generators(6, 4, 8)
     assert field.to_ints(bowe_hopwood.CRH.evaluate(B, bytes(range(12))))[0] == obh.evaluate(gb, 4, 8, bytes(range(12)))
+
+
+def test_table_variants_agree(cpa):
+    """the table digit width (Pedersen) / chunk grouping (Bowe-Hopwood) are tuning knobs: every setting must give
+    the same digests (AKP_PEDERSEN_DIGIT_BITS / AKP_BH_GROUP are read when the parameter handle is created)."""
+    import os
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    g = jj.pedersen_generators(77, 5, 13)   # 65 generators: not a multiple of any digit width
+    gb = jj.bowe_hopwood_generators(78, 7, 5)  # 35 chunks: not a multiple of 3
+    m = _msgs(40, 8, 5)
+    mb = _msgs(40, 13, 6)
+    ref_p = ref_b = None
+    try:
+        for D, grp in ((8, 3), (4, 1), (7, 3), (1, 1), (3, 3)):
+            os.environ["AKP_PEDERSEN_DIGIT_BITS"], os.environ["AKP_BH_GROUP"] = str(D), str(grp)
+            dp = pedersen.CRH.evaluate_batch(pedersen.Parameters(gens_array(g)), m)
+            db = bowe_hopwood.CRH.evaluate_batch(bowe_hopwood.Parameters(gens_array(gb)), mb)
+            if ref_p is None:
+                ref_p, ref_b = dp, db
+                for i in range(0, 40, 13):
+                    assert tuple(ints(dp[i])) == opd.evaluate(g, 5, 13, bytes(m[i]))
+                    assert ints(db[i])[0] == obh.evaluate(gb, 7, 5, bytes(mb[i]))
+            assert np.array_equal(dp, ref_p) and np.array_equal(db, ref_b), (D, grp)
+    finally:
+        os.environ.pop("AKP_PEDERSEN_DIGIT_BITS", None)
+        os.environ.pop("AKP_BH_GROUP", None)
