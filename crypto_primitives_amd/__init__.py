@@ -6,7 +6,7 @@ is the host-side mirror of the reference interface for that path.  Importing it 
 built library (lib/libakp.so); nothing here falls back to the CPU.
 """
 from ._lib import lib, AkpError, IncorrectInputLength, NotPowerOfTwo, Context, default_context, LIB_PATH  # noqa: F401
-from . import field, params, sponge, crh, merkle_tree  # noqa: F401
+from . import field, params, sponge, crh, merkle_tree, commitment, serialize  # noqa: F401
 from .sponge import PoseidonConfig, PoseidonSponge, get_default_poseidon_parameters  # noqa: F401
 from .merkle_tree import MerkleTree, Path, MultiPath, PoseidonFieldConfig, PedersenByteConfig, BoweHopwoodByteConfig  # noqa: F401
 

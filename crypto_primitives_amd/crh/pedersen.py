@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-from .._lib import lib, check, default_context, TE_PEDERSEN, TE_BOWE_HOPWOOD
+from .._lib import lib, check, default_context, TE_PEDERSEN, TE_BOWE_HOPWOOD, IncorrectInputLength  # noqa: F401
 
 
 class Window:

@@ -46,6 +46,16 @@ class PoseidonFieldConfig:
     def two_to_one_compress(two_params, left, right):
         return _pos.TwoToOneCRH.compress_batch(two_params, left, right)
 
+    @staticmethod
+    def verify_abi(leaf_params, two_params, root, leaves, idx, sibs, auth, depth):
+        x = np.ascontiguousarray(leaves, dtype=np.uint64)
+        m = len(idx)
+        k = x.size // (4 * m)
+        ok = np.zeros(m, dtype=np.uint8)
+        check(lib.akp_merkle_verify_paths_poseidon(leaf_params.handle().h, two_params.handle().h, root.ctypes.data, x.ctypes.data, m, k,
+                                                   idx.ctypes.data, sibs.ctypes.data, auth.ctypes.data if depth else None, depth, ok.ctypes.data))
+        return ok
+
 
 class _ByteConfig:
     """Leaf = [u8], ByteDigestConverter (:67-78): digests are serialised uncompressed before the
@@ -74,6 +84,14 @@ class _ByteConfig:
     @classmethod
     def two_to_one_compress(cls, two_params, left, right):
         return cls.TwoToOneHash.compress_batch(two_params, left, right)
+
+    @classmethod
+    def verify_abi(cls, leaf_params, two_params, root, leaves, idx, sibs, auth, depth):
+        mm, m, L = _ped._as_msgs(leaves)
+        ok = np.zeros(m, dtype=np.uint8)
+        check(lib.akp_merkle_verify_paths_te(leaf_params.handle().h, two_params.handle().h, root.ctypes.data, mm.ctypes.data if mm.size else None,
+                                             m, L, idx.ctypes.data, sibs.ctypes.data, auth.ctypes.data if depth else None, depth, ok.ctypes.data))
+        return ok
 
 
 class PedersenByteConfig(_ByteConfig):
@@ -138,31 +156,27 @@ class Path:
 
 
 def verify_paths(config, leaf_params, two_params, root_hash, paths, leaves):
-    """Batched Path::verify: all paths advance one level per GPU launch."""
+    """Batched Path::verify (:172-212): one ABI call; all paths advance one level per GPU launch."""
     n = len(paths)
     if n == 0:
         return []
-    claimed = config.hash_leaves(leaf_params, leaves)
-    sib = np.stack([np.asarray(p.leaf_sibling_hash) for p in paths])
-    idx = np.array([p.leaf_index for p in paths], dtype=np.int64)
-    is_left = (idx & 1) == 0  # select_left_right_child (:367-381)
-    sel = is_left.reshape((n,) + (1,) * (claimed.ndim - 1))
-    left = np.where(sel, claimed, sib)
-    right = np.where(sel, sib, claimed)
-    cur = config.two_to_one_evaluate(two_params, left, right)
-    idx >>= 1
     depth = len(paths[0].auth_path)
     assert all(len(p.auth_path) == depth for p in paths)
-    for level in range(depth - 1, -1, -1):
-        sibs = np.stack([np.asarray(p.auth_path[level]) for p in paths])
-        is_left = (idx & 1) == 0
-        sel = is_left.reshape((n,) + (1,) * (cur.ndim - 1))
-        left = np.where(sel, cur, sibs)
-        right = np.where(sel, sibs, cur)
-        cur = config.two_to_one_compress(two_params, left, right)
-        idx >>= 1
-    root = np.asarray(root_hash)
-    return [bool(np.array_equal(cur[i], root)) for i in range(n)]
+    if isinstance(leaves, np.ndarray):
+        leaves = [leaves[i] for i in range(n)]
+    idx = np.array([p.leaf_index for p in paths], dtype=np.uint64)
+    sibs = np.ascontiguousarray(np.stack([np.asarray(p.leaf_sibling_hash) for p in paths]), dtype=np.uint64)
+    if depth:
+        auth = np.ascontiguousarray(np.stack([np.stack([np.asarray(a) for a in p.auth_path]) for p in paths]), dtype=np.uint64)
+    else:
+        auth = np.zeros(0, dtype=np.uint64)
+    root = np.ascontiguousarray(root_hash, dtype=np.uint64)
+    if isinstance(leaves[0], (bytes, bytearray)):
+        lv = [bytes(x) for x in leaves]
+    else:
+        lv = np.stack([np.ascontiguousarray(x, dtype=np.uint64 if config is PoseidonFieldConfig else np.uint8) for x in leaves])
+    ok = config.verify_abi(leaf_params, two_params, root, lv, idx, sibs, auth, depth)
+    return [bool(v) for v in ok]
 
 
 class MultiPath:
@@ -233,6 +247,21 @@ class MerkleTree:
 
     def generate_proof(self, index) -> Path:  # :572-579
         return Path(self.config, self.get_leaf_sibling_hash(index), self.compute_auth_path(index), index)
+
+    def generate_proofs(self, indexes):
+        """generate_proof for many leaves in one ABI call (akp_merkle_gather_paths)."""
+        idx = np.ascontiguousarray(list(indexes), dtype=np.uint64)
+        m = len(idx)
+        shp = self.config.digest_shape
+        fe = 2 if shp == (2, 4) else 1
+        depth = self._height - 2
+        sibs = np.empty((m,) + shp, dtype=np.uint64)
+        auth = np.empty((m, max(depth, 0)) + shp, dtype=np.uint64)
+        ln = np.ascontiguousarray(self.leaf_nodes, dtype=np.uint64)
+        nl = np.ascontiguousarray(self.non_leaf_nodes, dtype=np.uint64)
+        check(lib.akp_merkle_gather_paths(ln.ctypes.data, nl.ctypes.data, len(ln), fe, idx.ctypes.data, m, sibs.ctypes.data,
+                                          auth.ctypes.data if depth > 0 else None))
+        return [Path(self.config, sibs[i], [auth[i, j] for j in range(max(depth, 0))], int(idx[i])) for i in range(m)]
 
     def generate_multi_proof(self, indexes) -> MultiPath:  # :592-625
         idxs = sorted(set(indexes))

@@ -168,6 +168,29 @@ int32_t akp_merkle_build_te_dev(akp_te_params* leaf_params, akp_te_params* two_t
                                 size_t n_leaves, size_t leaf_len, uint64_t* d_leaf_nodes, uint64_t* d_non_leaf_nodes,
                                 void* stream);
 
+/* ---- Merkle proofs (merkle_tree/mod.rs:146-213, 536-579) -------------------------------------------- */
+/* MerkleTree::generate_proof for m leaf indices at once (get_leaf_sibling_hash :536-544 + compute_auth_path
+ * :547-569): pure index arithmetic over the heap-ordered arrays.  fe_per_digest = 1 (Poseidon / Bowe-Hopwood)
+ * or 2 (Pedersen).  auth_paths is [m][depth] digests, root side first, depth = log2(n_leaves) - 1.
+ * Host variant works on host arrays (no device needed); _dev gathers from a tree resident in HBM. */
+int32_t akp_merkle_gather_paths(const uint64_t* leaf_nodes, const uint64_t* non_leaf_nodes, size_t n_leaves,
+                                uint32_t fe_per_digest, const uint64_t* leaf_indices, size_t m,
+                                uint64_t* leaf_sibling_hashes, uint64_t* auth_paths);
+int32_t akp_merkle_gather_paths_dev(akp_ctx* ctx, const uint64_t* d_leaf_nodes, const uint64_t* d_non_leaf_nodes,
+                                    size_t n_leaves, uint32_t fe_per_digest, const uint64_t* d_leaf_indices, size_t m,
+                                    uint64_t* d_leaf_sibling_hashes, uint64_t* d_auth_paths, void* stream);
+/* Path::verify (merkle_tree/mod.rs:172-212) for m paths of equal depth in one call: leaf hash, then depth + 1
+ * two-to-one levels, all m paths advancing together on the GPU.  ok_out[i] = 1 iff path i reproduces `root`.
+ * leaves: m x leaf_len Fr (Poseidon) / m x leaf_len bytes (te).  All pointers are host pointers. */
+int32_t akp_merkle_verify_paths_poseidon(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* root,
+                                         const uint64_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indices,
+                                         const uint64_t* leaf_sibling_hashes, const uint64_t* auth_paths, size_t depth,
+                                         uint8_t* ok_out);
+int32_t akp_merkle_verify_paths_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint64_t* root,
+                                   const uint8_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indices,
+                                   const uint64_t* leaf_sibling_hashes, const uint64_t* auth_paths, size_t depth,
+                                   uint8_t* ok_out);
+
 #ifdef __cplusplus
 }
 #endif

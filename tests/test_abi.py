@@ -118,3 +118,25 @@ def test_seeded_generators_equal_oracle(derived):
     gb = params.bowe_hopwood_generators(0xA5A50005, 3, 2)
     gbo = jj.bowe_hopwood_generators(0xA5A50005, 3, 2)
     assert field.to_ints(gb) == [v for row in gbo for pt in row for v in pt]
+
+
+def test_gather_paths_host_matches_oracle_indexing():
+    """akp_merkle_gather_paths is pure index arithmetic (no GPU): compare with the oracle tree's compute_auth_path"""
+    import crypto_primitives_amd as cpa
+    from oracle import merkle as omk
+    n = 32
+    leaf_nodes = np.arange(n * 4, dtype=np.uint64).reshape(n, 4) + 1000
+    non_leaf = np.arange((n - 1) * 4, dtype=np.uint64).reshape(n - 1, 4)
+    t = omk.MerkleTree.__new__(omk.MerkleTree)
+    t.leaf_nodes = [tuple(x) for x in leaf_nodes]
+    t.non_leaf_nodes = [tuple(x) for x in non_leaf]
+    t.height = 6
+    idx = np.array([0, 1, 7, 16, 31], dtype=np.uint64)
+    sib = np.zeros((5, 4), np.uint64); auth = np.zeros((5, 4, 4), np.uint64)
+    assert cpa.lib.akp_merkle_gather_paths(leaf_nodes.ctypes.data, non_leaf.ctypes.data, n, 1, idx.ctypes.data, 5, sib.ctypes.data, auth.ctypes.data) == 0
+    for k, i in enumerate(idx):
+        assert tuple(sib[k]) == t.get_leaf_sibling_hash(int(i))
+        assert [tuple(a) for a in auth[k]] == t.compute_auth_path(int(i))
+    assert cpa.lib.akp_merkle_gather_paths(leaf_nodes.ctypes.data, non_leaf.ctypes.data, 24, 1, idx.ctypes.data, 5, sib.ctypes.data, auth.ctypes.data) == 5
+    bad = np.array([32], dtype=np.uint64)
+    assert cpa.lib.akp_merkle_gather_paths(leaf_nodes.ctypes.data, non_leaf.ctypes.data, n, 1, bad.ctypes.data, 1, sib.ctypes.data, auth.ctypes.data) == 2

@@ -1,0 +1,70 @@
+"""GPU tests of the SURVEY.md section 8(f) rows: Pedersen commitment, ark-serialize encodings."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import jubjub as jj, commitment as ocm, fr as ofr, poseidon as po  # noqa: E402
+from helpers import ints, gens_array, rand_fr_array  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import crypto_primitives_amd as m
+    assert m.lib.akp_device_count() >= 1
+    return m
+
+
+def test_pedersen_commitment_vs_oracle(cpa):
+    from crypto_primitives_amd.commitment import pedersen as cped
+    from crypto_primitives_amd.crh import pedersen
+
+    class W(pedersen.Window):
+        WINDOW_SIZE, NUM_WINDOWS = 4, 16  # 64-bit inputs
+    P = cped.Commitment.setup(W, seed=9)
+    g = jj.pedersen_generators(9, 4, 16)
+    rg = [row[0] for row in jj.pedersen_generators(9 ^ 0x5EED, 252, 1)][0:1]
+    rg = jj.pedersen_generators(9 ^ 0x5EED, 252, 1)[0]  # 252 doubling powers of one base
+    assert ints(P.randomness_generator[3]) == list(rg[3])
+    rng = ofr.SplitMix64(4)
+    msgs = [rng.bytes(8), rng.bytes(8), bytes(8), rng.bytes(5)]
+    rs = [rng.fr() % cped.SCALAR_MODULUS, 0, cped.SCALAR_MODULUS - 1, 12345]
+    got = cped.Commitment.commit_batch(P, msgs[:3], rs[:3])
+    for i in range(3):
+        assert tuple(ints(got[i])) == ocm.commit(g, rg, 4, 16, msgs[i], rs[i])
+    assert tuple(ints(cped.Commitment.commit(P, msgs[3], rs[3]))) == ocm.commit(g, rg, 4, 16, msgs[3], rs[3])
+    # hiding term really is r * base: commit(0-message, r) == r * randomness base
+    assert tuple(ints(cped.Commitment.commit(P, bytes(8), 77))) == jj.mul(rg[0], 77)
+    with pytest.raises(cpa.IncorrectInputLength):
+        cped.Commitment.commit(P, bytes(9), 1)
+
+
+def test_serialization_roundtrips(cpa):
+    from crypto_primitives_amd import serialize as ser, field
+    from crypto_primitives_amd.crh import pedersen
+    c = cpa.get_default_poseidon_parameters(2, False)
+    b = ser.serialize_poseidon_config(c)
+    o = po.get_default_poseidon_parameters(2, False)
+    # layout: 3 u64, then Vec<Vec<Fr>> ... ; first ark element sits after 3*8 + 8 + 8 bytes, canonical LE
+    assert int.from_bytes(b[0:8], "little") == 8 and int.from_bytes(b[8:16], "little") == 31 and int.from_bytes(b[16:24], "little") == 17
+    assert int.from_bytes(b[24:32], "little") == 39 and int.from_bytes(b[32:40], "little") == 3
+    assert int.from_bytes(b[40:72], "little") == o.ark[0][0]
+    assert len(b) == 24 + 8 + 39 * (8 + 96) + 8 + 3 * (8 + 96) + 16
+    c2 = ser.deserialize_poseidon_config(b)
+    assert np.array_equal(c2.ark, c.ark) and np.array_equal(c2.mds, c.mds) and (c2.rate, c2.capacity, c2.alpha) == (2, 1, 17)
+    leaves = rand_fr_array(16, 3).reshape(16, 1, 4)
+    tree = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c2, c2, leaves)
+    p = tree.generate_proof(5)
+    pb = ser.serialize_path(p)
+    assert len(pb) == 32 + 8 + 3 * 32 + 8 and int.from_bytes(pb[-8:], "little") == 5
+    assert ser.deserialize_path(pb, cpa.PoseidonFieldConfig).verify(c, c, tree.root(), leaves[5])
+    mp = tree.generate_multi_proof(range(16))
+    mp2 = ser.deserialize_multi_path(ser.serialize_multi_path(mp), cpa.PoseidonFieldConfig)
+    assert mp2.auth_paths_prefix_lenghts == mp.auth_paths_prefix_lenghts and mp2.verify(c, c, tree.root(), leaves)
+    g = jj.pedersen_generators(5, 4, 8)
+    P = pedersen.Parameters(gens_array(g))
+    pbytes = ser.serialize_te_parameters(P)
+    assert len(pbytes) == 8 + 8 * (8 + 4 * 64) and pbytes[16:48] == g[0][0][0].to_bytes(32, "little")
+    P2 = ser.deserialize_te_parameters(pbytes, pedersen.Parameters)
+    assert np.array_equal(P2.generators, P.generators)
+    assert np.array_equal(pedersen.CRH.evaluate(P2, b"abcd"), pedersen.CRH.evaluate(P, b"abcd"))

@@ -156,3 +156,34 @@ def test_poseidon_tree_2pow20_sampled(cpa):
     assert np.array_equal(t.non_leaf_nodes[bottom], exp)
     assert np.array_equal(t.leaf_nodes[:2048], ora.crh_batch(leaves[:2048], 1, threads=8))
     assert t.generate_proof(123457).verify(c, c, t.root(), leaves[123457])
+
+
+def test_batched_proofs_all_configs(cpa):
+    """generate_proofs (one gather call) == generate_proof per leaf; batched verify accepts exactly the valid ones"""
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    c = cpa.get_default_poseidon_parameters(2, False)
+    n = 64
+    leaves = rand_fr_array(n * 2, 9).reshape(n, 2, 4)
+    tree = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
+    proofs = tree.generate_proofs(range(n))
+    for i in (0, 1, 17, 63):
+        p = tree.generate_proof(i)
+        assert np.array_equal(proofs[i].leaf_sibling_hash, p.leaf_sibling_hash) and proofs[i].leaf_index == i
+        assert all(np.array_equal(a, b) for a, b in zip(proofs[i].auth_path, p.auth_path)) and len(p.auth_path) == 5
+    shuffled = leaves.copy(); shuffled[[3, 40]] = shuffled[[40, 3]]
+    ok = cpa.merkle_tree.verify_paths(cpa.PoseidonFieldConfig, c, c, tree.root(), proofs, shuffled)
+    assert ok == [i not in (3, 40) for i in range(n)]
+    # two-leaf tree: empty auth path
+    t2 = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves[:2])
+    assert all(cpa.merkle_tree.verify_paths(cpa.PoseidonFieldConfig, c, c, t2.root(), t2.generate_proofs([0, 1]), leaves[:2]))
+    gb = jj.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    B = bowe_hopwood.Parameters(gens_array(gb))
+    lv = _byte_leaves(16, 32, 3)
+    tb = cpa.MerkleTree.new(cpa.BoweHopwoodByteConfig, B, B, lv)
+    pb = tb.generate_proofs(range(16))
+    bad = lv.copy(); bad[5, 0] ^= 1
+    assert cpa.merkle_tree.verify_paths(cpa.BoweHopwoodByteConfig, B, B, tb.root(), pb, [bytes(x) for x in bad]) == [i != 5 for i in range(16)]
+    g = jj.pedersen_generators(0xA5A50004, 4, 256)
+    P = pedersen.Parameters(gens_array(g))
+    tp = cpa.MerkleTree.new(cpa.PedersenByteConfig, P, P, lv[:8])
+    assert all(cpa.merkle_tree.verify_paths(cpa.PedersenByteConfig, P, P, tp.root(), tp.generate_proofs(range(8)), [bytes(x) for x in lv[:8]]))
