@@ -125,7 +125,7 @@ AKP_HD F29T<S> f29_weak_norm(const F29T<S>& a) {
 // ---- Montgomery reduction tail shared by mul / sqr / dot: columns 0..8 have been folded into m[] ----
 #define AKP_F29_MSTEP()                           \
     m[k] = (0u - (u32)acc) & AKP_MASK29;          \
-    acc += (W)(L)m[k];                            \
+    acc += (W)(u64)m[k];                          \
     acc >>= 29;
 
 // a * b / 2^261 (mod p).  Output normalised.
@@ -141,7 +141,7 @@ AKP_HD F29T<S> f29_mul(const F29T<S>& a, const F29T<S>& b) {
 #pragma unroll
         for (int i = 0; i <= k; ++i) acc += (W)a.l[i] * (W)b.l[k - i];
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
         AKP_F29_MSTEP()
     }
 #pragma unroll
@@ -149,7 +149,7 @@ AKP_HD F29T<S> f29_mul(const F29T<S>& a, const F29T<S>& b) {
 #pragma unroll
         for (int i = k - 8; i < 9; ++i) acc += (W)a.l[i] * (W)b.l[k - i];
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
         t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
         acc >>= 29;
     }
@@ -174,7 +174,7 @@ AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
         for (int i = 0; 2 * i < k; ++i) acc += (W)a2[i] * (W)a.l[k - i];
         if ((k & 1) == 0) acc += (W)a.l[k / 2] * (W)a.l[k / 2];
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
         AKP_F29_MSTEP()
     }
 #pragma unroll
@@ -183,7 +183,7 @@ AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
         for (int i = k - 8; 2 * i < k; ++i) acc += (W)a2[i] * (W)a.l[k - i];
         if ((k & 1) == 0) acc += (W)a.l[k / 2] * (W)a.l[k / 2];
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (W)(L)m[i] * (W)(L)p29(k - i);
+        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
         t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
         acc >>= 29;
     }
@@ -208,7 +208,7 @@ AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const
             acc += (W)a2.l[i] * (W)b2.l[k - i];
         }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (W)m[i] * (W)p29(k - i);
+        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
         AKP_F29_MSTEP()
     }
 #pragma unroll
@@ -220,7 +220,7 @@ AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const
             acc += (W)a2.l[i] * (W)b2.l[k - i];
         }
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (W)m[i] * (W)p29(k - i);
+        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
         t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
         acc >>= 29;
     }

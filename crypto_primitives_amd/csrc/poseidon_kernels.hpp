@@ -125,7 +125,10 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
         done += take;
         poseidon_permute_t3(D, C, s0, s1, s2);
     } while (done < k);
-    const FU out = D.capacity == 0 ? s0 : (D.capacity == 1 ? s1 : s2);  // squeeze_internal(0, 1) :156-186
+    // squeeze_internal(0, 1) :156-186 -- limb-wise selects (an array select would go through scratch)
+    FU out;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.l[i] = D.capacity == 0 ? s0.l[i] : (D.capacity == 1 ? s1.l[i] : s2.l[i]);
     return f29_to_wire(out);
 }
 

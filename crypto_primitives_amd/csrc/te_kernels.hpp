@@ -182,15 +182,18 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
                               size_t msg_len, u32 D, u32 n_groups, u32 n_steps) {
     Ext acc = ext_identity();
     if (n_steps == 0) return acc;
-    Niels q = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 0);
+    // Two steps per iteration with two entry buffers: the entry of step u+1 is fetched before the ~2000-instruction
+    // addition that consumes the entry of step u, and no register copies are needed to rotate the buffers.
+    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 0);
+    u32 u = 0;
 #pragma unroll 1
-    for (u32 u = 0; u < n_steps; ++u) {
-        // fetch the next entry before the ~2000-instruction addition that consumes the current one
-        const u32 un = (u + 1 < n_steps) ? u + 1 : u;
-        const Niels qn = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, un);
-        acc = te_madd(acc, q);
-        q = qn;
+    for (; u + 2 <= n_steps; u += 2) {
+        const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, u + 1);
+        acc = te_madd(acc, q0);
+        q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, (u + 2 < n_steps) ? u + 2 : u + 1);
+        acc = te_madd(acc, q1);
     }
+    if (u < n_steps) acc = te_madd(acc, q0);
     return acc;
 }
 // writes the extended-coordinate sum (X, Y, Z), internal form, to xyz[idx*3 ..]
