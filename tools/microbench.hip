@@ -175,6 +175,30 @@ __global__ void __launch_bounds__(256) k_f29_mulv(Fr* x, int iters) {
     x[i] = f29_to_wire(a);
 }
 
+// ---- hand-written assembly F29 routines (tools/asm_microbench.hsaco) vs the same loops in C++ on raw internal limbs ----
+__global__ void k_to_internal(const Fr* w, F29Pad* x, size_t n) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f29_store_pad(x + i, f29_from_wire<false>(w[i]));
+}
+__global__ void __launch_bounds__(256) k_raw_mul(F29Pad* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    FU a = f29_load_pad<false>(x + i); const FU b = f29_load_pad<false>(x + (i ^ 1));
+    for (int k = 0; k < iters; ++k) a = f29_mul(a, b);
+    f29_store_pad(x + i, a);
+}
+__global__ void __launch_bounds__(256) k_raw_sqr(F29Pad* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    FU a = f29_load_pad<false>(x + i);
+    for (int k = 0; k < iters; ++k) a = f29_sqr(a);
+    f29_store_pad(x + i, a);
+}
+__global__ void __launch_bounds__(256) k_raw_dot3(F29Pad* x, int iters) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    FU a = f29_load_pad<false>(x + i), b = f29_load_pad<false>(x + (i ^ 1)), c = f29_load_pad<false>(x + (i ^ 2));
+    for (int k = 0; k < iters; ++k) { const FU r = f29_dot3(a, b, b, c, c, b); c = b; b = a; a = r; }
+    f29_store_pad(x + i, a);
+}
+
 template <class F>
 static float time_ms(F&& launch, int reps = 3) {
     hipEvent_t e0, e1;
@@ -231,6 +255,45 @@ int main() {
             double ops = (double)blocks * 256 * miters * k.mul_per_iter;
             double cyc = ms * 1e-3 * clk / ((double)miters * k.mul_per_iter * wps);
             printf("%-22s %6d %12.3f %14.1f %16.4g\n", k.name, wps, ms, cyc, ops / (ms * 1e-3));
+        }
+    }
+    // ---- asm vs C++ on raw internal limbs: bit-exact comparison, then timing ----
+    {
+        hipModule_t mod;
+        const char* path = getenv("AKP_ASM_HSACO") ? getenv("AKP_ASM_HSACO") : "tools/asm_microbench.hsaco";
+        if (hipModuleLoad(&mod, path) != hipSuccess) { printf("asm microbench: cannot load %s (skipped)\n", path); return 0; }
+        const size_t n = (size_t)cus * 8 * 256;
+        F29Pad *xa, *xc, *x0;
+        CK(hipMalloc(&xa, n * sizeof(F29Pad))); CK(hipMalloc(&xc, n * sizeof(F29Pad))); CK(hipMalloc(&x0, n * sizeof(F29Pad)));
+        CK(hipMemcpy(df, h.data(), sizeof(Fr) * h.size(), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_to_internal, dim3((unsigned)(n / 256)), dim3(256), 0, 0, df, x0, n);
+        CK(hipDeviceSynchronize());
+        struct AK { const char* name; const char* sym; void (*cpp)(F29Pad*, int); };
+        AK aks[] = {{"f29_mul", "asm_f29_mul", k_raw_mul}, {"f29_sqr", "asm_f29_sqr", k_raw_sqr}, {"f29_dot3", "asm_f29_dot3", k_raw_dot3}};
+        printf("%-26s (asm vs C++ on raw limbs)\n", "routine");
+        for (auto& k : aks) {
+            hipFunction_t fn; CK(hipModuleGetFunction(&fn, mod, k.sym));
+            int it = 7;  // correctness: a few dependent iterations, every lane compared
+            CK(hipMemcpy(xa, x0, n * sizeof(F29Pad), hipMemcpyDeviceToDevice)); CK(hipMemcpy(xc, x0, n * sizeof(F29Pad), hipMemcpyDeviceToDevice));
+            struct { void* p; int iters; } args{xa, it};
+            size_t asz = 12;
+            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+            CK(hipModuleLaunchKernel(fn, (unsigned)(n / 256), 1, 1, 256, 1, 1, 0, 0, nullptr, cfg));
+            hipLaunchKernelGGL(k.cpp, dim3((unsigned)(n / 256)), dim3(256), 0, 0, xc, it);
+            CK(hipDeviceSynchronize());
+            std::vector<F29Pad> ra(n), rc(n);
+            CK(hipMemcpy(ra.data(), xa, n * sizeof(F29Pad), hipMemcpyDeviceToHost)); CK(hipMemcpy(rc.data(), xc, n * sizeof(F29Pad), hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < n; ++i) for (int j = 0; j < 9; ++j) if (ra[i].w[j] != rc[i].w[j]) { ++bad; break; }
+            printf("%-26s parity asm==C++: %s (%zu of %zu lanes differ)\n", k.name, bad ? "FAIL" : "ok", bad, n);
+            for (int wps : {1, 2, 4, 8}) {
+                const int blocks = cus * wps;
+                args.iters = miters; args.p = xa;
+                float ms1 = time_ms([&] { CK(hipModuleLaunchKernel(fn, blocks, 1, 1, 256, 1, 1, 0, 0, nullptr, cfg)); });
+                float ms2 = time_ms([&] { hipLaunchKernelGGL(k.cpp, dim3(blocks), dim3(256), 0, 0, xc, miters); });
+                printf("%-26s %6d   asm %8.3f ms %8.1f cyc   C++ %8.3f ms %8.1f cyc\n", k.name, wps, ms1, ms1 * 1e-3 * clk / ((double)miters * wps), ms2,
+                       ms2 * 1e-3 * clk / ((double)miters * wps));
+            }
         }
     }
     return 0;
