@@ -657,7 +657,7 @@ struct akp_te_params {
     u32 W = 0, N = 0;
     u32 n_gen = 0;             // W * N flat generators
     u32 digit_bits = 0;        // Pedersen: table digit width D (1..8)
-    u32 group = 1;             // Bowe-Hopwood: chunks per table step (1 or 3)
+    u32 group = 1;             // Bowe-Hopwood: chunks per table step (1..4)
     NielsPad* d_lut = nullptr;   // Pedersen: [ceil(n_gen/D)][2^D]; BH: triples [n_gen/3][256] (group 3) or singles
     NielsPad* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]
 };
@@ -689,9 +689,11 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
     if (kind == AKP_TE_PEDERSEN) {
-        // digit width: 8 bits unless the table would exceed ~64 MB (AKP_PEDERSEN_DIGIT_BITS overrides)
-        u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 8, 1, 8);
-        while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > ((size_t)64 << 20)) --D;
+        // digit width: 13 bits (4x256: 79 steps, 93 MB table, served from the 256 MB Infinity Cache) unless the table
+        // would exceed 192 MB; AKP_PEDERSEN_DIGIT_BITS overrides (1..14).  Measured 2^20 x 128 B on MI355X:
+        // D = 4: 73 M/s, 8: 151, 10: 177, 12: 199, 13: 209, 14: 220 (175 MB table).
+        u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 13, 1, 14);
+        while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > ((size_t)192 << 20)) --D;
         p->digit_bits = D;
         const size_t entries = ((n_gen + D - 1) / D) << D;
         if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
@@ -700,17 +702,19 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             e = hipGetLastError();
         }
     } else {
-        p->group = env_u32("AKP_BH_GROUP", 3, 1, 3) == 3 && n_gen >= 3 ? 3 : 1;
+        u32 G = env_u32("AKP_BH_GROUP", 4, 1, 4);
+        while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(NielsPad) > ((size_t)192 << 20))) --G;
+        p->group = G;
         if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(NielsPad));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, p->d_lut1);
             e = hipGetLastError();
         }
-        if (p->group == 3) {
-            const size_t triples = n_gen / 3;
-            if (e == hipSuccess) e = hipMalloc(&p->d_lut, triples * 256 * sizeof(NielsPad));
+        if (G > 1) {
+            const size_t entries = (n_gen / G) << (3 * G - 1);
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(te_build_bh_lut3, dim3((unsigned)((triples * 256 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)triples, p->d_lut);
+                hipLaunchKernelGGL(te_build_bh_lutg, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, G, (u32)entries, p->d_lut);
                 e = hipGetLastError();
             }
         }
@@ -747,9 +751,9 @@ static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32*
         return;
     }
     const size_t chunks = std::min<size_t>((bits + 2) / 3, (size_t)p->n_gen);
-    if (p->group == 3) {
-        *n_groups = (u32)(chunks / 3);
-        *n_steps = (u32)(chunks / 3 + chunks % 3);
+    if (p->group > 1) {
+        *n_groups = (u32)(chunks / p->group);
+        *n_steps = (u32)(chunks / p->group + chunks % p->group);
     } else {
         *n_groups = 0;
         *n_steps = (u32)chunks;
@@ -769,7 +773,7 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (p->kind == AKP_TE_PEDERSEN)
         hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
     else
-        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->group, groups, steps, (F29Pad*)xyz, n);
     HIP_TRY(hipGetLastError());
     // share one inversion among up to 64 messages per lane, but keep >= 64K lanes busy when n allows
     size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / 65536));

@@ -8,17 +8,17 @@
 //   Pedersen:  message bit g selects generators[g / W][g % W], i.e. FLAT generator index g, so the window
 //              structure is irrelevant to evaluation and the digit width D is a free tuning parameter:
 //              H(m) = sum over digits u of LUT[u][digit_u],  digit_u = message bits [uD, uD + D),
-//              LUT[u][v] = sum_b v_b * G[uD + b]   (valid for arbitrary generators; D = 8 by default, so a
-//              4x256 hash is 128 mixed additions instead of the reference's ~512 conditional + 255 window adds)
+//              LUT[u][v] = sum_b v_b * G[uD + b]   (valid for arbitrary generators; D = 13 by default, so a
+//              4x256 hash is 79 mixed additions instead of the reference's ~512 conditional + 255 window adds)
 //   Bowe-Hopwood: chunk c (3 bits) uses flat generator G[c]; digit = (1 + b0 + 2 b1) * (-1)^b2 (zero chunk = +g, :167).
-//              Three chunks per step: sum_i (-1)^{s_i} (k_i+1) G[3u+i] = (-1)^{s_0} * LUT3[u][k0,k1,k2,s1^s0,s2^s0]
-//              (256 entries per triple); the <= 2 chunks left over at the end of a message use LUT1[c][k] = (k+1) G[c].
+//              G chunks per step (G = 4 by default): sum_i (-1)^{s_i} (k_i+1) G[Gu+i] = (-1)^{s_0} * LUTG[u][k_0..k_{G-1}, s_i^s_0]
+//              (2^(3G-1) entries per group); the < G chunks left over at the end of a message use LUT1[c][k] = (k+1) G[c].
 // LUT entries are precomputed once per parameter set in halved "Niels" form ((y+x)/2, (y-x)/2, d*x*y),
 // so one step is a 7-product mixed addition (madd-2008-hwcd-3, a = -1, complete on Jubjub because d is a
 // non-square; every coordinate comes out scaled by 1/4, which the projective form absorbs and which
-// removes the doubling of Z).  One message per lane; the LUT (<= 600 KB) is read through L1/L2 -- per step
-// all 64 lanes gather from the same <= 2.3 KB group, and a step is ~2000 VALU instructions, so the path is
-// integer-ALU bound, not memory bound.
+// removes the doubling of Z).  One message per lane; the tables (tens of MB) live in L2 / the 256 MB Infinity
+// Cache -- per step a wavefront gathers 64 x 144 B (the entry of step u+1 is fetched before the addition of step u)
+// against ~1900 VALU instructions, so the path stays integer-ALU bound.
 // Arithmetic: signed lazy radix-2^29 form (f29.hpp, FS): subtraction is limb-wise, no reduction anywhere.
 // The projective -> affine conversion (crh/pedersen/mod.rs:128, bowe_hopwood/mod.rs:185) is one field
 // inversion per message in the reference; here a separate pass shares one inversion among up to 64 messages
@@ -120,29 +120,30 @@ __global__ void te_build_bh_lut(const Fr* __restrict__ gens_affine, u32 n_gen, N
     if (idx >= n_gen * 4u) return;
     store_niels(lut + idx, te_bh_lut_entry(gens_affine, idx));
 }
-// Bowe-Hopwood triple table: index = k0 | k1 << 2 | k2 << 4 | r1 << 6 | r2 << 7 with r_i = s_i ^ s_0:
-// (k0+1) G[3u] + (-1)^r1 (k1+1) G[3u+1] + (-1)^r2 (k2+1) G[3u+2].
-AKP_HD Niels te_bh_lut3_entry(const Fr* __restrict__ gens_affine, u32 idx) {
-    const u32 u = idx >> 8, v = idx & 255u;
+// Bowe-Hopwood group table (G = 2..4 chunks per step): index = k_0 | k_1 << 2 | ... | r_1 << 2G | r_2 << (2G+1) ...
+// with r_i = s_i ^ s_0:   (k_0+1) G[Gu] + sum_{i>=1} (-1)^{r_i} (k_i+1) G[Gu+i];   2^(3G-1) entries per group.
+AKP_HD Niels te_bh_lutg_entry(const Fr* __restrict__ gens_affine, u32 G, u32 idx) {
+    const u32 bits = 3u * G - 1u;
+    const u32 u = idx >> bits, v = idx & ((1u << bits) - 1u);
     Ext acc = ext_identity();
 #pragma unroll 1
-    for (u32 i = 0; i < 3; ++i) {
-        Niels gn = te_niels_of_gen(gens_affine, 3 * u + i);
-        if (i > 0 && ((v >> (5 + i)) & 1u)) gn = niels_neg(gn);
+    for (u32 i = 0; i < G; ++i) {
+        Niels gn = te_niels_of_gen(gens_affine, (size_t)G * u + i);
+        if (i > 0 && ((v >> (2u * G + i - 1u)) & 1u)) gn = niels_neg(gn);
         const u32 k = (v >> (2 * i)) & 3u;
 #pragma unroll 1
         for (u32 j = 0; j <= k; ++j) acc = te_madd(acc, gn);
     }
     return niels_of_ext(acc);
 }
-__global__ void te_build_bh_lut3(const Fr* __restrict__ gens_affine, u32 n_triples, NielsPad* __restrict__ lut) {
+__global__ void te_build_bh_lutg(const Fr* __restrict__ gens_affine, u32 G, u32 n_entries, NielsPad* __restrict__ lut) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_triples * 256u) return;
-    store_niels(lut + idx, te_bh_lut3_entry(gens_affine, idx));
+    if (idx >= n_entries) return;
+    store_niels(lut + idx, te_bh_lutg_entry(gens_affine, G, idx));
 }
 
 // ---- message bit access -----------------------------------------------------------------------
-// bits [o, o+w) (w <= 9) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
+// bits [o, o+w) (w <= 16) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
 // bits past the end read as zero (Pedersen zero padding :91-99 / Bowe-Hopwood chunk padding :131-138).
 AKP_HD u32 msg_bits(const uint8_t* __restrict__ msg, size_t len, size_t o, u32 w) {
     const size_t byte = o >> 3;
@@ -156,8 +157,8 @@ AKP_HD u32 msg_bits(const uint8_t* __restrict__ msg, size_t len, size_t o, u32 w
 // ---- accumulate: one message per lane ------------------------------------------------------------
 // Table entry of step u for this message.
 //  kind 0 (Pedersen): digit = msg_bits(u*D, D), entry lut[u << D | digit].
-//  kind 1 (Bowe-Hopwood): steps [0, n_groups) are chunk triples from lut (256 entries each), negated by s_0;
-//                         steps [n_groups, n_steps) are the left-over single chunks from lut1.
+//  kind 1 (Bowe-Hopwood): steps [0, n_groups) are groups of D (= G) chunks from lut (2^(3G-1) entries each),
+//                         negated by s_0; steps [n_groups, n_steps) are the left-over single chunks from lut1.
 template <int KIND>
 AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
                            size_t msg_len, u32 D, u32 n_groups, u32 u) {
@@ -165,14 +166,20 @@ AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __r
         const u32 digit = msg_bits(msg, msg_len, (size_t)u * D, D);
         return load_niels(lut + (((size_t)u << D) | digit));
     }
+    const u32 G = D;  // chunks per group step
     if (u < n_groups) {
-        const u32 b = msg_bits(msg, msg_len, (size_t)u * 9u, 9u);
-        const u32 s0 = (b >> 2) & 1u, s1 = (b >> 5) & 1u, s2 = (b >> 8) & 1u;
-        const u32 idx = (b & 3u) | (((b >> 3) & 3u) << 2) | (((b >> 6) & 3u) << 4) | ((s1 ^ s0) << 6) | ((s2 ^ s0) << 7);
-        const Niels q = load_niels(lut + (size_t)u * 256u + idx);
+        const u32 b = msg_bits(msg, msg_len, (size_t)u * 3u * G, 3u * G);
+        const u32 s0 = (b >> 2) & 1u;
+        u32 idx = b & 3u;
+#pragma unroll 1
+        for (u32 i = 1; i < G; ++i) {
+            idx |= ((b >> (3u * i)) & 3u) << (2u * i);
+            idx |= (((b >> (3u * i + 2u)) & 1u) ^ s0) << (2u * G + i - 1u);
+        }
+        const Niels q = load_niels(lut + ((size_t)u << (3u * G - 1u)) + idx);
         return s0 ? niels_neg(q) : q;
     }
-    const u32 c = 3u * n_groups + (u - n_groups);
+    const u32 c = G * n_groups + (u - n_groups);
     const u32 bits = msg_bits(msg, msg_len, (size_t)c * 3u, 3u);
     const Niels q = load_niels(lut1 + (size_t)c * 4u + (bits & 3u));
     return (bits & 4u) ? niels_neg(q) : q;

@@ -108,7 +108,8 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     delete th;
 }
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
-// kind 1 -> Bowe-Hopwood single table lut1 [n_gen][4] and, when group == 3, triple table lut [n_gen/3][256].
+// kind 1 -> Bowe-Hopwood single table lut1 [n_gen][4] and, when group > 1, group table lut [n_gen/G][2^(3G-1)]
+// (hh_te_crh then takes D = group for kind 1).
 void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t D, uint32_t group, NielsPad* lut, NielsPad* lut1) {
     const u32 n_gen = W * N;
     if (kind == 0) {
@@ -117,8 +118,8 @@ void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t 
         return;
     }
     for (u32 i = 0; i < n_gen * 4; ++i) store_niels(lut1 + i, te_bh_lut_entry(gens, i));
-    if (group == 3)
-        for (u32 i = 0; i < (n_gen / 3) * 256; ++i) store_niels(lut + i, te_bh_lut3_entry(gens, i));
+    if (group > 1)
+        for (u32 i = 0; i < ((n_gen / group) << (3 * group - 1)); ++i) store_niels(lut + i, te_bh_lutg_entry(gens, group, i));
 }
 void hh_te_crh(int kind, const NielsPad* lut, const NielsPad* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
                uint32_t groups, uint32_t steps, size_t lanes, Fr* out) {

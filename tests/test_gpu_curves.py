@@ -177,7 +177,7 @@ def test_table_variants_agree(cpa):
     mb = _msgs(40, 13, 6)
     ref_p = ref_b = None
     try:
-        for D, grp in ((8, 3), (4, 1), (7, 3), (1, 1), (3, 3)):
+        for D, grp in ((12, 4), (8, 3), (4, 1), (7, 2), (1, 1), (3, 3), (13, 4)):
             os.environ["AKP_PEDERSEN_DIGIT_BITS"], os.environ["AKP_BH_GROUP"] = str(D), str(grp)
             dp = pedersen.CRH.evaluate_batch(pedersen.Parameters(gens_array(g)), m)
             db = bowe_hopwood.CRH.evaluate_batch(bowe_hopwood.Parameters(gens_array(gb)), mb)

@@ -143,13 +143,13 @@ def test_pedersen_table_path(H, W, N, D):
             assert tuple(ints(out[i])) == pd.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, D, L)
 
 
-@pytest.mark.parametrize("W,N,group", [(63, 9, 1), (5, 3, 3), (5, 3, 1), (7, 2, 3), (63, 1, 3)])
+@pytest.mark.parametrize("W,N,group", [(63, 9, 1), (5, 3, 3), (5, 3, 1), (7, 2, 3), (63, 1, 3), (5, 3, 4), (7, 3, 2), (6, 2, 4)])
 def test_bowe_hopwood_table_path(H, W, N, group):
     g = jj.bowe_hopwood_generators(12, W, N)
     G = gens_array(g)
     n_gen = W * N
     lut1 = np.zeros((n_gen * 4, 36), np.uint32)
-    lut3 = np.zeros((max(n_gen // 3, 1) * 256, 36), np.uint32)
+    lut3 = np.zeros((max(n_gen // max(group, 1), 1) << (3 * group - 1), 36), np.uint32)
     H.hh_te_build_lut(1, P(G), W, N, 0, group, P(lut3), P(lut1))
     maxL = W * N * 3 // 8
     for L in sorted({maxL, 32 if 32 <= maxL else 1, 1, 0, 3, 2, 4, min(70, maxL), max(maxL - 1, 0)}):
@@ -157,8 +157,8 @@ def test_bowe_hopwood_table_path(H, W, N, group):
         m = np.frombuffer(ofr.SplitMix64(L + W).bytes(max(L, 1) * n), dtype=np.uint8).copy()
         out = np.zeros((n, 4), np.uint64)
         chunks = min((8 * L + 2) // 3, n_gen)
-        groups, steps = (chunks // 3, chunks // 3 + chunks % 3) if group == 3 else (0, chunks)
-        H.hh_te_crh(1, P(lut3), P(lut1), P(m), n, L, 0, groups, steps, 3, P(out))
+        groups, steps = (chunks // group, chunks // group + chunks % group) if group > 1 else (0, chunks)
+        H.hh_te_crh(1, P(lut3), P(lut1), P(m), n, L, group, groups, steps, 3, P(out))
         for i in range(n):
             assert ints(out[i])[0] == bh.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, group, L)
 
