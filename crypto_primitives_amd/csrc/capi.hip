@@ -151,7 +151,7 @@ struct akp_poseidon {
     Fr* d_mds = nullptr;
     F29Pad* d_ark29 = nullptr;        // internal radix-2^29 form read by the kernels
     F29Pad* d_mds29 = nullptr;
-    // t == 3: sparse-partial-round form (poseidon_opt.hpp); null when not applicable
+    // sparse-partial-round form (poseidon_opt.hpp); null when not applicable (singular block / no partial rounds)
     F29Pad* d_arkmod29 = nullptr;
     F29Pad* d_mpre29 = nullptr;
     F29Pad* d_sparse29 = nullptr;
@@ -214,7 +214,7 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
             delete p;
             return fail(AKP_ERR_HIP, "uploading Poseidon parameters: %s", hipGetErrorString(e));
         }
-        if (t == 3 && !getenv("AKP_POSEIDON_DENSE")) {
+        if (!getenv("AKP_POSEIDON_DENSE")) {
             const PoseidonOpt opt = poseidon_optimize(t, full_rounds, partial_rounds, p->ark, p->mds);
             if (opt.ok) {
                 int32_t rc = upload_f29(ctx, opt.ark_mod, &p->d_arkmod29);
@@ -368,9 +368,9 @@ static inline unsigned poseidon_block(u32 t) { return t <= 3 ? 256u : (t <= 7 ? 
 // LDS bytes of the generic kernel: two buffers of t elements, 9 dwords each, per lane
 static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)2 * t * 9 * 4 * B; }
 
-static inline PoseidonT3Consts t3_consts(const akp_poseidon* p) {
-    if (p->d_sparse29) return PoseidonT3Consts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29};
-    return PoseidonT3Consts{p->d_ark29, p->d_mds29, nullptr, nullptr};
+static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
+    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29};
+    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr};
 }
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
@@ -382,9 +382,9 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
     const unsigned B = poseidon_block(p->dims.t);
     const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
-    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, d_states, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), d_states, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), d_states, n);
+    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), d_states, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
@@ -398,9 +398,9 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     const unsigned B = poseidon_block(p->dims.t);
     const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
-    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, p->d_ark29, p->d_mds29, in0, in1, k, d_out, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
+    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }

@@ -17,7 +17,8 @@
 //   t == 3 (the rate-2 headline instance): state in 27 VGPRs, S-box x^alpha by square-and-multiply,
 //          each MDS row as ONE 3-term dot product with a single Montgomery reduction.
 //   any other t <= 16: the state lives in an LDS "register file" (lane-interleaved dwords, conflict-free)
-//          so loops over state elements are real loops; MDS rows are chunks of 3-term dots.
+//          so loops over state elements are real loops; MDS rows are chunks of 3-term dots; partial rounds
+//          run in the sparse form (in place) as well.
 // Values cross HBM in the ABI's wire format (ark-ff Montgomery, R = 2^256); one product with a constant
 // converts on load / store.
 #pragma once
@@ -57,12 +58,13 @@ __global__ void poseidon_convert_params_kernel(const Fr* __restrict__ in, F29Pad
 // Limb bounds: dot3 / product outputs are normalised (< 2^29); + round key (< 2^29) -> < 2^30, which is what
 // f29_sqr / f29_mul / f29_dot3 admit.  In the sparse block lanes 1,2 grow by < 2^29 per round and are
 // renormalised every second round (dot3 admits lanes < 1.46 * 2^30 next to a normalised lane 0).
-struct PoseidonT3Consts {
-    const F29Pad* ark;     // [R][3] round keys (with the residue folded in when sparse != nullptr)
-    const F29Pad* mds;     // [3][3]
-    const F29Pad* mpre;    // [3][3] or nullptr
-    const F29Pad* sparse;  // [RP][6] = q0, a00, u1, u2, w1, w2  or nullptr (dense partial rounds)
+struct PoseidonConsts {
+    const F29Pad* ark;     // [R][t] round keys (with the residue folded in when sparse != nullptr)
+    const F29Pad* mds;     // [t][t]
+    const F29Pad* mpre;    // [t][t] or nullptr
+    const F29Pad* sparse;  // [RP][2t] = q0, a00, u_1..u_{t-1}, w_1..w_{t-1}  or nullptr (dense partial rounds)
 };
+typedef PoseidonConsts PoseidonT3Consts;
 AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2) {
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
@@ -168,43 +170,68 @@ struct LdsFile29 {
 };
 // state in buffer `cur` of the file (slots [cur*t, cur*t + t)); on return the state is in the updated `cur`.
 // `File` is LdsFile29<BLOCK> on the device; tests/host_harness instantiates it with a plain array.
+// sum_j state[src + j] * row[j] over j in [0, T), 3 terms per Montgomery reduction; `first` (if non-null) replaces
+// the lane-0 operand (the freshly S-boxed element of a sparse partial round).  Result weakly normalised.
 template <class File>
-AKP_HD void poseidon_permute_file(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds,
-                                  const File& f, u32& cur) {
+AKP_HD FU poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restrict__ row, const FU* first) {
+    FU acc = f29_zero<false>();
+    u32 j = 0;
+#pragma unroll 1
+    for (; j + 3 <= T; j += 3) {
+        const FU a0 = (first && j == 0) ? *first : f.load(src + j);
+        acc = f29_add(acc, f29_dot3(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1), f.load(src + j + 2), ldc(row + j + 2)));
+    }
+#pragma unroll 1
+    for (; j < T; ++j) {
+        const FU a0 = (first && j == 0) ? *first : f.load(src + j);
+        acc = f29_add(acc, f29_mul(a0, ldc(row + j)));
+    }
+    return f29_weak_norm(acc);  // <= 6 normalised terms summed: back below 2^29 + 8
+}
+template <class File>
+AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C, const File& f, u32& cur) {
     const u32 T = D.t;
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
+    const bool opt = C.sparse != nullptr;
 #pragma unroll 1
     for (u32 r = 0; r < R; ++r) {
         const bool full = (r < half) || (r >= half + D.partial_rounds);
-        const u32 nsbox = full ? T : 1u;
-        const F29Pad* arkr = ark + (size_t)r * T;
         const u32 src = cur * T, dst = (cur ^ 1u) * T;
+        if (full || !opt) {
+            const u32 nsbox = full ? T : 1u;
+            const F29Pad* arkr = C.ark + (size_t)r * T;
 #pragma unroll 1
-        for (u32 e = 0; e < T; ++e) {  // ARK fused with the S-box
-            FU x = f29_add(f.load(src + e), ldc(arkr + e));
-            if (e < nsbox) x = f29_pow_small(x, D.alpha);
-            f.store(src + e, x);
+            for (u32 e = 0; e < T; ++e) {  // ARK fused with the S-box
+                FU x = f29_add(f.load(src + e), ldc(arkr + e));
+                if (e < nsbox) x = f29_pow_small(x, D.alpha);
+                f.store(src + e, x);
+            }
+            const F29Pad* m = (opt && r + 1 == half) ? C.mpre : C.mds;
+#pragma unroll 1
+            for (u32 i = 0; i < T; ++i)  // new[i] = sum_j state[j] * m[i][j]
+                f.store(dst + i, poseidon_row_dot(f, src, T, m + (size_t)i * T, nullptr));
+            cur ^= 1u;
+        } else {
+            // sparse partial round, in place: lane 0 <- a00*s + u . lanes;  lane i <- lane i + w_i * s
+            const u32 j = r - half;
+            const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
+            const FU sb = f29_pow_small(f29_add(f.load(src), ldc(sp)), D.alpha);
+            const FU n0 = poseidon_row_dot(f, src, T, sp + 1, &sb);
+            const bool norm = (j & 1u) || j + 1 == D.partial_rounds;  // lanes grow < 2^29 per round (see t3 notes)
+#pragma unroll 1
+            for (u32 i = 1; i < T; ++i) {
+                FU y = f29_add(f.load(src + i), f29_mul(sb, ldc(sp + T + i)));
+                if (norm) y = f29_weak_norm(y);
+                f.store(src + i, y);
+            }
+            f.store(src, n0);
         }
-#pragma unroll 1
-        for (u32 i = 0; i < T; ++i) {  // new[i] = sum_j state[j] * mds[i][j], 3 terms per reduction
-            const F29Pad* row = mds + (size_t)i * T;
-            FU acc = f29_zero<false>();
-            u32 j = 0;
-#pragma unroll 1
-            for (; j + 3 <= T; j += 3)
-                acc = f29_add(acc, f29_dot3(f.load(src + j), ldc(row + j), f.load(src + j + 1), ldc(row + j + 1),
-                                            f.load(src + j + 2), ldc(row + j + 2)));
-#pragma unroll 1
-            for (; j < T; ++j) acc = f29_add(acc, f29_mul(f.load(src + j), ldc(row + j)));
-            f.store(dst + i, f29_weak_norm(acc));  // <= 6 normalised terms summed: back below 2^29 + 8
-        }
-        cur ^= 1u;
     }
 }
 template <class File>
-AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const F29Pad* __restrict__ ark, const F29Pad* __restrict__ mds, const File& f,
-                            const Fr* __restrict__ in0, const Fr* __restrict__ in1, size_t k, size_t idx) {
+AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const PoseidonConsts& C, const File& f, const Fr* __restrict__ in0,
+                            const Fr* __restrict__ in1, size_t k, size_t idx) {
     u32 cur = 0;
 #pragma unroll 1
     for (u32 e = 0; e < D.t; ++e) f.store(e, f29_zero<false>());
@@ -220,14 +247,13 @@ AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const F29Pad* __restrict__ ar
             f.store(slot, f29_weak_norm(f29_add(f.load(slot), f29_from_wire<false>(load_fr_global(src)))));
         }
         done += take;
-        poseidon_permute_file(D, ark, mds, f, cur);
+        poseidon_permute_file(D, C, f, cur);
     } while (done < k);
     return f29_to_wire(f.load(cur * D.t + D.capacity));
 }
 
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
-                                                               const F29Pad* __restrict__ mds, Fr* states, size_t n) {
+__global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D, PoseidonConsts C, Fr* states, size_t n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsFile29<BLOCK> f{reinterpret_cast<u32*>(smem)};
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -236,19 +262,18 @@ __global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D,
     u32 cur = 0;
 #pragma unroll 1
     for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(load_fr_global(st + e)));
-    poseidon_permute_file(D, ark, mds, f, cur);
+    poseidon_permute_file(D, C, f, cur);
 #pragma unroll 1
     for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, f29_to_wire(f.load(cur * D.t + e)));
 }
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, const F29Pad* __restrict__ ark,
-                                                           const F29Pad* __restrict__ mds, const Fr* __restrict__ in0,
+__global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, PoseidonConsts C, const Fr* __restrict__ in0,
                                                            const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out, size_t n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsFile29<BLOCK> f{reinterpret_cast<u32*>(smem)};
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= n) return;
-    store_fr_global(out + idx, poseidon_crh_item(D, ark, mds, f, in0, in1, k, idx));
+    store_fr_global(out + idx, poseidon_crh_item(D, C, f, in0, in1, k, idx));
 }
 
 }  // namespace akp

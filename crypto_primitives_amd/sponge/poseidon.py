@@ -126,6 +126,31 @@ class PoseidonSponge:
         assert e.size == self.batch * k * 4
         check(lib.akp_sponge_absorb(self.h, e.ctypes.data, k))
 
+    @staticmethod
+    def bytes_to_field_elements(data: bytes) -> np.ndarray:
+        """`Absorb for &[u8]` / `Vec<u8>` (sponge/absorb.rs:124-143): the u64 LE length is prepended, then the byte
+        string is cut into 31-byte ((MODULUS_BIT_SIZE - 1) / 8) little-endian chunks, one field element each
+        (ark-ff's `ToConstraintField for [u8]`)."""
+        b = len(data).to_bytes(8, "little") + bytes(data)
+        vals = [int.from_bytes(b[i:i + 31], "little") for i in range(0, len(b), 31)]
+        return field.fr(vals)
+
+    def absorb_bytes(self, data: bytes):
+        """absorb(&data) for a byte slice; every sponge of the batch absorbs the same bytes."""
+        el = self.bytes_to_field_elements(data)
+        self.absorb(np.broadcast_to(el, (self.batch,) + el.shape).copy())
+
+    def clone(self):
+        """`Clone` (the reference sponge is a value type)."""
+        return PoseidonSponge.from_state(self.into_state(), self.config, self._ph.ctx)
+
+    def fork(self, domain: bytes):
+        """CryptographicSponge::fork (sponge/mod.rs:145-153): clone, then absorb  u64_le(len(domain)) || domain
+        as a byte vector (which itself is length-prefixed by the byte-slice encoding)."""
+        new = self.clone()
+        new.absorb_bytes(len(domain).to_bytes(8, "little") + bytes(domain))
+        return new
+
     def squeeze_native_field_elements(self, n: int) -> np.ndarray:
         out = np.empty((self.batch, n, 4), dtype=np.uint64)
         check(lib.akp_sponge_squeeze(self.h, out.ctypes.data, n))

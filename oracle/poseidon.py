@@ -234,6 +234,21 @@ class PoseidonSponge:
         return out[:num_bits]
 
 
+def bytes_to_field_elements(data: bytes, p=P):
+    """sponge/absorb.rs:124-143 (`Absorb for [u8]`): u64 LE length || bytes, 31-byte LE chunks (ark-ff
+    `ToConstraintField<F> for [u8]`; external crate, restated from its published behaviour -- unpinned)."""
+    b = len(data).to_bytes(8, "little") + bytes(data)
+    return [int.from_bytes(b[i:i + 31], "little") % p for i in range(0, len(b), 31)]
+
+
+def sponge_fork(sp: "PoseidonSponge", domain: bytes) -> "PoseidonSponge":
+    """sponge/mod.rs:145-153."""
+    new = PoseidonSponge(sp.cfg, sp.p)
+    new.state, new.mode = list(sp.state), sp.mode
+    new.absorb(bytes_to_field_elements(len(domain).to_bytes(8, "little") + bytes(domain), sp.p))
+    return new
+
+
 # -------------------------------------------------------------------- CRHs
 def crh_evaluate(cfg: PoseidonConfig, inputs: List[int], p=P) -> int:
     """crh/poseidon/mod.rs:30-40."""

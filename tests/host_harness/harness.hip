@@ -25,19 +25,20 @@ static std::vector<F29Pad> to29(const Fr* in, size_t n) {
     for (size_t i = 0; i < n; ++i) f29_store_pad(&out[i], f29_from_wire<false>(in[i]));
     return out;
 }
-// force_generic: 0 = t3 register path with sparse partial rounds (product default), 1 = generic file path,
-//                2 = t3 register path with dense partial rounds
-struct T3Host {
+// force_generic: 0 = product default (t == 3: register path, else LDS-file path; sparse partial rounds),
+//                1 = generic file path with sparse partial rounds even for t == 3,
+//                2 = dense partial rounds (t == 3: register path, else file path)
+struct T3Host {  // constants in internal form for any t (name kept from the t = 3 path)
     std::vector<F29Pad> ark, mds, mpre, sparse;
-    PoseidonT3Consts c;
-    T3Host(uint32_t rf, uint32_t rp, const Fr* a, const Fr* m, bool sparse_form) {
-        std::vector<Fr> av(a, a + (size_t)(rf + rp) * 3), mv(m, m + 9);
+    PoseidonConsts c;
+    T3Host(uint32_t t, uint32_t rf, uint32_t rp, const Fr* a, const Fr* m, bool sparse_form) {
+        std::vector<Fr> av(a, a + (size_t)(rf + rp) * t), mv(m, m + (size_t)t * t);
         PoseidonOpt o;
-        if (sparse_form) o = poseidon_optimize(3, rf, rp, av, mv);
-        mds = to29(mv.data(), 9);
-        if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), 9); sparse = to29(o.sparse.data(), o.sparse.size());
-                    c = PoseidonT3Consts{ark.data(), mds.data(), mpre.data(), sparse.data()}; }
-        else { ark = to29(av.data(), av.size()); c = PoseidonT3Consts{ark.data(), mds.data(), nullptr, nullptr}; }
+        if (sparse_form) o = poseidon_optimize(t, rf, rp, av, mv);
+        mds = to29(mv.data(), mv.size());
+        if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
+                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data()}; }
+        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr}; }
     }
 };
 static PoseidonDims mk(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap) {
@@ -78,12 +79,12 @@ void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int is_signed, Fr* o
 void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
                          Fr* states, size_t n, int force_generic) {
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
-    const std::vector<F29Pad> a29 = to29(ark, (size_t)(rf + rp) * D.t), m29 = to29(mds, (size_t)D.t * D.t);
     std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
-    T3Host* th = (D.t == 3 && force_generic != 1) ? new T3Host(rf, rp, ark, mds, force_generic == 0) : nullptr;
+    T3Host* th = new T3Host(D.t, rf, rp, ark, mds, force_generic != 2);
+    const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i) {
-        if (th) {  // the register-resident fast path
+        if (reg_path) {  // the register-resident fast path
             FU s0 = f29_from_wire<false>(states[i * 3]), s1 = f29_from_wire<false>(states[i * 3 + 1]), s2 = f29_from_wire<false>(states[i * 3 + 2]);
             poseidon_permute_t3(D, th->c, s0, s1, s2);
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
@@ -91,7 +92,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
         }
         u32 cur = 0;
         for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(states[i * D.t + e]));
-        poseidon_permute_file(D, a29.data(), m29.data(), f, cur);
+        poseidon_permute_file(D, th->c, f, cur);
         for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(cur * D.t + e));
     }
     delete th;
@@ -99,12 +100,12 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
 void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
                      const Fr* in0, const Fr* in1, size_t k, Fr* out, size_t n, int force_generic) {
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
-    const std::vector<F29Pad> a29 = to29(ark, (size_t)(rf + rp) * D.t), m29 = to29(mds, (size_t)D.t * D.t);
     std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
-    T3Host* th = (D.t == 3 && force_generic != 1) ? new T3Host(rf, rp, ark, mds, force_generic == 0) : nullptr;
+    T3Host* th = new T3Host(D.t, rf, rp, ark, mds, force_generic != 2);
+    const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i)
-        out[i] = th ? poseidon_crh_item_t3(D, th->c, in0, in1, k, i) : poseidon_crh_item(D, a29.data(), m29.data(), f, in0, in1, k, i);
+        out[i] = reg_path ? poseidon_crh_item_t3(D, th->c, in0, in1, k, i) : poseidon_crh_item(D, th->c, f, in0, in1, k, i);
     delete th;
 }
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);

@@ -1,0 +1,23 @@
+#!/bin/bash
+echo "== pytest gpu ==";  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for dense in 0 1; do
+echo "== dense=$dense"
+if [ $dense = 1 ]; then export AKP_POSEIDON_DENSE=1; fi
+timeout 600 python - <<PY 2>&1 | grep -v amdgpu.ids
+import sys, numpy as np, torch
+sys.path.insert(0,'.')
+import crypto_primitives_amd as cpa
+from crypto_primitives_amd import field
+from crypto_primitives_amd._lib import lib, check
+dev=torch.device('cuda',0); ctx=cpa.default_context(0); st=torch.cuda.current_stream().cuda_stream
+for rate,w in ((2,False),(3,False),(4,False),(8,False),(2,True),(8,True)):
+    c=cpa.get_default_poseidon_parameters(rate,w); h=c.handle(ctx); t=rate+1
+    n=1<<18
+    x=torch.from_numpy(field.random_fr(n*t,seed=rate).view(np.int64)).to(dev)
+    def run(): check(lib.akp_poseidon_permute_batch_dev(h.h,x.data_ptr(),n,st))
+    run(); torch.cuda.synchronize(); best=1e9
+    for _ in range(3):
+        a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True); a.record(); run(); b.record(); torch.cuda.synchronize(); best=min(best,a.elapsed_time(b))
+    print('rate %d weights=%s alpha=%d rounds=%d+%d: %.3f ms  %.1f M perm/s  %.1f M elements absorbed/s'%(rate,w,c.alpha,c.full_rounds,c.partial_rounds,best,n/best/1e3,n*rate/best/1e3))
+PY
+done
