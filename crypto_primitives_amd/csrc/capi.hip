@@ -363,10 +363,10 @@ extern "C" int32_t akp_poseidon_default_params(akp_ctx* ctx, uint32_t rate, int3
 
 // ------------------------------------------------------------------------------------------
 // Poseidon launches
-static inline unsigned poseidon_block(u32 t) { return t <= 3 ? 256u : (t <= 7 ? 128u : 64u); }  // 72*t*B bytes of LDS <= 64 KiB
+static inline unsigned poseidon_block(u32 t) { return t <= 7 ? 256u : (t <= 14 ? 128u : 64u); }  // 36*t*B bytes of LDS <= 64 KiB
 
-// LDS bytes of the generic kernel: two buffers of t elements, 9 dwords each, per lane
-static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)2 * t * 9 * 4 * B; }
+// LDS bytes of the generic kernel: t elements of 9 dwords per lane
+static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)t * 9 * 4 * B; }
 
 static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29};

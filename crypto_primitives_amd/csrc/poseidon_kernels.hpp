@@ -102,11 +102,16 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
         }
     }
 }
-// absorb: lane += input, renormalised so that the following ARK add stays below 2^30
+// absorb: lane[slot] += input, renormalised so that the following ARK add stays below 2^30.  Value selects per limb
+// (a pointer select on `slot` would force the three lanes into scratch memory).
 AKP_HD void t3_add_slot(FU& s0, FU& s1, FU& s2, u32 slot, const FU& v) {
-    if (slot == 0) s0 = f29_weak_norm(f29_add(s0, v));
-    else if (slot == 1) s1 = f29_weak_norm(f29_add(s1, v));
-    else s2 = f29_weak_norm(f29_add(s2, v));
+    const FU n0 = f29_weak_norm(f29_add(s0, v)), n1 = f29_weak_norm(f29_add(s1, v)), n2 = f29_weak_norm(f29_add(s2, v));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        s0.l[i] = slot == 0 ? n0.l[i] : s0.l[i];
+        s1.l[i] = slot == 1 ? n1.l[i] : s1.l[i];
+        s2.l[i] = slot == 2 ? n2.l[i] : s2.l[i];
+    }
 }
 // Fixed-length sponge CRH of item idx on a fresh sponge: squeeze1(absorb(in[0..k))).
 // Element e of item idx is in0[idx*k + e] (in1 == nullptr), or in0[idx] / in1[idx] for e = 0 / 1.
@@ -168,7 +173,6 @@ struct LdsFile29 {
         for (int i = 0; i < 9; ++i) base[(slot * 9 + i) * BLOCK + threadIdx.x] = v.l[i];
     }
 };
-// state in buffer `cur` of the file (slots [cur*t, cur*t + t)); on return the state is in the updated `cur`.
 // `File` is LdsFile29<BLOCK> on the device; tests/host_harness instantiates it with a plain array.
 // sum_j state[src + j] * row[j] over j in [0, T), 3 terms per Montgomery reduction; `first` (if non-null) replaces
 // the lane-0 operand (the freshly S-boxed element of a sparse partial round).  Result weakly normalised.
@@ -188,51 +192,55 @@ AKP_HD FU poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restri
     }
     return f29_weak_norm(acc);  // <= 6 normalised terms summed: back below 2^29 + 8
 }
+#define AKP_POSEIDON_MAX_T 16
+// The state occupies slots [0, t) of the file.  Sparse partial rounds update it in place; a dense layer needs all
+// old lanes for every new lane, so its t results are parked in a small private (scratch-memory) array and copied
+// back -- that happens in the 8 full rounds only, and keeps the LDS footprint at t (not 2t) slots per lane, which
+// is what bounds occupancy for wide states.
 template <class File>
-AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C, const File& f, u32& cur) {
+AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C, const File& f) {
     const u32 T = D.t;
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
     const bool opt = C.sparse != nullptr;
+    FU tmp[AKP_POSEIDON_MAX_T];
 #pragma unroll 1
     for (u32 r = 0; r < R; ++r) {
         const bool full = (r < half) || (r >= half + D.partial_rounds);
-        const u32 src = cur * T, dst = (cur ^ 1u) * T;
         if (full || !opt) {
             const u32 nsbox = full ? T : 1u;
             const F29Pad* arkr = C.ark + (size_t)r * T;
 #pragma unroll 1
             for (u32 e = 0; e < T; ++e) {  // ARK fused with the S-box
-                FU x = f29_add(f.load(src + e), ldc(arkr + e));
+                FU x = f29_add(f.load(e), ldc(arkr + e));
                 if (e < nsbox) x = f29_pow_small(x, D.alpha);
-                f.store(src + e, x);
+                f.store(e, x);
             }
             const F29Pad* m = (opt && r + 1 == half) ? C.mpre : C.mds;
 #pragma unroll 1
-            for (u32 i = 0; i < T; ++i)  // new[i] = sum_j state[j] * m[i][j]
-                f.store(dst + i, poseidon_row_dot(f, src, T, m + (size_t)i * T, nullptr));
-            cur ^= 1u;
+            for (u32 i = 0; i < T; ++i) tmp[i] = poseidon_row_dot(f, 0, T, m + (size_t)i * T, nullptr);  // new[i] = sum_j state[j] * m[i][j]
+#pragma unroll 1
+            for (u32 i = 0; i < T; ++i) f.store(i, tmp[i]);
         } else {
             // sparse partial round, in place: lane 0 <- a00*s + u . lanes;  lane i <- lane i + w_i * s
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
-            const FU sb = f29_pow_small(f29_add(f.load(src), ldc(sp)), D.alpha);
-            const FU n0 = poseidon_row_dot(f, src, T, sp + 1, &sb);
+            const FU sb = f29_pow_small(f29_add(f.load(0), ldc(sp)), D.alpha);
+            const FU n0 = poseidon_row_dot(f, 0, T, sp + 1, &sb);
             const bool norm = (j & 1u) || j + 1 == D.partial_rounds;  // lanes grow < 2^29 per round (see t3 notes)
 #pragma unroll 1
             for (u32 i = 1; i < T; ++i) {
-                FU y = f29_add(f.load(src + i), f29_mul(sb, ldc(sp + T + i)));
+                FU y = f29_add(f.load(i), f29_mul(sb, ldc(sp + T + i)));
                 if (norm) y = f29_weak_norm(y);
-                f.store(src + i, y);
+                f.store(i, y);
             }
-            f.store(src, n0);
+            f.store(0, n0);
         }
     }
 }
 template <class File>
 AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const PoseidonConsts& C, const File& f, const Fr* __restrict__ in0,
                             const Fr* __restrict__ in1, size_t k, size_t idx) {
-    u32 cur = 0;
 #pragma unroll 1
     for (u32 e = 0; e < D.t; ++e) f.store(e, f29_zero<false>());
     size_t done = 0;
@@ -242,14 +250,14 @@ AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const PoseidonConsts& C, cons
         for (size_t j = 0; j < take; ++j) {
             const size_t e = done + j;
             const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
-            const u32 slot = cur * D.t + D.capacity + (u32)j;
+            const u32 slot = D.capacity + (u32)j;
             // the rate lane holds a weakly normalised MDS output (or zero): keep it that way
             f.store(slot, f29_weak_norm(f29_add(f.load(slot), f29_from_wire<false>(load_fr_global(src)))));
         }
         done += take;
-        poseidon_permute_file(D, C, f, cur);
+        poseidon_permute_file(D, C, f);
     } while (done < k);
-    return f29_to_wire(f.load(cur * D.t + D.capacity));
+    return f29_to_wire(f.load(D.capacity));
 }
 
 template <int BLOCK>
@@ -259,12 +267,11 @@ __global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D,
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= n) return;  // lanes never exchange data: no barriers anywhere
     Fr* st = states + idx * D.t;
-    u32 cur = 0;
 #pragma unroll 1
     for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(load_fr_global(st + e)));
-    poseidon_permute_file(D, C, f, cur);
+    poseidon_permute_file(D, C, f);
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, f29_to_wire(f.load(cur * D.t + e)));
+    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, f29_to_wire(f.load(e)));
 }
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, PoseidonConsts C, const Fr* __restrict__ in0,

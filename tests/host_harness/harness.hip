@@ -90,10 +90,9 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
             continue;
         }
-        u32 cur = 0;
         for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(states[i * D.t + e]));
-        poseidon_permute_file(D, th->c, f, cur);
-        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(cur * D.t + e));
+        poseidon_permute_file(D, th->c, f);
+        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(e));
     }
     delete th;
 }
