@@ -372,8 +372,10 @@ static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29};
     return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr};
 }
+#define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
+    if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3) {
         hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), d_states, n);
         HIP_TRY(hipGetLastError());
@@ -390,6 +392,7 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
 }
 static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
+    if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3) {
         hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
@@ -764,6 +767,7 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (msg_len * 8 > te_input_bits(p))
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
     if (n == 0) return AKP_OK;
+    if (n > ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32", n);
     void *xyz = nullptr, *prefix = nullptr;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz)) return rc;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix)) return rc;
