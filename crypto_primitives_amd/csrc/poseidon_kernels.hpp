@@ -95,7 +95,10 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             s0 = f29_dot3(s, ldc(sp + 1), s1, ldc(sp + 2), s2, ldc(sp + 3));
             s1 = f29_add(s1, f29_mul(s, ldc(sp + 4)));
             s2 = f29_add(s2, f29_mul(s, ldc(sp + 5)));
-            if ((j & 1u) || j + 1 == D.partial_rounds) {
+            if ((j & 31u) == 31u) {  // lanes 1,2 gain < 2.1p per round and are never reduced mod p: fold them back
+                s1 = f29_mul(s1, f29_one<false>());  // every 32 rounds so the top limb stays far below 2^32 for any RP
+                s2 = f29_mul(s2, f29_one<false>());
+            } else if ((j & 1u) || j + 1 == D.partial_rounds) {
                 s1 = f29_weak_norm(s1);
                 s2 = f29_weak_norm(s2);
             }
@@ -227,11 +230,13 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
             const FU sb = f29_pow_small(f29_add(f.load(0), ldc(sp)), D.alpha);
             const FU n0 = poseidon_row_dot(f, 0, T, sp + 1, &sb);
-            const bool norm = (j & 1u) || j + 1 == D.partial_rounds;  // lanes grow < 2^29 per round (see t3 notes)
+            const bool norm = (j & 1u) || j + 1 == D.partial_rounds;  // lanes grow < 2^29 per limb per round (see t3 notes)
+            const bool refold = (j & 31u) == 31u;                       // ... and < 2.1p in value: fold back mod p every 32 rounds
 #pragma unroll 1
             for (u32 i = 1; i < T; ++i) {
                 FU y = f29_add(f.load(i), f29_mul(sb, ldc(sp + T + i)));
-                if (norm) y = f29_weak_norm(y);
+                if (refold) y = f29_mul(y, f29_one<false>());
+                else if (norm) y = f29_weak_norm(y);
                 f.store(i, y);
             }
             f.store(0, n0);

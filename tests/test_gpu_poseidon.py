@@ -194,7 +194,7 @@ def _custom_cfg(cpa, rate, capacity, rf, rp, alpha, mds_ints, seed):
     return c, o
 
 
-@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5_random", "rp_even", "no_partial", "alpha3_t3"])
+@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5_random", "rp_even", "no_partial", "alpha3_t3", "many_partial"])
 def test_custom_t3_parameters(cpa, case):
     """t = 3 instances other than the default one: exercises the sparse-partial-round derivation, its fallback to
     dense rounds when a block is singular (the near-MDS matrix of merkle_tree/tests/test_utils.rs:643-653), other
@@ -209,6 +209,7 @@ def test_custom_t3_parameters(cpa, case):
         "rp_even": lambda: _custom_cfg(cpa, 2, 1, 6, 10, 17, rnd, 4),
         "no_partial": lambda: _custom_cfg(cpa, 2, 1, 8, 0, 5, rnd, 5),
         "alpha3_t3": lambda: _custom_cfg(cpa, 2, 1, 2, 1, 3, rnd, 6),
+        "many_partial": lambda: _custom_cfg(cpa, 2, 1, 2, 140, 3, rnd, 7),
     }[case]()
     ora = cref_poseidon(o)
     n = 300
@@ -226,10 +227,10 @@ def test_custom_t3_parameters(cpa, case):
 
 def test_generic_kernel_on_custom_t(cpa):
     """t = 2 and t = 4 with non-default parameters (generic LDS-file kernel)"""
-    for rate, cap in ((1, 1), (2, 2), (3, 1)):
+    for rate, cap, rp in ((1, 1, 7), (2, 2, 7), (3, 1, 70)):
         t = rate + cap
         mds = [rand_fr(t, 200 + i + t) for i in range(t)]
-        c, o = _custom_cfg(cpa, rate, cap, 4, 7, 5, mds, 10 + t)
+        c, o = _custom_cfg(cpa, rate, cap, 4, rp, 5, mds, 10 + t)
         ora = cref_poseidon(o)
         st = rand_fr_array(70 * t, 3).reshape(70, t, 4)
         assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st).reshape(70, t, 4))

@@ -182,13 +182,14 @@ def test_digest_serialisation(H):
     assert bytes(buf[0]) == (jj.fq_serialize(pts[0][0]) + jj.fq_serialize(pts[1][0]))[:63]
 
 
-@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5", "rp_even", "no_partial"])
+@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5", "rp_even", "no_partial", "many_partial"])
 def test_poseidon_t3_custom_parameters(H, case):
     """sparse-partial-round derivation on non-default t = 3 instances, incl. the singular-block fallback"""
     near = [[1, 0, 1], [1, 1, 0], [0, 1, 1]]
     rnd = [rand_fr(3, 70 + i) for i in range(3)]
     rate, cap, rf, rp, alpha, mdsi = {"near_mds": (2, 1, 8, 29, 17, near), "rate1_cap2": (1, 2, 8, 31, 17, rnd), "alpha5": (2, 1, 8, 56, 5, rnd),
-                                      "rp_even": (2, 1, 6, 10, 17, rnd), "no_partial": (2, 1, 8, 0, 5, rnd)}[case]
+                                      "rp_even": (2, 1, 6, 10, 17, rnd), "no_partial": (2, 1, 8, 0, 5, rnd),
+                                      "many_partial": (2, 1, 2, 140, 3, rnd)}[case]
     arki = rand_fr((rf + rp) * 3, 9)
     c = po.PoseidonConfig(rf, rp, alpha, [arki[i * 3:(i + 1) * 3] for i in range(rf + rp)], mdsi, rate, cap)
     ark, mds = mont(arki), mont([x for r in mdsi for x in r])
@@ -203,3 +204,17 @@ def test_poseidon_t3_custom_parameters(H, case):
             O = np.zeros((1, 4), np.uint64)
             H.hh_poseidon_crh(rf, rp, alpha, rate, cap, P(ark), P(mds), P(I), None, k, P(O), 1, mode)
             assert ints(O) == [po.crh_evaluate(c, ins[0])], (case, mode, k)
+
+
+def test_poseidon_generic_many_partial_rounds(H):
+    """t = 4 with 100 partial rounds: sparse in-place rounds incl. the periodic re-fold of the linear lanes"""
+    t, rf, rp, alpha = 4, 4, 100, 3
+    mdsi = [rand_fr(t, 300 + i) for i in range(t)]
+    arki = rand_fr((rf + rp) * t, 19)
+    c = po.PoseidonConfig(rf, rp, alpha, [arki[i * t:(i + 1) * t] for i in range(rf + rp)], mdsi, 3, 1)
+    ark, mds = mont(arki), mont([x for r in mdsi for x in r])
+    sts = [rand_fr(t, 40 + i) for i in range(2)]
+    for mode in (0, 2):
+        S = mont([x for s in sts for x in s])
+        H.hh_poseidon_permute(rf, rp, alpha, 3, 1, P(ark), P(mds), P(S), 2, mode)
+        assert ints(S) == [x for s in sts for x in po.permute(c, s)], mode
