@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-states", type=int, default=20)
     ap.add_argument("--merkle-log2", type=int, default=24, help="total leaves of the Merkle leg (0 disables)")
+    ap.add_argument("--bh-merkle-log2", type=int, default=0, help="also build a Bowe-Hopwood 63x9 tree over 2^k 32-byte leaves (BASELINE config 5 shape), sharded like the Poseidon tree")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -146,6 +147,34 @@ def main():
                   "permutations": 2 * total - 1, "root_limb0": int(np.asarray(res["root"]).reshape(-1)[0]),
                   "algorithmic_GBps": 160.0 * total / msec / 1e9}
 
+    bh_merkle = None
+    if args.bh_merkle_log2:
+        from crypto_primitives_amd import params as cparams
+        from crypto_primitives_amd.crh import bowe_hopwood
+        from crypto_primitives_amd.distributed import GpuTeBackend
+        total = 1 << args.bh_merkle_log2
+        per = total // world
+        B = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9))
+        leaves = np.random.default_rng(0xA5A50005 + rank).integers(0, 256, size=(per, 32), dtype=np.uint8)
+        d_leaves = torch.from_numpy(leaves).to(dev)
+        tb = GpuTeBackend(B, B, device=dev)
+        build_sharded(tb, d_leaves[: max(per // 64, 2)], max(total // 64, 2 * world), dist)  # warm-up (tables, scratch, RCCL)
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        m0 = time.perf_counter()
+        res = build_sharded(tb, d_leaves, total, dist)
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        bsec = time.perf_counter() - m0
+        if dist:
+            tt = torch.tensor([bsec], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            bsec = float(tt.item())
+        bh_merkle = {"hash": "Bowe-Hopwood 63x9 over Jubjub, 32-byte leaves, ByteDigestConverter", "leaves": total, "seconds": bsec,
+                     "leaves_per_s": total / bsec, "scaling": "strong", "algorithmic_GBps": 160.0 * total / bsec / 1e9}
+
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -184,6 +213,8 @@ def main():
     }
     if merkle:
         out["merkle"] = merkle
+    if bh_merkle:
+        out["bh_merkle"] = bh_merkle
     if not args.no_cpu_baseline and world == 1:
         from oracle import cref
         threads = cref.hardware_threads()

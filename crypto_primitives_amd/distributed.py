@@ -105,3 +105,41 @@ class GpuPoseidonBackend:
     def two_to_one_compress(self, left, right):
         from .crh.poseidon import TwoToOneCRH
         return TwoToOneCRH.compress_batch(self.two_params, np.ascontiguousarray(left), np.ascontiguousarray(right))
+
+
+class GpuTeBackend:
+    """Pedersen / Bowe-Hopwood leaf + two-to-one hashes with ByteDigestConverter on this rank's GPU (BASELINE
+    config 5: Bowe-Hopwood tree over byte leaves).  Leaves are a uint8 cuda tensor [n_local, leaf_len]; digests
+    are int64 tensors viewed as Fr wire format (1 Fr per node for Bowe-Hopwood, 2 for Pedersen)."""
+
+    def __init__(self, leaf_params, two_params, device=None):
+        import torch
+        from ._lib import default_context
+        self.torch = torch
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.ctx = default_context(self.device.index or 0)
+        self.leaf_h = leaf_params.handle(self.ctx)
+        self.two_h = two_params.handle(self.ctx)
+        self.two_params = two_params
+        self.fe = 2 if two_params._KIND == 0 else 1
+
+    def comm_device(self):
+        return self.device
+
+    def build_subtree(self, d_leaves):
+        from ._lib import lib, check
+        torch = self.torch
+        n, L = d_leaves.shape[0], d_leaves.shape[1]
+        leaf_nodes = torch.empty((n, self.fe * 4), dtype=torch.int64, device=self.device)
+        non_leaf = torch.empty((n - 1, self.fe * 4), dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.akp_merkle_build_te_dev(self.leaf_h.h, self.two_h.h, d_leaves.data_ptr(), n, L, leaf_nodes.data_ptr(),
+                                          non_leaf.data_ptr(), stream))
+        root = non_leaf[0].cpu().numpy().view(np.uint64)
+        return leaf_nodes, non_leaf, root
+
+    def two_to_one_compress(self, left, right):
+        from .crh import pedersen, bowe_hopwood
+        cls = pedersen.TwoToOneCRH if self.fe == 2 else bowe_hopwood.TwoToOneCRH
+        out = cls.compress_batch(self.two_params, np.ascontiguousarray(left), np.ascontiguousarray(right))
+        return np.ascontiguousarray(out).reshape(len(out), -1)

@@ -35,7 +35,7 @@ def test_bench_single_process():
 def test_bench_under_torchrun_world1():
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29531", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2-states", "14",
-                        "--merkle-log2", "10", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--merkle-log2", "10", "--bh-merkle-log2", "8", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
     d = _check(p.stdout)
-    assert d["n_gpus"] == 1 and "merkle" in d
+    assert d["n_gpus"] == 1 and "merkle" in d and d["bh_merkle"]["leaves"] == 256

@@ -113,3 +113,24 @@ def test_large_tree_equals_combined_subtrees(cpa):
             assert np.array_equal(nlr_host[lstart:lstart + cnt], nl_host[gstart:gstart + cnt]), (r, lvl)
     top = combine_top(be.two_to_one_compress, np.stack(subs))
     assert np.array_equal(top[0], root) and np.array_equal(top, nl_host[: G - 1])
+
+
+def test_te_backend_subtrees_combine(cpa):
+    """Bowe-Hopwood byte-leaf tree (BASELINE config 5 shape): one-shot build == sub-trees + combined top (the N-GPU path)"""
+    import torch
+    from crypto_primitives_amd import params
+    from crypto_primitives_amd.crh import bowe_hopwood
+    from crypto_primitives_amd.distributed import GpuTeBackend, combine_top
+    B = bowe_hopwood.Parameters(params.bowe_hopwood_generators(0xA5A50005, 63, 9))
+    dev = torch.device("cuda", 0)
+    be = GpuTeBackend(B, B, device=dev)
+    n, G = 1 << 12, 4
+    leaves = np.random.default_rng(3).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    d = torch.from_numpy(leaves).to(dev)
+    ln, nl, root = be.build_subtree(d)
+    torch.cuda.synchronize()
+    ref = cpa.MerkleTree.new(cpa.BoweHopwoodByteConfig, B, B, leaves)
+    assert np.array_equal(nl.cpu().numpy().view(np.uint64), ref.non_leaf_nodes)
+    subs = [be.build_subtree(d[r * (n // G):(r + 1) * (n // G)])[2].copy() for r in range(G)]
+    top = combine_top(be.two_to_one_compress, np.stack(subs))
+    assert np.array_equal(top, ref.non_leaf_nodes[: G - 1]) and np.array_equal(top[0], root)
