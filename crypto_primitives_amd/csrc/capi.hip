@@ -1052,10 +1052,11 @@ static int32_t verify_paths_common(akp_ctx* c, u32 fe, const uint64_t* root, siz
     if (int32_t rc = ctx_scratch(c, SCR_G, m * dig, &d_cur)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_H, m * dig, &d_l)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_I, m * dig, &d_r)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_J, m * 8 + m * dig + dig + m, &d_misc)) return rc;
+    const size_t idx_bytes = (m * 8 + 15) & ~(size_t)15;  // keep the digests behind the index array 16-byte aligned
+    if (int32_t rc = ctx_scratch(c, SCR_J, idx_bytes + m * dig + dig + m, &d_misc)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_K, std::max<size_t>(m * depth * dig, 16), &d_auth)) return rc;
     d_idx = d_misc;
-    d_sib = (char*)d_misc + m * 8;
+    d_sib = (char*)d_misc + idx_bytes;
     void* d_root = (char*)d_sib + m * dig;
     uint8_t* d_ok = (uint8_t*)d_root + dig;
     hipStream_t s = c->stream;
