@@ -90,6 +90,9 @@ def _load():
         "akp_merkle_build_poseidon": (i32, [vp, vp, u64p, sz, sz, u64p, u64p, u64p]),
         "akp_merkle_build_poseidon_dev": (i32, [vp, vp, u64p, sz, sz, u64p, u64p, vp]),
         "akp_merkle_inner_poseidon_dev": (i32, [vp, u64p, sz, u64p, vp]),
+        "akp_merkle_inner_poseidon": (i32, [vp, u64p, sz, u64p]),
+        "akp_merkle_inner_te": (i32, [vp, u64p, sz, u64p]),
+        "akp_merkle_inner_te_dev": (i32, [vp, u64p, sz, u64p, vp]),
         "akp_merkle_build_te": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, u64p]),
         "akp_merkle_build_te_dev": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, vp]),
         "akp_merkle_gather_paths": (i32, [u64p, u64p, sz, u32, u64p, sz, u64p, u64p]),

@@ -897,6 +897,21 @@ extern "C" int32_t akp_merkle_inner_poseidon_dev(akp_poseidon* two, const uint64
     }
     return AKP_OK;
 }
+extern "C" int32_t akp_merkle_inner_poseidon(akp_poseidon* two, const uint64_t* leaf_nodes, size_t n, uint64_t* non_leaf) {
+    NEED_DEV(two, "akp_merkle_inner_poseidon");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    if (!leaf_nodes || !non_leaf) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    akp_ctx* c = two->ctx;
+    void *dln = nullptr, *dnl = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dln)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * sizeof(Fr), &dnl)) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(dln, leaf_nodes, n * sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (int32_t rc = akp_merkle_inner_poseidon_dev(two, (const uint64_t*)dln, n, (uint64_t*)dnl, (void*)s)) return rc;
+    HIP_TRY(hipMemcpyAsync(non_leaf, dnl, (n - 1) * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
 extern "C" int32_t akp_merkle_build_poseidon_dev(akp_poseidon* leafp, akp_poseidon* two, const uint64_t* d_leaves, size_t n, size_t leaf_len,
                                                  uint64_t* d_leaf_nodes, uint64_t* d_non_leaf, void* stream) {
     NEED_DEV(leafp, "akp_merkle_build_poseidon_dev");
@@ -928,6 +943,36 @@ extern "C" int32_t akp_merkle_build_poseidon(akp_poseidon* leafp, akp_poseidon* 
     return AKP_OK;
 }
 
+extern "C" int32_t akp_merkle_inner_te_dev(akp_te_params* two, const uint64_t* d_leaf_nodes, size_t n, uint64_t* d_non_leaf, void* stream) {
+    NEED_TE(two, "akp_merkle_inner_te_dev");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    hipStream_t s = pick_stream(two->ctx, stream);
+    const u32 fe = te_fe_per_digest(two);
+    Fr* nl = (Fr*)d_non_leaf;
+    const Fr* child = (const Fr*)d_leaf_nodes;
+    for (size_t width = n / 2; width >= 1; width /= 2) {
+        const size_t first = width - 1;
+        if (int32_t rc = te_compress_dev(two, child, nullptr, width, nl + first * fe, s)) return rc;
+        child = nl + first * fe;
+    }
+    return AKP_OK;
+}
+extern "C" int32_t akp_merkle_inner_te(akp_te_params* two, const uint64_t* leaf_nodes, size_t n, uint64_t* non_leaf) {
+    NEED_TE(two, "akp_merkle_inner_te");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    if (!leaf_nodes || !non_leaf) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    akp_ctx* c = two->ctx;
+    const size_t fe = te_fe_per_digest(two);
+    void *dln = nullptr, *dnl = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl)) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(dln, leaf_nodes, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (int32_t rc = akp_merkle_inner_te_dev(two, (const uint64_t*)dln, n, (uint64_t*)dnl, (void*)s)) return rc;
+    HIP_TRY(hipMemcpyAsync(non_leaf, dnl, (n - 1) * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
 extern "C" int32_t akp_merkle_build_te_dev(akp_te_params* leafp, akp_te_params* two, const uint8_t* d_leaves, size_t n, size_t leaf_len,
                                            uint64_t* d_leaf_nodes, uint64_t* d_non_leaf, void* stream) {
     NEED_TE(leafp, "akp_merkle_build_te_dev");
@@ -936,18 +981,8 @@ extern "C" int32_t akp_merkle_build_te_dev(akp_te_params* leafp, akp_te_params* 
     if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "parameters belong to different contexts");
     if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
     hipStream_t s = pick_stream(leafp->ctx, stream);
-    const u32 fe = te_fe_per_digest(two);
     if (int32_t rc = te_crh_dev(leafp, d_leaves, n, leaf_len, (Fr*)d_leaf_nodes, s)) return rc;
-    Fr* nl = (Fr*)d_non_leaf;
-    const Fr* child = (const Fr*)d_leaf_nodes;
-    // bottom level: TwoToOneHash::evaluate(convert(l), convert(r)) with ByteDigestConverter (:454-483);
-    // upper levels: compress(l, r) (:486-515) -- both serialise the digests uncompressed first.
-    for (size_t width = n / 2; width >= 1; width /= 2) {
-        const size_t first = width - 1;
-        if (int32_t rc = te_compress_dev(two, child, nullptr, width, nl + first * fe, s)) return rc;
-        child = nl + first * fe;
-    }
-    return AKP_OK;
+    return akp_merkle_inner_te_dev(two, d_leaf_nodes, n, d_non_leaf, (void*)s);
 }
 extern "C" int32_t akp_merkle_build_te(akp_te_params* leafp, akp_te_params* two, const uint8_t* leaves, size_t n, size_t leaf_len,
                                        uint64_t* leaf_nodes, uint64_t* non_leaf, uint64_t* root_out) {

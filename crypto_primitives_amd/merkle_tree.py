@@ -33,6 +33,15 @@ class PoseidonFieldConfig:
         return leaf_nodes, non_leaf
 
     @staticmethod
+    def build_inner(two_params, leaf_digests):
+        ln = np.ascontiguousarray(leaf_digests, dtype=np.uint64).reshape(-1, 4)
+        non_leaf = np.empty((max(len(ln) - 1, 0), 4), dtype=np.uint64)
+        check(lib.akp_merkle_inner_poseidon(two_params.handle().h, ln.ctypes.data, len(ln), non_leaf.ctypes.data))
+        return ln, non_leaf
+
+    default_leaf_digest = staticmethod(lambda: np.zeros(4, dtype=np.uint64))  # Fr::default() == 0
+
+    @staticmethod
     def hash_leaves(leaf_params, leaves):
         x = np.ascontiguousarray(leaves, dtype=np.uint64)
         n = x.shape[0]
@@ -71,6 +80,19 @@ class _ByteConfig:
                                       n, L, leaf_nodes.ctypes.data, non_leaf.ctypes.data, None))
         shp = cls.digest_shape
         return leaf_nodes.reshape((n,) + shp), non_leaf.reshape((max(n - 1, 0),) + shp)
+
+    @classmethod
+    def build_inner(cls, two_params, leaf_digests):
+        ln = np.ascontiguousarray(leaf_digests, dtype=np.uint64).reshape((-1,) + cls.digest_shape)
+        non_leaf = np.empty((max(len(ln) - 1, 0),) + cls.digest_shape, dtype=np.uint64)
+        check(lib.akp_merkle_inner_te(two_params.handle().h, ln.ctypes.data, len(ln), non_leaf.ctypes.data))
+        return ln, non_leaf
+
+    @classmethod
+    def default_leaf_digest(cls):
+        # Default of an affine TE point is the identity (0, 1); of an Fq digest it is 0
+        from . import field
+        return field.fr([0, 1]).reshape(2, 4) if cls.digest_shape == (2, 4) else np.zeros(4, dtype=np.uint64)
 
     @classmethod
     def hash_leaves(cls, leaf_params, leaves):
@@ -226,6 +248,21 @@ class MerkleTree:
             raise NotPowerOfTwo(5, "`leaves.len() should be power of two and greater than one")
         leaf_nodes, non_leaf = config.build(leaf_hash_param, two_to_one_hash_param, leaves)
         return cls(config, leaf_hash_param, two_to_one_hash_param, leaf_nodes, non_leaf)
+
+    @classmethod
+    def new_with_leaf_digest(cls, config, leaf_hash_param, two_to_one_hash_param, leaf_digests):
+        """MerkleTree::new_with_leaf_digest (:424-523): inner levels only, from given leaf digests."""
+        n = len(leaf_digests)
+        if n < 2 or n & (n - 1):
+            raise NotPowerOfTwo(5, "`leaves.len() should be power of two and greater than one")
+        leaf_nodes, non_leaf = config.build_inner(two_to_one_hash_param, leaf_digests)
+        return cls(config, leaf_hash_param, two_to_one_hash_param, leaf_nodes.copy(), non_leaf)
+
+    @classmethod
+    def blank(cls, config, leaf_hash_param, two_to_one_hash_param, height):
+        """MerkleTree::blank (:400-408): all leaf digests are `LeafDigest::default()`."""
+        d = config.default_leaf_digest()
+        return cls.new_with_leaf_digest(config, leaf_hash_param, two_to_one_hash_param, np.stack([d] * (1 << (height - 1))))
 
     def root(self):
         return self.non_leaf_nodes[0].copy()

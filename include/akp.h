@@ -158,6 +158,15 @@ int32_t akp_merkle_build_poseidon_dev(akp_poseidon* leaf_params, akp_poseidon* t
 /* MerkleTree::new_with_leaf_digest (merkle_tree/mod.rs:424-523): inner levels only. */
 int32_t akp_merkle_inner_poseidon_dev(akp_poseidon* two_to_one_params, const uint64_t* d_leaf_nodes, size_t n_leaves,
                                       uint64_t* d_non_leaf_nodes, void* stream);
+/* host-pointer form of the above: leaf_nodes in (n_leaves Fr), non_leaf_nodes out (n_leaves - 1 Fr) */
+int32_t akp_merkle_inner_poseidon(akp_poseidon* two_to_one_params, const uint64_t* leaf_nodes, size_t n_leaves,
+                                  uint64_t* non_leaf_nodes);
+/* MerkleTree::new_with_leaf_digest for Pedersen / Bowe-Hopwood digests (ByteDigestConverter): leaf_nodes are
+ * n_leaves digests (2 Fr / 1 Fr each) */
+int32_t akp_merkle_inner_te(akp_te_params* two_to_one_params, const uint64_t* leaf_nodes, size_t n_leaves,
+                            uint64_t* non_leaf_nodes);
+int32_t akp_merkle_inner_te_dev(akp_te_params* two_to_one_params, const uint64_t* d_leaf_nodes, size_t n_leaves,
+                                uint64_t* d_non_leaf_nodes, void* stream);
 /* MerkleTree::new over byte leaves with Pedersen or Bowe-Hopwood hashes and ByteDigestConverter
  * (merkle_tree/mod.rs:67-78; config shape merkle_tree/tests/mod.rs:13-33).  Both parameter sets
  * must have the same kind.  Digest = 2 Fr (Pedersen) / 1 Fr (Bowe-Hopwood) per node. */

@@ -187,3 +187,33 @@ def test_batched_proofs_all_configs(cpa):
     P = pedersen.Parameters(gens_array(g))
     tp = cpa.MerkleTree.new(cpa.PedersenByteConfig, P, P, lv[:8])
     assert all(cpa.merkle_tree.verify_paths(cpa.PedersenByteConfig, P, P, tp.root(), tp.generate_proofs(range(8)), [bytes(x) for x in lv[:8]]))
+
+
+def test_new_with_leaf_digest_and_blank(cpa):
+    """MerkleTree::new_with_leaf_digest (:424-523) == the inner levels of MerkleTree::new; blank (:400-408)"""
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    c = cpa.get_default_poseidon_parameters(2, False)
+    leaves = rand_fr_array(32 * 2, 4).reshape(32, 2, 4)
+    t = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
+    t2 = cpa.MerkleTree.new_with_leaf_digest(cpa.PoseidonFieldConfig, c, c, t.leaf_nodes)
+    assert np.array_equal(t2.non_leaf_nodes, t.non_leaf_nodes) and t2.height() == 6
+    b = cpa.MerkleTree.blank(cpa.PoseidonFieldConfig, c, c, 4)
+    ora = cref_poseidon(po.get_default_poseidon_parameters(2, False))
+    z = np.zeros((8, 4), np.uint64)
+    lvl = ora.two_to_one_batch(z[0::2], z[1::2]); lvl = ora.two_to_one_batch(lvl[0::2], lvl[1::2]); lvl = ora.two_to_one_batch(lvl[0::2], lvl[1::2])
+    assert np.array_equal(b.root(), lvl[0]) and len(b.leaf_nodes) == 8
+    with pytest.raises(cpa.NotPowerOfTwo):
+        cpa.MerkleTree.new_with_leaf_digest(cpa.PoseidonFieldConfig, c, c, t.leaf_nodes[:3])
+    gb = jj.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    B = bowe_hopwood.Parameters(gens_array(gb))
+    lv = _byte_leaves(16, 32, 8)
+    tb = cpa.MerkleTree.new(cpa.BoweHopwoodByteConfig, B, B, lv)
+    assert np.array_equal(cpa.MerkleTree.new_with_leaf_digest(cpa.BoweHopwoodByteConfig, B, B, tb.leaf_nodes).non_leaf_nodes, tb.non_leaf_nodes)
+    g = jj.pedersen_generators(0xA5A50004, 4, 256)
+    Pp = pedersen.Parameters(gens_array(g))
+    tp = cpa.MerkleTree.new(cpa.PedersenByteConfig, Pp, Pp, lv[:4])
+    assert np.array_equal(cpa.MerkleTree.new_with_leaf_digest(cpa.PedersenByteConfig, Pp, Pp, tp.leaf_nodes).non_leaf_nodes, tp.non_leaf_nodes)
+    bp = cpa.MerkleTree.blank(cpa.PedersenByteConfig, Pp, Pp, 3)  # 4 identity leaves
+    ident = jj.serialize_uncompressed(jj.IDENTITY)
+    lvl1 = opd.two_to_one_evaluate(g, 4, 256, ident, ident)
+    assert tuple(ints(bp.root())) == opd.two_to_one_compress(g, 4, 256, lvl1, lvl1)
