@@ -134,3 +134,65 @@ def test_te_backend_subtrees_combine(cpa):
     subs = [be.build_subtree(d[r * (n // G):(r + 1) * (n // G)])[2].copy() for r in range(G)]
     top = combine_top(be.two_to_one_compress, np.stack(subs))
     assert np.array_equal(top, ref.non_leaf_nodes[: G - 1]) and np.array_equal(top[0], root)
+
+
+def test_full_size_tree_2pow24(cpa):
+    """BASELINE config 3 size: 2^24 one-element leaves, built on the device.  Size-independent checks: the root equals
+    the combination of the two 2^23 sub-tree roots; sampled nodes of every level equal compress(children) (oracle)."""
+    import torch
+    from crypto_primitives_amd.distributed import GpuPoseidonBackend, combine_top
+    c = cpa.get_default_poseidon_parameters(2, False)
+    ora = cref_poseidon_fixture()
+    n = 1 << 24
+    leaves = rand_fr_array(n, 0xA5A50003).reshape(n, 1, 4)
+    dev = torch.device("cuda", 0)
+    be = GpuPoseidonBackend(c, c, leaf_len=1, device=dev)
+    d_all = torch.from_numpy(leaves.view(np.int64)).to(dev)
+    ln, nl, root = be.build_subtree(d_all)
+    torch.cuda.synchronize()
+    r0 = be.build_subtree(d_all[: n // 2])[2].copy()
+    r1 = be.build_subtree(d_all[n // 2:])[2].copy()
+    assert np.array_equal(combine_top(be.two_to_one_compress, np.stack([r0, r1]))[0], root)
+    rng = np.random.default_rng(24)
+    idx = np.unique(np.concatenate([np.arange(0, 1024), rng.integers(0, n // 2 - 1, 4096), (1 << np.arange(1, 23)) - 1]))
+    idx_t = torch.from_numpy(idx).to(dev)
+    nodes = nl[idx_t].cpu().numpy().view(np.uint64)
+    lch = nl[2 * idx_t + 1].cpu().numpy().view(np.uint64)
+    rch = nl[2 * idx_t + 2].cpu().numpy().view(np.uint64)
+    assert np.array_equal(nodes, ora.two_to_one_batch(lch, rch, threads=8))
+    bottom = torch.from_numpy(rng.integers(0, n // 2, 2048)).to(dev)
+    bn = nl[(n // 2 - 1) + bottom].cpu().numpy().view(np.uint64)
+    bl, br = ln[2 * bottom].cpu().numpy().view(np.uint64), ln[2 * bottom + 1].cpu().numpy().view(np.uint64)
+    assert np.array_equal(bn, ora.two_to_one_batch(bl, br, threads=8))
+    li = rng.integers(0, n, 2048)
+    assert np.array_equal(ln[torch.from_numpy(li).to(dev)].cpu().numpy().view(np.uint64), ora.crh_batch(leaves[li], 1, threads=8))
+
+
+def cref_poseidon_fixture():
+    from helpers import cref_poseidon
+    return cref_poseidon(po.get_default_poseidon_parameters(2, False))
+
+
+def test_full_size_pedersen_2pow20(cpa):
+    """BASELINE config 4 size: 2^20 messages of 128 bytes, Jubjub 4x256.  Size-independent property: the hash is a
+    subset sum over message bits, so H(m) = H(m with the high half zeroed) + H(m with the low half zeroed)
+    (checked with the oracle's point addition on samples); plus sampled digests against the C oracle."""
+    from crypto_primitives_amd import params
+    from crypto_primitives_amd.crh import pedersen
+    from oracle import cref
+    gens = params.pedersen_generators(0xA5A50004, 4, 256)
+    P = pedersen.Parameters(gens)
+    n = 1 << 20
+    msgs = np.random.default_rng(0xA5A50004).integers(0, 256, size=(n, 128), dtype=np.uint8)
+    full = pedersen.CRH.evaluate_batch(P, msgs)
+    lo, hi = msgs.copy(), msgs.copy()
+    lo[:, 64:] = 0
+    hi[:, :64] = 0
+    hlo, hhi = pedersen.CRH.evaluate_batch(P, lo), pedersen.CRH.evaluate_batch(P, hi)
+    assert np.array_equal(hlo, pedersen.CRH.evaluate_batch(P, np.ascontiguousarray(msgs[:, :64])))  # zero padding == short message
+    for i in np.random.default_rng(1).integers(0, n, 48):
+        assert tuple(ints(full[i])) == jj.add(tuple(ints(hlo[i])), tuple(ints(hhi[i])))
+    C = cref.CurveParams(4, 256, gens)
+    idx = np.random.default_rng(2).integers(0, n, 512)
+    assert np.array_equal(full[idx], C.pedersen_crh_batch(np.ascontiguousarray(msgs[idx]), len(idx), 128, threads=8))
+    assert len(np.unique(full.reshape(n, -1)[:, 0])) == n  # no accidental collisions / duplicated lanes
