@@ -40,6 +40,28 @@ VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # measured: one v_mad_u64_u32 (wa
 MADS_PER_PERM = 8 * (3 * (4 * 118 + 154) + 3 * 316) + 31 * ((4 * 118 + 154) + 316 + 2 * 154)  # v_mad per permutation (ISA counts: sqr 118, mul 154, dot3 316; sparse partial rounds)
 
 
+def measure_hbm_copy(torch, dev, nbytes=1 << 30, reps=10):
+    """Read+write GB/s of a plain 1 GiB device-to-device copy on this box (report the measured HBM rate
+    beside the vendor 8 TB/s).  Measurement plumbing only -- not part of the hashed path."""
+    try:
+        a = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        b = torch.empty_like(a)
+        a.zero_()
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        secs = e0.elapsed_time(e1) / 1e3 / reps
+        del a, b
+        return 2 * nbytes / secs / 1e9
+    except Exception:  # pragma: no cover - measurement is best effort
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +205,7 @@ def main():
     total_perms = n * world * args.steps
     value = total_perms / elapsed
     achieved = ALGO_BYTES_PER_PERM * n / kern_avg_s / 1e9
+    hbm_copy_gbs = measure_hbm_copy(torch, dev)
     out = {
         "metric": "poseidon_bls12_381_fr_permutations_per_sec",
         "value": value,
@@ -202,6 +225,7 @@ def main():
         "parity_probe_bit_exact": parity,
         "roofline": {"bound": "hbm", "kernel": "poseidon_permute_t3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_PERM * n,
+                     "peak_measured_copy": hbm_copy_gbs, "frac_of_measured_copy": achieved / hbm_copy_gbs if hbm_copy_gbs else None,
                      "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction (profiles/r01_s3)",
                      "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PERM * n,
                      "valu": {"note": "the path is integer-ALU bound (~%d reference-shaped Montgomery products per 192 B); "
@@ -219,18 +243,32 @@ def main():
         from oracle import cref
         threads = cref.hardware_threads()
         ora = cref.Poseidon(cfg.full_rounds, cfg.partial_rounds, cfg.alpha, cfg.rate, cfg.capacity, cfg.ark, cfg.mds)
-        # calibrate on 2^12 states, then size the sample for ~cpu_seconds
-        cal = host_states[:4096]
+        # calibrate: the box may expose more hardware threads than its cgroup lets us use, so try a few thread counts on
+        # 2^14 states each and keep the fastest; then size the sample for ~cpu_seconds
+        hw = threads
+        cal = host_states[:16384]
+        best = (0.0, 1)
+        for cand in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), min(hw, 16)}, reverse=True):
+            c0 = time.perf_counter()
+            ora.permute_batch(cal, threads=cand)
+            r = len(cal) / (time.perf_counter() - c0)
+            if r > best[0]:
+                best = (r, cand)
+        rate, threads = best
+        sample = int(min(n, max(16384, rate * args.cpu_seconds)))
+        passes = 0
         c0 = time.perf_counter()
-        ora.permute_batch(cal, threads=threads)
-        rate = 4096 / (time.perf_counter() - c0)
-        sample = int(min(n, max(4096, rate * args.cpu_seconds)))
-        c0 = time.perf_counter()
-        ora.permute_batch(host_states[:sample], threads=threads)
-        cpu_s = time.perf_counter() - c0
+        while True:  # whole passes over the sample until ~cpu_seconds have been spent
+            ora.permute_batch(host_states[:sample], threads=threads)
+            passes += 1
+            cpu_s = time.perf_counter() - c0
+            if sample < n or cpu_s >= args.cpu_seconds:
+                break
+        sample *= passes
         out["cpu_baseline"] = {"value": sample / cpu_s, "unit": "permutations/s", "cores": threads, "kind": "port",
-                               "sample": "%d of the same 2^%d states, reference-shaped C restatement "
-                                         "(oracle/c/akp_oracle.c), %d pthreads" % (sample, args.log2_states, threads)}
+                               "sample": "%d permutations over the same 2^%d states, reference-shaped C restatement "
+                                         "(oracle/c/akp_oracle.c), %d pthreads (best of a thread-count sweep; %d hardware threads)"
+                                         % (sample, args.log2_states, threads, hw)}
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if dist:
