@@ -10,6 +10,6 @@ echo "== bench ==";       timeout 600 python bench.py > $OUT/bench.log 2>&1; tai
 echo "== rocprof ==";     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/rocprof.log 2>&1); head -5 $OUT/prof/trace_kernel_stats.csv | cut -c1-260
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python $OLDPWD/bench.py --steps 3 --warmup 1 --merkle-log2 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1)
-  grep "permute_t3" $OUT/pmc_$C/pmc_counter_collection.csv | tail -2 | cut -d, -f7,16,17
+  grep "permute_t3" $OUT/pmc_$C/pmc_counter_collection.csv | tail -2 | awk -F, '{print $(NF-3), $(NF-2)}'
 done
 find $OUT -name "*kernel_trace.csv" -size +1M -delete
