@@ -390,10 +390,23 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
+// AKP_POSEIDON_COOP_MAX: largest batch routed to the 3-wave latency kernel (0 disables it)
+static size_t coop_max_items() {
+    const char* e = getenv("AKP_POSEIDON_COOP_MAX");
+    if (e && *e) return (size_t)strtoull(e, nullptr, 10);
+    return (size_t)1 << 15;
+}
 static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3) {
+        // small batches (tree tops) are bound by the latency of one permutation: spread each one over three waves
+        static const size_t coop_max = coop_max_items();
+        if (n <= coop_max && p->d_sparse29 && p->dims.capacity == 1 && k <= p->dims.rate) {
+            hipLaunchKernelGGL(poseidon_crh_t3_coop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(192), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
+            HIP_TRY(hipGetLastError());
+            return AKP_OK;
+        }
         hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;

@@ -234,3 +234,48 @@ def test_generic_kernel_on_custom_t(cpa):
         ora = cref_poseidon(o)
         st = rand_fr_array(70 * t, 3).reshape(70, t, 4)
         assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st).reshape(70, t, 4))
+
+
+# ---- the CRH path has two kernels for t = 3: one lane per item (large batches) and the 3-wave latency kernel
+# (batches <= AKP_POSEIDON_COOP_MAX, default 2^15).  Both must equal the oracle on every shape.
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 191, 193, 5000, (1 << 15), (1 << 15) + 1, 40000])
+def test_crh_t3_small_and_large_batches(cpa, n):
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    c, o, ora = _cfg_pair(cpa, 2)
+    l, r = rand_fr_array(n, 100 + n), rand_fr_array(n, 200 + n)
+    assert np.array_equal(pcrh.TwoToOneCRH.compress_batch(c, l, r), ora.two_to_one_batch(l, r, threads=8))
+    one = np.ascontiguousarray(l.reshape(n, 1, 4))
+    assert np.array_equal(pcrh.CRH.evaluate_batch(c, one), ora.crh_batch(one, 1, threads=8))
+    two = np.ascontiguousarray(np.stack([l, r], axis=1))
+    assert np.array_equal(pcrh.CRH.evaluate_batch(c, two), ora.crh_batch(two, 2, threads=8))
+    if n <= 5000:  # three elements = two permutations: never the latency kernel
+        three = np.ascontiguousarray(np.stack([l, r, l], axis=1))
+        assert np.array_equal(pcrh.CRH.evaluate_batch(c, three), ora.crh_batch(three, 3, threads=8))
+
+
+def test_crh_t3_empty_input_small_batch(cpa):
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    c, o, ora = _cfg_pair(cpa, 2)
+    got = pcrh.CRH.evaluate_batch(c, np.zeros((5, 0, 4), dtype=np.uint64))
+    assert got.shape == (5, 4) and np.array_equal(got, np.repeat(ora.crh_empty(), 5, axis=0))
+    assert ints(got[:1])[0] == po.crh_evaluate(o, [])
+
+
+def test_crh_t3_latency_kernel_disabled_matches(cpa, tmp_path):
+    """AKP_POSEIDON_COOP_MAX=0 routes small batches through the one-lane-per-item kernel: same digests."""
+    import subprocess, sys, os
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    c, o, ora = _cfg_pair(cpa, 2)
+    n = 777
+    l, r = rand_fr_array(n, 31), rand_fr_array(n, 32)
+    np.save(tmp_path / "l.npy", l)
+    np.save(tmp_path / "r.npy", r)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import crypto_primitives_amd as cpa; "
+            "from crypto_primitives_amd.crh import poseidon as pcrh; "
+            "c = cpa.get_default_poseidon_parameters(2, False); "
+            "np.save(%r, pcrh.TwoToOneCRH.compress_batch(c, np.load(%r), np.load(%r)))"
+            % (root, str(tmp_path / "o.npy"), str(tmp_path / "l.npy"), str(tmp_path / "r.npy")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, AKP_POSEIDON_COOP_MAX="0"), timeout=300)
+    assert np.array_equal(np.load(tmp_path / "o.npy"), pcrh.TwoToOneCRH.compress_batch(c, l, r))
+    assert np.array_equal(np.load(tmp_path / "o.npy"), ora.two_to_one_batch(l, r, threads=8))
