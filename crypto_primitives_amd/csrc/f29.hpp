@@ -76,6 +76,8 @@ AKP_F29_CONST(f29_one, 0x1fffffbau, 0x0000022fu, 0x1cb61180u, 0x0a4e5c00u, 0x0ee
 AKP_F29_CONST(f29_k_in, 0x1ffff72bu, 0x000046a7u, 0x1f5f3540u, 0x0ce3021cu, 0x118f3661u, 0x008176cbu, 0x054e487cu, 0x102e8190u, 0x001e092eu)
 AKP_F29_CONST(f29_k_out, 0x1ffffffeu, 0x0000000fu, 0x00d20080u, 0x096ff400u, 0x04ff5588u, 0x07f7f65eu, 0x15be6631u, 0x0b3598a0u, 0x001824b1u)
 AKP_F29_CONST(f29_te_d, 0x0e9ed5e8u, 0x12245679u, 0x002d9f52u, 0x03bb3367u, 0x0d9bfb3du, 0x18ebb3ccu, 0x1c29ceccu, 0x0a7b6020u, 0x0020d725u)
+// 2^522 mod p: plain integer -> internal representation in one product
+AKP_F29_CONST(f29_r2, 0x0a71b3c0u, 0x1d32207eu, 0x1663d999u, 0x1c5abc93u, 0x03b58c44u, 0x0be37438u, 0x0829f771u, 0x1660139eu, 0x0027fd91u)
 AKP_F29_CONST(f29_4p, 0x00000004u, 0x1fffffe0u, 0x1e5bfeffu, 0x0d2017ffu, 0x160154efu, 0x10101343u, 0x1483339du, 0x0994cebeu, 0x01cfb69du)
 AKP_F29_CONST(f29_2p, 0x00000002u, 0x1ffffff0u, 0x1f2dff7fu, 0x16900bffu, 0x1b00aa77u, 0x180809a1u, 0x0a4199ceu, 0x14ca675fu, 0x00e7db4eu)
 AKP_F29_CONST(f29_p, 0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u)
@@ -241,9 +243,9 @@ AKP_HD F29T<S> f29_pow_small(const F29T<S>& x, u64 e) {
     }
     return r;
 }
-// a^(p-2); a == 0 -> 0
+// a^(p-2); a == 0 -> 0.  255 squarings + 127 products; kept as the cross-check of f29_inv
 template <bool S>
-AKP_HD F29T<S> f29_inv(const F29T<S>& a) {
+AKP_HD F29T<S> f29_inv_fermat(const F29T<S>& a) {
     const u32 E[8] = {0xffffffffu, 0xfffffffeu, AKP_P2, AKP_P3, AKP_P4, AKP_P5, AKP_P6, AKP_P7};  // p - 2
     F29T<S> r = a;  // bit 254 of p-2 is set
 #pragma unroll 1
@@ -335,6 +337,138 @@ AKP_HD FS f29_to_signed(const FU& a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = (int32_t)a.l[i];
     return r;
+}
+
+// ---- modular inverse by batched division steps (Bernstein-Yang "safegcd", the half-delta variant) --------------
+// The 29-bit signed-limb layout is the natural one for it: 29 division steps on the low words of (f, g) give a 2x2
+// transition matrix with entries |.| <= 2^29, one limb; applying it to (f, g) and to the Bezout pair (d, e) is a
+// 9-limb by 1-limb multiply-accumulate whose division by 2^29 is a limb shift, and p = 1 (mod 2^29) makes the
+// "add a multiple of p so the low limb vanishes" step a negation.  21 batches = 609 >= 590 steps, enough for any
+// 256-bit input.  ~16 k cheap VALU instructions with no data-dependent branch, against ~84 k for a^(p-2).
+struct F29Trans {
+    int32_t u, v, q, r;
+};
+AKP_HD int32_t f29_divsteps29(int32_t zeta, u32 f, u32 g, F29Trans& t) {
+    u32 u = 1, v = 0, q = 0, r = 1;
+#pragma unroll
+    for (int i = 0; i < 29; ++i) {
+        u32 c1 = (u32)(zeta >> 31);  // zeta < 0
+        const u32 c2 = 0u - (g & 1u);  // g odd
+        const u32 x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;  // (f, u, v) or their negatives
+        g += x & c2;
+        q += y & c2;
+        r += z & c2;
+        c1 &= c2;                               // swap case: zeta < 0 and g odd
+        zeta = (int32_t)((u32)zeta ^ c1) - 1;   // -zeta - 2 or zeta - 1
+        f += g & c1;
+        u += q & c1;
+        v += r & c1;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+    }
+    t.u = (int32_t)u;
+    t.v = (int32_t)v;
+    t.q = (int32_t)q;
+    t.r = (int32_t)r;
+    return zeta;
+}
+// (f, g) <- t * (f, g) / 2^29 (exact).  Limbs 0..7 in [0, 2^29), limb 8 carries the sign.
+AKP_HD void f29_update_fg(int32_t* f, int32_t* g, const F29Trans& t) {
+    int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0];
+    int64_t cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
+    cf >>= 29;
+    cg >>= 29;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
+        cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
+        f[i - 1] = (int32_t)((u32)cf & AKP_MASK29);
+        g[i - 1] = (int32_t)((u32)cg & AKP_MASK29);
+        cf >>= 29;
+        cg >>= 29;
+    }
+    f[8] = (int32_t)cf;
+    g[8] = (int32_t)cg;
+}
+// (d, e) <- t * (d, e) / 2^29 (mod p), both kept in (-2p, p)
+AKP_HD void f29_update_de(int32_t* d, int32_t* e, const F29Trans& t) {
+    const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+    int32_t md = (t.u & sd) + (t.v & se);
+    int32_t me = (t.q & sd) + (t.r & se);
+    int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0];
+    int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
+    md -= (int32_t)(((u32)cd + (u32)md) & AKP_MASK29);  // p^-1 = 1 (mod 2^29): cd + p * md = 0 (mod 2^29)
+    me -= (int32_t)(((u32)ce + (u32)me) & AKP_MASK29);
+    cd += (int64_t)md;  // p limb 0 is 1
+    ce += (int64_t)me;
+    cd >>= 29;
+    ce >>= 29;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int64_t pi = (int64_t)p29(i);
+        cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + pi * md;
+        ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + pi * me;
+        d[i - 1] = (int32_t)((u32)cd & AKP_MASK29);
+        e[i - 1] = (int32_t)((u32)ce & AKP_MASK29);
+        cd >>= 29;
+        ce >>= 29;
+    }
+    d[8] = (int32_t)cd;
+    e[8] = (int32_t)ce;
+}
+// 1/a in the internal (x * 2^261) representation; a == 0 -> 0
+template <bool S>
+AKP_HD F29T<S> f29_inv(const F29T<S>& a) {
+    typedef typename F29T<S>::L L;
+    const F29T<false> x = f29_unpack<false>(f29_to_canonical_int(a));  // the plain integer in [0, p)
+    int32_t f[9], g[9], d[9], e[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        f[i] = (int32_t)p29(i);
+        g[i] = (int32_t)x.l[i];
+        d[i] = 0;
+        e[i] = 0;
+    }
+    e[0] = 1;
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 21; ++it) {
+        F29Trans t;
+        zeta = f29_divsteps29(zeta, (u32)f[0] | ((u32)f[1] << 29), (u32)g[0] | ((u32)g[1] << 29), t);
+        f29_update_de(d, e, t);
+        f29_update_fg(f, g, t);
+    }
+    // f = +-1 (or p when a == 0): the inverse is sign(f) * d, brought from (-2p, p) to [0, p)
+    const int32_t neg = f[8] >> 31;
+    int32_t c = 0;
+    const int32_t add0 = d[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int32_t v = d[i] + ((int32_t)p29(i) & add0);
+        v = (v ^ neg) - neg;
+        v += c;
+        if (i < 8) {
+            d[i] = (int32_t)((u32)v & AKP_MASK29);
+            c = v >> 29;
+        } else {
+            d[i] = v;
+        }
+    }
+    c = 0;
+    const int32_t add1 = d[8] >> 31;
+    F29T<S> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int32_t v = d[i] + ((int32_t)p29(i) & add1) + c;
+        if (i < 8) {
+            r.l[i] = (L)((u32)v & AKP_MASK29);
+            c = v >> 29;
+        } else {
+            r.l[i] = (L)v;
+        }
+    }
+    return f29_mul(r, f29_r2<S>());  // plain 1/x -> (1/x) * 2^261
 }
 
 // 12-dword padded storage (three 16-byte vectors) for tables / scratch in global memory

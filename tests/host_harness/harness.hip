@@ -67,6 +67,14 @@ void hh_f29_ops(const Fr* a, const Fr* b, const Fr* c, const Fr* d, Fr* o) {
     o[9] = f29_to_wire(f29_sqr(f29_add(ua, ub)));
     o[10] = f29_to_wire(f29_neg(f29_sub(sa, sb)));
 }
+// inverses: out = [safegcd (FS), safegcd (FU), a^(p-2) (FS), safegcd of the lazy value a - b (FS)]
+void hh_f29_inv(const Fr* a, const Fr* b, Fr* o) {
+    const FS sa = f29_from_wire<true>(*a), sb = f29_from_wire<true>(*b);
+    o[0] = f29_to_wire(f29_inv(sa));
+    o[1] = f29_to_wire(f29_inv(f29_from_wire<false>(*a)));
+    o[2] = f29_to_wire(f29_inv_fermat(sa));
+    o[3] = f29_to_wire(f29_inv(f29_sub(sa, sb)));
+}
 // worst-case limb patterns fed straight into the multipliers (internal limbs, not via the wire):
 // returns a*b/2^261 mod p canonical for FU (limbs given), and for FS.
 void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int is_signed, Fr* o) {

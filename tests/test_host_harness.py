@@ -21,6 +21,7 @@ def H():
     h.hh_poseidon_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t, C.c_int]
     h.hh_poseidon_crh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int]
     h.hh_f29_raw_mul.argtypes = [vp, vp, C.c_int, vp]
+    h.hh_f29_inv.argtypes = [vp, vp, vp]
     h.hh_te_build_lut.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     h.hh_te_crh.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
     h.hh_te_serialize_pairs.argtypes = [vp, vp, C.c_uint32, C.c_size_t, vp, C.c_size_t]
@@ -63,6 +64,24 @@ def test_f29_core_ops(H):
                (a + b) ** 2 % p, (b - a) % p]
         assert got == exp, (a, b, c, d)
         assert ofr.canon_array_to_ints(O[8:9])[0] == a
+
+
+def test_f29_inverse_safegcd(H):
+    """f29_inv (batched division steps) against python pow(x, -1, p) and against the a^(p-2) chain."""
+    p = ofr.P
+    rng = ofr.SplitMix64(29)
+    vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 2 ** 254, 2 ** 255 % p, 2 ** 29, 2 ** 29 - 1, 2 ** 58 + 1,
+            2 ** 232, 2 ** 261 % p, pow(2, -261, p), pow(2, -29, p), 0x1fffffff * (2 ** 29 + 1), 3 ** 160 % p]
+    vals += [1 << k for k in range(0, 255, 7)] + [p - (1 << k) for k in range(0, 255, 11)]
+    vals += [rng.fr() for _ in range(3000)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        O = np.zeros((4, 4), np.uint64)
+        H.hh_f29_inv(P(mont([a])), P(mont([b])), P(O))
+        got = ints(O)
+        inv = pow(a, -1, p) if a else 0
+        assert got[0] == inv and got[1] == inv and got[2] == inv, hex(a)
+        assert got[3] == (pow((a - b) % p, -1, p) if (a - b) % p else 0), (hex(a), hex(b))
 
 
 def test_f29_worst_case_limbs(H):
