@@ -393,8 +393,7 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
 // AKP_POSEIDON_COOP_MAX: largest batch routed to the 3-wave latency kernel (0 disables it)
 static size_t coop_max_items() {
     const char* e = getenv("AKP_POSEIDON_COOP_MAX");
-    if (e && *e) return (size_t)strtoull(e, nullptr, 10);
-    return (size_t)1 << 15;
+    return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 15);
 }
 static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
@@ -681,6 +680,10 @@ static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == A
 static inline size_t te_input_bits(const akp_te_params* p) {  // max message bits before the reference panics
     return p->kind == AKP_TE_PEDERSEN ? (size_t)p->W * p->N : (size_t)p->W * p->N * 3;
 }
+static size_t env_size(const char* name, size_t dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : dflt;
+}
 static u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
     const char* e = getenv(name);
     if (!e) return dflt;
@@ -781,11 +784,22 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
     if (n == 0) return AKP_OK;
     if (n > ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32", n);
+    u32 groups = 0, steps = 0;
+    te_steps(p, msg_len, &groups, &steps);
+    // small batches (tree tops) are bound by the latency of one message: split each one over AKP_TE_SPLIT waves
+    static const size_t split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
+    if (n <= split_max) {
+        const unsigned sgrid = (unsigned)((n + 63) / 64);
+        if (p->kind == AKP_TE_PEDERSEN)
+            hipLaunchKernelGGL(te_crh_small_kernel<0>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, d_out, n);
+        else
+            hipLaunchKernelGGL(te_crh_small_kernel<1>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->group, groups, steps, d_out, n);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
     void *xyz = nullptr, *prefix = nullptr;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz)) return rc;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix)) return rc;
-    u32 groups = 0, steps = 0;
-    te_steps(p, msg_len, &groups, &steps);
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (p->kind == AKP_TE_PEDERSEN)
         hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);

@@ -61,6 +61,18 @@ AKP_HD Ext te_madd(const Ext& p, const Niels& q) {
     return Ext{f29_mul(e, f), f29_mul(g, h), f29_mul(f, g), f29_mul(e, h)};
 }
 
+// P + Q, both extended (9 products; unified, complete for a = -1, d non-square).  Used to combine partial sums.
+// Limb bounds as above: one operand of every product is (re)normalised.
+AKP_HD Ext te_add_ext(const Ext& p, const Ext& q) {
+    const FS a = f29_mul(f29_weak_norm(f29_sub(p.Y, p.X)), f29_sub(q.Y, q.X));
+    const FS b = f29_mul(f29_weak_norm(f29_add(p.Y, p.X)), f29_add(q.Y, q.X));
+    const FS c = f29_mul(f29_mul(p.T, q.T), f29_dbl(f29_te_d<true>()));
+    const FS zz = f29_mul(p.Z, q.Z);
+    const FS d = f29_dbl(zz);
+    const FS e = f29_sub(b, a), f = f29_sub(d, c), g = f29_weak_norm(f29_add(d, c)), h = f29_add(b, a);
+    return Ext{f29_mul(e, f), f29_mul(g, h), f29_mul(f, g), f29_mul(e, h)};
+}
+
 AKP_HD Fr load_fr_g(const Fr* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     const uint4 lo = q[0], hi = q[1];
@@ -203,6 +215,22 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
     if (u < n_steps) acc = te_madd(acc, q0);
     return acc;
 }
+// partial sum over steps first, first + stride, ... (the whole message for first = 0, stride = 1)
+template <int KIND>
+AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
+                                 size_t msg_len, u32 D, u32 n_groups, u32 n_steps, u32 first, u32 stride) {
+    Ext acc = ext_identity();
+    if (first >= n_steps) return acc;
+    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, first);
+#pragma unroll 1
+    for (u32 u = first; u < n_steps; u += stride) {
+        const u32 nxt = (u + stride < n_steps) ? u + stride : u;
+        const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, nxt);  // fetched ahead of the addition
+        acc = te_madd(acc, q0);
+        q0 = q1;
+    }
+    return acc;
+}
 // writes the extended-coordinate sum (X, Y, Z), internal form, to xyz[idx*3 ..]
 template <int KIND>
 __global__ void __launch_bounds__(256) te_accumulate_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
@@ -251,6 +279,58 @@ __global__ void __launch_bounds__(256) te_finalize_kernel(const F29Pad* __restri
     if (l >= lanes || l >= n) return;
     te_finalize_lane<KIND>(xyz, prefix, out, n, lanes, l);
 }
+
+#if defined(__HIPCC__)
+// ---- latency variant for small batches (the upper levels of a byte-digest tree) ---------------------------------
+// One workgroup of S waves per 64 messages: wave j sums the table entries of steps j, j + S, ..., the S partial sums
+// are combined by a log2(S)-deep tree of full additions through LDS, and wave 0 converts to affine with its own
+// inversion.  Depth ceil(steps/S) mixed additions + log2(S) full additions instead of `steps` mixed additions, and
+// one launch instead of two.
+#define AKP_TE_SPLIT 8
+template <int KIND>
+__global__ void __launch_bounds__(64 * AKP_TE_SPLIT) te_crh_small_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
+                                                                        const uint8_t* __restrict__ msgs, size_t msg_len, u32 D,
+                                                                        u32 n_groups, u32 n_steps, Fr* __restrict__ out, size_t n) {
+    __shared__ u32 part[AKP_TE_SPLIT - 1][36][64];
+    const u32 j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u32 lane = threadIdx.x & 63u;
+    const size_t item = (size_t)blockIdx.x * 64 + lane;
+    const size_t idx = item < n ? item : n - 1;
+    Ext acc = te_accumulate_strided<KIND>(lut, lut1, msgs + idx * msg_len, msg_len, D, n_groups, n_steps, j, AKP_TE_SPLIT);
+#pragma unroll 1
+    for (u32 stride = 1; stride < AKP_TE_SPLIT; stride <<= 1) {
+        if ((j & (2 * stride - 1)) == stride) {  // each wave j > 0 publishes exactly once, in slot j - 1
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                part[j - 1][i][lane] = (u32)acc.X.l[i];
+                part[j - 1][9 + i][lane] = (u32)acc.Y.l[i];
+                part[j - 1][18 + i][lane] = (u32)acc.Z.l[i];
+                part[j - 1][27 + i][lane] = (u32)acc.T.l[i];
+            }
+        }
+        __syncthreads();
+        if ((j & (2 * stride - 1)) == 0) {
+            Ext o;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                o.X.l[i] = (int32_t)part[j + stride - 1][i][lane];
+                o.Y.l[i] = (int32_t)part[j + stride - 1][9 + i][lane];
+                o.Z.l[i] = (int32_t)part[j + stride - 1][18 + i][lane];
+                o.T.l[i] = (int32_t)part[j + stride - 1][27 + i][lane];
+            }
+            acc = te_add_ext(acc, o);
+        }
+    }
+    if (j != 0 || item >= n) return;
+    const FS zi = f29_inv(acc.Z);  // Z != 0 always (complete formulas)
+    if (KIND == 0) {
+        store_fr_g(out + item * 2, f29_to_wire(f29_mul(acc.X, zi)));
+        store_fr_g(out + item * 2 + 1, f29_to_wire(f29_mul(acc.Y, zi)));
+    } else {
+        store_fr_g(out + item, f29_to_wire(f29_mul(acc.X, zi)));
+    }
+}
+#endif
 
 // ---- helpers for TwoToOneCRH / ByteDigestConverter ---------------------------------------------------
 // buffer[i] = zeros(buflen); buffer[i][0..] = left[i] || right[i], zip-truncated

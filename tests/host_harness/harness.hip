@@ -142,6 +142,22 @@ void hh_te_crh(int kind, const NielsPad* lut, const NielsPad* lut1, const uint8_
         else te_finalize_lane<1>(xyz.data(), prefix.data(), out, n, lanes, l);
     }
 }
+// the small-batch kernel's arithmetic (te_crh_small_kernel) on the CPU: `split` strided partial sums, a binary tree of
+// full additions, one inversion per message
+void hh_te_crh_split(int kind, const NielsPad* lut, const NielsPad* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
+                     uint32_t groups, uint32_t steps, uint32_t split, Fr* out) {
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<Ext> part(split);
+        for (u32 j = 0; j < split; ++j)
+            part[j] = kind == 0 ? te_accumulate_strided<0>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps, j, split)
+                                : te_accumulate_strided<1>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps, j, split);
+        for (u32 stride = 1; stride < split; stride <<= 1)
+            for (u32 j = 0; j + stride < split; j += 2 * stride) part[j] = te_add_ext(part[j], part[j + stride]);
+        const FS zi = f29_inv(part[0].Z);
+        if (kind == 0) { out[2 * i] = f29_to_wire(f29_mul(part[0].X, zi)); out[2 * i + 1] = f29_to_wire(f29_mul(part[0].Y, zi)); }
+        else out[i] = f29_to_wire(f29_mul(part[0].X, zi));
+    }
+}
 void hh_te_serialize_pairs(const Fr* left, const Fr* right, uint32_t fe, size_t buflen, uint8_t* buf, size_t n) {
     for (size_t t = 0; t < n * 2 * fe; ++t) te_serialize_pair_fe(left, right, fe, buflen, buf, t);
 }

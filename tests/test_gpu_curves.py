@@ -190,3 +190,45 @@ def test_table_variants_agree(cpa):
     finally:
         os.environ.pop("AKP_PEDERSEN_DIGIT_BITS", None)
         os.environ.pop("AKP_BH_GROUP", None)
+
+
+# ---- two device paths: accumulate + shared-inversion finalize (large batches) and the 8-wave split kernel
+# (batches <= AKP_TE_SPLIT_MAX, default 2^14).  Both must equal the oracle on every shape.
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 1 << 14, (1 << 14) + 1, 40000])
+def test_both_device_paths_pedersen(cpa, ped, n):
+    from crypto_primitives_amd.crh import pedersen
+    P, g, C = ped
+    for L in (128, 32):
+        m = _msgs(n, L, 7000 + n + L)
+        assert np.array_equal(pedersen.CRH.evaluate_batch(P, m), C.pedersen_crh_batch(m, n, L, threads=16)), (n, L)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 1 << 14, (1 << 14) + 1, 40000])
+def test_both_device_paths_bowe_hopwood(cpa, bhp, n):
+    from crypto_primitives_amd.crh import bowe_hopwood
+    P, g, C = bhp
+    for L in (70, 32, 1):
+        m = _msgs(n, L, 9000 + n + L)
+        assert np.array_equal(bowe_hopwood.CRH.evaluate_batch(P, m), C.bh_crh_batch(m, n, L, threads=16)), (n, L)
+
+
+def test_split_kernel_disabled_matches(cpa, ped, bhp, tmp_path):
+    """AKP_TE_SPLIT_MAX=0 sends small batches through accumulate + finalize: same digests."""
+    import os, subprocess, sys
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    P, _, _ = ped
+    B, _, _ = bhp
+    mp, mb = _msgs(333, 128, 1), _msgs(333, 70, 2)
+    np.save(tmp_path / "mp.npy", mp)
+    np.save(tmp_path / "mb.npy", mb)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+            "from oracle import jubjub as jj; from helpers import gens_array; "
+            "from crypto_primitives_amd.crh import pedersen, bowe_hopwood; "
+            "P = pedersen.Parameters(gens_array(jj.pedersen_generators(0xA5A50004, 4, 256))); "
+            "B = bowe_hopwood.Parameters(gens_array(jj.bowe_hopwood_generators(0xA5A50005, 63, 9))); "
+            "np.save(%r, pedersen.CRH.evaluate_batch(P, np.load(%r))); np.save(%r, bowe_hopwood.CRH.evaluate_batch(B, np.load(%r)))"
+            % (root, os.path.join(root, "tests"), str(tmp_path / "op.npy"), str(tmp_path / "mp.npy"), str(tmp_path / "ob.npy"), str(tmp_path / "mb.npy")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, AKP_TE_SPLIT_MAX="0"), timeout=600)
+    assert np.array_equal(np.load(tmp_path / "op.npy"), pedersen.CRH.evaluate_batch(P, mp))
+    assert np.array_equal(np.load(tmp_path / "ob.npy"), bowe_hopwood.CRH.evaluate_batch(B, mb))

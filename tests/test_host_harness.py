@@ -24,6 +24,7 @@ def H():
     h.hh_f29_inv.argtypes = [vp, vp, vp]
     h.hh_te_build_lut.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     h.hh_te_crh.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
+    h.hh_te_crh_split.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     h.hh_te_serialize_pairs.argtypes = [vp, vp, C.c_uint32, C.c_size_t, vp, C.c_size_t]
     h.hh_fr_pow.argtypes = [vp, C.c_uint64, vp]
     return h
@@ -160,6 +161,10 @@ def test_pedersen_table_path(H, W, N, D):
         H.hh_te_crh(0, P(lut), None, P(m), n, L, D, 0, _pedersen_steps(n_gen, D, L), 2, P(out))
         for i in range(n):
             assert tuple(ints(out[i])) == pd.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, D, L)
+        for split in (8, 2):  # the small-batch kernel's form: strided partial sums + tree of full additions
+            out2 = np.zeros_like(out)
+            H.hh_te_crh_split(0, P(lut), None, P(m), n, L, D, 0, _pedersen_steps(n_gen, D, L), split, P(out2))
+            assert np.array_equal(out2, out), (W, N, D, L, split)
 
 
 @pytest.mark.parametrize("W,N,group", [(63, 9, 1), (5, 3, 3), (5, 3, 1), (7, 2, 3), (63, 1, 3), (5, 3, 4), (7, 3, 2), (6, 2, 4)])
@@ -180,6 +185,10 @@ def test_bowe_hopwood_table_path(H, W, N, group):
         H.hh_te_crh(1, P(lut3), P(lut1), P(m), n, L, group, groups, steps, 3, P(out))
         for i in range(n):
             assert ints(out[i])[0] == bh.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, group, L)
+        for split in (8, 4):
+            out2 = np.zeros_like(out)
+            H.hh_te_crh_split(1, P(lut3), P(lut1), P(m), n, L, group, groups, steps, split, P(out2))
+            assert np.array_equal(out2, out), (W, N, group, L, split)
 
 
 def test_digest_serialisation(H):

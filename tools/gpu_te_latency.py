@@ -15,7 +15,7 @@ stream = torch.cuda.current_stream(dev).cuda_stream
 rng = np.random.default_rng(1)
 for name, prm, ln, fe in (("bh 70B", B, 70, 1), ("bh 32B", B, 32, 1), ("pedersen 128B", P, 128, 2)):
     h = prm.handle(ctx)
-    for log2n in (0, 6, 10, 12, 14, 16, 18, 20):
+    for log2n in (0, 6, 10, 12, 14, 15, 16, 17, 18, 20):
         n = 1 << log2n
         msgs = torch.from_numpy(rng.integers(0, 256, size=(n, ln), dtype=np.uint8)).to(dev)
         out = torch.empty((n, fe * 4), dtype=torch.int64, device=dev)
