@@ -59,6 +59,16 @@ def build_sharded(backend, local_leaves, n_leaves_global: int, dist=None):
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     shard_range(n_leaves_global, rank, world)  # validates the partition
+    if hasattr(backend, "combine_top_tensor"):
+        # tensor-resident flow (the GPU backends): the sub-root is gathered straight from the node array and the top
+        # G-1 nodes are one more inner-level build over the gathered digests -- no host copy before the root
+        leaf_nodes, non_leaf = backend.build_subtree_tensors(local_leaves)
+        subs = torch.empty((world,) + tuple(non_leaf.shape[1:]), dtype=non_leaf.dtype, device=non_leaf.device)
+        dist.all_gather_into_tensor(subs, non_leaf[0:1].contiguous())  # the one collective of the tree build
+        top_t = backend.combine_top_tensor(subs)
+        top = top_t.cpu().numpy().view(np.uint64)
+        root = top[0] if len(top) else subs[0].cpu().numpy().view(np.uint64)
+        return {"root": root, "top_nodes": top, "leaf_nodes": leaf_nodes, "non_leaf_nodes": non_leaf}
     leaf_nodes, non_leaf, sub_root = backend.build_subtree(local_leaves)
     sub_root = np.ascontiguousarray(sub_root, dtype=np.uint64)
     dev = backend.comm_device()
@@ -89,7 +99,7 @@ class GpuPoseidonBackend:
     def comm_device(self):
         return self.device
 
-    def build_subtree(self, d_leaves):
+    def build_subtree_tensors(self, d_leaves):
         """d_leaves: int64 cuda tensor [n_local, leaf_len, 4]."""
         from ._lib import lib, check
         torch = self.torch
@@ -99,8 +109,23 @@ class GpuPoseidonBackend:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(lib.akp_merkle_build_poseidon_dev(self.leaf_h.h, self.two_h.h, d_leaves.data_ptr(), n, self.leaf_len,
                                                 leaf_nodes.data_ptr(), non_leaf.data_ptr(), stream))
-        root = non_leaf[0].cpu().numpy().view(np.uint64)
-        return leaf_nodes, non_leaf, root
+        return leaf_nodes, non_leaf
+
+    def build_subtree(self, d_leaves):
+        leaf_nodes, non_leaf = self.build_subtree_tensors(d_leaves)
+        return leaf_nodes, non_leaf, non_leaf[0].cpu().numpy().view(np.uint64)
+
+    def combine_top_tensor(self, subs):
+        """subs: [G, 4] gathered sub-roots on this device -> the top G-1 nodes, heap order (root first): the inner
+        levels of a tree whose leaf digests are the sub-roots (merkle_tree/mod.rs:441-515)."""
+        from ._lib import lib, check
+        torch = self.torch
+        g = subs.shape[0]
+        top = torch.empty((g - 1, 4), dtype=torch.int64, device=self.device)
+        if g > 1:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            check(lib.akp_merkle_inner_poseidon_dev(self.two_h.h, subs.data_ptr(), g, top.data_ptr(), stream))
+        return top
 
     def two_to_one_compress(self, left, right):
         from .crh.poseidon import TwoToOneCRH
@@ -126,7 +151,7 @@ class GpuTeBackend:
     def comm_device(self):
         return self.device
 
-    def build_subtree(self, d_leaves):
+    def build_subtree_tensors(self, d_leaves):
         from ._lib import lib, check
         torch = self.torch
         n, L = d_leaves.shape[0], d_leaves.shape[1]
@@ -135,8 +160,21 @@ class GpuTeBackend:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(lib.akp_merkle_build_te_dev(self.leaf_h.h, self.two_h.h, d_leaves.data_ptr(), n, L, leaf_nodes.data_ptr(),
                                           non_leaf.data_ptr(), stream))
-        root = non_leaf[0].cpu().numpy().view(np.uint64)
-        return leaf_nodes, non_leaf, root
+        return leaf_nodes, non_leaf
+
+    def build_subtree(self, d_leaves):
+        leaf_nodes, non_leaf = self.build_subtree_tensors(d_leaves)
+        return leaf_nodes, non_leaf, non_leaf[0].cpu().numpy().view(np.uint64)
+
+    def combine_top_tensor(self, subs):
+        from ._lib import lib, check
+        torch = self.torch
+        g = subs.shape[0]
+        top = torch.empty((g - 1, self.fe * 4), dtype=torch.int64, device=self.device)
+        if g > 1:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            check(lib.akp_merkle_inner_te_dev(self.two_h.h, subs.data_ptr(), g, top.data_ptr(), stream))
+        return top
 
     def two_to_one_compress(self, left, right):
         from .crh import pedersen, bowe_hopwood

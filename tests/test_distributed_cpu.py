@@ -15,7 +15,7 @@ WORKER = r'''
 import os, sys, json
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
 import numpy as np, torch, torch.distributed as dist
-from crypto_primitives_amd.distributed import build_sharded, shard_range, global_node_slices
+from crypto_primitives_amd.distributed import build_sharded, shard_range, global_node_slices, combine_top
 from oracle import poseidon as po
 from helpers import cref_poseidon, rand_fr_array
 
@@ -27,13 +27,23 @@ class OracleBackend:  # test double: same interface as GpuPoseidonBackend, CPU h
         return ln, nl, nl[0].copy()
     def two_to_one_compress(self, l, r): return self.ora.two_to_one_batch(np.ascontiguousarray(l), np.ascontiguousarray(r))
 
+class TensorBackend(OracleBackend):  # same control flow as the GPU backends: node arrays are torch tensors, the
+    # sub-root is gathered straight from them and the top nodes come from one combine call on the gathered tensor
+    def build_subtree_tensors(self, leaves):
+        ln, nl = self.ora.merkle_build(self.ora, leaves, 1)
+        return torch.from_numpy(ln.view(np.int64)), torch.from_numpy(nl.view(np.int64))
+    def combine_top_tensor(self, subs):
+        top = combine_top(self.two_to_one_compress, subs.numpy().view(np.uint64))
+        return torch.from_numpy(np.ascontiguousarray(top).view(np.int64))
+
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
 n = 64
 leaves = rand_fr_array(n, 1234).reshape(n, 1, 4)
 lo, hi = shard_range(n, rank, world)
-b = OracleBackend()
+b = TensorBackend() if os.environ.get("AKP_TEST_BACKEND") == "tensor" else OracleBackend()
 res = build_sharded(b, leaves[lo:hi], n, dist)
+res["non_leaf_nodes"] = np.asarray(res["non_leaf_nodes"]).view(np.uint64); res["leaf_nodes"] = np.asarray(res["leaf_nodes"]).view(np.uint64)
 # full tree on every rank for comparison
 ln, nl = b.ora.merkle_build(b.ora, leaves, 1)
 assert np.array_equal(res["root"], nl[0]), "root mismatch"
@@ -50,11 +60,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_world(world):
+def _run_world(world, backend="numpy"):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AKP_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
@@ -68,6 +78,14 @@ def test_sharded_tree_world2_gloo():
 
 def test_sharded_tree_world4_gloo():
     _run_world(4)
+
+
+def test_sharded_tree_tensor_flow_world2_gloo():
+    _run_world(2, "tensor")
+
+
+def test_sharded_tree_tensor_flow_world4_gloo():
+    _run_world(4, "tensor")
 
 
 def test_partition_helpers():

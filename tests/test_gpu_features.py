@@ -113,6 +113,11 @@ def test_large_tree_equals_combined_subtrees(cpa):
             assert np.array_equal(nlr_host[lstart:lstart + cnt], nl_host[gstart:gstart + cnt]), (r, lvl)
     top = combine_top(be.two_to_one_compress, np.stack(subs))
     assert np.array_equal(top[0], root) and np.array_equal(top, nl_host[: G - 1])
+    # the tensor-resident form the N-GPU run uses: gathered sub-roots -> top nodes in one inner-level build
+    for g in (2, 4, 8):
+        lvl = nl[g - 1: 2 * g - 1].contiguous()  # global level log2(g) = what the all-gather would deliver
+        assert np.array_equal(be.combine_top_tensor(lvl).cpu().numpy().view(np.uint64), nl_host[: g - 1]), g
+    assert be.combine_top_tensor(nl[0:1].contiguous()).shape[0] == 0
 
 
 def test_te_backend_subtrees_combine(cpa):
@@ -134,6 +139,9 @@ def test_te_backend_subtrees_combine(cpa):
     subs = [be.build_subtree(d[r * (n // G):(r + 1) * (n // G)])[2].copy() for r in range(G)]
     top = combine_top(be.two_to_one_compress, np.stack(subs))
     assert np.array_equal(top, ref.non_leaf_nodes[: G - 1]) and np.array_equal(top[0], root)
+    for g in (2, 4, 8):
+        lvl = nl[g - 1: 2 * g - 1].contiguous()
+        assert np.array_equal(be.combine_top_tensor(lvl).cpu().numpy().view(np.uint64), ref.non_leaf_nodes[: g - 1]), g
 
 
 def test_full_size_tree_2pow24(cpa):
