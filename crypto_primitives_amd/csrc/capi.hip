@@ -373,11 +373,36 @@ static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr};
 }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
+// generic (t != 3) Poseidon kernels: batches up to AKP_POSEIDON_GENERIC_COOP_MAX (default 2^15) use one wave per state
+// lane (2-3x lower latency), larger ones the LDS-file kernel (one lane per item, up to 1.7x the throughput)
+static bool generic_coop(size_t n) {
+    static const size_t coop_max = [] {
+        const char* e = getenv("AKP_POSEIDON_GENERIC_COOP_MAX");
+        return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 15);
+    }();
+    return n <= coop_max;
+}
+static size_t coop_lds(u32 t) {
+    // t = 15, 16 need more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
+    static const bool raised = [] {
+        const int cap = 2 * AKP_POSEIDON_MAX_T * 9 * 64 * (int)sizeof(u32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poseidon_permute_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poseidon_crh_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        return true;
+    }();
+    (void)raised;
+    return (size_t)2 * t * 9 * 64 * sizeof(u32);
+}
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3) {
         hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), d_states, n);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
+    if (generic_coop(n)) {
+        hipLaunchKernelGGL(poseidon_permute_coop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * p->dims.t), coop_lds(p->dims.t), s, p->dims, t3_consts(p), d_states, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -407,6 +432,11 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
             return AKP_OK;
         }
         hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
+    if (generic_coop(n)) {
+        hipLaunchKernelGGL(poseidon_crh_coop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * p->dims.t), coop_lds(p->dims.t), s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }

@@ -351,4 +351,119 @@ __global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, Pos
     store_fr_global(out + idx, poseidon_crh_item(D, C, f, in0, in1, k, idx));
 }
 
+#if defined(__HIPCC__)
+// =============================== any t: one wave per state lane ================================================
+// Workgroup of t waves per 64 items; wave w keeps lane w of the 64 states in registers.  Every round publishes one
+// value per wave in a double-buffered LDS tile (t x 9 x 64 dwords per buffer) and has one barrier:
+//   full round      wave w: S-box of its lane, publish, then its MDS row over the t published values;
+//   sparse partial  wave 0: S-box, publish s;  wave i > 0: publish u_i * y_i;  then
+//                   wave 0: a00 * s + sum of the published terms;  wave i: y_i += w_i * s;
+//   dense partial   (parameter sets poseidon_optimize rejects) like a full round with the S-box on wave 0 only.
+// Same constants, same schedule and the same field routines as poseidon_permute_file, so the digests are identical.
+// No lane of a wave ever touches another item's data; all operand traffic of the arithmetic is registers + SGPR
+// constants, the LDS tile only carries the t values a round exchanges.
+struct CoopTile {
+    u32* base;  // [2][T][9][64]
+    u32 T, lane;
+    AKP_D void put(u32 buf, u32 slot, const FU& v) const {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) base[((buf * T + slot) * 9 + i) * 64 + lane] = v.l[i];
+    }
+    AKP_D FU get(u32 buf, u32 slot) const {
+        FU v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v.l[i] = base[((buf * T + slot) * 9 + i) * 64 + lane];
+        return v;
+    }
+};
+// sum_j published[j] * row[j], three terms per Montgomery reduction; result weakly normalised
+AKP_D FU coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ row) {
+    FU acc = f29_zero<false>();
+    u32 j = 0;
+#pragma unroll 1
+    for (; j + 3 <= tile.T; j += 3)
+        acc = f29_add(acc, f29_dot3(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1), tile.get(buf, j + 2), ldc(row + j + 2)));
+#pragma unroll 1
+    for (; j < tile.T; ++j) acc = f29_add(acc, f29_mul(tile.get(buf, j), ldc(row + j)));
+    return f29_weak_norm(acc);
+}
+// one permutation; x is lane w of the state (weakly normalised in and out); buf is the tile buffer to use next
+AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C, const CoopTile& tile, u32 w, FU& x, u32& buf) {
+    const u32 T = D.t;
+    const u32 half = D.full_rounds / 2;
+    const u32 R = D.full_rounds + D.partial_rounds;
+    const bool opt = C.sparse != nullptr;
+#pragma unroll 1
+    for (u32 r = 0; r < R; ++r) {
+        const bool full = (r < half) || (r >= half + D.partial_rounds);
+        if (full || !opt) {
+            x = f29_add(x, ldc(C.ark + (size_t)r * T + w));
+            if (full || w == 0) x = f29_pow_small(x, D.alpha);
+            tile.put(buf, w, x);
+            __syncthreads();
+            const F29Pad* m = ((opt && r + 1 == half) ? C.mpre : C.mds) + (size_t)w * T;
+            x = coop_row_dot(tile, buf, m);
+        } else {
+            const u32 j = r - half;
+            const F29Pad* sp = C.sparse + (size_t)j * 2 * T;  // q0, a00, u_1..u_{T-1}, w_1..w_{T-1}
+            if (w == 0) {
+                x = f29_pow_small(f29_add(x, ldc(sp)), D.alpha);
+                tile.put(buf, 0, x);
+            } else {
+                tile.put(buf, w, f29_mul(x, ldc(sp + 1 + w)));
+            }
+            __syncthreads();
+            if (w == 0) {
+                FU acc = f29_mul(x, ldc(sp + 1));
+#pragma unroll 1
+                for (u32 i = 1; i < T; ++i) {
+                    acc = f29_add(acc, tile.get(buf, i));
+                    if ((i & 3u) == 3u) acc = f29_weak_norm(acc);  // <= 4 normalised terms between renormalisations
+                }
+                x = f29_weak_norm(acc);
+            } else {
+                x = f29_add(x, f29_mul(tile.get(buf, 0), ldc(sp + T + w)));
+                if ((j & 31u) == 31u) x = f29_mul(x, f29_one<false>());
+                else if ((j & 1u) || j + 1 == D.partial_rounds) x = f29_weak_norm(x);
+            }
+        }
+        buf ^= 1u;
+    }
+}
+__global__ void __launch_bounds__(1024) poseidon_permute_coop_kernel(PoseidonDims D, PoseidonConsts C, Fr* states, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const CoopTile tile{reinterpret_cast<u32*>(smem), D.t, threadIdx.x & 63u};
+    const size_t item = (size_t)blockIdx.x * 64 + tile.lane;
+    const size_t idx = item < n ? item : n - 1;  // every lane walks all barriers; only valid items are stored
+    FU x = f29_weak_norm(f29_from_wire<false>(load_fr_global(states + idx * D.t + w)));
+    u32 buf = 0;
+    poseidon_permute_coop(D, C, tile, w, x, buf);
+    if (item < n) store_fr_global(states + item * D.t + w, f29_to_wire(x));
+}
+// fixed-length sponge CRH on a fresh sponge (same contract as poseidon_crh_item)
+__global__ void __launch_bounds__(1024) poseidon_crh_coop_kernel(PoseidonDims D, PoseidonConsts C, const Fr* __restrict__ in0,
+                                                                const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const CoopTile tile{reinterpret_cast<u32*>(smem), D.t, threadIdx.x & 63u};
+    const size_t item = (size_t)blockIdx.x * 64 + tile.lane;
+    const size_t idx = item < n ? item : n - 1;
+    FU x = f29_zero<false>();
+    u32 buf = 0;
+    size_t done = 0;
+    do {
+        const size_t take = (k - done) < D.rate ? (k - done) : D.rate;
+        if (w >= D.capacity && (size_t)(w - D.capacity) < take) {  // absorb_internal :124-153: state[capacity + j] += input
+            const size_t e = done + (w - D.capacity);
+            const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
+            x = f29_weak_norm(f29_add(x, f29_from_wire<false>(load_fr_global(src))));
+        }
+        done += take;
+        poseidon_permute_coop(D, C, tile, w, x, buf);
+    } while (done < k);
+    if (w == D.capacity && item < n) store_fr_global(out + item, f29_to_wire(x));  // squeeze_internal(0, 1)
+}
+#endif
+
 }  // namespace akp

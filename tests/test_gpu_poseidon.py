@@ -225,15 +225,41 @@ def test_custom_t3_parameters(cpa, case):
     assert np.array_equal(pcrh.TwoToOneCRH.compress_batch(c, l, r), ora.two_to_one_batch(l, r))
 
 
-def test_generic_kernel_on_custom_t(cpa):
-    """t = 2 and t = 4 with non-default parameters (generic LDS-file kernel)"""
-    for rate, cap, rp in ((1, 1, 7), (2, 2, 7), (3, 1, 70)):
-        t = rate + cap
-        mds = [rand_fr(t, 200 + i + t) for i in range(t)]
-        c, o = _custom_cfg(cpa, rate, cap, 4, rp, 5, mds, 10 + t)
-        ora = cref_poseidon(o)
-        st = rand_fr_array(70 * t, 3).reshape(70, t, 4)
-        assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st).reshape(70, t, 4))
+GENERIC_SHAPES = ((1, 1, 4, 7, 5), (2, 2, 4, 7, 5), (3, 1, 4, 70, 5), (7, 2, 8, 20, 5), (12, 4, 2, 3, 3), (15, 1, 4, 9, 5))
+
+
+@pytest.mark.parametrize("shape", GENERIC_SHAPES)
+def test_generic_kernel_on_custom_t(cpa, shape):
+    """t = 2 .. 16 with non-default parameters through the generic kernels (batches up to
+    AKP_POSEIDON_GENERIC_COOP_MAX: one wave per state lane; above: state in an LDS file, one lane per item -- see
+    test_generic_kernels_both_ways): permutation on a ragged batch, CRH with 0, 1, rate, rate + 1, 2*rate + 3 inputs."""
+    from crypto_primitives_amd.crh import poseidon as pcrh
+    rate, cap, rf, rp, alpha = shape
+    t = rate + cap
+    mds = [rand_fr(t, 200 + i + t) for i in range(t)]
+    c, o = _custom_cfg(cpa, rate, cap, rf, rp, alpha, mds, 10 + t)
+    ora = cref_poseidon(o)
+    n = 130
+    st = rand_fr_array(n * t, 3).reshape(n, t, 4)
+    assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st, threads=8).reshape(n, t, 4))
+    for k in (0, 1, rate, rate + 1, 2 * rate + 3):
+        x = rand_fr_array(70 * max(k, 1), 40 + k).reshape(70, max(k, 1), 4)[:, :k]
+        got = pcrh.CRH.evaluate_batch(c, np.ascontiguousarray(x))
+        exp = np.repeat(ora.crh_empty(), 70, axis=0) if k == 0 else ora.crh_batch(np.ascontiguousarray(x), k, threads=8)
+        assert np.array_equal(got, exp), (shape, k)
+
+
+@pytest.mark.parametrize("coop_max", ["0", "1000000000"])
+def test_generic_kernels_both_ways(cpa, coop_max):
+    """the same checks with every batch forced through the LDS-file kernels (0) / the wave-per-lane kernels (10^9),
+    in a fresh process (the switch is read once)"""
+    import os, subprocess, sys
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                        "test_generic_kernel_on_custom_t or test_crh_other_rates or test_permute_all_default_configs"],
+                       env=dict(os.environ, AKP_POSEIDON_GENERIC_COOP_MAX=coop_max), capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 # ---- the CRH path has two kernels for t = 3: one lane per item (large batches) and the 3-wave latency kernel
