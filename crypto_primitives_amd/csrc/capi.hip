@@ -373,6 +373,14 @@ static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr};
 }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
+// AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the 3-wave latency kernels (0 disables them)
+static size_t coop_max_items() {
+    static const size_t v = [] {
+        const char* e = getenv("AKP_POSEIDON_COOP_MAX");
+        return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 15);
+    }();
+    return v;
+}
 // generic (t != 3) Poseidon kernels: batches up to AKP_POSEIDON_GENERIC_COOP_MAX (default 2^15) use one wave per state
 // lane (2-3x lower latency), larger ones the LDS-file kernel (one lane per item, up to 1.7x the throughput)
 static bool generic_coop(size_t n) {
@@ -396,12 +404,12 @@ static size_t coop_lds(u32 t) {
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
-    if (p->dims.t == 3) {
+    if (p->dims.t == 3 && n > coop_max_items()) {
         hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), d_states, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
-    if (generic_coop(n)) {
+    if (p->dims.t == 3 || generic_coop(n)) {  // t = 3 reaches this point only for small batches (sponge steps, few states)
         hipLaunchKernelGGL(poseidon_permute_coop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * p->dims.t), coop_lds(p->dims.t), s, p->dims, t3_consts(p), d_states, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
@@ -415,27 +423,16 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
-// AKP_POSEIDON_COOP_MAX: largest batch routed to the 3-wave latency kernel (0 disables it)
-static size_t coop_max_items() {
-    const char* e = getenv("AKP_POSEIDON_COOP_MAX");
-    return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 15);
-}
 static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
-    if (p->dims.t == 3) {
-        // small batches (tree tops) are bound by the latency of one permutation: spread each one over three waves
-        static const size_t coop_max = coop_max_items();
-        if (n <= coop_max && p->d_sparse29 && p->dims.capacity == 1 && k <= p->dims.rate) {
-            hipLaunchKernelGGL(poseidon_crh_t3_coop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(192), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
-            HIP_TRY(hipGetLastError());
-            return AKP_OK;
-        }
+    if (p->dims.t == 3 && n > coop_max_items()) {
         hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
-    if (generic_coop(n)) {
+    // small batches (tree tops, single sponges) are bound by the latency of one permutation: one wave per state lane
+    if (p->dims.t == 3 || generic_coop(n)) {
         hipLaunchKernelGGL(poseidon_crh_coop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * p->dims.t), coop_lds(p->dims.t), s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;

@@ -160,69 +160,6 @@ __global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, Po
     store_fr_global(out + idx, poseidon_crh_item_t3(D, C, in0, in1, k, idx));
 }
 
-#if defined(__HIPCC__)
-// Latency variant for small batches (the upper levels of a tree): one 3-wave workgroup per 64 items, wave w owns
-// state lane w.  The waves exchange the S-boxed lane(s) through a double-buffered LDS tile, one barrier per round:
-// a full round costs each wave one S-box + one MDS row (instead of three of each), a sparse partial round costs
-// wave 0 the S-box + one product while waves 1,2 do two products (their term of the lane-0 row, their own update).  Same schedule and arithmetic as
-// poseidon_permute_t3; ~0.6x its single-wave latency, at 3x the wave slots -- the host picks it below a batch size.
-// Requires: t = 3, capacity 1, sparse constants present, k <= rate (one permutation on a fresh sponge).
-__global__ void __launch_bounds__(192) poseidon_crh_t3_coop_kernel(PoseidonDims D, PoseidonT3Consts C, const Fr* __restrict__ in0,
-                                                                  const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out, size_t n) {
-    __shared__ u32 xch[2][3][9][64];
-    const u32 w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const u32 lane = threadIdx.x & 63u;
-    const size_t item = (size_t)blockIdx.x * 64 + lane;
-    const size_t idx = item < n ? item : n - 1;  // every lane walks all barriers; only valid items are stored
-    FU x = f29_zero<false>();                    // PoseidonSponge::new :223-234, then absorb_internal(0, ..) :124-153
-    if (w >= 1 && (size_t)(w - 1) < k) {
-        const size_t e = w - 1;
-        const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
-        x = f29_weak_norm(f29_from_wire<false>(load_fr_global(src)));
-    }
-    const u32 half = D.full_rounds / 2;
-    const u32 R = D.full_rounds + D.partial_rounds;
-    u32 buf = 0;
-    auto put = [&](u32 slot, const FU& v) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) xch[buf][slot][i][lane] = v.l[i];
-    };
-    auto get = [&](u32 slot) {
-        FU v;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) v.l[i] = xch[buf][slot][i][lane];
-        return v;
-    };
-#pragma unroll 1
-    for (u32 r = 0; r < R; ++r) {
-        const bool full = (r < half) || (r >= half + D.partial_rounds);
-        if (full) {
-            x = f29_pow_small(f29_add(x, ldc(C.ark + (size_t)r * 3 + w)), D.alpha);
-            put(w, x);
-            __syncthreads();
-            const F29Pad* m = ((r + 1 == half) ? C.mpre : C.mds) + 3 * w;
-            x = f29_dot3(get(0), ldc(m), get(1), ldc(m + 1), get(2), ldc(m + 2));
-        } else {
-            const u32 j = r - half;
-            const F29Pad* sp = C.sparse + (size_t)j * 6;
-            // wave 0: the S-boxed lane; waves 1,2 use the wait to form their term u_w * y_w of the lane-0 row
-            if (w == 0) x = f29_pow_small(f29_add(x, ldc(sp)), D.alpha);
-            put(w, w == 0 ? x : f29_mul(x, ldc(sp + 1 + w)));
-            __syncthreads();
-            if (w == 0) {
-                x = f29_weak_norm(f29_add(f29_add(f29_mul(x, ldc(sp + 1)), get(1)), get(2)));
-            } else {
-                x = f29_add(x, f29_mul(get(0), ldc(sp + 3 + w)));
-                if ((j & 31u) == 31u) x = f29_mul(x, f29_one<false>());
-                else if ((j & 1u) || j + 1 == D.partial_rounds) x = f29_weak_norm(x);
-            }
-        }
-        buf ^= 1u;
-    }
-    if (w == 1 && item < n) store_fr_global(out + item, f29_to_wire(x));  // squeeze_internal(0, 1): state[capacity]
-}
-#endif
-
 // =============================== any t: LDS "register file" ========================================
 // slot s, limb i, lane l -> dword (s*9 + i)*BLOCK + l : consecutive lanes hit consecutive banks.
 template <int BLOCK>

@@ -262,7 +262,7 @@ def test_generic_kernels_both_ways(cpa, coop_max):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-# ---- the CRH path has two kernels for t = 3: one lane per item (large batches) and the 3-wave latency kernel
+# ---- the CRH path has two kernels for t = 3: one lane per item (large batches) and the wave-per-lane latency kernel
 # (batches <= AKP_POSEIDON_COOP_MAX, default 2^15).  Both must equal the oracle on every shape.
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 191, 193, 5000, (1 << 15), (1 << 15) + 1, 40000])
 def test_crh_t3_small_and_large_batches(cpa, n):
