@@ -346,6 +346,36 @@ class MerkleTree:
         self._apply(index, new_hash, path)
         return True
 
+    def update_batch(self, indices, new_leaves):
+        """Batched form of `update` (extension): equal to calling update(i, leaf) for each pair in
+        order (a repeated index keeps its last leaf), but every level is ONE batched hash call over the distinct
+        touched nodes: log2(n) launches in total instead of log2(n) per leaf."""
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        assert idx.size == len(new_leaves), "one leaf per index"
+        if idx.size == 0:
+            return
+        assert idx.min() >= 0 and idx.max() < len(self.leaf_nodes), "index out of range"
+        cfg = self.config
+        hashes = cfg.hash_leaves(self.leaf_hash_param, new_leaves)
+        last = {}
+        for k, i in enumerate(idx.tolist()):  # last write wins, as with sequential updates
+            last[i] = k
+        keep = np.fromiter(last.values(), dtype=np.int64)
+        self.leaf_nodes[idx[keep]] = hashes[keep]
+        if self._height < 2:
+            return
+        # bottom inner level: parents of leaf pairs (evaluate on converted leaf digests, :643-654)
+        pairs = np.unique(idx >> 1)
+        cur = cfg.two_to_one_evaluate(self.two_to_one_hash_param, np.ascontiguousarray(self.leaf_nodes[2 * pairs]),
+                                      np.ascontiguousarray(self.leaf_nodes[2 * pairs + 1]))
+        nodes = pairs + (1 << (self._height - 2)) - 1  # heap indices of those parents
+        self.non_leaf_nodes[nodes] = cur
+        while nodes[0] != 0:  # upper levels: compress (:656-672); all nodes of a round sit on one level
+            nodes = np.unique((nodes - 1) >> 1)
+            cur = cfg.two_to_one_compress(self.two_to_one_hash_param, np.ascontiguousarray(self.non_leaf_nodes[2 * nodes + 1]),
+                                          np.ascontiguousarray(self.non_leaf_nodes[2 * nodes + 2]))
+            self.non_leaf_nodes[nodes] = cur
+
     def _apply(self, index, new_hash, path_bottom_to_top):
         self.leaf_nodes[index] = new_hash
         cur = convert_index_to_last_level(index, self._height)
