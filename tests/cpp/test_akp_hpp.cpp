@@ -10,7 +10,54 @@
 using namespace akp;
 #define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
 
-int main() {
+// Pedersen / Bowe-Hopwood classes against cases written by the python test (generators, message, expected digest from
+// the oracle).  Record: u32 kind, W, N, msg_len; N*W affine generators (8 u64 each, wire format); msg; expected digest.
+static int te_cases(const Context& ctx, const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    REQUIRE(f != nullptr);
+    uint32_t hdr[4];
+    int cases = 0;
+    while (std::fread(hdr, sizeof hdr, 1, f) == 1) {
+        const uint32_t kind = hdr[0], W = hdr[1], N = hdr[2], L = hdr[3];
+        std::vector<AffineWire> gens((size_t)W * N);
+        REQUIRE(std::fread(gens.data(), sizeof(AffineWire), gens.size(), f) == gens.size());
+        std::vector<uint8_t> msg(L);
+        REQUIRE(L == 0 || std::fread(msg.data(), 1, L, f) == L);
+        const std::vector<uint8_t> lo(msg.begin(), msg.begin() + L / 2), hi(msg.begin() + L / 2, msg.begin() + 2 * (L / 2));
+        if (kind == AKP_TE_PEDERSEN) {
+            AffineWire want;
+            REQUIRE(std::fread(&want, sizeof want, 1, f) == 1);
+            pedersen::Parameters P(ctx, W, N, gens);
+            const AffineWire got = pedersen::CRH::evaluate(P, msg);
+            REQUIRE(got.x == want.x && got.y == want.y);
+            const AffineWire id = pedersen::CRH::evaluate(P, {});  // identity (crh/pedersen/mod.rs:116-122)
+            REQUIRE(fr_to_canonical({id.x})[0] == (FrWire{0, 0, 0, 0}) && fr_to_canonical({id.y})[0] == (FrWire{1, 0, 0, 0}));
+            if (L % 2 == 0 && (size_t)L * 8 == (size_t)W * N) {  // halves fill the buffer exactly: evaluate(l, r) == CRH(l || r)
+                const AffineWire two = pedersen::TwoToOneCRH::evaluate(P, lo, hi);
+                REQUIRE(two.x == want.x && two.y == want.y);
+            }
+            try { pedersen::CRH::evaluate(P, std::vector<uint8_t>((size_t)W * N / 8 + 1)); REQUIRE(false); }
+            catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_LENGTH); }  // the reference panics (:82-89)
+            auto batch = pedersen::CRH::evaluate_batch(P, std::vector<uint8_t>(msg), L);
+            REQUIRE(batch.size() == 1 && batch[0].x == want.x);
+        } else {
+            FrWire want;
+            REQUIRE(std::fread(&want, sizeof want, 1, f) == 1);
+            bowe_hopwood::Parameters B(ctx, W, N, gens);
+            REQUIRE(bowe_hopwood::CRH::evaluate(B, msg) == want);
+            REQUIRE(fr_to_canonical({bowe_hopwood::CRH::evaluate(B, {})})[0] == (FrWire{0, 0, 0, 0}));  // empty message: x of the identity
+            try { bowe_hopwood::TwoToOneCRH::evaluate(B, lo, std::vector<uint8_t>(lo.size() + 1)); REQUIRE(false); }
+            catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_LENGTH); }
+        }
+        ++cases;
+    }
+    std::fclose(f);
+    REQUIRE(cases >= 2);
+    std::printf("te cases %d\n", cases);
+    return 0;
+}
+
+int main(int argc, char** argv) {
     if (akp_device_count() < 1) { std::fprintf(stderr, "no HIP device\n"); return 2; }
     Context ctx(0);
     PoseidonConfig cfg = PoseidonConfig::get_default_poseidon_parameters(ctx, 2, false);
@@ -50,6 +97,7 @@ int main() {
     catch (const Error& e) { REQUIRE(e.code == AKP_ERR_NOT_POW2); }
     // reference returns None for rate 9
     try { PoseidonConfig::get_default_poseidon_parameters(ctx, 9, false); REQUIRE(false); } catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_PARAMS); }
+    if (argc > 1 && te_cases(ctx, argv[1]) != 0) return 1;
     std::printf("OK\n");
     return 0;
 }

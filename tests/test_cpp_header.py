@@ -15,17 +15,39 @@ def _build():
                            "-L", lib, "-lakp", f"-Wl,-rpath,{lib}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
 
 
+def _write_te_cases(tmp_path):
+    """generators + message + expected digest (oracle) for the Pedersen / Bowe-Hopwood classes of akp.hpp"""
+    import struct
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import jubjub as jj, pedersen as opd, bowe_hopwood as obh
+    from helpers import gens_array, mont
+    path = os.path.join(str(tmp_path), "te_cases.bin")
+    with open(path, "wb") as f:
+        for kind, W, N, L in ((0, 4, 16, 8), (0, 5, 9, 3), (1, 7, 3, 6)):
+            g = jj.pedersen_generators(90 + W, W, N) if kind == 0 else jj.bowe_hopwood_generators(91 + W, W, N)
+            msg = bytes((37 * i + 11) & 0xFF for i in range(L))
+            f.write(struct.pack("<4I", kind, W, N, L))
+            f.write(np.ascontiguousarray(gens_array(g), dtype=np.uint64).tobytes())
+            f.write(msg)
+            want = list(opd.evaluate(g, W, N, msg)) if kind == 0 else [obh.evaluate(g, W, N, msg)]
+            f.write(mont(want).tobytes())
+    return path
+
+
 def test_cpp_header_compiles_and_links():
     _build()
     assert os.path.exists(EXE)
 
 
 @pytest.mark.gpu
-def test_cpp_header_program_runs():
+def test_cpp_header_program_runs(tmp_path):
     _build()
-    p = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    case_file = _write_te_cases(tmp_path)
+    p = subprocess.run([EXE, case_file], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "OK" in p.stdout
+    assert "OK" in p.stdout and "te cases 3" in p.stdout
     # root of the 8-leaf tree [1]..[8] (tests/golden/derived_vectors.json)
     import json
     d = json.load(open(os.path.join(ROOT, "tests", "golden", "derived_vectors.json")))
