@@ -373,7 +373,7 @@ static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr};
 }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
-// AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the 3-wave latency kernels (0 disables them)
+// AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the wave-per-lane latency kernels (0 disables them)
 static size_t coop_max_items() {
     static const size_t v = [] {
         const char* e = getenv("AKP_POSEIDON_COOP_MAX");

@@ -1,4 +1,4 @@
-"""3-wave latency kernel vs the one-lane-per-item kernel: two_to_one timings over a batch-size sweep, plus an
+"""wave-per-lane latency kernel vs the one-lane-per-item kernel: two_to_one timings over a batch-size sweep, plus an
 equality check of the digests.  Run once per mode (the switch is read once per process):
   AKP_POSEIDON_COOP_MAX=0 python tools/gpu_coop.py ; AKP_POSEIDON_COOP_MAX=1000000000 python tools/gpu_coop.py"""
 import os, sys, hashlib, numpy as np, torch
