@@ -391,15 +391,13 @@ static bool generic_coop(size_t n) {
     return n <= coop_max;
 }
 static size_t coop_lds(u32 t) {
-    // t = 15, 16 need more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
-    static const bool raised = [] {
-        const int cap = 2 * AKP_POSEIDON_MAX_T * 9 * 64 * (int)sizeof(u32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poseidon_permute_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poseidon_crh_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        return true;
-    }();
-    (void)raised;
-    return (size_t)2 * t * 9 * 64 * sizeof(u32);
+    const size_t bytes = (size_t)2 * t * 9 * 64 * sizeof(u32);
+    if (bytes > 65536) {  // t = 15, 16: above the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU);
+        // set on every such launch: the attribute belongs to the current device's copy of the kernel
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poseidon_permute_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poseidon_crh_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    }
+    return bytes;
 }
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
