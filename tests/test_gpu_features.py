@@ -204,3 +204,19 @@ def test_full_size_pedersen_2pow20(cpa):
     idx = np.random.default_rng(2).integers(0, n, 512)
     assert np.array_equal(full[idx], C.pedersen_crh_batch(np.ascontiguousarray(msgs[idx]), len(idx), 128, threads=8))
     assert len(np.unique(full.reshape(n, -1)[:, 0])) == n  # no accidental collisions / duplicated lanes
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_build_real_backends_multi_rank(cpa, world):
+    """N > 1 control flow with the REAL GPU backends: `world` ranks share GPU 0 (gloo carries the one all-gather, on
+    device tensors), each builds its leaf-range sub-tree with GpuPoseidonBackend / GpuTeBackend, and root + top nodes
+    must equal a single-process build (tools/gpu_gloo2.py)."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "gpu_gloo2.py")],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    for k in range(world):
+        assert "rank %d ok" % k in r.stdout
