@@ -77,6 +77,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_bench_contract.py): AKP_BENCH_SHARED_GPU=1 puts every rank on GPU 0 and carries the
+    # collectives over gloo, so the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
+    shared_gpu = os.environ.get("AKP_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -85,7 +90,10 @@ def main():
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import crypto_primitives_amd as cpa
     from crypto_primitives_amd import field

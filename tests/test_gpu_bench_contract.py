@@ -39,3 +39,19 @@ def test_bench_under_torchrun_world1():
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
     d = _check(p.stdout)
     assert d["n_gpus"] == 1 and "merkle" in d and d["bh_merkle"]["leaves"] == 256
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_code_path_on_one_gpu(world):
+    """The N > 1 branch of bench.py (rank env, barriers, MAX-reduced timing, sharded Merkle legs, rank-0 printing) with
+    `world` ranks sharing GPU 0 and gloo carrying the collectives (AKP_BENCH_SHARED_GPU=1, a test hook)."""
+    args = ["--steps", "2", "--warmup", "1", "--log2-states", "14", "--merkle-log2", "12", "--bh-merkle-log2", "10", "--no-cpu-baseline"]
+    env = dict(os.environ, AKP_BENCH_SHARED_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                        "127.0.0.1", "--master-port", str(29540 + world), "bench.py", "--gpus", str(world)] + args,
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    d = _check(p.stdout)
+    assert d["n_gpus"] == world and d["config"]["states_per_gpu"] == 1 << 14 and "cpu_baseline" not in d
+    assert d["merkle"]["leaves"] == 1 << 12 and d["bh_merkle"]["leaves"] == 1 << 10
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1  # rank 0 only
