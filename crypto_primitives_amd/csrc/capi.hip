@@ -363,7 +363,12 @@ extern "C" int32_t akp_poseidon_default_params(akp_ctx* ctx, uint32_t rate, int3
 
 // ------------------------------------------------------------------------------------------
 // Poseidon launches
-static inline unsigned poseidon_block(u32 t) { return t <= 7 ? 256u : (t <= 14 ? 128u : 64u); }  // 36*t*B bytes of LDS <= 64 KiB
+static inline unsigned poseidon_block(u32 t) {
+    if (const char* e = getenv("AKP_POSEIDON_FILE_BLOCK")) { const unsigned b = (unsigned)atoi(e); if (b == 64 || b == 128 || b == 256) return (36u * t * b <= 65536u) ? b : 64u; }
+    // 36*t*B bytes of LDS per block (<= 64 KiB): 256 is fastest while four blocks still fit a CU; from t = 9 on the file
+    // is what limits the waves per CU and the finer 64-lane granularity fits one more (tools/gpu_file_block.sh)
+    return t <= 7 ? 256u : (t == 8 ? 128u : 64u);
+}
 
 // LDS bytes of the generic kernel: t elements of 9 dwords per lane
 static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)t * 9 * 4 * B; }
