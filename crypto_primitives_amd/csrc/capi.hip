@@ -155,6 +155,7 @@ struct akp_poseidon {
     F29Pad* d_arkmod29 = nullptr;
     F29Pad* d_mpre29 = nullptr;
     F29Pad* d_sparse29 = nullptr;
+    F29Pad* d_sbox0_29 = nullptr;     // (round-0 key)^alpha per lane, see PoseidonConsts::sbox0
 };
 static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) {
     Fr* tmp = nullptr;
@@ -220,10 +221,17 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
                 int32_t rc = upload_f29(ctx, opt.ark_mod, &p->d_arkmod29);
                 if (!rc) rc = upload_f29(ctx, opt.mpre, &p->d_mpre29);
                 if (!rc) rc = upload_f29(ctx, opt.sparse, &p->d_sparse29);
+                if (!rc && full_rounds >= 2) rc = upload_f29(ctx, poseidon_sbox0(opt.ark_mod, t, alpha), &p->d_sbox0_29);
                 if (rc) {
                     akp_poseidon_params_destroy(p);
                     return rc;
                 }
+            }
+        }
+        if (!p->d_sbox0_29 && full_rounds >= 2) {
+            if (int32_t rc = upload_f29(ctx, poseidon_sbox0(p->ark, t, alpha), &p->d_sbox0_29)) {
+                akp_poseidon_params_destroy(p);
+                return rc;
             }
         }
     }
@@ -240,6 +248,7 @@ extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (p->d_arkmod29) (void)hipFree(p->d_arkmod29);
     if (p->d_mpre29) (void)hipFree(p->d_mpre29);
     if (p->d_sparse29) (void)hipFree(p->d_sparse29);
+    if (p->d_sbox0_29) (void)hipFree(p->d_sbox0_29);
     delete p;
 }
 extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
@@ -374,8 +383,8 @@ static inline unsigned poseidon_block(u32 t) {
 static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)t * 9 * 4 * B; }
 
 static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
-    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29};
-    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr};
+    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29};
+    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29};
 }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
 // AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the wave-per-lane latency kernels (0 disables them)

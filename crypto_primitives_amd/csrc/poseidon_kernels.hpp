@@ -63,9 +63,12 @@ struct PoseidonConsts {
     const F29Pad* mds;     // [t][t]
     const F29Pad* mpre;    // [t][t] or nullptr
     const F29Pad* sparse;  // [RP][2t] = q0, a00, u_1..u_{t-1}, w_1..w_{t-1}  or nullptr (dense partial rounds)
+    const F29Pad* sbox0;   // [t] (0 + ark[0][i])^alpha: round-0 S-box output of a lane that enters as zero (the capacity
+                           // lane and the unused rate lanes of a fresh sponge); nullptr when round 0 is not a full round
 };
 typedef PoseidonConsts PoseidonT3Consts;
-AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2) {
+// zero_lanes: bit i set = lane i is known to be zero on entry (uniform over the batch): its first S-box is a constant
+AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2, u32 zero_lanes = 0) {
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
     const bool opt = C.sparse != nullptr;
@@ -74,12 +77,16 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
         const bool full = (r < half) || (r >= half + D.partial_rounds);
         if (full || !opt) {
             const F29Pad* a = C.ark + (size_t)r * 3;
-            s0 = f29_pow_small(f29_add(s0, ldc(a)), D.alpha);
+            const u32 z = (r == 0 && full && C.sbox0 != nullptr) ? zero_lanes : 0u;
+            if (z & 1u) s0 = ldc(C.sbox0);
+            else s0 = f29_pow_small(f29_add(s0, ldc(a)), D.alpha);
             s1 = f29_add(s1, ldc(a + 1));
             s2 = f29_add(s2, ldc(a + 2));
             if (full) {
-                s1 = f29_pow_small(s1, D.alpha);
-                s2 = f29_pow_small(s2, D.alpha);
+                if (z & 2u) s1 = ldc(C.sbox0 + 1);
+                else s1 = f29_pow_small(s1, D.alpha);
+                if (z & 4u) s2 = ldc(C.sbox0 + 2);
+                else s2 = f29_pow_small(s2, D.alpha);
             }
             const F29Pad* m = (opt && r + 1 == half) ? C.mpre : C.mds;
             const FU n0 = f29_dot3(s0, ldc(m + 0), s1, ldc(m + 1), s2, ldc(m + 2));
@@ -132,8 +139,10 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
             const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
             t3_add_slot(s0, s1, s2, D.capacity + (u32)j, f29_from_wire<false>(load_fr_global(src)));
         }
+        // fresh sponge: every lane outside [capacity, capacity + take) is still zero in the first permutation
+        const u32 zero_lanes = done == 0 ? (7u & ~(((1u << take) - 1u) << D.capacity)) : 0u;
         done += take;
-        poseidon_permute_t3(D, C, s0, s1, s2);
+        poseidon_permute_t3(D, C, s0, s1, s2, zero_lanes);
     } while (done < k);
     // squeeze_internal(0, 1) :156-186 -- limb-wise selects (an array select would go through scratch)
     FU out;

@@ -144,4 +144,12 @@ inline PoseidonOpt poseidon_optimize(unsigned t, unsigned full_rounds, unsigned 
     return o;
 }
 
+// (round-0 key of lane i)^alpha for the round keys the kernels actually use: what the first S-box of a lane that
+// enters the permutation as zero produces (PoseidonConsts::sbox0)
+inline std::vector<Fr> poseidon_sbox0(const std::vector<Fr>& ark_used, uint32_t t, uint64_t alpha) {
+    std::vector<Fr> out(t);
+    for (uint32_t i = 0; i < t; ++i) out[i] = fr_pow_small(ark_used[i], alpha);
+    return out;
+}
+
 }  // namespace akp

@@ -29,16 +29,21 @@ static std::vector<F29Pad> to29(const Fr* in, size_t n) {
 //                1 = generic file path with sparse partial rounds even for t == 3,
 //                2 = dense partial rounds (t == 3: register path, else file path)
 struct T3Host {  // constants in internal form for any t (name kept from the t = 3 path)
-    std::vector<F29Pad> ark, mds, mpre, sparse;
+    std::vector<F29Pad> ark, mds, mpre, sparse, sbox0;
     PoseidonConsts c;
-    T3Host(uint32_t t, uint32_t rf, uint32_t rp, const Fr* a, const Fr* m, bool sparse_form) {
+    T3Host(uint32_t t, uint32_t rf, uint32_t rp, uint64_t alpha, const Fr* a, const Fr* m, bool sparse_form) {
         std::vector<Fr> av(a, a + (size_t)(rf + rp) * t), mv(m, m + (size_t)t * t);
         PoseidonOpt o;
         if (sparse_form) o = poseidon_optimize(t, rf, rp, av, mv);
         mds = to29(mv.data(), mv.size());
         if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
-                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data()}; }
-        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr}; }
+                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr}; }
+        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr}; }
+        if (rf >= 2) {  // as capi.hip does: from the round keys the kernels use
+            const std::vector<Fr> s0 = poseidon_sbox0(o.ok ? o.ark_mod : av, t, alpha);
+            sbox0 = to29(s0.data(), s0.size());
+            c.sbox0 = sbox0.data();
+        }
     }
 };
 static PoseidonDims mk(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap) {
@@ -89,7 +94,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
     std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
-    T3Host* th = new T3Host(D.t, rf, rp, ark, mds, force_generic != 2);
+    T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i) {
         if (reg_path) {  // the register-resident fast path
@@ -109,7 +114,7 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
     std::vector<FU> buf(2 * D.t);
     HostFile f{buf.data()};
-    T3Host* th = new T3Host(D.t, rf, rp, ark, mds, force_generic != 2);
+    T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i)
         out[i] = reg_path ? poseidon_crh_item_t3(D, th->c, in0, in1, k, i) : poseidon_crh_item(D, th->c, f, in0, in1, k, i);
