@@ -67,8 +67,10 @@ struct PoseidonConsts {
                            // lane and the unused rate lanes of a fresh sponge); nullptr when round 0 is not a full round
 };
 typedef PoseidonConsts PoseidonT3Consts;
-// zero_lanes: bit i set = lane i is known to be zero on entry (uniform over the batch): its first S-box is a constant
-AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2, u32 zero_lanes = 0) {
+// zero_lanes: bit i set = lane i is known to be zero on entry (uniform over the batch): its first S-box is a constant.
+// need_lanes: bit i set = lane i of the result is used; the other rows of the last linear layer are skipped.
+AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2, u32 zero_lanes = 0,
+                                u32 need_lanes = 7u) {
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
     const bool opt = C.sparse != nullptr;
@@ -89,9 +91,11 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
                 else s2 = f29_pow_small(s2, D.alpha);
             }
             const F29Pad* m = (opt && r + 1 == half) ? C.mpre : C.mds;
-            const FU n0 = f29_dot3(s0, ldc(m + 0), s1, ldc(m + 1), s2, ldc(m + 2));
-            const FU n1 = f29_dot3(s0, ldc(m + 3), s1, ldc(m + 4), s2, ldc(m + 5));
-            const FU n2 = f29_dot3(s0, ldc(m + 6), s1, ldc(m + 7), s2, ldc(m + 8));
+            const u32 need = (r + 1 == R) ? need_lanes : 7u;
+            FU n0 = s0, n1 = s1, n2 = s2;
+            if (need & 1u) n0 = f29_dot3(s0, ldc(m + 0), s1, ldc(m + 1), s2, ldc(m + 2));
+            if (need & 2u) n1 = f29_dot3(s0, ldc(m + 3), s1, ldc(m + 4), s2, ldc(m + 5));
+            if (need & 4u) n2 = f29_dot3(s0, ldc(m + 6), s1, ldc(m + 7), s2, ldc(m + 8));
             s0 = n0;
             s1 = n1;
             s2 = n2;
@@ -142,7 +146,8 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
         // fresh sponge: every lane outside [capacity, capacity + take) is still zero in the first permutation
         const u32 zero_lanes = done == 0 ? (7u & ~(((1u << take) - 1u) << D.capacity)) : 0u;
         done += take;
-        poseidon_permute_t3(D, C, s0, s1, s2, zero_lanes);
+        // only state[capacity] of the last permutation is squeezed (:156-186)
+        poseidon_permute_t3(D, C, s0, s1, s2, zero_lanes, done < k ? 7u : (1u << D.capacity));
     } while (done < k);
     // squeeze_internal(0, 1) :156-186 -- limb-wise selects (an array select would go through scratch)
     FU out;
