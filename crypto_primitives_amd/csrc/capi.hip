@@ -156,6 +156,7 @@ struct akp_poseidon {
     F29Pad* d_mpre29 = nullptr;
     F29Pad* d_sparse29 = nullptr;
     F29Pad* d_sbox0_29 = nullptr;     // (round-0 key)^alpha per lane, see PoseidonConsts::sbox0
+    bool scaled = false;              // sparse constants rescaled (poseidon_rescale_sparse)
 };
 static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) {
     Fr* tmp = nullptr;
@@ -216,7 +217,9 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
             return fail(AKP_ERR_HIP, "uploading Poseidon parameters: %s", hipGetErrorString(e));
         }
         if (!getenv("AKP_POSEIDON_DENSE")) {
-            const PoseidonOpt opt = poseidon_optimize(t, full_rounds, partial_rounds, p->ark, p->mds);
+            PoseidonOpt opt = poseidon_optimize(t, full_rounds, partial_rounds, p->ark, p->mds);
+            if (opt.ok && !getenv("AKP_POSEIDON_NO_RESCALE")) poseidon_rescale_sparse(opt, t, partial_rounds, alpha);
+            p->scaled = opt.scaled;
             if (opt.ok) {
                 int32_t rc = upload_f29(ctx, opt.ark_mod, &p->d_arkmod29);
                 if (!rc) rc = upload_f29(ctx, opt.mpre, &p->d_mpre29);
@@ -383,8 +386,8 @@ static inline unsigned poseidon_block(u32 t) {
 static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)t * 9 * 4 * B; }
 
 static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
-    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29};
-    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29};
+    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u};
+    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u};
 }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
 // AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the wave-per-lane latency kernels (0 disables them)

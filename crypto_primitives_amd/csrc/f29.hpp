@@ -230,6 +230,40 @@ AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const
     return t;
 }
 
+// (a0*b0 + a1*b1) / 2^261: two products, one reduction (same operand bounds as f29_dot3)
+AKP_HD FU f29_dot2(const FU& a0, const FU& b0, const FU& a1, const FU& b1) {
+    typedef u32 L;
+    typedef u64 W;
+    W acc = 0;
+    u32 m[9];
+    FU t;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) {
+            acc += (W)a0.l[i] * (W)b0.l[k - i];
+            acc += (W)a1.l[i] * (W)b1.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        AKP_F29_MSTEP()
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) {
+            acc += (W)a0.l[i] * (W)b0.l[k - i];
+            acc += (W)a1.l[i] * (W)b1.l[k - i];
+        }
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
+        acc >>= 29;
+    }
+    t.l[8] = (L)acc;
+    return t;
+}
+
 // x^e, small public exponent (S-box).  MSB-first from x; equals ark-ff Field::pow for e >= 1.
 template <bool S>
 AKP_HD F29T<S> f29_pow_small(const F29T<S>& x, u64 e) {

@@ -27,6 +27,7 @@ struct PoseidonOpt {
     std::vector<Fr> ark_mod;  // [R][t]: original keys; row (half + RP) has the residue folded in
     std::vector<Fr> mpre;     // [t][t]
     std::vector<Fr> sparse;   // [RP][2t]
+    bool scaled = false;      // poseidon_rescale_sparse applied: a00 == 1 in all partial rounds but the last
 };
 
 namespace optdetail {
@@ -142,6 +143,36 @@ inline PoseidonOpt poseidon_optimize(unsigned t, unsigned full_rounds, unsigned 
     for (unsigned i = 0; i < t; ++i) nxt[i] = fr_add(nxt[i], d[i]);
     o.ok = true;
     return o;
+}
+
+// Remove the multiplication a00 * S(x) from the sparse partial rounds.  Lane 0 is carried scaled by a per-round constant
+// d_j (d_0 = 1): the kernel holds lambda_j = d_j * lane0_j, adds q0'_j = d_j * q0_j and raises to alpha, which gives
+// T_j = d_j^alpha * s_j.  With d_{j+1} = d_j^alpha / a00_j the next scaled lane is simply
+//     lambda_{j+1} = T_j + sum_i (d_{j+1} u_i) y_i          (no product on the S-box output),
+// the other lanes take y_i += (w_i / d_j^alpha) T_j, and the last partial round returns to the true lane with
+// a00' = a00 / d_j^alpha.  Pure re-parameterisation: every state the full rounds see is unchanged.
+// Needs a00_j != 0 for all but the last round; otherwise the constants are left as they are (scaled stays false).
+inline void poseidon_rescale_sparse(PoseidonOpt& o, unsigned t, unsigned partial_rounds, uint64_t alpha) {
+    if (!o.ok || partial_rounds < 2) return;
+    const unsigned n1 = t - 1;
+    for (unsigned j = 0; j + 1 < partial_rounds; ++j)
+        if (fr_is_zero(o.sparse[(size_t)j * 2 * t + 1])) return;
+    Fr d = fr_one();
+    for (unsigned j = 0; j < partial_rounds; ++j) {
+        Fr* s = &o.sparse[(size_t)j * 2 * t];
+        const Fr e = fr_pow_small(d, alpha), einv = fr_inv(e);
+        s[0] = fr_mul(s[0], d);
+        for (unsigned i = 0; i < n1; ++i) s[2 + n1 + i] = fr_mul(s[2 + n1 + i], einv);
+        if (j + 1 < partial_rounds) {
+            const Fr dn = fr_mul(e, fr_inv(s[1]));
+            s[1] = fr_one();  // kernels that still multiply by the a00 slot stay correct
+            for (unsigned i = 0; i < n1; ++i) s[2 + i] = fr_mul(s[2 + i], dn);
+            d = dn;
+        } else {
+            s[1] = fr_mul(s[1], einv);
+        }
+    }
+    o.scaled = true;
 }
 
 // (round-0 key of lane i)^alpha for the round keys the kernels actually use: what the first S-box of a lane that

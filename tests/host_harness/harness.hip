@@ -34,11 +34,11 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
     T3Host(uint32_t t, uint32_t rf, uint32_t rp, uint64_t alpha, const Fr* a, const Fr* m, bool sparse_form) {
         std::vector<Fr> av(a, a + (size_t)(rf + rp) * t), mv(m, m + (size_t)t * t);
         PoseidonOpt o;
-        if (sparse_form) o = poseidon_optimize(t, rf, rp, av, mv);
+        if (sparse_form) { o = poseidon_optimize(t, rf, rp, av, mv); poseidon_rescale_sparse(o, t, rp, alpha); }
         mds = to29(mv.data(), mv.size());
         if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
-                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr}; }
-        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr}; }
+                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr, o.scaled ? 1u : 0u}; }
+        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr, 0u}; }
         if (rf >= 2) {  // as capi.hip does: from the round keys the kernels use
             const std::vector<Fr> s0 = poseidon_sbox0(o.ok ? o.ark_mod : av, t, alpha);
             sbox0 = to29(s0.data(), s0.size());
