@@ -157,6 +157,8 @@ struct akp_poseidon {
     F29Pad* d_sparse29 = nullptr;
     F29Pad* d_sbox0_29 = nullptr;     // (round-0 key)^alpha per lane, see PoseidonConsts::sbox0
     bool scaled = false;              // sparse constants rescaled (poseidon_rescale_sparse)
+    F29Pad* d_mpre_w29 = nullptr;     // lane-1 form for the t = 3 register kernels (poseidon_rescale_sparse_lane1)
+    F29Pad* d_sparse_w29 = nullptr;
 };
 static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) {
     Fr* tmp = nullptr;
@@ -218,8 +220,18 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
         }
         if (!getenv("AKP_POSEIDON_DENSE")) {
             PoseidonOpt opt = poseidon_optimize(t, full_rounds, partial_rounds, p->ark, p->mds);
-            if (opt.ok && !getenv("AKP_POSEIDON_NO_RESCALE")) poseidon_rescale_sparse(opt, t, partial_rounds, alpha);
+            PoseidonOpt optw = opt;
+            const bool rescale = opt.ok && !getenv("AKP_POSEIDON_NO_RESCALE");
+            if (rescale) poseidon_rescale_sparse(opt, t, partial_rounds, alpha);
             p->scaled = opt.scaled;
+            if (rescale && t == 3 && poseidon_rescale_sparse_lane1(optw, t, partial_rounds, alpha)) {
+                int32_t rc = upload_f29(ctx, optw.mpre, &p->d_mpre_w29);
+                if (!rc) rc = upload_f29(ctx, optw.sparse, &p->d_sparse_w29);
+                if (rc) {
+                    akp_poseidon_params_destroy(p);
+                    return rc;
+                }
+            }
             if (opt.ok) {
                 int32_t rc = upload_f29(ctx, opt.ark_mod, &p->d_arkmod29);
                 if (!rc) rc = upload_f29(ctx, opt.mpre, &p->d_mpre29);
@@ -252,6 +264,8 @@ extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (p->d_mpre29) (void)hipFree(p->d_mpre29);
     if (p->d_sparse29) (void)hipFree(p->d_sparse29);
     if (p->d_sbox0_29) (void)hipFree(p->d_sbox0_29);
+    if (p->d_mpre_w29) (void)hipFree(p->d_mpre_w29);
+    if (p->d_sparse_w29) (void)hipFree(p->d_sparse_w29);
     delete p;
 }
 extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
@@ -389,6 +403,11 @@ static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u};
     return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u};
 }
+// constants for the t = 3 register kernels: the lane-1 form when it exists
+static inline PoseidonConsts t3_reg_consts(const akp_poseidon* p) {
+    if (p->d_sparse_w29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre_w29, p->d_sparse_w29, p->d_sbox0_29, 2u};
+    return t3_consts(p);
+}
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
 // AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the wave-per-lane latency kernels (0 disables them)
 static size_t coop_max_items() {
@@ -420,7 +439,7 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
-        hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), d_states, n);
+        hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_reg_consts(p), d_states, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -442,7 +461,7 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
-        hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
+        hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }

@@ -66,7 +66,9 @@ struct PoseidonConsts {
     const F29Pad* sbox0;   // [t] (0 + ark[0][i])^alpha: round-0 S-box output of a lane that enters as zero (the capacity
                            // lane and the unused rate lanes of a fresh sponge); nullptr when round 0 is not a full round
     u32 scaled;            // 1: the sparse constants are in the rescaled form (poseidon_rescale_sparse): in every partial
-                           // round but the last the S-box output enters lane 0 with coefficient 1
+                           // round but the last the S-box output enters lane 0 with coefficient 1;
+                           // 2: lane-1 form (poseidon_rescale_sparse_lane1): lane 1 takes the S-box output with
+                           // coefficient 1 (register kernel for t = 3 only)
 };
 typedef PoseidonConsts PoseidonT3Consts;
 // zero_lanes: bit i set = lane i is known to be zero on entry (uniform over the batch): its first S-box is a constant.
@@ -105,9 +107,10 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 6;
             const FU s = f29_pow_small(f29_add(s0, ldc(sp)), D.alpha);
-            if (C.scaled && j + 1 < D.partial_rounds) s0 = f29_weak_norm(f29_add(s, f29_dot2(s1, ldc(sp + 2), s2, ldc(sp + 3))));
+            if (C.scaled == 1u && j + 1 < D.partial_rounds) s0 = f29_weak_norm(f29_add(s, f29_dot2(s1, ldc(sp + 2), s2, ldc(sp + 3))));
             else s0 = f29_dot3(s, ldc(sp + 1), s1, ldc(sp + 2), s2, ldc(sp + 3));
-            s1 = f29_add(s1, f29_mul(s, ldc(sp + 4)));
+            if (C.scaled == 2u) s1 = f29_add(s1, s);
+            else s1 = f29_add(s1, f29_mul(s, ldc(sp + 4)));
             s2 = f29_add(s2, f29_mul(s, ldc(sp + 5)));
             if ((j & 31u) == 31u) {  // lanes 1,2 gain < 2.1p per round and are never reduced mod p: fold them back
                 s1 = f29_mul(s1, f29_one<false>());  // every 32 rounds so the top limb stays far below 2^32 for any RP
@@ -368,7 +371,7 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
             }
             __syncthreads();
             if (w == 0) {
-                FU acc = (C.scaled && j + 1 < D.partial_rounds) ? x : f29_mul(x, ldc(sp + 1));
+                FU acc = (C.scaled == 1u && j + 1 < D.partial_rounds) ? x : f29_mul(x, ldc(sp + 1));
 #pragma unroll 1
                 for (u32 i = 1; i < T; ++i) {
                     acc = f29_add(acc, tile.get(buf, i));

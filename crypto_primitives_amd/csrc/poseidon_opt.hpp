@@ -175,6 +175,81 @@ inline void poseidon_rescale_sparse(PoseidonOpt& o, unsigned t, unsigned partial
     o.scaled = true;
 }
 
+// Second re-parameterisation, for kernels whose cost is instruction count rather than the latency of lane 0: make the
+// FIRST-COLUMN coefficient of lane 1 equal to 1, so that lane 1 takes the S-box output with a plain addition
+// (a whole field product less per partial round; row 0 keeps its three products).  Lane 0 is carried as
+// lambda_j = d_j * lane0_j with d_j = w_{1,j}^(1/alpha)  =>  T_j = (lambda_j + d_j q0_j)^alpha = w_{1,j} s_j, hence
+//     y_1 += T_j,    y_i += (w_{i,j} / w_{1,j}) T_j  (i >= 2),
+//     lambda_{j+1} = (d_{j+1} a00_j / w_{1,j}) T_j + sum_i (d_{j+1} u_{i,j}) y_i      (last round: d_{j+1} := 1),
+// and row 0 of M_pre is multiplied by d_0.  The d_j are independent of each other (no recursion).  Requires
+// gcd(alpha, p - 1) = 1 (alpha-th roots) and w_{1,j} != 0; otherwise returns false and leaves `o` untouched.
+namespace optdetail {
+// x^e, e given as little-endian 64-bit words
+inline Fr fr_pow_words(const Fr& x, const uint64_t* e, int words) {
+    Fr r = fr_one();
+    for (int i = 64 * words - 1; i >= 0; --i) {
+        r = fr_sqr(r);
+        if ((e[i >> 6] >> (i & 63)) & 1) r = fr_mul(r, x);
+    }
+    return r;
+}
+// alpha^-1 mod (p - 1) as 4 words, for 2 <= alpha < 2^16 with gcd(alpha, p - 1) = 1:  (1 + k (p - 1)) / alpha for the
+// k < alpha that makes the division exact
+inline bool inv_alpha_mod_pm1(uint64_t alpha, uint64_t out[4]) {
+    if (alpha < 2 || alpha >= 65536) return false;
+    const uint64_t pm1[4] = {((uint64_t)AKP_P1 << 32) | (uint64_t)(AKP_P0 - 1u), ((uint64_t)AKP_P3 << 32) | AKP_P2,
+                             ((uint64_t)AKP_P5 << 32) | AKP_P4, ((uint64_t)AKP_P7 << 32) | AKP_P6};
+    for (uint64_t k = 1; k < alpha; ++k) {
+        uint64_t v[5];
+        unsigned __int128 c = 1;  // v = 1 + k * (p - 1)
+        for (int i = 0; i < 4; ++i) {
+            c += (unsigned __int128)pm1[i] * k;
+            v[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        v[4] = (uint64_t)c;
+        unsigned __int128 rem = 0;  // v / alpha, most significant word first
+        uint64_t q[5];
+        for (int i = 4; i >= 0; --i) {
+            const unsigned __int128 cur = (rem << 64) | v[i];
+            q[i] = (uint64_t)(cur / alpha);
+            rem = cur % alpha;
+        }
+        if (rem == 0 && q[4] == 0) {
+            for (int i = 0; i < 4; ++i) out[i] = q[i];
+            return true;
+        }
+    }
+    return false;
+}
+}  // namespace optdetail
+inline bool poseidon_rescale_sparse_lane1(PoseidonOpt& o, unsigned t, unsigned partial_rounds, uint64_t alpha) {
+    if (!o.ok || o.scaled || partial_rounds < 1 || t < 2) return false;
+    const unsigned n1 = t - 1;
+    uint64_t einv[4];
+    if (!optdetail::inv_alpha_mod_pm1(alpha, einv)) return false;
+    std::vector<Fr> d(partial_rounds + 1);
+    for (unsigned j = 0; j < partial_rounds; ++j) {
+        const Fr w1 = o.sparse[(size_t)j * 2 * t + 2 + n1];
+        if (fr_is_zero(w1)) return false;
+        d[j] = optdetail::fr_pow_words(w1, einv, 4);
+        if (!fr_eq(fr_pow_small(d[j], alpha), w1)) return false;  // alpha-th root does not exist / is not this one
+    }
+    d[partial_rounds] = fr_one();
+    for (unsigned j = 0; j < partial_rounds; ++j) {
+        Fr* s = &o.sparse[(size_t)j * 2 * t];
+        const Fr w1inv = fr_inv(s[2 + n1]);
+        s[0] = fr_mul(s[0], d[j]);
+        s[1] = fr_mul(fr_mul(s[1], w1inv), d[j + 1]);
+        for (unsigned i = 0; i < n1; ++i) {
+            s[2 + i] = fr_mul(s[2 + i], d[j + 1]);
+            s[2 + n1 + i] = (i == 0) ? fr_one() : fr_mul(s[2 + n1 + i], w1inv);
+        }
+    }
+    for (unsigned c = 0; c < t; ++c) o.mpre[c] = fr_mul(o.mpre[c], d[0]);  // row 0 of M_pre
+    return true;
+}
+
 // (round-0 key of lane i)^alpha for the round keys the kernels actually use: what the first S-box of a lane that
 // enters the permutation as zero produces (PoseidonConsts::sbox0)
 inline std::vector<Fr> poseidon_sbox0(const std::vector<Fr>& ark_used, uint32_t t, uint64_t alpha) {

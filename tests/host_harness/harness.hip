@@ -29,12 +29,20 @@ static std::vector<F29Pad> to29(const Fr* in, size_t n) {
 //                1 = generic file path with sparse partial rounds even for t == 3,
 //                2 = dense partial rounds (t == 3: register path, else file path)
 struct T3Host {  // constants in internal form for any t (name kept from the t = 3 path)
-    std::vector<F29Pad> ark, mds, mpre, sparse, sbox0;
-    PoseidonConsts c;
+    std::vector<F29Pad> ark, mds, mpre, sparse, sbox0, mpre_w, sparse_w;
+    PoseidonConsts c;    // what the wave-per-lane / LDS-file kernels get
+    PoseidonConsts creg; // what the t = 3 register kernels get (lane-1 form when it exists), as capi.hip does
     T3Host(uint32_t t, uint32_t rf, uint32_t rp, uint64_t alpha, const Fr* a, const Fr* m, bool sparse_form) {
         std::vector<Fr> av(a, a + (size_t)(rf + rp) * t), mv(m, m + (size_t)t * t);
         PoseidonOpt o;
-        if (sparse_form) { o = poseidon_optimize(t, rf, rp, av, mv); poseidon_rescale_sparse(o, t, rp, alpha); }
+        PoseidonOpt ow;
+        bool have_w = false;
+        if (sparse_form) {
+            o = poseidon_optimize(t, rf, rp, av, mv);
+            ow = o;
+            poseidon_rescale_sparse(o, t, rp, alpha);
+            have_w = t == 3 && poseidon_rescale_sparse_lane1(ow, t, rp, alpha);
+        }
         mds = to29(mv.data(), mv.size());
         if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
                     c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr, o.scaled ? 1u : 0u}; }
@@ -43,6 +51,14 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
             const std::vector<Fr> s0 = poseidon_sbox0(o.ok ? o.ark_mod : av, t, alpha);
             sbox0 = to29(s0.data(), s0.size());
             c.sbox0 = sbox0.data();
+        }
+        creg = c;
+        if (have_w) {
+            mpre_w = to29(ow.mpre.data(), ow.mpre.size());
+            sparse_w = to29(ow.sparse.data(), ow.sparse.size());
+            creg.mpre = mpre_w.data();
+            creg.sparse = sparse_w.data();
+            creg.scaled = 2u;
         }
     }
 };
@@ -99,7 +115,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
     for (size_t i = 0; i < n; ++i) {
         if (reg_path) {  // the register-resident fast path
             FU s0 = f29_from_wire<false>(states[i * 3]), s1 = f29_from_wire<false>(states[i * 3 + 1]), s2 = f29_from_wire<false>(states[i * 3 + 2]);
-            poseidon_permute_t3(D, th->c, s0, s1, s2);
+            poseidon_permute_t3(D, th->creg, s0, s1, s2);
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
             continue;
         }
@@ -117,7 +133,7 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i)
-        out[i] = reg_path ? poseidon_crh_item_t3(D, th->c, in0, in1, k, i) : poseidon_crh_item(D, th->c, f, in0, in1, k, i);
+        out[i] = reg_path ? poseidon_crh_item_t3(D, th->creg, in0, in1, k, i) : poseidon_crh_item(D, th->c, f, in0, in1, k, i);
     delete th;
 }
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
