@@ -157,7 +157,7 @@ struct akp_poseidon {
     F29Pad* d_sparse29 = nullptr;
     F29Pad* d_sbox0_29 = nullptr;     // (round-0 key)^alpha per lane, see PoseidonConsts::sbox0
     bool scaled = false;              // sparse constants rescaled (poseidon_rescale_sparse)
-    F29Pad* d_mpre_w29 = nullptr;     // lane-1 form for the t = 3 register kernels (poseidon_rescale_sparse_lane1)
+    F29Pad* d_mpre_w29 = nullptr;     // lane-1 form for the one-lane-per-item kernels (poseidon_rescale_sparse_lane1)
     F29Pad* d_sparse_w29 = nullptr;
 };
 static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) {
@@ -224,7 +224,7 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
             const bool rescale = opt.ok && !getenv("AKP_POSEIDON_NO_RESCALE");
             if (rescale) poseidon_rescale_sparse(opt, t, partial_rounds, alpha);
             p->scaled = opt.scaled;
-            if (rescale && t == 3 && poseidon_rescale_sparse_lane1(optw, t, partial_rounds, alpha)) {
+            if (rescale && poseidon_rescale_sparse_lane1(optw, t, partial_rounds, alpha)) {
                 int32_t rc = upload_f29(ctx, optw.mpre, &p->d_mpre_w29);
                 if (!rc) rc = upload_f29(ctx, optw.sparse, &p->d_sparse_w29);
                 if (rc) {
@@ -403,7 +403,7 @@ static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u};
     return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u};
 }
-// constants for the t = 3 register kernels: the lane-1 form when it exists
+// constants for the one-lane-per-item kernels (t = 3 register kernels, LDS-file kernels): the lane-1 form when it exists
 static inline PoseidonConsts t3_reg_consts(const akp_poseidon* p) {
     if (p->d_sparse_w29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre_w29, p->d_sparse_w29, p->d_sbox0_29, 2u};
     return t3_consts(p);
@@ -451,9 +451,9 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
     const unsigned B = poseidon_block(p->dims.t);
     const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), d_states, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), d_states, n);
-    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), d_states, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), d_states, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), d_states, n);
+    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), d_states, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
@@ -474,9 +474,9 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     const unsigned B = poseidon_block(p->dims.t);
     const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
-    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
+    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }

@@ -254,7 +254,8 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
             const bool refold = (j & 31u) == 31u;                       // ... and < 2.1p in value: fold back mod p every 32 rounds
 #pragma unroll 1
             for (u32 i = 1; i < T; ++i) {
-                FU y = f29_add(f.load(i), f29_mul(sb, ldc(sp + T + i)));
+                // lane-1 form (scaled == 2): lane 1 takes the S-box output with coefficient 1
+                FU y = (i == 1 && C.scaled == 2u) ? f29_add(f.load(1), sb) : f29_add(f.load(i), f29_mul(sb, ldc(sp + T + i)));
                 if (refold) y = f29_mul(y, f29_one<false>());
                 else if (norm) y = f29_weak_norm(y);
                 f.store(i, y);

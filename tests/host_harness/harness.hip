@@ -41,7 +41,7 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
             o = poseidon_optimize(t, rf, rp, av, mv);
             ow = o;
             poseidon_rescale_sparse(o, t, rp, alpha);
-            have_w = t == 3 && poseidon_rescale_sparse_lane1(ow, t, rp, alpha);
+            have_w = poseidon_rescale_sparse_lane1(ow, t, rp, alpha);
         }
         mds = to29(mv.data(), mv.size());
         if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
@@ -120,7 +120,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             continue;
         }
         for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(states[i * D.t + e]));
-        poseidon_permute_file(D, th->c, f);
+        poseidon_permute_file(D, th->creg, f);
         for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(e));
     }
     delete th;
@@ -133,7 +133,7 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i)
-        out[i] = reg_path ? poseidon_crh_item_t3(D, th->creg, in0, in1, k, i) : poseidon_crh_item(D, th->c, f, in0, in1, k, i);
+        out[i] = reg_path ? poseidon_crh_item_t3(D, th->creg, in0, in1, k, i) : poseidon_crh_item(D, th->creg, f, in0, in1, k, i);
     delete th;
 }
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
