@@ -11,7 +11,7 @@ from crypto_primitives_amd._lib import lib, check
 dev=torch.device('cuda',0); ctx=cpa.default_context(0); st=torch.cuda.current_stream().cuda_stream
 for rate,w in ((3,False),(4,False),(5,False),(8,False),(8,True)):
     c=cpa.get_default_poseidon_parameters(rate,w); h=c.handle(ctx); t=rate+1
-    for log2n in (10, 20):
+    for log2n in (10, 14, 16, 18, 20):
         n=1<<log2n
         x=torch.from_numpy(field.random_fr(n*t,seed=rate).view(np.int64)).to(dev)
         def run(): check(lib.akp_poseidon_permute_batch_dev(h.h,x.data_ptr(),n,st))
