@@ -159,6 +159,10 @@ struct akp_poseidon {
     bool scaled = false;              // sparse constants rescaled (poseidon_rescale_sparse)
     F29Pad* d_mpre_w29 = nullptr;     // lane-1 form for the one-lane-per-item kernels (poseidon_rescale_sparse_lane1)
     F29Pad* d_sparse_w29 = nullptr;
+    F29Pad* d_ark_f29 = nullptr;      // full form for the t = 3 register kernels (poseidon_full_form)
+    F29Pad* d_fmats_f29 = nullptr;
+    F29Pad* d_sparse_f29 = nullptr;
+    F29Pad* d_kout_f29 = nullptr;
 };
 static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) {
     Fr* tmp = nullptr;
@@ -222,6 +226,17 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
             PoseidonOpt opt = poseidon_optimize(t, full_rounds, partial_rounds, p->ark, p->mds);
             PoseidonOpt optw = opt;
             const bool rescale = opt.ok && !getenv("AKP_POSEIDON_NO_RESCALE");
+            PoseidonFullForm ff;
+            if (rescale && t == 3 && !getenv("AKP_POSEIDON_NO_FULL_FORM") && poseidon_full_form(opt, t, full_rounds, partial_rounds, alpha, p->mds, ff)) {
+                int32_t rc = upload_f29(ctx, ff.ark, &p->d_ark_f29);
+                if (!rc) rc = upload_f29(ctx, ff.fmats, &p->d_fmats_f29);
+                if (!rc) rc = upload_f29(ctx, ff.sparse, &p->d_sparse_f29);
+                if (!rc) rc = upload_f29(ctx, ff.kout, &p->d_kout_f29);
+                if (rc) {
+                    akp_poseidon_params_destroy(p);
+                    return rc;
+                }
+            }
             if (rescale) poseidon_rescale_sparse(opt, t, partial_rounds, alpha);
             p->scaled = opt.scaled;
             if (rescale && poseidon_rescale_sparse_lane1(optw, t, partial_rounds, alpha)) {
@@ -266,6 +281,10 @@ extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (p->d_sbox0_29) (void)hipFree(p->d_sbox0_29);
     if (p->d_mpre_w29) (void)hipFree(p->d_mpre_w29);
     if (p->d_sparse_w29) (void)hipFree(p->d_sparse_w29);
+    if (p->d_ark_f29) (void)hipFree(p->d_ark_f29);
+    if (p->d_fmats_f29) (void)hipFree(p->d_fmats_f29);
+    if (p->d_sparse_f29) (void)hipFree(p->d_sparse_f29);
+    if (p->d_kout_f29) (void)hipFree(p->d_kout_f29);
     delete p;
 }
 extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
@@ -400,13 +419,18 @@ static inline unsigned poseidon_block(u32 t) {
 static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)t * 9 * 4 * B; }
 
 static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
-    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u};
-    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u};
+    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u, nullptr};
+    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u, nullptr};
 }
-// constants for the one-lane-per-item kernels (t = 3 register kernels, LDS-file kernels): the lane-1 form when it exists
-static inline PoseidonConsts t3_reg_consts(const akp_poseidon* p) {
-    if (p->d_sparse_w29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre_w29, p->d_sparse_w29, p->d_sbox0_29, 2u};
+// constants for the LDS-file kernels: the lane-1 form when it exists
+static inline PoseidonConsts file_consts(const akp_poseidon* p) {
+    if (p->d_sparse_w29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre_w29, p->d_sparse_w29, p->d_sbox0_29, 2u, nullptr};
     return t3_consts(p);
+}
+// constants for the t = 3 register kernels: the full form when it exists, else as above
+static inline PoseidonConsts t3_reg_consts(const akp_poseidon* p) {
+    if (p->d_sparse_f29) return PoseidonConsts{p->d_ark_f29, p->d_fmats_f29, nullptr, p->d_sparse_f29, p->d_sbox0_29, 3u, p->d_kout_f29};
+    return file_consts(p);
 }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
 // AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the wave-per-lane latency kernels (0 disables them)
@@ -439,7 +463,9 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
-        hipLaunchKernelGGL(poseidon_permute_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_reg_consts(p), d_states, n);
+        const PoseidonConsts c = t3_reg_consts(p);
+        if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_permute_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, d_states, n);
+        else hipLaunchKernelGGL(poseidon_permute_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, d_states, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -451,9 +477,9 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
     const unsigned B = poseidon_block(p->dims.t);
     const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), d_states, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), d_states, n);
-    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), d_states, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_permute_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, file_consts(p), d_states, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_permute_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, file_consts(p), d_states, n);
+    else hipLaunchKernelGGL(poseidon_permute_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, file_consts(p), d_states, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
@@ -461,7 +487,9 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
-        hipLaunchKernelGGL(poseidon_crh_t3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
+        const PoseidonConsts c = t3_reg_consts(p);
+        if (c.scaled == 3u && k <= p->dims.rate) hipLaunchKernelGGL(poseidon_crh_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
+        else hipLaunchKernelGGL(poseidon_crh_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c.scaled == 3u ? file_consts(p) : c, in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -474,9 +502,9 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     const unsigned B = poseidon_block(p->dims.t);
     const size_t lds = poseidon_lds(p->dims.t, B);
     const unsigned grid = (unsigned)((n + B - 1) / B);
-    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
-    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
-    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, t3_reg_consts(p), in0, in1, k, d_out, n);
+    if (B == 256) hipLaunchKernelGGL(poseidon_crh_kernel<256>, dim3(grid), dim3(B), lds, s, p->dims, file_consts(p), in0, in1, k, d_out, n);
+    else if (B == 128) hipLaunchKernelGGL(poseidon_crh_kernel<128>, dim3(grid), dim3(B), lds, s, p->dims, file_consts(p), in0, in1, k, d_out, n);
+    else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, file_consts(p), in0, in1, k, d_out, n);
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }

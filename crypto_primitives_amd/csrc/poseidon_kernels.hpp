@@ -68,13 +68,22 @@ struct PoseidonConsts {
     u32 scaled;            // 1: the sparse constants are in the rescaled form (poseidon_rescale_sparse): in every partial
                            // round but the last the S-box output enters lane 0 with coefficient 1;
                            // 2: lane-1 form (poseidon_rescale_sparse_lane1): lane 1 takes the S-box output with
-                           // coefficient 1 (register kernel for t = 3 only)
+                           // coefficient 1 (one-lane-per-item kernels);
+                           // 3: full form (poseidon_full_form, t = 3 register kernels only): lane-1 form + one matrix
+                           // per full round in `mds` ([RF][t][t]) with unit diagonal except row 0 of the round before
+                           // the partial block; a00 = 1 in the last partial round; `ark` scaled; lane i leaves the
+                           // permutation scaled and `kout[i]` replaces the wire-conversion constant
+    const F29Pad* kout;    // [t], full form only
 };
 typedef PoseidonConsts PoseidonT3Consts;
 // zero_lanes: bit i set = lane i is known to be zero on entry (uniform over the batch): its first S-box is a constant.
 // need_lanes: bit i set = lane i of the result is used; the other rows of the last linear layer are skipped.
+// FULLFORM: the constants are in the full form (C.scaled == 3) -- a compile-time switch so that each instantiation
+// carries only the row variants it uses (the kernel has to stay inside the 64 KB instruction cache)
+template <bool FULLFORM>
 AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2, u32 zero_lanes = 0,
                                 u32 need_lanes = 7u) {
+    const u32 form = FULLFORM ? 3u : (C.scaled == 3u ? 0u : C.scaled);
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
     const bool opt = C.sparse != nullptr;
@@ -95,11 +104,24 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
                 else s2 = f29_pow_small(s2, D.alpha);
             }
             const F29Pad* m = (opt && r + 1 == half) ? C.mpre : C.mds;
+            bool unit0 = false, unit12 = false;  // full form: the diagonal coefficient of the row is 1
+            if (FULLFORM) {
+                m = C.mds + 9 * (size_t)(r < half ? r : r - D.partial_rounds);
+                unit12 = true;
+                unit0 = r + 1 != half;
+            }
             const u32 need = (r + 1 == R) ? need_lanes : 7u;
             FU n0 = s0, n1 = s1, n2 = s2;
-            if (need & 1u) n0 = f29_dot3(s0, ldc(m + 0), s1, ldc(m + 1), s2, ldc(m + 2));
-            if (need & 2u) n1 = f29_dot3(s0, ldc(m + 3), s1, ldc(m + 4), s2, ldc(m + 5));
-            if (need & 4u) n2 = f29_dot3(s0, ldc(m + 6), s1, ldc(m + 7), s2, ldc(m + 8));
+            if (unit0) {
+                if (need & 1u) n0 = f29_weak_norm(f29_add(s0, f29_dot2(s1, ldc(m + 1), s2, ldc(m + 2))));
+            } else if (need & 1u) n0 = f29_dot3(s0, ldc(m + 0), s1, ldc(m + 1), s2, ldc(m + 2));
+            if (unit12) {
+                if (need & 2u) n1 = f29_weak_norm(f29_add(s1, f29_dot2(s0, ldc(m + 3), s2, ldc(m + 5))));
+                if (need & 4u) n2 = f29_weak_norm(f29_add(s2, f29_dot2(s0, ldc(m + 6), s1, ldc(m + 7))));
+            } else {
+                if (need & 2u) n1 = f29_dot3(s0, ldc(m + 3), s1, ldc(m + 4), s2, ldc(m + 5));
+                if (need & 4u) n2 = f29_dot3(s0, ldc(m + 6), s1, ldc(m + 7), s2, ldc(m + 8));
+            }
             s0 = n0;
             s1 = n1;
             s2 = n2;
@@ -107,9 +129,12 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 6;
             const FU s = f29_pow_small(f29_add(s0, ldc(sp)), D.alpha);
-            if (C.scaled == 1u && j + 1 < D.partial_rounds) s0 = f29_weak_norm(f29_add(s, f29_dot2(s1, ldc(sp + 2), s2, ldc(sp + 3))));
+            // the S-box output enters lane 0 with coefficient 1: lane-0 form in all partial rounds but the last, full form
+            // in the last one
+            if ((form == 1u && j + 1 < D.partial_rounds) || (FULLFORM && j + 1 == D.partial_rounds))
+                s0 = f29_weak_norm(f29_add(s, f29_dot2(s1, ldc(sp + 2), s2, ldc(sp + 3))));
             else s0 = f29_dot3(s, ldc(sp + 1), s1, ldc(sp + 2), s2, ldc(sp + 3));
-            if (C.scaled == 2u) s1 = f29_add(s1, s);
+            if (form >= 2u) s1 = f29_add(s1, s);
             else s1 = f29_add(s1, f29_mul(s, ldc(sp + 4)));
             s2 = f29_add(s2, f29_mul(s, ldc(sp + 5)));
             if ((j & 31u) == 31u) {  // lanes 1,2 gain < 2.1p per round and are never reduced mod p: fold them back
@@ -137,6 +162,7 @@ AKP_HD void t3_add_slot(FU& s0, FU& s1, FU& s2, u32 slot, const FU& v) {
 // Element e of item idx is in0[idx*k + e] (in1 == nullptr), or in0[idx] / in1[idx] for e = 0 / 1.
 // absorb_internal from index 0 (:124-153) + the squeeze permutation (:324-344): ceil(k/rate)
 // permutations, or one permutation of the zero state when k == 0 (:238-240).
+template <bool FULLFORM>
 AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C, const Fr* __restrict__ in0,
                                const Fr* __restrict__ in1, size_t k, size_t idx) {
     FU s0 = f29_zero<false>(), s1 = s0, s2 = s0;  // PoseidonSponge::new :223-234
@@ -153,31 +179,42 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
         const u32 zero_lanes = done == 0 ? (7u & ~(((1u << take) - 1u) << D.capacity)) : 0u;
         done += take;
         // only state[capacity] of the last permutation is squeezed (:156-186)
-        poseidon_permute_t3(D, C, s0, s1, s2, zero_lanes, done < k ? 7u : (1u << D.capacity));
-    } while (done < k);
+        poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2, zero_lanes, done < k ? 7u : (1u << D.capacity));
+        // the full form leaves the lanes scaled: it serves single-permutation hashes only (k <= rate; the host routes
+        // longer inputs to the other instantiation), which also keeps this instantiation's code small
+    } while (!FULLFORM && done < k);
     // squeeze_internal(0, 1) :156-186 -- limb-wise selects (an array select would go through scratch)
     FU out;
 #pragma unroll
     for (int i = 0; i < 9; ++i) out.l[i] = D.capacity == 0 ? s0.l[i] : (D.capacity == 1 ? s1.l[i] : s2.l[i]);
+    if (FULLFORM) return f29_canonical_pack(f29_mul(out, ldc(C.kout + D.capacity)));  // undoes the lane's scale as well
     return f29_to_wire(out);
 }
 
+template <bool FULLFORM>
 __global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D, PoseidonT3Consts C, Fr* states, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     Fr* st = states + idx * 3;
     FU s0 = f29_from_wire<false>(load_fr_global(st)), s1 = f29_from_wire<false>(load_fr_global(st + 1)),
        s2 = f29_from_wire<false>(load_fr_global(st + 2));
-    poseidon_permute_t3(D, C, s0, s1, s2);
+    poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2);
+    if (FULLFORM) {  // the per-lane constant undoes the lane's scale as well
+        store_fr_global(st, f29_canonical_pack(f29_mul(s0, ldc(C.kout))));
+        store_fr_global(st + 1, f29_canonical_pack(f29_mul(s1, ldc(C.kout + 1))));
+        store_fr_global(st + 2, f29_canonical_pack(f29_mul(s2, ldc(C.kout + 2))));
+        return;
+    }
     store_fr_global(st, f29_to_wire(s0));
     store_fr_global(st + 1, f29_to_wire(s1));
     store_fr_global(st + 2, f29_to_wire(s2));
 }
+template <bool FULLFORM>
 __global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, PoseidonT3Consts C, const Fr* __restrict__ in0,
                                                              const Fr* __restrict__ in1, size_t k, Fr* __restrict__ out, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    store_fr_global(out + idx, poseidon_crh_item_t3(D, C, in0, in1, k, idx));
+    store_fr_global(out + idx, poseidon_crh_item_t3<FULLFORM>(D, C, in0, in1, k, idx));
 }
 
 // =============================== any t: LDS "register file" ========================================

@@ -250,6 +250,103 @@ inline bool poseidon_rescale_sparse_lane1(PoseidonOpt& o, unsigned t, unsigned p
     return true;
 }
 
+// Third form ("full form", register kernel for t = 3): the lane scaling of the lane-1 form is extended through the full
+// rounds.  Lane i enters a full round multiplied by delta_i, its key is scaled likewise, the S-box output is
+// T_i = delta_i^alpha s_i, and the output scale of row i is chosen as delta'_i = delta_i^alpha / M_ii so that the
+// DIAGONAL coefficient of the (per-round) linear layer is 1:  row i = T_i + sum_{j != i} F_ij T_j  -- one product
+// less per row.  Exception: row 0 of the round before the partial block must deliver lane 0 with the scale the
+// lane-1 form prescribes (d_0).  The last partial round uses its free output scale to make a00 = 1, and the scales the
+// lanes leave the last round with are divided out by the wire conversion (kout).  Lanes 1.. run through the partial block with the constant scales g_i they got from the last
+// full round before it.  Input: the plain sparse form (poseidon_optimize).  Output: keys [R][t] (partial-round rows
+// unused), one matrix per full round [RF][t][t], sparse [RP][2t].  Returns false (outputs untouched) when a required
+// coefficient is zero or alpha-th roots do not exist.
+struct PoseidonFullForm {
+    std::vector<Fr> ark, fmats, sparse;
+    std::vector<Fr> kout;  // [t]: the last round keeps its unit diagonal too; lane i leaves the permutation multiplied by
+                           // delta_i and the conversion to the wire format multiplies by kout[i] (= 2^256 / delta_i as a
+                           // plain integer, pre-divided by 2^5 because the upload path multiplies by 2^5) instead of 2^256
+};
+inline bool poseidon_full_form(const PoseidonOpt& o, unsigned t, unsigned full_rounds, unsigned partial_rounds, uint64_t alpha,
+                               const std::vector<Fr>& mds, PoseidonFullForm& out) {
+    if (!o.ok || o.scaled || t < 2 || partial_rounds < 1) return false;
+    const unsigned half = full_rounds / 2, RP = partial_rounds, R = full_rounds + RP, n1 = t - 1;
+    uint64_t einv[4];
+    if (!optdetail::inv_alpha_mod_pm1(alpha, einv)) return false;
+    PoseidonFullForm f;
+    f.ark = o.ark_mod;
+    f.fmats.assign((size_t)full_rounds * t * t, fr_zero());
+    f.sparse = o.sparse;
+    std::vector<Fr> delta(t, fr_one()), e(t), dn(t);
+    auto sp = [&](unsigned j, unsigned k) -> const Fr& { return o.sparse[(size_t)j * 2 * t + k]; };
+    // d_j = (g_1 w_{1,j})^(1/alpha); g_1 is known once the round before the block has chosen its row scales
+    auto root = [&](const Fr& v, Fr& r) {
+        r = optdetail::fr_pow_words(v, einv, 4);
+        return fr_eq(fr_pow_small(r, alpha), v);
+    };
+    auto full_round = [&](unsigned r, unsigned fr_index, const std::vector<Fr>& mat, const Fr* row0_scale) {
+        for (unsigned i = 0; i < t; ++i) {
+            f.ark[(size_t)r * t + i] = fr_mul(delta[i], o.ark_mod[(size_t)r * t + i]);
+            e[i] = fr_pow_small(delta[i], alpha);
+        }
+        for (unsigned i = 0; i < t; ++i) {
+            if (i == 0 && row0_scale) dn[i] = *row0_scale;
+            else {
+                if (fr_is_zero(mat[(size_t)i * t + i])) return false;
+                dn[i] = fr_mul(e[i], fr_inv(mat[(size_t)i * t + i]));
+            }
+        }
+        for (unsigned i = 0; i < t; ++i)
+            for (unsigned j = 0; j < t; ++j)
+                f.fmats[((size_t)fr_index * t + i) * t + j] = fr_mul(fr_mul(dn[i], mat[(size_t)i * t + j]), fr_inv(e[j]));
+        return true;
+    };
+    for (unsigned r = 0; r + 1 < half; ++r) {
+        if (!full_round(r, r, mds, nullptr)) return false;
+        delta = dn;
+    }
+    // round before the block: rows 1.. first (their scales g_i define d_0), then row 0 with the prescribed scale
+    {
+        const unsigned r = half - 1;
+        std::vector<Fr> ee(t);
+        for (unsigned i = 0; i < t; ++i) ee[i] = fr_pow_small(delta[i], alpha);
+        if (fr_is_zero(o.mpre[(size_t)1 * t + 1]) || fr_is_zero(sp(0, 2 + n1))) return false;
+        const Fr g1 = fr_mul(ee[1], fr_inv(o.mpre[(size_t)1 * t + 1]));
+        Fr d0;
+        if (!root(fr_mul(g1, sp(0, 2 + n1)), d0)) return false;
+        if (!full_round(r, r, o.mpre, &d0)) return false;
+        delta = dn;
+    }
+    std::vector<Fr> g(delta);  // g[i], i >= 1: lane scales through the block
+    std::vector<Fr> d(RP + 1);
+    for (unsigned j = 0; j < RP; ++j) {
+        if (fr_is_zero(sp(j, 2 + n1))) return false;
+        if (!root(fr_mul(g[1], sp(j, 2 + n1)), d[j])) return false;
+    }
+    if (!fr_eq(d[0], delta[0])) return false;
+    if (fr_is_zero(sp(RP - 1, 1))) return false;
+    d[RP] = fr_mul(fr_mul(g[1], sp(RP - 1, 2 + n1)), fr_inv(sp(RP - 1, 1)));  // makes a00 of the last partial round 1
+    for (unsigned j = 0; j < RP; ++j) {
+        Fr* s = &f.sparse[(size_t)j * 2 * t];
+        const Fr gw1inv = fr_inv(fr_mul(g[1], sp(j, 2 + n1)));
+        s[0] = fr_mul(d[j], sp(j, 0));
+        s[1] = fr_mul(fr_mul(d[j + 1], sp(j, 1)), gw1inv);  // == 1 in the last round
+        for (unsigned i = 0; i < n1; ++i) {
+            s[2 + i] = fr_mul(fr_mul(d[j + 1], sp(j, 2 + i)), fr_inv(g[1 + i]));
+            s[2 + n1 + i] = (i == 0) ? fr_one() : fr_mul(fr_mul(g[1 + i], sp(j, 2 + n1 + i)), gw1inv);
+        }
+    }
+    delta[0] = d[RP];
+    for (unsigned r = half + RP; r < R; ++r) {
+        if (!full_round(r, r - RP, mds, nullptr)) return false;
+        delta = dn;
+    }
+    const Fr inv32 = fr_inv(fr_to_mont(Fr{{32u, 0, 0, 0, 0, 0, 0, 0}}));
+    f.kout.resize(t);
+    for (unsigned i = 0; i < t; ++i) f.kout[i] = fr_mul(fr_inv(delta[i]), inv32);
+    out = std::move(f);
+    return true;
+}
+
 // (round-0 key of lane i)^alpha for the round keys the kernels actually use: what the first S-box of a lane that
 // enters the permutation as zero produces (PoseidonConsts::sbox0)
 inline std::vector<Fr> poseidon_sbox0(const std::vector<Fr>& ark_used, uint32_t t, uint64_t alpha) {

@@ -29,36 +29,47 @@ static std::vector<F29Pad> to29(const Fr* in, size_t n) {
 //                1 = generic file path with sparse partial rounds even for t == 3,
 //                2 = dense partial rounds (t == 3: register path, else file path)
 struct T3Host {  // constants in internal form for any t (name kept from the t = 3 path)
-    std::vector<F29Pad> ark, mds, mpre, sparse, sbox0, mpre_w, sparse_w;
-    PoseidonConsts c;    // what the wave-per-lane / LDS-file kernels get
-    PoseidonConsts creg; // what the t = 3 register kernels get (lane-1 form when it exists), as capi.hip does
+    std::vector<F29Pad> ark, mds, mpre, sparse, sbox0, mpre_w, sparse_w, ark_f, fmats_f, sparse_f, kout_f;
+    PoseidonConsts c;     // what the wave-per-lane kernels get (lane-0 form)
+    PoseidonConsts cfile; // what the LDS-file kernels get (lane-1 form when it exists), as capi.hip does
+    PoseidonConsts creg;  // what the t = 3 register kernels get (full form when it exists, else cfile)
     T3Host(uint32_t t, uint32_t rf, uint32_t rp, uint64_t alpha, const Fr* a, const Fr* m, bool sparse_form) {
         std::vector<Fr> av(a, a + (size_t)(rf + rp) * t), mv(m, m + (size_t)t * t);
         PoseidonOpt o;
         PoseidonOpt ow;
-        bool have_w = false;
+        PoseidonFullForm ff;
+        bool have_w = false, have_f = false;
         if (sparse_form) {
             o = poseidon_optimize(t, rf, rp, av, mv);
             ow = o;
+            have_f = t == 3 && poseidon_full_form(o, t, rf, rp, alpha, mv, ff);
             poseidon_rescale_sparse(o, t, rp, alpha);
             have_w = poseidon_rescale_sparse_lane1(ow, t, rp, alpha);
         }
         mds = to29(mv.data(), mv.size());
         if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
-                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr, o.scaled ? 1u : 0u}; }
-        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr, 0u}; }
+                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr, o.scaled ? 1u : 0u, nullptr}; }
+        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr, 0u, nullptr}; }
         if (rf >= 2) {  // as capi.hip does: from the round keys the kernels use
             const std::vector<Fr> s0 = poseidon_sbox0(o.ok ? o.ark_mod : av, t, alpha);
             sbox0 = to29(s0.data(), s0.size());
             c.sbox0 = sbox0.data();
         }
-        creg = c;
+        cfile = c;
         if (have_w) {
             mpre_w = to29(ow.mpre.data(), ow.mpre.size());
             sparse_w = to29(ow.sparse.data(), ow.sparse.size());
-            creg.mpre = mpre_w.data();
-            creg.sparse = sparse_w.data();
-            creg.scaled = 2u;
+            cfile.mpre = mpre_w.data();
+            cfile.sparse = sparse_w.data();
+            cfile.scaled = 2u;
+        }
+        creg = cfile;
+        if (have_f) {
+            ark_f = to29(ff.ark.data(), ff.ark.size());
+            fmats_f = to29(ff.fmats.data(), ff.fmats.size());
+            sparse_f = to29(ff.sparse.data(), ff.sparse.size());
+            kout_f = to29(ff.kout.data(), ff.kout.size());
+            creg = PoseidonConsts{ark_f.data(), fmats_f.data(), nullptr, sparse_f.data(), c.sbox0, 3u, kout_f.data()};
         }
     }
 };
@@ -115,15 +126,27 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
     for (size_t i = 0; i < n; ++i) {
         if (reg_path) {  // the register-resident fast path
             FU s0 = f29_from_wire<false>(states[i * 3]), s1 = f29_from_wire<false>(states[i * 3 + 1]), s2 = f29_from_wire<false>(states[i * 3 + 2]);
-            poseidon_permute_t3(D, th->creg, s0, s1, s2);
+            if (th->creg.scaled == 3u) {  // as poseidon_permute_t3_kernel<true>
+                poseidon_permute_t3<true>(D, th->creg, s0, s1, s2);
+                states[i * 3] = f29_canonical_pack(f29_mul(s0, ldc(th->creg.kout)));
+                states[i * 3 + 1] = f29_canonical_pack(f29_mul(s1, ldc(th->creg.kout + 1)));
+                states[i * 3 + 2] = f29_canonical_pack(f29_mul(s2, ldc(th->creg.kout + 2)));
+                continue;
+            }
+            poseidon_permute_t3<false>(D, th->creg, s0, s1, s2);
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
             continue;
         }
         for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(states[i * D.t + e]));
-        poseidon_permute_file(D, th->creg, f);
+        poseidon_permute_file(D, th->cfile, f);
         for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(e));
     }
     delete th;
+}
+// which constant forms exist for a parameter set: bit 0 sparse, bit 1 lane-0 rescaling, bit 2 lane-1 form, bit 3 full form
+int hh_poseidon_forms(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds) {
+    T3Host th(rate + cap, rf, rp, alpha, ark, mds, true);
+    return (th.c.sparse ? 1 : 0) | (th.c.scaled == 1u ? 2 : 0) | (th.cfile.scaled == 2u ? 4 : 0) | (th.creg.scaled == 3u ? 8 : 0);
 }
 void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
                      const Fr* in0, const Fr* in1, size_t k, Fr* out, size_t n, int force_generic) {
@@ -133,7 +156,7 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i)
-        out[i] = reg_path ? poseidon_crh_item_t3(D, th->creg, in0, in1, k, i) : poseidon_crh_item(D, th->creg, f, in0, in1, k, i);
+        out[i] = reg_path ? ((th->creg.scaled == 3u && k <= rate) ? poseidon_crh_item_t3<true>(D, th->creg, in0, in1, k, i) : poseidon_crh_item_t3<false>(D, th->creg.scaled == 3u ? th->cfile : th->creg, in0, in1, k, i)) : poseidon_crh_item(D, th->cfile, f, in0, in1, k, i);
     delete th;
 }
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
