@@ -162,7 +162,7 @@ struct akp_poseidon {
     F29Pad* d_ark_f29 = nullptr;      // full form for the t = 3 register kernels (poseidon_full_form)
     F29Pad* d_fmats_f29 = nullptr;
     F29Pad* d_sparse_f29 = nullptr;
-    F29Pad* d_kout_f29 = nullptr;
+    F29Pad* d_sbox0_f29 = nullptr;
 };
 static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) {
     Fr* tmp = nullptr;
@@ -231,7 +231,7 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
                 int32_t rc = upload_f29(ctx, ff.ark, &p->d_ark_f29);
                 if (!rc) rc = upload_f29(ctx, ff.fmats, &p->d_fmats_f29);
                 if (!rc) rc = upload_f29(ctx, ff.sparse, &p->d_sparse_f29);
-                if (!rc) rc = upload_f29(ctx, ff.kout, &p->d_kout_f29);
+                if (!rc) rc = upload_f29(ctx, poseidon_sbox0(ff.ark, t, alpha), &p->d_sbox0_f29);  // full_rounds >= 2 here
                 if (rc) {
                     akp_poseidon_params_destroy(p);
                     return rc;
@@ -284,7 +284,7 @@ extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (p->d_ark_f29) (void)hipFree(p->d_ark_f29);
     if (p->d_fmats_f29) (void)hipFree(p->d_fmats_f29);
     if (p->d_sparse_f29) (void)hipFree(p->d_sparse_f29);
-    if (p->d_kout_f29) (void)hipFree(p->d_kout_f29);
+    if (p->d_sbox0_f29) (void)hipFree(p->d_sbox0_f29);
     delete p;
 }
 extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
@@ -419,17 +419,17 @@ static inline unsigned poseidon_block(u32 t) {
 static inline size_t poseidon_lds(u32 t, unsigned B) { return (size_t)t * 9 * 4 * B; }
 
 static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
-    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u, nullptr};
-    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u, nullptr};
+    if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u};
+    return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u};
 }
 // constants for the LDS-file kernels: the lane-1 form when it exists
 static inline PoseidonConsts file_consts(const akp_poseidon* p) {
-    if (p->d_sparse_w29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre_w29, p->d_sparse_w29, p->d_sbox0_29, 2u, nullptr};
+    if (p->d_sparse_w29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre_w29, p->d_sparse_w29, p->d_sbox0_29, 2u};
     return t3_consts(p);
 }
 // constants for the t = 3 register kernels: the full form when it exists, else as above
 static inline PoseidonConsts t3_reg_consts(const akp_poseidon* p) {
-    if (p->d_sparse_f29) return PoseidonConsts{p->d_ark_f29, p->d_fmats_f29, nullptr, p->d_sparse_f29, p->d_sbox0_29, 3u, p->d_kout_f29};
+    if (p->d_sparse_f29) return PoseidonConsts{p->d_ark_f29, p->d_fmats_f29, nullptr, p->d_sparse_f29, p->d_sbox0_f29, 3u};
     return file_consts(p);
 }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */

@@ -71,9 +71,8 @@ struct PoseidonConsts {
                            // coefficient 1 (one-lane-per-item kernels);
                            // 3: full form (poseidon_full_form, t = 3 register kernels only): lane-1 form + one matrix
                            // per full round in `mds` ([RF][t][t]) with unit diagonal except row 0 of the round before
-                           // the partial block; a00 = 1 in the last partial round; `ark` scaled; lane i leaves the
-                           // permutation scaled and `kout[i]` replaces the wire-conversion constant
-    const F29Pad* kout;    // [t], full form only
+                           // the partial block and the last round; a00 = 1 in the last partial round; `ark` scaled.  Lanes
+                           // enter and leave scaled by 2^-5, i.e. as the wire value x * 2^256: no conversion products
 };
 typedef PoseidonConsts PoseidonT3Consts;
 // zero_lanes: bit i set = lane i is known to be zero on entry (uniform over the batch): its first S-box is a constant.
@@ -107,8 +106,8 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             bool unit0 = false, unit12 = false;  // full form: the diagonal coefficient of the row is 1
             if (FULLFORM) {
                 m = C.mds + 9 * (size_t)(r < half ? r : r - D.partial_rounds);
-                unit12 = true;
-                unit0 = r + 1 != half;
+                unit12 = r + 1 != R;
+                unit0 = unit12 && r + 1 != half;
             }
             const u32 need = (r + 1 == R) ? need_lanes : 7u;
             FU n0 = s0, n1 = s1, n2 = s2;
@@ -173,7 +172,7 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
         for (size_t j = 0; j < take; ++j) {
             const size_t e = done + j;
             const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
-            t3_add_slot(s0, s1, s2, D.capacity + (u32)j, f29_from_wire<false>(load_fr_global(src)));
+            t3_add_slot(s0, s1, s2, D.capacity + (u32)j, FULLFORM ? f29_unpack<false>(load_fr_global(src)) : f29_from_wire<false>(load_fr_global(src)));
         }
         // fresh sponge: every lane outside [capacity, capacity + take) is still zero in the first permutation
         const u32 zero_lanes = done == 0 ? (7u & ~(((1u << take) - 1u) << D.capacity)) : 0u;
@@ -187,7 +186,7 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
     FU out;
 #pragma unroll
     for (int i = 0; i < 9; ++i) out.l[i] = D.capacity == 0 ? s0.l[i] : (D.capacity == 1 ? s1.l[i] : s2.l[i]);
-    if (FULLFORM) return f29_canonical_pack(f29_mul(out, ldc(C.kout + D.capacity)));  // undoes the lane's scale as well
+    if (FULLFORM) return f29_canonical_pack(out);  // the lane already holds x * 2^256
     return f29_to_wire(out);
 }
 
@@ -196,13 +195,21 @@ __global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     Fr* st = states + idx * 3;
-    FU s0 = f29_from_wire<false>(load_fr_global(st)), s1 = f29_from_wire<false>(load_fr_global(st + 1)),
-       s2 = f29_from_wire<false>(load_fr_global(st + 2));
+    FU s0, s1, s2;
+    if (FULLFORM) {  // the full form takes the wire value x * 2^256 as it is
+        s0 = f29_unpack<false>(load_fr_global(st));
+        s1 = f29_unpack<false>(load_fr_global(st + 1));
+        s2 = f29_unpack<false>(load_fr_global(st + 2));
+    } else {
+        s0 = f29_from_wire<false>(load_fr_global(st));
+        s1 = f29_from_wire<false>(load_fr_global(st + 1));
+        s2 = f29_from_wire<false>(load_fr_global(st + 2));
+    }
     poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2);
-    if (FULLFORM) {  // the per-lane constant undoes the lane's scale as well
-        store_fr_global(st, f29_canonical_pack(f29_mul(s0, ldc(C.kout))));
-        store_fr_global(st + 1, f29_canonical_pack(f29_mul(s1, ldc(C.kout + 1))));
-        store_fr_global(st + 2, f29_canonical_pack(f29_mul(s2, ldc(C.kout + 2))));
+    if (FULLFORM) {  // the lanes already hold x * 2^256
+        store_fr_global(st, f29_canonical_pack(s0));
+        store_fr_global(st + 1, f29_canonical_pack(s1));
+        store_fr_global(st + 2, f29_canonical_pack(s2));
         return;
     }
     store_fr_global(st, f29_to_wire(s0));

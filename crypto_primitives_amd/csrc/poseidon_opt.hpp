@@ -255,16 +255,15 @@ inline bool poseidon_rescale_sparse_lane1(PoseidonOpt& o, unsigned t, unsigned p
 // T_i = delta_i^alpha s_i, and the output scale of row i is chosen as delta'_i = delta_i^alpha / M_ii so that the
 // DIAGONAL coefficient of the (per-round) linear layer is 1:  row i = T_i + sum_{j != i} F_ij T_j  -- one product
 // less per row.  Exception: row 0 of the round before the partial block must deliver lane 0 with the scale the
-// lane-1 form prescribes (d_0).  The last partial round uses its free output scale to make a00 = 1, and the scales the
-// lanes leave the last round with are divided out by the wire conversion (kout).  Lanes 1.. run through the partial block with the constant scales g_i they got from the last
+// lane-1 form prescribes (d_0), and the last round delivers every lane with the scale 2^-5.  The lanes also ENTER with
+// the scale 2^-5: x * 2^261 * 2^-5 = x * 2^256 is the wire value itself, so the kernel's conversions from and to the
+// wire format are a re-limbing and a canonicalisation, with no field product.  The last partial round uses its free
+// output scale to make a00 = 1.  Lanes 1.. run through the partial block with the constant scales g_i they got from the last
 // full round before it.  Input: the plain sparse form (poseidon_optimize).  Output: keys [R][t] (partial-round rows
 // unused), one matrix per full round [RF][t][t], sparse [RP][2t].  Returns false (outputs untouched) when a required
 // coefficient is zero or alpha-th roots do not exist.
 struct PoseidonFullForm {
     std::vector<Fr> ark, fmats, sparse;
-    std::vector<Fr> kout;  // [t]: the last round keeps its unit diagonal too; lane i leaves the permutation multiplied by
-                           // delta_i and the conversion to the wire format multiplies by kout[i] (= 2^256 / delta_i as a
-                           // plain integer, pre-divided by 2^5 because the upload path multiplies by 2^5) instead of 2^256
 };
 inline bool poseidon_full_form(const PoseidonOpt& o, unsigned t, unsigned full_rounds, unsigned partial_rounds, uint64_t alpha,
                                const std::vector<Fr>& mds, PoseidonFullForm& out) {
@@ -276,20 +275,22 @@ inline bool poseidon_full_form(const PoseidonOpt& o, unsigned t, unsigned full_r
     f.ark = o.ark_mod;
     f.fmats.assign((size_t)full_rounds * t * t, fr_zero());
     f.sparse = o.sparse;
-    std::vector<Fr> delta(t, fr_one()), e(t), dn(t);
+    const Fr inv32 = fr_inv(fr_to_mont(Fr{{32u, 0, 0, 0, 0, 0, 0, 0}}));
+    std::vector<Fr> delta(t, inv32), e(t), dn(t);
     auto sp = [&](unsigned j, unsigned k) -> const Fr& { return o.sparse[(size_t)j * 2 * t + k]; };
     // d_j = (g_1 w_{1,j})^(1/alpha); g_1 is known once the round before the block has chosen its row scales
     auto root = [&](const Fr& v, Fr& r) {
         r = optdetail::fr_pow_words(v, einv, 4);
         return fr_eq(fr_pow_small(r, alpha), v);
     };
-    auto full_round = [&](unsigned r, unsigned fr_index, const std::vector<Fr>& mat, const Fr* row0_scale) {
+    auto full_round = [&](unsigned r, unsigned fr_index, const std::vector<Fr>& mat, bool last, const Fr* row0_scale) {
         for (unsigned i = 0; i < t; ++i) {
             f.ark[(size_t)r * t + i] = fr_mul(delta[i], o.ark_mod[(size_t)r * t + i]);
             e[i] = fr_pow_small(delta[i], alpha);
         }
         for (unsigned i = 0; i < t; ++i) {
-            if (i == 0 && row0_scale) dn[i] = *row0_scale;
+            if (last) dn[i] = inv32;
+            else if (i == 0 && row0_scale) dn[i] = *row0_scale;
             else {
                 if (fr_is_zero(mat[(size_t)i * t + i])) return false;
                 dn[i] = fr_mul(e[i], fr_inv(mat[(size_t)i * t + i]));
@@ -301,7 +302,7 @@ inline bool poseidon_full_form(const PoseidonOpt& o, unsigned t, unsigned full_r
         return true;
     };
     for (unsigned r = 0; r + 1 < half; ++r) {
-        if (!full_round(r, r, mds, nullptr)) return false;
+        if (!full_round(r, r, mds, false, nullptr)) return false;
         delta = dn;
     }
     // round before the block: rows 1.. first (their scales g_i define d_0), then row 0 with the prescribed scale
@@ -313,7 +314,7 @@ inline bool poseidon_full_form(const PoseidonOpt& o, unsigned t, unsigned full_r
         const Fr g1 = fr_mul(ee[1], fr_inv(o.mpre[(size_t)1 * t + 1]));
         Fr d0;
         if (!root(fr_mul(g1, sp(0, 2 + n1)), d0)) return false;
-        if (!full_round(r, r, o.mpre, &d0)) return false;
+        if (!full_round(r, r, o.mpre, false, &d0)) return false;
         delta = dn;
     }
     std::vector<Fr> g(delta);  // g[i], i >= 1: lane scales through the block
@@ -337,12 +338,9 @@ inline bool poseidon_full_form(const PoseidonOpt& o, unsigned t, unsigned full_r
     }
     delta[0] = d[RP];
     for (unsigned r = half + RP; r < R; ++r) {
-        if (!full_round(r, r - RP, mds, nullptr)) return false;
+        if (!full_round(r, r - RP, mds, r + 1 == R, nullptr)) return false;
         delta = dn;
     }
-    const Fr inv32 = fr_inv(fr_to_mont(Fr{{32u, 0, 0, 0, 0, 0, 0, 0}}));
-    f.kout.resize(t);
-    for (unsigned i = 0; i < t; ++i) f.kout[i] = fr_mul(fr_inv(delta[i]), inv32);
     out = std::move(f);
     return true;
 }

@@ -29,7 +29,7 @@ static std::vector<F29Pad> to29(const Fr* in, size_t n) {
 //                1 = generic file path with sparse partial rounds even for t == 3,
 //                2 = dense partial rounds (t == 3: register path, else file path)
 struct T3Host {  // constants in internal form for any t (name kept from the t = 3 path)
-    std::vector<F29Pad> ark, mds, mpre, sparse, sbox0, mpre_w, sparse_w, ark_f, fmats_f, sparse_f, kout_f;
+    std::vector<F29Pad> ark, mds, mpre, sparse, sbox0, mpre_w, sparse_w, ark_f, fmats_f, sparse_f, sbox0_f;
     PoseidonConsts c;     // what the wave-per-lane kernels get (lane-0 form)
     PoseidonConsts cfile; // what the LDS-file kernels get (lane-1 form when it exists), as capi.hip does
     PoseidonConsts creg;  // what the t = 3 register kernels get (full form when it exists, else cfile)
@@ -48,8 +48,8 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
         }
         mds = to29(mv.data(), mv.size());
         if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
-                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr, o.scaled ? 1u : 0u, nullptr}; }
-        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr, 0u, nullptr}; }
+                    c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr, o.scaled ? 1u : 0u}; }
+        else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr, 0u}; }
         if (rf >= 2) {  // as capi.hip does: from the round keys the kernels use
             const std::vector<Fr> s0 = poseidon_sbox0(o.ok ? o.ark_mod : av, t, alpha);
             sbox0 = to29(s0.data(), s0.size());
@@ -68,8 +68,9 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
             ark_f = to29(ff.ark.data(), ff.ark.size());
             fmats_f = to29(ff.fmats.data(), ff.fmats.size());
             sparse_f = to29(ff.sparse.data(), ff.sparse.size());
-            kout_f = to29(ff.kout.data(), ff.kout.size());
-            creg = PoseidonConsts{ark_f.data(), fmats_f.data(), nullptr, sparse_f.data(), c.sbox0, 3u, kout_f.data()};
+            const std::vector<Fr> s0f = poseidon_sbox0(ff.ark, t, alpha);
+            sbox0_f = to29(s0f.data(), s0f.size());
+            creg = PoseidonConsts{ark_f.data(), fmats_f.data(), nullptr, sparse_f.data(), sbox0_f.data(), 3u};
         }
     }
 };
@@ -126,11 +127,10 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
     for (size_t i = 0; i < n; ++i) {
         if (reg_path) {  // the register-resident fast path
             FU s0 = f29_from_wire<false>(states[i * 3]), s1 = f29_from_wire<false>(states[i * 3 + 1]), s2 = f29_from_wire<false>(states[i * 3 + 2]);
-            if (th->creg.scaled == 3u) {  // as poseidon_permute_t3_kernel<true>
+            if (th->creg.scaled == 3u) {  // as poseidon_permute_t3_kernel<true>: the lanes are the wire values
+                s0 = f29_unpack<false>(states[i * 3]); s1 = f29_unpack<false>(states[i * 3 + 1]); s2 = f29_unpack<false>(states[i * 3 + 2]);
                 poseidon_permute_t3<true>(D, th->creg, s0, s1, s2);
-                states[i * 3] = f29_canonical_pack(f29_mul(s0, ldc(th->creg.kout)));
-                states[i * 3 + 1] = f29_canonical_pack(f29_mul(s1, ldc(th->creg.kout + 1)));
-                states[i * 3 + 2] = f29_canonical_pack(f29_mul(s2, ldc(th->creg.kout + 2)));
+                states[i * 3] = f29_canonical_pack(s0); states[i * 3 + 1] = f29_canonical_pack(s1); states[i * 3 + 2] = f29_canonical_pack(s2);
                 continue;
             }
             poseidon_permute_t3<false>(D, th->creg, s0, s1, s2);
