@@ -194,7 +194,8 @@ def _custom_cfg(cpa, rate, capacity, rf, rp, alpha, mds_ints, seed):
     return c, o
 
 
-@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5_random", "rp_even", "no_partial", "alpha3_t3", "many_partial"])
+@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5_random", "rp_even", "no_partial", "alpha3_t3", "many_partial",
+                                  "many_partial_full_form", "rf2_full_form", "one_partial_full_form"])
 def test_custom_t3_parameters(cpa, case):
     """t = 3 instances other than the default one: exercises the sparse-partial-round derivation, its fallback to
     dense rounds when a block is singular (the near-MDS matrix of merkle_tree/tests/test_utils.rs:643-653), other
@@ -210,6 +211,10 @@ def test_custom_t3_parameters(cpa, case):
         "no_partial": lambda: _custom_cfg(cpa, 2, 1, 8, 0, 5, rnd, 5),
         "alpha3_t3": lambda: _custom_cfg(cpa, 2, 1, 2, 1, 3, rnd, 6),
         "many_partial": lambda: _custom_cfg(cpa, 2, 1, 2, 140, 3, rnd, 7),
+        # parameter sets that admit every re-parameterised form (alpha coprime to p - 1), at the corners of the derivation
+        "many_partial_full_form": lambda: _custom_cfg(cpa, 2, 1, 4, 140, 5, rnd, 8),
+        "rf2_full_form": lambda: _custom_cfg(cpa, 2, 1, 2, 9, 5, rnd, 9),
+        "one_partial_full_form": lambda: _custom_cfg(cpa, 2, 1, 4, 1, 17, rnd, 10),
     }[case]()
     ora = cref_poseidon(o)
     n = 300
@@ -223,6 +228,16 @@ def test_custom_t3_parameters(cpa, case):
         assert np.array_equal(got, exp), (case, k)
     l, r = rand_fr_array(32, 8), rand_fr_array(32, 9)
     assert np.array_equal(pcrh.TwoToOneCRH.compress_batch(c, l, r), ora.two_to_one_batch(l, r))
+    # above the latency-kernel switch: the one-lane-per-item register kernels
+    n = 33000
+    st = rand_fr_array(n * 3, 6).reshape(n, 3, 4)
+    st[0] = 0
+    assert np.array_equal(_permute(cpa, c, st), ora.permute_batch(st, threads=16).reshape(n, 3, 4))
+    for k in (0, 1, 2, 3):
+        x = rand_fr_array(n * max(k, 1), 60 + k).reshape(n, max(k, 1), 4)[:, :k]
+        got = pcrh.CRH.evaluate_batch(c, np.ascontiguousarray(x))
+        exp = np.repeat(ora.crh_empty(), n, axis=0) if k == 0 else ora.crh_batch(np.ascontiguousarray(x), k, threads=16)
+        assert np.array_equal(got, exp), (case, k, "register kernel")
 
 
 GENERIC_SHAPES = ((1, 1, 4, 7, 5), (2, 2, 4, 7, 5), (3, 1, 4, 70, 5), (7, 2, 8, 20, 5), (12, 4, 2, 3, 3), (15, 1, 4, 9, 5))

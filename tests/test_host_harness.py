@@ -225,21 +225,29 @@ def test_digest_serialisation(H):
     assert bytes(buf[0]) == (jj.fq_serialize(pts[0][0]) + jj.fq_serialize(pts[1][0]))[:63]
 
 
-@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5", "rp_even", "no_partial", "many_partial"])
+@pytest.mark.parametrize("case", ["near_mds", "rate1_cap2", "alpha5", "rp_even", "no_partial", "many_partial", "many_partial_full_form",
+                                  "rf2_full_form", "one_partial_full_form"])
 def test_poseidon_t3_custom_parameters(H, case):
     """sparse-partial-round derivation on non-default t = 3 instances, incl. the singular-block fallback"""
     near = [[1, 0, 1], [1, 1, 0], [0, 1, 1]]
     rnd = [rand_fr(3, 70 + i) for i in range(3)]
     rate, cap, rf, rp, alpha, mdsi = {"near_mds": (2, 1, 8, 29, 17, near), "rate1_cap2": (1, 2, 8, 31, 17, rnd), "alpha5": (2, 1, 8, 56, 5, rnd),
                                       "rp_even": (2, 1, 6, 10, 17, rnd), "no_partial": (2, 1, 8, 0, 5, rnd),
-                                      "many_partial": (2, 1, 2, 140, 3, rnd)}[case]
+                                      "many_partial": (2, 1, 2, 140, 3, rnd),
+                                      # alpha = 5 admits the re-parameterised forms: 140 rounds exercise the periodic re-fold
+                                      # of the lanes that only ever take additions; rf = 2 puts the scaled block between the
+                                      # M_pre round and the last round; rp = 1 makes the first partial round also the last
+                                      "many_partial_full_form": (2, 1, 4, 140, 5, rnd), "rf2_full_form": (2, 1, 2, 9, 5, rnd),
+                                      "one_partial_full_form": (2, 1, 4, 1, 17, rnd)}[case]
     arki = rand_fr((rf + rp) * 3, 9)
     c = po.PoseidonConfig(rf, rp, alpha, [arki[i * 3:(i + 1) * 3] for i in range(rf + rp)], mdsi, rate, cap)
     ark, mds = mont(arki), mont([x for r in mdsi for x in r])
-    sts = [rand_fr(3, 40 + i) for i in range(2)]
-    for mode in (0, 2):
+    sts = [rand_fr(3, 40 + i) for i in range(2)] + [[0, 0, 0], [ofr.P - 1, ofr.P - 1, ofr.P - 1]]
+    if case.endswith("full_form"):
+        assert H.hh_poseidon_forms(rf, rp, alpha, rate, cap, P(ark), P(mds)) == (13 if rp == 1 else 15)  # one round: nothing for the lane-0 form
+    for mode in (0, 1, 2):
         S = mont([x for s in sts for x in s])
-        H.hh_poseidon_permute(rf, rp, alpha, rate, cap, P(ark), P(mds), P(S), 2, mode)
+        H.hh_poseidon_permute(rf, rp, alpha, rate, cap, P(ark), P(mds), P(S), len(sts), mode)
         assert ints(S) == [x for s in sts for x in po.permute(c, s)], (case, mode)
         for k in (0, 1, 2, 3):
             ins = [rand_fr(k, 90 + k)]
