@@ -73,6 +73,12 @@ AKP_HD Ext te_add_ext(const Ext& p, const Ext& q) {
     return Ext{f29_mul(e, f), f29_mul(g, h), f29_mul(f, g), f29_mul(e, h)};
 }
 
+// the affine point of a table entry as an extended point (1 product instead of a 7-product addition to the identity)
+AKP_HD Ext ext_from_niels(const Niels& q) {
+    const FS x = f29_sub(q.ypx, q.ymx), y = f29_weak_norm(f29_add(q.ypx, q.ymx));  // (y+x)/2 -+ (y-x)/2
+    return Ext{x, y, f29_one<true>(), f29_mul(x, y)};
+}
+
 AKP_HD Fr load_fr_g(const Fr* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     const uint4 lo = q[0], hi = q[1];
@@ -199,12 +205,14 @@ AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __r
 template <int KIND>
 AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
                               size_t msg_len, u32 D, u32 n_groups, u32 n_steps) {
-    Ext acc = ext_identity();
-    if (n_steps == 0) return acc;
+    if (n_steps == 0) return ext_identity();
     // Two steps per iteration with two entry buffers: the entry of step u+1 is fetched before the ~2000-instruction
     // addition that consumes the entry of step u, and no register copies are needed to rotate the buffers.
-    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 0);
-    u32 u = 0;
+    // Step 0 is not an addition: the sum starts as the first entry itself.
+    Ext acc = ext_from_niels(te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 0));
+    if (n_steps == 1) return acc;
+    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 1);
+    u32 u = 1;
 #pragma unroll 1
     for (; u + 2 <= n_steps; u += 2) {
         const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, u + 1);
@@ -219,11 +227,12 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
 template <int KIND>
 AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
                                  size_t msg_len, u32 D, u32 n_groups, u32 n_steps, u32 first, u32 stride) {
-    Ext acc = ext_identity();
-    if (first >= n_steps) return acc;
-    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, first);
+    if (first >= n_steps) return ext_identity();
+    Ext acc = ext_from_niels(te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, first));  // first term: no addition
+    if (first + stride >= n_steps) return acc;
+    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, first + stride);
 #pragma unroll 1
-    for (u32 u = first; u < n_steps; u += stride) {
+    for (u32 u = first + stride; u < n_steps; u += stride) {
         const u32 nxt = (u + stride < n_steps) ? u + stride : u;
         const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, nxt);  // fetched ahead of the addition
         acc = te_madd(acc, q0);
