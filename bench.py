@@ -32,13 +32,14 @@ import torch  # noqa: E402  (imported before the product so both share one HIP r
 ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODMUL_PER_PERM_REF = 626        # reference-shaped count
-# HBM bytes per 2^20-state launch from the PMC passes of profiles/r01_s13/pmc_{FETCH,WRITE}_SIZE_counter_collection.csv
+# HBM bytes per 2^20-state launch from the PMC passes of profiles/r01_s15/pmc_{FETCH,WRITE}_SIZE_counter_collection.csv
 # (separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 reports half of a wide coalesced read):
-# (2 * 49 619 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.9 B per permutation  (algorithmic: 192 B)
-PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49619.0 + 98304.0) * 1024 / (1 << 20)
+# (2 * 49 616 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.9 B per permutation  (algorithmic: 192 B)
+PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49616.0 + 98304.0) * 1024 / (1 << 20)
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # measured: one v_mad_u64_u32 (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
-MADS_PER_PERM = 8 * (3 * (4 * 118 + 154) + 3 * 316) + 31 * ((4 * 118 + 154) + 316 + 154) + 6 * 154  # v_mad per permutation (ISA counts: sqr 118,
-# mul 154, dot3 316; sparse partial rounds in the lane-1 form: S-box + one dot3 + one product; 6 wire conversions)
+MADS_PER_PERM = 55 * (4 * 118 + 154) + (20 * 235 + 4 * 316) + (30 * (316 + 154) + (235 + 154))  # v_mad per permutation, ISA counts
+# (sqr 118, mul 154, dot3 316, dot2 235) of the full form: 55 S-boxes; full-round rows: 20 with unit diagonal (dot2), 4 dot3;
+# partial rounds: dot3 + one product (lane-1 form), the last one dot2 + one product; no conversion products
 
 
 def measure_hbm_copy(torch, dev, nbytes=1 << 30, reps=10):
@@ -238,7 +239,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "poseidon_permute_t3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_PERM * n,
                      "peak_measured_copy": hbm_copy_gbs, "frac_of_measured_copy": achieved / hbm_copy_gbs if hbm_copy_gbs else None,
-                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction (profiles/r01_s13; same within 1.5 % in every session since r01_s3)",
+                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction (profiles/r01_s15; same within 1.5 % in every session since r01_s3)",
                      "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PERM * n,
                      "valu": {"note": "the path is integer-ALU bound (~%d reference-shaped Montgomery products per 192 B); "
                                       "fraction of the measured v_mad_u64_u32 issue peak spent on multiplies" % MODMUL_PER_PERM_REF,
