@@ -14,13 +14,17 @@
 // Arithmetic runs in the lazy radix-2^29 form of f29.hpp (unsigned flavour: Poseidon only adds and
 // multiplies).  Round keys and the MDS matrix are converted to that form once per parameter set and are
 // wave-uniform: they come through the scalar cache (s_load) straight into SGPR operands of v_mad_u64_u32.
-//   t == 3 (the rate-2 headline instance): state in 27 VGPRs, S-box x^alpha by square-and-multiply,
-//          each MDS row as ONE 3-term dot product with a single Montgomery reduction.
-//   any other t <= 16: the state lives in an LDS "register file" (lane-interleaved dwords, conflict-free)
-//          so loops over state elements are real loops; MDS rows are chunks of 3-term dots; partial rounds
-//          run in the sparse form (in place) as well.
-// Values cross HBM in the ABI's wire format (ark-ff Montgomery, R = 2^256); one product with a constant
-// converts on load / store.
+//   t == 3, large batches (the rate-2 headline instance): one item per lane, state in 27 VGPRs, S-box x^alpha by
+//          square-and-multiply, each linear-layer row one dot product with a single Montgomery reduction.
+//   any other t <= 16, large batches: one item per lane, the state lives in an LDS "register file"
+//          (lane-interleaved dwords, conflict-free) so loops over state elements are real loops; rows are chunks
+//          of 3-term dots; partial rounds run in the sparse form (in place) as well.
+//   small batches, any t (tree tops, single sponges): one WAVE per state lane, t waves per 64 items (bottom of
+//          this file): 40 % lower latency, lower throughput.
+// The host derives algebraically equivalent constant sets that remove products (poseidon_opt.hpp: sparse partial
+// rounds, then the lane-0 / lane-1 / full re-parameterisations); `PoseidonConsts::scaled` says which one a kernel got.
+// Values cross HBM in the ABI's wire format (ark-ff Montgomery, R = 2^256); one product with a constant converts
+// on load / store, except in the full form, which computes on the wire values directly.
 #pragma once
 #include "f29.hpp"
 
