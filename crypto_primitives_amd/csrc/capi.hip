@@ -227,7 +227,7 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
             PoseidonOpt optw = opt;
             const bool rescale = opt.ok && !getenv("AKP_POSEIDON_NO_RESCALE");
             PoseidonFullForm ff;
-            if (rescale && t == 3 && !getenv("AKP_POSEIDON_NO_FULL_FORM") && poseidon_full_form(opt, t, full_rounds, partial_rounds, alpha, p->mds, ff)) {
+            if (rescale && !getenv("AKP_POSEIDON_NO_FULL_FORM") && poseidon_full_form(opt, t, full_rounds, partial_rounds, alpha, p->mds, ff)) {
                 int32_t rc = upload_f29(ctx, ff.ark, &p->d_ark_f29);
                 if (!rc) rc = upload_f29(ctx, ff.fmats, &p->d_fmats_f29);
                 if (!rc) rc = upload_f29(ctx, ff.sparse, &p->d_sparse_f29);
@@ -422,16 +422,14 @@ static inline PoseidonConsts t3_consts(const akp_poseidon* p) {
     if (p->d_sparse29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre29, p->d_sparse29, p->d_sbox0_29, p->scaled ? 1u : 0u};
     return PoseidonConsts{p->d_ark29, p->d_mds29, nullptr, nullptr, p->d_sbox0_29, 0u};
 }
-// constants for the LDS-file kernels: the lane-1 form when it exists
+// constants for the one-lane-per-item kernels (LDS-file kernels, t = 3 register kernels): the full form when it exists,
+// else the lane-1 form, else what the wave-per-lane kernels use
 static inline PoseidonConsts file_consts(const akp_poseidon* p) {
+    if (p->d_sparse_f29) return PoseidonConsts{p->d_ark_f29, p->d_fmats_f29, nullptr, p->d_sparse_f29, p->d_sbox0_f29, 3u};
     if (p->d_sparse_w29) return PoseidonConsts{p->d_arkmod29, p->d_mds29, p->d_mpre_w29, p->d_sparse_w29, p->d_sbox0_29, 2u};
     return t3_consts(p);
 }
-// constants for the t = 3 register kernels: the full form when it exists, else as above
-static inline PoseidonConsts t3_reg_consts(const akp_poseidon* p) {
-    if (p->d_sparse_f29) return PoseidonConsts{p->d_ark_f29, p->d_fmats_f29, nullptr, p->d_sparse_f29, p->d_sbox0_f29, 3u};
-    return file_consts(p);
-}
+static inline PoseidonConsts t3_reg_consts(const akp_poseidon* p) { return file_consts(p); }
 #define AKP_MAX_BATCH ((size_t)1 << 36)  /* grid.x = n / 256 must stay below 2^31 */
 // AKP_POSEIDON_COOP_MAX: largest t = 3 batch routed to the wave-per-lane latency kernels (0 disables them)
 static size_t coop_max_items() {
@@ -488,8 +486,8 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
         const PoseidonConsts c = t3_reg_consts(p);
-        if (c.scaled == 3u && k <= p->dims.rate) hipLaunchKernelGGL(poseidon_crh_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
-        else hipLaunchKernelGGL(poseidon_crh_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c.scaled == 3u ? file_consts(p) : c, in0, in1, k, d_out, n);
+        if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_crh_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
+        else hipLaunchKernelGGL(poseidon_crh_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }

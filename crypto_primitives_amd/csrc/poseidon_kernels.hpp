@@ -183,9 +183,9 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
         done += take;
         // only state[capacity] of the last permutation is squeezed (:156-186)
         poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2, zero_lanes, done < k ? 7u : (1u << D.capacity));
-        // the full form leaves the lanes scaled: it serves single-permutation hashes only (k <= rate; the host routes
-        // longer inputs to the other instantiation), which also keeps this instantiation's code small
-    } while (!FULLFORM && done < k);
+        // (full form: the lanes leave the permutation as they entered it, as wire values, so the next block is absorbed
+        // the same way)
+    } while (done < k);
     // squeeze_internal(0, 1) :156-186 -- limb-wise selects (an array select would go through scratch)
     FU out;
 #pragma unroll
@@ -256,12 +256,37 @@ AKP_HD FU poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restri
         const FU a0 = (first && j == 0) ? *first : f.load(src + j);
         acc = f29_add(acc, f29_dot3(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1), f.load(src + j + 2), ldc(row + j + 2)));
     }
-#pragma unroll 1
-    for (; j < T; ++j) {
+    if (j + 2 == T) {  // two terms left: one reduction
+        const FU a0 = (first && j == 0) ? *first : f.load(src + j);
+        acc = f29_add(acc, f29_dot2(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1)));
+    } else if (j < T) {
         const FU a0 = (first && j == 0) ? *first : f.load(src + j);
         acc = f29_add(acc, f29_mul(a0, ldc(row + j)));
     }
     return f29_weak_norm(acc);  // <= 6 normalised terms summed: back below 2^29 + 8
+}
+// the same sum without term `skip` (full form: that coefficient is 1 and the element is added by the caller).
+// `first` (if non-null) stands for state[0], as above.  Result NOT normalised (the caller adds and normalises).
+template <class File>
+AKP_HD FU poseidon_row_dot_skip(const File& f, u32 T, const F29Pad* __restrict__ row, u32 skip, const FU* first) {
+    FU acc = f29_zero<false>();
+    u32 c = 0;  // running index over the T - 1 remaining terms
+#pragma unroll 1
+    for (; c + 3 <= T - 1; c += 3) {
+        const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip), j2 = c + 2 + (c + 2 >= skip);
+        const FU a0 = (first && j0 == 0) ? *first : f.load(j0);
+        acc = f29_add(acc, f29_dot3(a0, ldc(row + j0), f.load(j1), ldc(row + j1), f.load(j2), ldc(row + j2)));
+    }
+    if (c + 2 == T - 1) {  // two terms left: one reduction
+        const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip);
+        const FU a0 = (first && j0 == 0) ? *first : f.load(j0);
+        acc = f29_add(acc, f29_dot2(a0, ldc(row + j0), f.load(j1), ldc(row + j1)));
+    } else if (c < T - 1) {
+        const u32 j0 = c + (c >= skip);
+        const FU a0 = (first && j0 == 0) ? *first : f.load(j0);
+        acc = f29_add(acc, f29_mul(a0, ldc(row + j0)));
+    }
+    return acc;  // <= 6 normalised terms
 }
 #define AKP_POSEIDON_MAX_T 16
 // The state occupies slots [0, t) of the file.  Sparse partial rounds update it in place; a dense layer needs all
@@ -287,9 +312,14 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
                 if (e < nsbox) x = f29_pow_small(x, D.alpha);
                 f.store(e, x);
             }
-            const F29Pad* m = (opt && r + 1 == half) ? C.mpre : C.mds;
+            const bool ff = C.scaled == 3u;  // full form: one matrix per full round, unit diagonal where flagged
+            const F29Pad* m = ff ? C.mds + (size_t)(r < half ? r : r - D.partial_rounds) * T * T : ((opt && r + 1 == half) ? C.mpre : C.mds);
+            const bool unit_rest = ff && r + 1 != R, unit0 = unit_rest && r + 1 != half;
 #pragma unroll 1
-            for (u32 i = 0; i < T; ++i) tmp[i] = poseidon_row_dot(f, 0, T, m + (size_t)i * T, nullptr);  // new[i] = sum_j state[j] * m[i][j]
+            for (u32 i = 0; i < T; ++i) {  // new[i] = sum_j state[j] * m[i][j]
+                if (i == 0 ? unit0 : unit_rest) tmp[i] = f29_weak_norm(f29_add(f.load(i), poseidon_row_dot_skip(f, T, m + (size_t)i * T, i, nullptr)));
+                else tmp[i] = poseidon_row_dot(f, 0, T, m + (size_t)i * T, nullptr);
+            }
 #pragma unroll 1
             for (u32 i = 0; i < T; ++i) f.store(i, tmp[i]);
         } else {
@@ -297,13 +327,15 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
             const FU sb = f29_pow_small(f29_add(f.load(0), ldc(sp)), D.alpha);
-            const FU n0 = poseidon_row_dot(f, 0, T, sp + 1, &sb);
+            // full form, last partial round: a00 = 1
+            const FU n0 = (C.scaled == 3u && j + 1 == D.partial_rounds) ? f29_weak_norm(f29_add(sb, poseidon_row_dot_skip(f, T, sp + 1, 0, &sb)))
+                                                                        : poseidon_row_dot(f, 0, T, sp + 1, &sb);
             const bool norm = (j & 1u) || j + 1 == D.partial_rounds;  // lanes grow < 2^29 per limb per round (see t3 notes)
             const bool refold = (j & 31u) == 31u;                       // ... and < 2.1p in value: fold back mod p every 32 rounds
 #pragma unroll 1
             for (u32 i = 1; i < T; ++i) {
                 // lane-1 form (scaled == 2): lane 1 takes the S-box output with coefficient 1
-                FU y = (i == 1 && C.scaled == 2u) ? f29_add(f.load(1), sb) : f29_add(f.load(i), f29_mul(sb, ldc(sp + T + i)));
+                FU y = (i == 1 && C.scaled >= 2u) ? f29_add(f.load(1), sb) : f29_add(f.load(i), f29_mul(sb, ldc(sp + T + i)));
                 if (refold) y = f29_mul(y, f29_one<false>());
                 else if (norm) y = f29_weak_norm(y);
                 f.store(i, y);
@@ -326,12 +358,14 @@ AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const PoseidonConsts& C, cons
             const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
             const u32 slot = D.capacity + (u32)j;
             // the rate lane holds a weakly normalised MDS output (or zero): keep it that way
-            f.store(slot, f29_weak_norm(f29_add(f.load(slot), f29_from_wire<false>(load_fr_global(src)))));
+            // full form: the lanes hold wire values (x * 2^256), inputs are taken as they are
+            const FU in = C.scaled == 3u ? f29_unpack<false>(load_fr_global(src)) : f29_from_wire<false>(load_fr_global(src));
+            f.store(slot, f29_weak_norm(f29_add(f.load(slot), in)));
         }
         done += take;
         poseidon_permute_file(D, C, f);
     } while (done < k);
-    return f29_to_wire(f.load(D.capacity));
+    return C.scaled == 3u ? f29_canonical_pack(f.load(D.capacity)) : f29_to_wire(f.load(D.capacity));
 }
 
 template <int BLOCK>
@@ -342,10 +376,10 @@ __global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D,
     if (idx >= n) return;  // lanes never exchange data: no barriers anywhere
     Fr* st = states + idx * D.t;
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(load_fr_global(st + e)));
+    for (u32 e = 0; e < D.t; ++e) f.store(e, C.scaled == 3u ? f29_unpack<false>(load_fr_global(st + e)) : f29_from_wire<false>(load_fr_global(st + e)));
     poseidon_permute_file(D, C, f);
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, f29_to_wire(f.load(e)));
+    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, C.scaled == 3u ? f29_canonical_pack(f.load(e)) : f29_to_wire(f.load(e)));
 }
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, PoseidonConsts C, const Fr* __restrict__ in0,
@@ -389,8 +423,8 @@ AKP_D FU coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ 
 #pragma unroll 1
     for (; j + 3 <= tile.T; j += 3)
         acc = f29_add(acc, f29_dot3(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1), tile.get(buf, j + 2), ldc(row + j + 2)));
-#pragma unroll 1
-    for (; j < tile.T; ++j) acc = f29_add(acc, f29_mul(tile.get(buf, j), ldc(row + j)));
+    if (j + 2 == tile.T) acc = f29_add(acc, f29_dot2(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1)));
+    else if (j < tile.T) acc = f29_add(acc, f29_mul(tile.get(buf, j), ldc(row + j)));
     return f29_weak_norm(acc);
 }
 // one permutation; x is lane w of the state (weakly normalised in and out); buf is the tile buffer to use next

@@ -30,9 +30,10 @@ static std::vector<F29Pad> to29(const Fr* in, size_t n) {
 //                2 = dense partial rounds (t == 3: register path, else file path)
 struct T3Host {  // constants in internal form for any t (name kept from the t = 3 path)
     std::vector<F29Pad> ark, mds, mpre, sparse, sbox0, mpre_w, sparse_w, ark_f, fmats_f, sparse_f, sbox0_f;
+    bool has_lane1 = false, has_full = false;
     PoseidonConsts c;     // what the wave-per-lane kernels get (lane-0 form)
-    PoseidonConsts cfile; // what the LDS-file kernels get (lane-1 form when it exists), as capi.hip does
-    PoseidonConsts creg;  // what the t = 3 register kernels get (full form when it exists, else cfile)
+    PoseidonConsts cfile; // what the one-lane-per-item kernels get: full form, else lane-1 form, else c (as capi.hip does)
+    PoseidonConsts creg;  // == cfile (kept for the t = 3 register-path call sites)
     T3Host(uint32_t t, uint32_t rf, uint32_t rp, uint64_t alpha, const Fr* a, const Fr* m, bool sparse_form) {
         std::vector<Fr> av(a, a + (size_t)(rf + rp) * t), mv(m, m + (size_t)t * t);
         PoseidonOpt o;
@@ -42,7 +43,7 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
         if (sparse_form) {
             o = poseidon_optimize(t, rf, rp, av, mv);
             ow = o;
-            have_f = t == 3 && poseidon_full_form(o, t, rf, rp, alpha, mv, ff);
+            have_f = poseidon_full_form(o, t, rf, rp, alpha, mv, ff);
             poseidon_rescale_sparse(o, t, rp, alpha);
             have_w = poseidon_rescale_sparse_lane1(ow, t, rp, alpha);
         }
@@ -63,15 +64,17 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
             cfile.sparse = sparse_w.data();
             cfile.scaled = 2u;
         }
-        creg = cfile;
+        has_lane1 = have_w;
+        has_full = have_f;
         if (have_f) {
             ark_f = to29(ff.ark.data(), ff.ark.size());
             fmats_f = to29(ff.fmats.data(), ff.fmats.size());
             sparse_f = to29(ff.sparse.data(), ff.sparse.size());
             const std::vector<Fr> s0f = poseidon_sbox0(ff.ark, t, alpha);
             sbox0_f = to29(s0f.data(), s0f.size());
-            creg = PoseidonConsts{ark_f.data(), fmats_f.data(), nullptr, sparse_f.data(), sbox0_f.data(), 3u};
+            cfile = PoseidonConsts{ark_f.data(), fmats_f.data(), nullptr, sparse_f.data(), sbox0_f.data(), 3u};
         }
+        creg = cfile;
     }
 };
 static PoseidonDims mk(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap) {
@@ -137,16 +140,17 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
             continue;
         }
-        for (u32 e = 0; e < D.t; ++e) f.store(e, f29_from_wire<false>(states[i * D.t + e]));
+        const bool wire = th->cfile.scaled == 3u;  // as poseidon_permute_kernel
+        for (u32 e = 0; e < D.t; ++e) f.store(e, wire ? f29_unpack<false>(states[i * D.t + e]) : f29_from_wire<false>(states[i * D.t + e]));
         poseidon_permute_file(D, th->cfile, f);
-        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = f29_to_wire(f.load(e));
+        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = wire ? f29_canonical_pack(f.load(e)) : f29_to_wire(f.load(e));
     }
     delete th;
 }
 // which constant forms exist for a parameter set: bit 0 sparse, bit 1 lane-0 rescaling, bit 2 lane-1 form, bit 3 full form
 int hh_poseidon_forms(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds) {
     T3Host th(rate + cap, rf, rp, alpha, ark, mds, true);
-    return (th.c.sparse ? 1 : 0) | (th.c.scaled == 1u ? 2 : 0) | (th.cfile.scaled == 2u ? 4 : 0) | (th.creg.scaled == 3u ? 8 : 0);
+    return (th.c.sparse ? 1 : 0) | (th.c.scaled == 1u ? 2 : 0) | (th.has_lane1 ? 4 : 0) | (th.has_full ? 8 : 0);
 }
 void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
                      const Fr* in0, const Fr* in1, size_t k, Fr* out, size_t n, int force_generic) {
@@ -156,7 +160,7 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i)
-        out[i] = reg_path ? ((th->creg.scaled == 3u && k <= rate) ? poseidon_crh_item_t3<true>(D, th->creg, in0, in1, k, i) : poseidon_crh_item_t3<false>(D, th->creg.scaled == 3u ? th->cfile : th->creg, in0, in1, k, i)) : poseidon_crh_item(D, th->cfile, f, in0, in1, k, i);
+        out[i] = reg_path ? (th->creg.scaled == 3u ? poseidon_crh_item_t3<true>(D, th->creg, in0, in1, k, i) : poseidon_crh_item_t3<false>(D, th->creg, in0, in1, k, i)) : poseidon_crh_item(D, th->cfile, f, in0, in1, k, i);
     delete th;
 }
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);

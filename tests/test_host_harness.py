@@ -70,13 +70,13 @@ def test_f29_core_ops(H):
 
 def test_constant_forms_of_the_default_parameter_sets(H):
     """every default parameter set of the reference (sponge/test.rs:13-31) admits the re-parameterised forms the fast
-    kernels use: sparse + lane-0 + lane-1 for all, the full form for t = 3; alpha = 3 (3 | p - 1: no cube roots) keeps
-    the plain sparse form with the lane-0 rescaling only."""
+    kernels use: sparse + lane-0 + lane-1 + full form; alpha = 3 (3 | p - 1: no cube roots) keeps the plain sparse form
+    with the lane-0 rescaling only."""
     for rate, weights in [(2, False), (2, True), (3, False), (8, False), (8, True)]:
         c = po.get_default_poseidon_parameters(rate, weights)
         ark = mont([x for row in c.ark for x in row]); mds = mont([x for row in c.mds for x in row])
         forms = H.hh_poseidon_forms(c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity, P(ark), P(mds))
-        assert forms == (15 if rate == 2 else 7), (rate, weights, forms)
+        assert forms == 15, (rate, weights, forms)
     c = po.get_default_poseidon_parameters(2, False)
     ark = mont([x for row in c.ark for x in row]); mds = mont([x for row in c.mds for x in row])
     assert H.hh_poseidon_forms(c.full_rounds, c.partial_rounds, 3, c.rate, c.capacity, P(ark), P(mds)) == 3
