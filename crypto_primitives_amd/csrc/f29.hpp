@@ -130,9 +130,17 @@ AKP_HD F29T<S> f29_weak_norm(const F29T<S>& a) {
     acc += (W)(u64)m[k];                          \
     acc >>= 29;
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+// single-accumulator-chain inline assembly for the field routines (generated, asm/gen_inline.py)
+#include "asm/f29_asm.inc"
+#endif
+
 // a * b / 2^261 (mod p).  Output normalised.
 template <bool S>
 AKP_HD F29T<S> f29_mul(const F29T<S>& a, const F29T<S>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    return f29_mul_asm(a, b);
+#endif
     typedef typename F29T<S>::L L;
     typedef typename F29T<S>::W W;
     W acc = 0;
@@ -159,9 +167,22 @@ AKP_HD F29T<S> f29_mul(const F29T<S>& a, const F29T<S>& b) {
     return t;
 }
 
+// a * c / 2^261 for a wave-uniform c (a constant): same value as f29_mul; the assembly version keeps c in SGPRs
+template <bool S>
+AKP_HD F29T<S> f29_mulc(const F29T<S>& a, const F29T<S>& c) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    return f29_mulc_asm(a, c);
+#else
+    return f29_mul(a, c);
+#endif
+}
+
 // a^2 / 2^261: off-diagonal products use the doubled operand (45 products instead of 81)
 template <bool S>
 AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    return f29_sqr_asm(a);
+#endif
     typedef typename F29T<S>::L L;
     typedef typename F29T<S>::W W;
     L a2[9];
@@ -195,7 +216,11 @@ AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
 
 // (a0*b0 + a1*b1 + a2*b2) / 2^261: one reduction for three products (the MDS row of a t = 3 state).
 // FU only: a limbs < 2^30, b limbs < 2^29  =>  27 * 2^59 + 9 * 2^58 + carry < 2^64.
+// On the device b0..b2 must be wave-uniform (constants): the assembly version takes them in SGPRs.
 AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const FU& a2, const FU& b2) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    return f29_dot3_asm(a0, b0, a1, b1, a2, b2);
+#endif
     typedef u32 L;
     typedef u64 W;
     W acc = 0;
@@ -232,6 +257,9 @@ AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const
 
 // (a0*b0 + a1*b1) / 2^261: two products, one reduction (same operand bounds as f29_dot3)
 AKP_HD FU f29_dot2(const FU& a0, const FU& b0, const FU& a1, const FU& b1) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    return f29_dot2_asm(a0, b0, a1, b1);
+#endif
     typedef u32 L;
     typedef u64 W;
     W acc = 0;
@@ -306,7 +334,7 @@ AKP_HD F29T<S> f29_unpack(const Fr& w) {  // plain re-limbing of a 256-bit integ
 }
 template <bool S>
 AKP_HD F29T<S> f29_from_wire(const Fr& w) {
-    return f29_mul(f29_unpack<S>(w), f29_k_in<S>());
+    return f29_mulc(f29_unpack<S>(w), f29_k_in<S>());
 }
 // canonical representative in [0, p) of a value with |v| < 4p (FS) / 0 <= v < 8p (FU), as 8 x u32
 template <bool S>
@@ -357,14 +385,14 @@ AKP_HD Fr f29_canonical_pack(const F29T<S>& a) {
 }
 template <bool S>
 AKP_HD Fr f29_to_wire(const F29T<S>& a) {
-    return f29_canonical_pack(f29_mul(a, f29_k_out<S>()));
+    return f29_canonical_pack(f29_mulc(a, f29_k_out<S>()));
 }
 // canonical little-endian integer of the field element (ark-serialize's encoding of Fq)
 template <bool S>
 AKP_HD Fr f29_to_canonical_int(const F29T<S>& a) {
     F29T<S> one = f29_zero<S>();
     one.l[0] = 1;
-    return f29_canonical_pack(f29_mul(a, one));  // a / R' = x
+    return f29_canonical_pack(f29_mulc(a, one));  // a / R' = x
 }
 AKP_HD FS f29_to_signed(const FU& a) {
     FS r;
@@ -502,7 +530,7 @@ AKP_HD F29T<S> f29_inv(const F29T<S>& a) {
             r.l[i] = (L)v;
         }
     }
-    return f29_mul(r, f29_r2<S>());  // plain 1/x -> (1/x) * 2^261
+    return f29_mulc(r, f29_r2<S>());  // plain 1/x -> (1/x) * 2^261
 }
 
 // 12-dword padded storage (three 16-byte vectors) for tables / scratch in global memory

@@ -138,11 +138,11 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
                 s0 = f29_weak_norm(f29_add(s, f29_dot2(s1, ldc(sp + 2), s2, ldc(sp + 3))));
             else s0 = f29_dot3(s, ldc(sp + 1), s1, ldc(sp + 2), s2, ldc(sp + 3));
             if (form >= 2u) s1 = f29_add(s1, s);
-            else s1 = f29_add(s1, f29_mul(s, ldc(sp + 4)));
-            s2 = f29_add(s2, f29_mul(s, ldc(sp + 5)));
+            else s1 = f29_add(s1, f29_mulc(s, ldc(sp + 4)));
+            s2 = f29_add(s2, f29_mulc(s, ldc(sp + 5)));
             if ((j & 31u) == 31u) {  // lanes 1,2 gain < 2.1p per round and are never reduced mod p: fold them back
-                s1 = f29_mul(s1, f29_one<false>());  // every 32 rounds so the top limb stays far below 2^32 for any RP
-                s2 = f29_mul(s2, f29_one<false>());
+                s1 = f29_mulc(s1, f29_one<false>());  // every 32 rounds so the top limb stays far below 2^32 for any RP
+                s2 = f29_mulc(s2, f29_one<false>());
             } else if ((j & 1u) || j + 1 == D.partial_rounds) {
                 s1 = f29_weak_norm(s1);
                 s2 = f29_weak_norm(s2);
@@ -261,7 +261,7 @@ AKP_HD FU poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restri
         acc = f29_add(acc, f29_dot2(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1)));
     } else if (j < T) {
         const FU a0 = (first && j == 0) ? *first : f.load(src + j);
-        acc = f29_add(acc, f29_mul(a0, ldc(row + j)));
+        acc = f29_add(acc, f29_mulc(a0, ldc(row + j)));
     }
     return f29_weak_norm(acc);  // <= 6 normalised terms summed: back below 2^29 + 8
 }
@@ -284,7 +284,7 @@ AKP_HD FU poseidon_row_dot_skip(const File& f, u32 T, const F29Pad* __restrict__
     } else if (c < T - 1) {
         const u32 j0 = c + (c >= skip);
         const FU a0 = (first && j0 == 0) ? *first : f.load(j0);
-        acc = f29_add(acc, f29_mul(a0, ldc(row + j0)));
+        acc = f29_add(acc, f29_mulc(a0, ldc(row + j0)));
     }
     return acc;  // <= 6 normalised terms
 }
@@ -335,8 +335,8 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
 #pragma unroll 1
             for (u32 i = 1; i < T; ++i) {
                 // lane-1 form (scaled == 2): lane 1 takes the S-box output with coefficient 1
-                FU y = (i == 1 && C.scaled >= 2u) ? f29_add(f.load(1), sb) : f29_add(f.load(i), f29_mul(sb, ldc(sp + T + i)));
-                if (refold) y = f29_mul(y, f29_one<false>());
+                FU y = (i == 1 && C.scaled >= 2u) ? f29_add(f.load(1), sb) : f29_add(f.load(i), f29_mulc(sb, ldc(sp + T + i)));
+                if (refold) y = f29_mulc(y, f29_one<false>());
                 else if (norm) y = f29_weak_norm(y);
                 f.store(i, y);
             }
@@ -424,7 +424,7 @@ AKP_D FU coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ 
     for (; j + 3 <= tile.T; j += 3)
         acc = f29_add(acc, f29_dot3(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1), tile.get(buf, j + 2), ldc(row + j + 2)));
     if (j + 2 == tile.T) acc = f29_add(acc, f29_dot2(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1)));
-    else if (j < tile.T) acc = f29_add(acc, f29_mul(tile.get(buf, j), ldc(row + j)));
+    else if (j < tile.T) acc = f29_add(acc, f29_mulc(tile.get(buf, j), ldc(row + j)));
     return f29_weak_norm(acc);
 }
 // one permutation; x is lane w of the state (weakly normalised in and out); buf is the tile buffer to use next
@@ -450,11 +450,11 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
                 x = f29_pow_small(f29_add(x, ldc(sp)), D.alpha);
                 tile.put(buf, 0, x);
             } else {
-                tile.put(buf, w, f29_mul(x, ldc(sp + 1 + w)));
+                tile.put(buf, w, f29_mulc(x, ldc(sp + 1 + w)));
             }
             __syncthreads();
             if (w == 0) {
-                FU acc = (C.scaled == 1u && j + 1 < D.partial_rounds) ? x : f29_mul(x, ldc(sp + 1));
+                FU acc = (C.scaled == 1u && j + 1 < D.partial_rounds) ? x : f29_mulc(x, ldc(sp + 1));
 #pragma unroll 1
                 for (u32 i = 1; i < T; ++i) {
                     acc = f29_add(acc, tile.get(buf, i));
@@ -462,8 +462,8 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
                 }
                 x = f29_weak_norm(acc);
             } else {
-                x = f29_add(x, f29_mul(tile.get(buf, 0), ldc(sp + T + w)));
-                if ((j & 31u) == 31u) x = f29_mul(x, f29_one<false>());
+                x = f29_add(x, f29_mulc(tile.get(buf, 0), ldc(sp + T + w)));
+                if ((j & 31u) == 31u) x = f29_mulc(x, f29_one<false>());
                 else if ((j & 1u) || j + 1 == D.partial_rounds) x = f29_weak_norm(x);
             }
         }
