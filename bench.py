@@ -37,9 +37,11 @@ MODMUL_PER_PERM_REF = 626        # reference-shaped count
 # (2 * 49 616 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.9 B per permutation  (algorithmic: 192 B)
 PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49616.0 + 98304.0) * 1024 / (1 << 20)
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # measured: one v_mad_u64_u32 (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
-MADS_PER_PERM = 55 * (4 * 118 + 154) + (20 * 235 + 4 * 316) + (30 * (316 + 154) + (235 + 154))  # v_mad per permutation, ISA counts
-# (sqr 118, mul 154, dot3 316, dot2 235) of the full form: 55 S-boxes; full-round rows: 20 with unit diagonal (dot2), 4 dot3;
-# partial rounds: dot3 + one product (lane-1 form), the last one dot2 + one product; no conversion products
+MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
+# (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:
+# 55 S-boxes; full-round rows: 20 with unit diagonal (dot2), 4 dot3; partial rounds: dot3 + one product (lane-1 form), the
+# last one dot2 + one product; no conversion products.  (The assembly routines issue 9 more v_mad per routine to add the
+# quotient digits; they are not counted as multiplies.)
 
 
 def measure_hbm_copy(torch, dev, nbytes=1 << 30, reps=10):
