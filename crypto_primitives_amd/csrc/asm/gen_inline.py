@@ -15,8 +15,11 @@ MASK = "0x1fffffff"
 ACC = 2  # v[2:3]
 
 
-def emit_routine(name, kind, signed=False, terms=1):
-    """kind: "sqr" | "mul" (terms = 1) | "dot" (terms = 2 or 3: sum of a_k * b_k with the b_k in SGPRs)."""
+def emit_routine(name, kind, signed=False, terms=1, inplace=False):
+    """kind: "sqr" | "mul" | "mulc" (terms = 1) | "dot" (terms = 2 or 3: sum of a_k * b_k with the b_k in SGPRs).
+    inplace (sqr / mul): the result overwrites a -- limb j of a is last read at column j + 8 and limb j of the result is
+    written at column 9 + j -- and the quotient digits get registers of their own; a loop `r = r * r` then needs no
+    copies between iterations."""
     lines = []
     e = lines.append
     acc64, acclo = "v[%d:%d]" % (ACC, ACC + 1), "v%d" % ACC
@@ -30,6 +33,8 @@ def emit_routine(name, kind, signed=False, terms=1):
         # quotient digits and p are non-negative and < 2^29: the signed multiply-add takes them as they are
         e("%s %s, vcc, %s, %s, %s" % (madop, acc64, x, y, src2))
 
+    M = "m" if inplace else "t"  # quotient digits: own registers (in place) or the result registers
+    O = "a" if inplace else "t"  # result limbs
     if kind == "sqr":
         for i in range(9):
             e("v_lshlrev_b32_e32 %%[d%d], 1, %%[a%d]" % (i, i))
@@ -46,26 +51,30 @@ def emit_routine(name, kind, signed=False, terms=1):
                 for term in range(terms):
                     mad("%%[a%d_%d]" % (term, i), "%%[b%d_%d]" % (term, j))
         for i in range(max(0, k - 8), min(k - 1, 8) + 1):  # quotient digits times p[k - i], k - i >= 1
-            mad("%%[t%d]" % i, "%%[p%d]" % (k - i))  # signed flavour: [p.] holds -p[.]
+            mad("%%[%s%d]" % (M, i), "%%[p%d]" % (k - i))  # signed flavour: [p.] holds -p[.]
         if k < 9:
             if signed:
                 # subtractive reduction: m = acc mod 2^29, acc -= m * p  (p[0] = 1).  Saves the negation; the result is
                 # (ab - mp) / 2^261 in (-2.1p, 1.1p) instead of (ab + mp) / 2^261 in (-1.1p, 2.1p): same magnitude bound
-                e("v_and_b32_e32 %%[t%d], %s, %s" % (k, MASK, acclo))
-                mad("%%[t%d]" % k, "-1")
+                e("v_and_b32_e32 %%[%s%d], %s, %s" % (M, k, MASK, acclo))
+                mad("%%[%s%d]" % (M, k), "-1")
             else:
-                e("v_sub_u32_e32 %%[t%d], 0, %s" % (k, acclo))
-                e("v_and_b32_e32 %%[t%d], %s, %%[t%d]" % (k, MASK, k))
-                mad("%%[t%d]" % k, "1")
+                e("v_sub_u32_e32 %%[%s%d], 0, %s" % (M, k, acclo))
+                e("v_and_b32_e32 %%[%s%d], %s, %%[%s%d]" % (M, k, MASK, M, k))
+                mad("%%[%s%d]" % (M, k), "1")
             e("%s %s, 29, %s" % (shr, acc64, acc64))
         else:
-            e("v_and_b32_e32 %%[t%d], %s, %s" % (k - 9, MASK, acclo))
+            e("v_and_b32_e32 %%[%s%d], %s, %s" % (O, k - 9, MASK, acclo))
             e("%s %s, 29, %s" % (shr, acc64, acc64))
-    e("v_mov_b32_e32 %%[t8], %s" % acclo)
+    e("v_mov_b32_e32 %%[%s8], %s" % (O, acclo))
     n_instr = len(lines)
     body = "\n".join('        "%s\\n"' % l for l in lines)
     T = "FS" if signed else "FU"
-    outs = ", ".join('[t%d] "=&v"(t.l[%d])' % (i, i) for i in range(9))
+    L = "int32_t" if signed else "u32"
+    if inplace:
+        outs = ", ".join('[a%d] "+v"(a.l[%d])' % (i, i) for i in range(9)) + ", " + ", ".join('[m%d] "=&v"(m%d)' % (i, i) for i in range(9))
+    else:
+        outs = ", ".join('[t%d] "=&v"(t.l[%d])' % (i, i) for i in range(9))
     if kind == "sqr":
         outs += ", " + ", ".join('[d%d] "=&v"(d%d)' % (i, i) for i in range(9))
     outs += ', [acc] "=&{v[%d:%d]}"(acc)' % (ACC, ACC + 1)
@@ -74,12 +83,19 @@ def emit_routine(name, kind, signed=False, terms=1):
         ins += ", " + ", ".join('[b%d_%d] "s"(b%d.l[%d])' % (k, i, k, i) for k in range(terms) for i in range(9))
         args = ", ".join("const %s& a%d, const %s& b%d" % (T, k, T, k) for k in range(terms))
     else:
-        ins = ", ".join('[a%d] "v"(a.l[%d])' % (i, i) for i in range(9))
+        ins = "" if inplace else ", ".join('[a%d] "v"(a.l[%d])' % (i, i) for i in range(9))
         if kind in ("mul", "mulc"):
-            ins += ", " + ", ".join('[b%d] "%s"(b.l[%d])' % (i, "v" if kind == "mul" else "s", i) for i in range(9))
-        args = "const %s& a" % T if kind == "sqr" else "const %s& a, const %s& b" % (T, T)
-    ins += ", " + ", ".join('[p%d] "s"(%sp29(%d))' % (i, "-(int32_t)" if signed else "", i) for i in range(1, 9))
-    decl = "    %s " % ("int32_t" if signed else "u32") + ", ".join("d%d" % i for i in range(9)) + ";\n" if kind == "sqr" else ""
+            ins += (", " if ins else "") + ", ".join('[b%d] "%s"(b.l[%d])' % (i, "v" if kind == "mul" else "s", i) for i in range(9))
+        a_arg = ("%s& a" if inplace else "const %s& a") % T
+        args = a_arg if kind == "sqr" else a_arg + ", const %s& b" % T
+    ins += (", " if ins else "") + ", ".join('[p%d] "s"(%sp29(%d))' % (i, "-(int32_t)" if signed else "", i) for i in range(1, 9))
+    decl = ""
+    if kind == "sqr":
+        decl += "    %s " % L + ", ".join("d%d" % i for i in range(9)) + ";\n"
+    if inplace:
+        decl += "    u32 " + ", ".join("m%d" % i for i in range(9)) + ";\n"
+        return ("// %d instructions, in place\n__device__ __forceinline__ void %s(%s) {\n    %s acc;\n%s    asm(\n%s\n        : %s\n        : %s\n        : \"vcc\");\n    (void)acc;\n}\n"
+                % (n_instr, name, args, "int64_t" if signed else "u64", decl, body, outs, ins))
     return ("// %d instructions\n__device__ __forceinline__ %s %s(%s) {\n    %s t;\n    %s acc;\n%s    asm(\n%s\n        : %s\n        : %s\n        : \"vcc\");\n    (void)acc;\n    return t;\n}\n"
             % (n_instr, T, name, args, T, "int64_t" if signed else "u64", decl, body, outs, ins))
 
@@ -87,6 +103,9 @@ def emit_routine(name, kind, signed=False, terms=1):
 print("// GENERATED by asm/gen_inline.py -- do not edit.  Single-chain inline-assembly field routines (device only).")
 print(emit_routine("f29_sqr_asm", "sqr"))
 print(emit_routine("f29_mul_asm", "mul"))
+print("// in-place forms for chains r = r * r, r = r * x (the S-box): no register copies between the steps")
+print(emit_routine("f29_sqr_ip_asm", "sqr", inplace=True))
+print(emit_routine("f29_mul_ip_asm", "mul", inplace=True))
 print("// wave-uniform second operands (b, b_k) in SGPRs: products with constants, the linear layers of Poseidon")
 print(emit_routine("f29_mulc_asm", "mulc"))
 print(emit_routine("f29_dot2_asm", "dot", terms=2))

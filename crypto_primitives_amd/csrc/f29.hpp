@@ -298,6 +298,16 @@ AKP_HD F29T<S> f29_pow_small(const F29T<S>& x, u64 e) {
     if (e == 0) return f29_one<S>();
     int top = 63 - __builtin_clzll(e);
     F29T<S> r = x;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    if constexpr (!S) {  // in-place assembly steps: the chain r = r * r, r = r * x needs no register copies
+#pragma unroll 1
+        for (int i = top - 1; i >= 0; --i) {
+            f29_sqr_ip_asm(r);
+            if ((e >> i) & 1) f29_mul_ip_asm(r, x);
+        }
+        return r;
+    }
+#endif
 #pragma unroll 1
     for (int i = top - 1; i >= 0; --i) {
         r = f29_sqr(r);
