@@ -249,8 +249,8 @@ def main():
                               "v_mad_per_s": MADS_PER_PERM * n / kern_avg_s,
                               "v_mad_peak_per_s": VALU_PEAK_WAVE_INSTR * 64,
                               "frac_of_mad_issue_peak": MADS_PER_PERM * n / kern_avg_s / (VALU_PEAK_WAVE_INSTR * 64),
-                              "valu_busy_pmc_percent": 102.0,
-                              "valu_busy_source": "rocprofv3 --pmc VALUBusy on this kernel (profiles/r01_s14/pmc_valu_counters.txt)"}},
+                              "valu_busy_pmc_percent": 98.0,
+                              "valu_busy_source": "rocprofv3 --pmc VALUBusy on this kernel (profiles/r01_s19/pmc_valu_counters.txt)"}},
     }
     if merkle:
         out["merkle"] = merkle
