@@ -4,49 +4,101 @@
 Metric (BASELINE.json): Poseidon-BLS12-381-Fr permutations/sec.  One "step" = one pass of the batched
 permutation kernel over `--log2-states` (default 2^20, BASELINE configs[1]) synthetic sponge states of
 t = 3 field elements (rate 2, alpha 17, R_F = 8, R_P = 31), inputs already resident in HBM.
-N > 1: one process per GPU (torchrun), every rank permutes its own 2^20 states (weak scaling, the batch
-shards with no data-path collective); `value` = states permuted by all ranks / max-over-ranks time.
 
-Extra objects on the same JSON line:
-  roofline      dominant kernel (poseidon_permute_kernel) -- algorithmic bytes (192 B / permutation,
-                SURVEY.md section 8d) / average launch duration measured with events on the launch stream,
-                against the 8 TB/s HBM peak; `valu` gives the integer-ALU view (the real bound).
-  cpu_baseline  oracle C restatement ("port") timed on this host on a bounded sample, rank 0 / N = 1 only.
-  merkle        MerkleTree::new over `--merkle-log2` Poseidon leaves (default 2^24 at N = 1... see below),
-                leaf shards per rank + one all-gather of sub-roots (RCCL); seconds and leaves/s.
-The oracle is used only as checker (a 256-state parity probe outside the timed region) and as the
-`cpu_baseline` leg.
+Launch: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment the
+script re-launches itself under `torch.distributed.run` with N ranks (one process per GPU, nccl = RCCL); under an
+existing torchrun launch it uses the ranks it was given and asserts world size == --gpus.  Every rank permutes its
+own 2^20 states (weak scaling, the batch shards with no data-path collective); `value` = states permuted by all
+ranks / max-over-ranks time between barriers.
+
+Extra objects on the same JSON line (rank 0):
+  roofline      dominant kernel -- algorithmic bytes (192 B / permutation) / average launch
+                duration measured with events on the launch stream, against the 8 TB/s HBM peak; `valu` gives the
+                integer-ALU view (the real bound).  Fields copied from earlier profiling sessions say so
+                (`static_from`).
+  parity        which kernel the probe exercised and how many states of the TIMED buffer were checked
+  sustained     the same launch looped for >= `--sustain-seconds` (2^20 and 2^24 states): rate, min / median / max
+                launch time, GPU clock read from sysfs before / after
+  merkle        BASELINE config 3: MerkleTree::new over 2^24 Poseidon leaves (strong scaling over ranks; leaf
+                shards + ONE all-gather of sub-roots over RCCL)
+  pedersen      BASELINE config 4: Pedersen 4x256 CRH over 2^20 x 128 B per GPU, sampled oracle parity, roofline
+  bh_merkle     BASELINE config 5: Bowe-Hopwood 63x9 tree, 2^23 x 32 B leaves per GPU (2^26 on 8 GPUs)
+  host_path     PCIe-inclusive rates of the host-pointer entry points (pageable and pinned buffers)
+  cpu_baseline  oracle C restatement ("port") on this host: 1 thread and the best thread count
+The oracle is used only as checker and as the `cpu_baseline` leg.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402  (imported before the product so both share one HIP runtime)
-
 ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODMUL_PER_PERM_REF = 626        # reference-shaped count (SURVEY.md section 8a)
-# HBM bytes per 2^20-state launch from the PMC passes of profiles/r01_s15/pmc_{FETCH,WRITE}_SIZE_counter_collection.csv
-# (separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 reports half of a wide coalesced read):
-# (2 * 49 616 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.9 B per permutation  (algorithmic: 192 B)
+# HBM bytes per permutation from PMC passes of an earlier session (NOT measured in this run; see `static_from`):
+# (2 * 49 616 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.9 B  (algorithmic: 192 B)
 PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49616.0 + 98304.0) * 1024 / (1 << 20)
-VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # measured: one v_mad_u64_u32 (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
+PMC_TRAFFIC_SOURCE = "profiles/r01_s15/pmc_{FETCH,WRITE}_SIZE_counter_collection.csv"
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
 MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
 # (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:
 # 55 S-boxes; full-round rows: 20 with unit diagonal (dot2), 4 dot3; partial rounds: dot3 + one product (lane-1 form), the
-# last one dot2 + one product; no conversion products.  (The assembly routines issue 9 more v_mad per routine to add the
-# quotient digits; they are not counted as multiplies.)
+# last one dot2 + one product; no conversion products.
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def gpu_clock_mhz(index=0):
+    """current shader clock from sysfs (the line pp_dpm_sclk marks with '*'); None when unreadable"""
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        txt = open(cards[min(index, len(cards) - 1)]).read()
+        for line in txt.splitlines():
+            if line.strip().endswith("*"):
+                return float(line.split(":")[1].strip().split("M")[0])
+    except Exception:
+        pass
+    return None
+
+
+def cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = None
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "affinity_cpus": aff, "cgroup_cpu_quota": quota}
 
 
 def measure_hbm_copy(torch, dev, nbytes=1 << 30, reps=10):
-    """Read+write GB/s of a plain 1 GiB device-to-device copy on this box (report the measured HBM rate
-    beside the vendor 8 TB/s).  Measurement plumbing only -- not part of the hashed path."""
+    """Read+write GB/s of a plain 1 GiB device-to-device copy on this box (the measured HBM rate beside the
+    vendor 8 TB/s).  Measurement plumbing only -- not part of the hashed path."""
     try:
         a = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
         b = torch.empty_like(a)
@@ -72,25 +124,51 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-states", type=int, default=20)
-    ap.add_argument("--merkle-log2", type=int, default=24, help="total leaves of the Merkle leg (0 disables)")
-    ap.add_argument("--bh-merkle-log2", type=int, default=0, help="also build a Bowe-Hopwood 63x9 tree over 2^k 32-byte leaves (BASELINE config 5 shape), sharded like the Poseidon tree")
+    ap.add_argument("--merkle-log2", type=int, default=24, help="total leaves of the Poseidon Merkle leg (0 disables)")
+    ap.add_argument("--pedersen-log2", type=int, default=20, help="Pedersen 4x256 messages per GPU (BASELINE config 4; 0 disables)")
+    ap.add_argument("--bh-merkle-log2", type=int, default=23,
+                    help="Bowe-Hopwood 63x9 tree: leaves PER GPU (BASELINE config 5 is 2^23 per GPU on 8 GPUs; 0 disables)")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of each sustained loop (0 disables)")
+    ap.add_argument("--sustain-log2-big", type=int, default=24, help="second sustained size (0 disables)")
+    ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (tests/test_gpu_bench_contract.py): AKP_BENCH_SHARED_GPU=1 puts every rank on GPU 0 and carries the
     # collectives over gloo, so the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
     shared_gpu = os.environ.get("AKP_BENCH_SHARED_GPU") == "1"
+
+    # ---- N > 1 from a plain `python bench.py --gpus N`: become the launcher of N ranks ------------------------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not shared_gpu:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, ndev))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+
+    import numpy as np
+    import torch  # imported before the product so both share one HIP runtime
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if shared_gpu:
         local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants device %d, only %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rank_devices = [local_rank]
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -98,42 +176,51 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, "world size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(dev)})
+        rank_devices = [g["device"] for g in gathered]
 
     import crypto_primitives_amd as cpa
     from crypto_primitives_amd import field
-    from crypto_primitives_amd._lib import lib, check, Context
-    from crypto_primitives_amd.distributed import GpuPoseidonBackend, build_sharded
+    from crypto_primitives_amd._lib import lib, check
+    from crypto_primitives_amd.distributed import GpuPoseidonBackend, GpuTeBackend, build_sharded
 
     ctx = cpa.default_context(local_rank)
     cfg = cpa.get_default_poseidon_parameters(2, False)
     ph = cfg.handle(ctx)
     n = 1 << args.log2_states
     t = cfg.t
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ora_threads = max(1, min(32, (os.cpu_count() or 1)))
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if not dist:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev if not shared_gpu else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     # synthetic states (seed per BASELINE.md config 2), resident in HBM before the timed region
     host_states = field.random_fr(n * t, seed=0xA5A50002 + rank).reshape(n, t, 4)
     d_states = torch.from_numpy(host_states.view(np.int64)).to(dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
         check(lib.akp_poseidon_permute_batch_dev(ph.h, d_states.data_ptr(), n, stream))
 
-    # parity probe (checker only, outside the timed region)
-    parity = None
+    ora = None
     if rank == 0:
         from oracle import cref
         ora = cref.Poseidon(cfg.full_rounds, cfg.partial_rounds, cfg.alpha, cfg.rate, cfg.capacity, cfg.ark, cfg.mds)
-        probe = torch.from_numpy(host_states[:256].copy().view(np.int64)).to(dev)
-        check(lib.akp_poseidon_permute_batch_dev(ph.h, probe.data_ptr(), 256, stream))
-        torch.cuda.synchronize(dev)
-        parity = bool(np.array_equal(probe.cpu().numpy().view(np.uint64).reshape(256, t, 4),
-                                     ora.permute_batch(host_states[:256]).reshape(256, t, 4)))
-        if not parity:
-            raise SystemExit("parity probe FAILED: GPU permutation differs from the oracle")
 
-    # ---- Merkle leg: sharded MerkleTree::new (strong scaling over the same total leaf count).  Runs before the
-    # permutation timing: from an idle device the first ~12 launches run up to 20 % slower while the clocks ramp
-    # (tools/gpu_ramp.py), so the side legs go first and the W warm-up + K timed steps see the steady-state clock ----
+    # ================= side legs first: from an idle device the first launches run on ramping clocks =================
+    # ---- BASELINE config 3: sharded MerkleTree::new, Poseidon, strong scaling over the same total leaf count ---------
     merkle = None
     if args.merkle_log2:
         total = 1 << args.merkle_log2
@@ -141,84 +228,236 @@ def main():
         leaves = field.random_fr(per, seed=0xA5A50003 + rank).reshape(per, 1, 4)
         d_leaves = torch.from_numpy(leaves.view(np.int64)).to(dev)
         backend = GpuPoseidonBackend(cfg, cfg, leaf_len=1, device=dev)
-        build_sharded(backend, d_leaves, total, dist)  # untimed full-size warm-up build (allocations, RCCL, device clocks)
-        torch.cuda.synchronize(dev)
-        if dist:
-            dist.barrier()
+        build_sharded(backend, d_leaves, total, dist)  # untimed full-size warm-up build (allocations, RCCL, clocks)
+        barrier()
         m0 = time.perf_counter()
         res = build_sharded(backend, d_leaves, total, dist)
-        torch.cuda.synchronize(dev)
-        if dist:
-            dist.barrier()
-        msec = time.perf_counter() - m0
-        if dist:
-            tt = torch.tensor([msec], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            msec = float(tt.item())
-        merkle = {"leaves": total, "seconds": msec, "leaves_per_s": total / msec, "scaling": "strong",
-                  "permutations": 2 * total - 1, "root_limb0": int(np.asarray(res["root"]).reshape(-1)[0]),
-                  "algorithmic_GBps": 160.0 * total / msec / 1e9}
+        barrier()
+        msec = max_over_ranks(time.perf_counter() - m0)
+        merkle = {"config": "BASELINE configs[2]: MerkleTree::new, Poseidon leaf + two-to-one, 1-Fr leaves", "leaves": total, "seconds": msec,
+                  "leaves_per_s": total / msec, "scaling": "strong", "permutations": 2 * total - 1,
+                  "root_limb0": int(np.asarray(res["root"]).reshape(-1)[0]), "algorithmic_GBps": 160.0 * total / msec / 1e9,
+                  "hbm_frac": 160.0 * total / msec / 1e9 / HBM_PEAK_GBS}
+        if rank == 0:
+            # sampled parity on rank 0's sub-tree: leaf digests, and inner nodes recomputed by the oracle from their children
+            ln = res["leaf_nodes"].cpu().numpy().view(np.uint64).reshape(per, 4)
+            nl = res["non_leaf_nodes"].cpu().numpy().view(np.uint64).reshape(per - 1, 4)
+            si = np.unique(np.linspace(0, per - 1, 257).astype(np.int64))
+            ok = np.array_equal(ln[si], ora.crh_batch(np.ascontiguousarray(leaves[si]), 1, threads=ora_threads))
+            ni = np.unique(np.concatenate([np.arange(0, min(64, per - 1)), np.linspace(0, per - 2, 257).astype(np.int64)]))
 
+            def child(ix):  # heap children: inner nodes below per - 1, then the leaf digests
+                return np.where((ix < per - 1)[:, None], nl[np.clip(ix, 0, per - 2)], ln[np.clip(ix - (per - 1), 0, per - 1)])
+            ok = ok and np.array_equal(nl[ni], ora.two_to_one_batch(np.ascontiguousarray(child(2 * ni + 1)), np.ascontiguousarray(child(2 * ni + 2)),
+                                                                    threads=ora_threads))
+            merkle["sampled_parity_bit_exact"] = bool(ok)
+            if not ok:
+                raise SystemExit("Merkle leg: sampled nodes differ from the oracle")
+        del d_leaves, res, backend
+
+    # ---- BASELINE config 4: Pedersen 4x256 over Jubjub, 2^k x 128 B per GPU ------------------------------------------
+    pedersen = None
+    if args.pedersen_log2:
+        from crypto_primitives_amd import params as cparams
+        from crypto_primitives_amd.crh import pedersen as cped
+        npd = 1 << args.pedersen_log2
+        gens = cparams.pedersen_generators(0xA5A50004, 4, 256)
+        PP = cped.Parameters(gens)
+        hP = PP.handle(ctx)
+        msgs = np.random.default_rng(0xA5A50004 + rank).integers(0, 256, size=(npd, 128), dtype=np.uint8)
+        d_msgs = torch.from_numpy(msgs).to(dev)
+        d_out = torch.empty((npd, 8), dtype=torch.int64, device=dev)
+
+        def ped_step():
+            check(lib.akp_te_crh_batch_dev(hP.h, d_msgs.data_ptr(), npd, 128, d_out.data_ptr(), stream))
+        for _ in range(3):
+            ped_step()
+        barrier()
+        reps = 10
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        p0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            ped_step()
+            b.record()
+        barrier()
+        psec = max_over_ranks(time.perf_counter() - p0)
+        kms = sorted(a.elapsed_time(b) for a, b in evs)
+        kavg = sum(kms) / len(kms) / 1e3
+        pedersen = {"config": "BASELINE configs[3]: pedersen::CRH, Jubjub, window 4x256, 128-byte messages", "messages_per_gpu": npd,
+                    "hashes_per_s": npd * world * reps / psec, "ms_per_batch": psec / reps * 1e3,
+                    "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<0> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
+                                 "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": 192.0 * npd / kavg / 1e9 / HBM_PEAK_GBS,
+                                 "table_bytes_gathered_per_hash": 79 * 144, "gather_over_algorithmic": 79 * 144 / 192.0,
+                                 "valu": {"table_steps_per_hash": 79, "field_products_per_step": 7,
+                                          "note": "VALU-issue bound like the permutation: 79 mixed additions of 7 products; the "
+                                                  "93 MB table is gathered through L2 / Infinity Cache (counters: profiles/r02_*)"}}}
+        if rank == 0:
+            from oracle import cref
+            cur = cref.CurveParams(4, 256, gens)
+            si = np.unique(np.concatenate([np.arange(64), np.linspace(0, npd - 1, 193).astype(np.int64)]))
+            got = d_out.cpu().numpy().view(np.uint64).reshape(npd, 2, 4)[si]
+            ok = bool(np.array_equal(got, cur.pedersen_crh_batch(np.ascontiguousarray(msgs[si]), len(si), 128, threads=ora_threads)))
+            pedersen["sampled_parity_bit_exact"] = ok
+            pedersen["parity_samples"] = int(len(si))
+            if not ok:
+                raise SystemExit("Pedersen leg: sampled digests differ from the oracle")
+        del d_msgs, d_out
+
+    # ---- BASELINE config 5: Bowe-Hopwood 63x9 tree, 2^k x 32 B leaves PER GPU (weak: 2^26 on 8 GPUs) ------------------
     bh_merkle = None
     if args.bh_merkle_log2:
         from crypto_primitives_amd import params as cparams
         from crypto_primitives_amd.crh import bowe_hopwood
-        from crypto_primitives_amd.distributed import GpuTeBackend
-        total = 1 << args.bh_merkle_log2
-        per = total // world
-        B = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9))
+        per = 1 << args.bh_merkle_log2
+        total = per * world
+        gens = cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+        B = bowe_hopwood.Parameters(gens)
         leaves = np.random.default_rng(0xA5A50005 + rank).integers(0, 256, size=(per, 32), dtype=np.uint8)
         d_leaves = torch.from_numpy(leaves).to(dev)
         tb = GpuTeBackend(B, B, device=dev)
-        build_sharded(tb, d_leaves[: max(per // 64, 2)], max(total // 64, 2 * world), dist)  # warm-up (tables, scratch, RCCL)
-        torch.cuda.synchronize(dev)
-        if dist:
-            dist.barrier()
+        build_sharded(tb, d_leaves, total, dist)  # untimed full-size warm-up (tables, scratch, RCCL)
+        barrier()
+        reps = 3
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         m0 = time.perf_counter()
-        res = build_sharded(tb, d_leaves, total, dist)
-        torch.cuda.synchronize(dev)
-        if dist:
-            dist.barrier()
-        bsec = time.perf_counter() - m0
-        if dist:
-            tt = torch.tensor([bsec], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            bsec = float(tt.item())
-        bh_merkle = {"hash": "Bowe-Hopwood 63x9 over Jubjub, 32-byte leaves, ByteDigestConverter", "leaves": total, "seconds": bsec,
-                     "leaves_per_s": total / bsec, "scaling": "strong", "algorithmic_GBps": 160.0 * total / bsec / 1e9}
+        for a, b in evs:
+            a.record()
+            res = build_sharded(tb, d_leaves, total, dist)
+            b.record()
+        barrier()
+        bsec = max_over_ranks(time.perf_counter() - m0) / reps
+        dev_ms = sum(a.elapsed_time(b) for a, b in evs) / reps
+        bh_merkle = {"config": "BASELINE configs[4]: MerkleTree::new, Bowe-Hopwood 63x9 over Jubjub, 32-byte leaves, ByteDigestConverter",
+                     "leaves": total, "leaves_per_gpu": per, "seconds": bsec, "leaves_per_s": total / bsec, "scaling": "weak",
+                     "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<1> + te_finalize_kernel<1> + te_serialize_pairs_kernel per level",
+                                  "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                  "valu": {"table_steps": "23 per leaf (21 quads + 2 singles), 49 per inner node (46 + 3)", "field_products_per_step": 7}}}
+        if rank == 0:
+            from oracle import cref
+            cur = cref.CurveParams(63, 9, gens)
+            ln = res["leaf_nodes"].cpu().numpy().view(np.uint64).reshape(per, 4)
+            nl = res["non_leaf_nodes"].cpu().numpy().view(np.uint64).reshape(per - 1, 4)
+            si = np.unique(np.linspace(0, per - 1, 129).astype(np.int64))
+            ok = np.array_equal(ln[si], cur.bh_crh_batch(np.ascontiguousarray(leaves[si]), len(si), 32, threads=ora_threads))
+            # inner nodes from their children: buffer = LE(left) || LE(right) zero-padded to (63 * 9) / 8 = 70 bytes
+            ni = np.unique(np.concatenate([np.arange(0, min(32, per - 1)), np.linspace(0, per - 2, 97).astype(np.int64)]))
 
+            def child(ix):
+                return np.where((ix < per - 1)[:, None], nl[np.clip(ix, 0, per - 2)], ln[np.clip(ix - (per - 1), 0, per - 1)])
+            buf = np.zeros((len(ni), 70), np.uint8)
+            buf[:, :32] = cref.from_mont(np.ascontiguousarray(child(2 * ni + 1))).view(np.uint8).reshape(len(ni), 32)
+            buf[:, 32:64] = cref.from_mont(np.ascontiguousarray(child(2 * ni + 2))).view(np.uint8).reshape(len(ni), 32)
+            ok = ok and np.array_equal(nl[ni], cur.bh_crh_batch(buf, len(ni), 70, threads=ora_threads))
+            bh_merkle["sampled_parity_bit_exact"] = bool(ok)
+            if not ok:
+                raise SystemExit("Bowe-Hopwood leg: sampled nodes differ from the oracle")
+        del d_leaves, res, tb
+
+    # ================= the headline: W warm-up + K timed steps of the 2^20-state permutation ==========================
+    parity = {"probe_kernel": lib.akp_poseidon_kernel_for(ph.h, n, 0).decode(), "timed_buffer_states_checked": 0, "bit_exact": None}
+    step()  # one pass outside W: its output is checked against the oracle on a strided sample of the TIMED buffer
+    torch.cuda.synchronize(dev)
+    if rank == 0:
+        si = np.unique(np.concatenate([np.arange(128), np.linspace(0, n - 1, 385).astype(np.int64), np.arange(n - 128, n)]))
+        got = d_states[torch.from_numpy(si).to(dev)].cpu().numpy().view(np.uint64).reshape(len(si), t, 4)
+        exp = ora.permute_batch(np.ascontiguousarray(host_states[si]), threads=ora_threads).reshape(len(si), t, 4)
+        parity["timed_buffer_states_checked"] = int(len(si))
+        parity["bit_exact"] = bool(np.array_equal(got, exp))
+        if not parity["bit_exact"]:
+            raise SystemExit("parity probe FAILED: the timed kernel's output differs from the oracle")
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    clk0 = gpu_clock_mhz(local_rank)
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
         step()
         b.record()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    clk1 = gpu_clock_mhz(local_rank)
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_avg_s = (sum(kern_ms) / len(kern_ms)) / 1e3
 
+    # ---- sustained: the same launch looped for seconds (rank 0's device; other ranks idle at the barrier) ------------
+    sustained = None
+    if args.sustain_seconds > 0 and rank == 0:
+        sustained = {}
+        for lg in sorted({args.log2_states, args.sustain_log2_big} - {0}):
+            ns = 1 << lg
+            if ns == n:
+                buf = d_states
+            else:
+                try:
+                    buf = torch.from_numpy(field.random_fr(min(ns, 1 << 20) * t, seed=0xA5A50012).reshape(-1, t, 4).view(np.int64)).to(dev).repeat(max(1, ns >> 20), 1, 1)
+                except Exception:
+                    continue
+            per_launch = max(kern_avg_s * ns / n, 1e-4)
+            count = int(min(4000, max(8, args.sustain_seconds / per_launch)))
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
+            c0 = gpu_clock_mhz(local_rank)
+            torch.cuda.synchronize(dev)
+            s0 = time.perf_counter()
+            for a, b in evs:
+                a.record()
+                check(lib.akp_poseidon_permute_batch_dev(ph.h, buf.data_ptr(), ns, stream))
+                b.record()
+            cmid = gpu_clock_mhz(local_rank)
+            torch.cuda.synchronize(dev)
+            secs = time.perf_counter() - s0
+            ms = sorted(a.elapsed_time(b) for a, b in evs)
+            sustained["2^%d" % lg] = {"launches": count, "seconds": secs, "permutations_per_s": ns * count / secs,
+                                      "launch_ms_min": ms[0], "launch_ms_median": ms[len(ms) // 2], "launch_ms_max": ms[-1],
+                                      "sclk_mhz_before": c0, "sclk_mhz_during": cmid, "sclk_mhz_after": gpu_clock_mhz(local_rank)}
+            if buf is not d_states:
+                del buf
+
+    # ---- host-pointer entry points (what a Rust host calls): PCIe-inclusive -----------------------------------------
+    host_path = None
+    if not args.no_host_path and rank == 0:
+        import ctypes as C
+        host_path = {"states": n, "pcie_bound_note": "96 B in + 96 B out per permutation; PCIe Gen5 x16 is 63 GB/s per direction (spec)"}
+        work = host_states.copy()
+        for label in ("pageable", "pinned"):
+            if label == "pinned":
+                pp = C.c_void_p()
+                check(lib.akp_host_alloc(work.nbytes, C.byref(pp)))
+                arr = np.ctypeslib.as_array((C.c_uint64 * (work.size)).from_address(pp.value))
+                arr[:] = host_states.reshape(-1)
+                ptr = pp
+            else:
+                ptr = work.ctypes.data
+            check(lib.akp_poseidon_permute_batch(ph.h, ptr, n))  # warm-up (scratch, streams)
+            reps = 5
+            h0 = time.perf_counter()
+            for _ in range(reps):
+                check(lib.akp_poseidon_permute_batch(ph.h, ptr, n))
+            hs = (time.perf_counter() - h0) / reps
+            host_path[label] = {"permutations_per_s": n / hs, "ms_per_batch": hs * 1e3, "GBps_each_direction": 96.0 * n / hs / 1e9}
+            if label == "pinned":
+                check(lib.akp_host_free(pp))
+        if args.merkle_log2:
+            ntree = 1 << min(args.merkle_log2, 22)
+            lv = field.random_fr(ntree, seed=0xA5A50013).reshape(ntree, 1, 4)
+            root = np.empty(4, np.uint64)
+            check(lib.akp_merkle_build_poseidon(ph.h, ph.h, lv.ctypes.data, ntree, 1, None, None, root.ctypes.data))
+            h0 = time.perf_counter()
+            check(lib.akp_merkle_build_poseidon(ph.h, ph.h, lv.ctypes.data, ntree, 1, None, None, root.ctypes.data))
+            host_path["merkle_root_only"] = {"leaves": ntree, "seconds": time.perf_counter() - h0}
+
     if rank != 0:
         if dist:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     total_perms = n * world * args.steps
     value = total_perms / elapsed
-
     achieved = ALGO_BYTES_PER_PERM * n / kern_avg_s / 1e9
     hbm_copy_gbs = measure_hbm_copy(torch, dev)
     out = {
@@ -232,40 +471,44 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 limbs (255-bit Montgomery integers, radix 2^29 x 9, 64-bit v_mad accumulation)",
+        "dtype": "i32 limbs (255-bit Montgomery integers, radix 2^29 x 9, 64-bit v_mad_i64_i32 accumulation)",
         "data": "synthetic",
-        "config": {"workload": "batched Poseidon permutation, BLS12-381 Fr, t=3 rate=2 alpha=17 RF=8 RP=31 "
+        "config": {"workload": "BASELINE configs[1]: batched Poseidon permutation, BLS12-381 Fr, t=3 rate=2 alpha=17 RF=8 RP=31 "
                                "(default Grain-LFSR parameters), 2^%d states per GPU, in place in HBM" % args.log2_states,
-                   "states_per_gpu": n, "parallelism": "shard%d (no collective)" % world},
-        "parity_probe_bit_exact": parity,
-        "roofline": {"bound": "hbm", "kernel": "poseidon_permute_t3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                   "states_per_gpu": n, "parallelism": "shard%d (no data-path collective)" % world},
+        "launch": {"ranks": world, "backend": None if not dist else ("gloo (shared-GPU test hook)" if shared_gpu else "nccl (RCCL)"),
+                   "rank_devices": rank_devices},
+        "parity_probe_bit_exact": parity["bit_exact"],
+        "parity": parity,
+        "roofline": {"bound": "hbm", "kernel": parity["probe_kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_PERM * n,
+                     "traffic_static_from": PMC_TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
+                                            "correction; NOT measured in this run)",
                      "peak_measured_copy": hbm_copy_gbs, "frac_of_measured_copy": achieved / hbm_copy_gbs if hbm_copy_gbs else None,
-                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction (profiles/r01_s15; same within 1.5 % in every session since r01_s3)",
-                     "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PERM * n,
+                     "kernel_avg_ms": kern_avg_s * 1e3, "kernel_min_ms": min(kern_ms), "kernel_max_ms": max(kern_ms),
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PERM * n,
+                     "sclk_mhz_before": clk0, "sclk_mhz_after": clk1,
                      "valu": {"note": "the path is integer-ALU bound (~%d reference-shaped Montgomery products per 192 B); "
-                                      "fraction of the measured v_mad_u64_u32 issue peak spent on multiplies" % MODMUL_PER_PERM_REF,
+                                      "fraction of the measured v_mad issue peak spent on multiplies" % MODMUL_PER_PERM_REF,
                               "ref_modmul_per_s": MODMUL_PER_PERM_REF * n / kern_avg_s,
                               "v_mad_per_s": MADS_PER_PERM * n / kern_avg_s,
                               "v_mad_peak_per_s": VALU_PEAK_WAVE_INSTR * 64,
                               "frac_of_mad_issue_peak": MADS_PER_PERM * n / kern_avg_s / (VALU_PEAK_WAVE_INSTR * 64),
-                              "valu_busy_pmc_percent": 98.0,
-                              "valu_busy_source": "rocprofv3 --pmc VALUBusy on this kernel (profiles/r01_s19/pmc_valu_counters.txt)"}},
+                              "valu_counters_static_from": "profiles/r02_*/pmc_valu_counters.txt (SQ_INSTS_VALU, VALUBusy; NOT measured in this run)"}},
     }
-    if merkle:
-        out["merkle"] = merkle
-    if bh_merkle:
-        out["bh_merkle"] = bh_merkle
+    for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("host_path", host_path)):
+        if leg:
+            out[key] = leg
     if not args.no_cpu_baseline and world == 1:
         from oracle import cref
-        threads = cref.hardware_threads()
-        ora = cref.Poseidon(cfg.full_rounds, cfg.partial_rounds, cfg.alpha, cfg.rate, cfg.capacity, cfg.ark, cfg.mds)
-        # calibrate: the box may expose more hardware threads than its cgroup lets us use, so try a few thread counts on
-        # 2^14 states each and keep the fastest; then size the sample for ~cpu_seconds
-        hw = threads
-        cal = host_states[:16384]
-        best = (0.0, 1)
-        for cand in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), min(hw, 16)}, reverse=True):
+        hw = cref.hardware_threads()
+        info = cpu_info()
+        cal = host_states[:8192]
+        c0 = time.perf_counter()
+        ora.permute_batch(cal[:2048], threads=1)
+        rate1 = 2048 / (time.perf_counter() - c0)
+        best = (rate1, 1)
+        for cand in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), min(hw, 16), min(hw, 8)}, reverse=True):
             c0 = time.perf_counter()
             ora.permute_batch(cal, threads=cand)
             r = len(cal) / (time.perf_counter() - c0)
@@ -282,13 +525,18 @@ def main():
             if sample < n or cpu_s >= args.cpu_seconds:
                 break
         sample *= passes
-        out["cpu_baseline"] = {"value": sample / cpu_s, "unit": "permutations/s", "cores": threads, "kind": "port",
-                               "sample": "%d permutations over the same 2^%d states, reference-shaped C restatement "
-                                         "(oracle/c/akp_oracle.c), %d pthreads (best of a thread-count sweep; %d hardware threads)"
-                                         % (sample, args.log2_states, threads, hw)}
-        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        rate_n = sample / cpu_s
+        out["cpu_baseline"] = {"value": rate_n, "unit": "permutations/s", "cores": threads, "kind": "port",
+                               "threads_used": threads, "rate_1_thread": rate1, "effective_cores": rate_n / rate1,
+                               "hardware_threads": hw, **info,
+                               "sample": "%d permutations over the same 2^%d states, reference-shaped C restatement (oracle/c/akp_oracle.c: "
+                                         "dense MDS, square-and-multiply, one permutation per call as the reference), %d pthreads (best of a "
+                                         "thread-count sweep); `effective_cores` = that rate / the 1-thread rate: what the container's CPU "
+                                         "share really delivered" % (sample, args.log2_states, threads)}
+        out["gpu_over_cpu"] = value / rate_n
     print(json.dumps(out))
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

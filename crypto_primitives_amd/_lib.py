@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AKP_LIB", os.path.join(_HERE, "lib", "libakp.so"))
 
 AKP_OK, AKP_ERR_BAD_LENGTH, AKP_ERR_BAD_PARAMS, AKP_ERR_HIP, AKP_ERR_RCCL, AKP_ERR_NOT_POW2 = 0, 1, 2, 3, 4, 5
+AKP_ABI_VERSION = 2
 TE_PEDERSEN, TE_BOWE_HOPWOOD = 0, 1
 
 
@@ -99,6 +100,33 @@ def _load():
         "akp_merkle_gather_paths_dev": (i32, [vp, u64p, u64p, sz, u32, u64p, sz, u64p, u64p, vp]),
         "akp_merkle_verify_paths_poseidon": (i32, [vp, vp, u64p, u64p, sz, sz, u64p, u64p, u64p, sz, u8p]),
         "akp_merkle_verify_paths_te": (i32, [vp, vp, u64p, u8p, sz, sz, u64p, u64p, u64p, sz, u8p]),
+        "akp_poseidon_kernel_for": (C.c_char_p, [vp, sz, i32]),
+        "akp_host_alloc": (i32, [sz, pp]),
+        "akp_host_free": (i32, [vp]),
+        "akp_host_register": (i32, [vp, sz]),
+        "akp_host_unregister": (i32, [vp]),
+        "akp_merkle_tree_build_poseidon": (i32, [vp, vp, u64p, sz, sz, pp]),
+        "akp_merkle_tree_build_te": (i32, [vp, vp, u8p, sz, sz, pp]),
+        "akp_merkle_tree_from_digests_poseidon": (i32, [vp, vp, u64p, sz, pp]),
+        "akp_merkle_tree_from_digests_te": (i32, [vp, vp, u64p, sz, pp]),
+        "akp_merkle_tree_destroy": (None, [vp]),
+        "akp_merkle_tree_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz)]),
+        "akp_merkle_tree_root": (i32, [vp, u64p]),
+        "akp_merkle_tree_export": (i32, [vp, u64p, u64p]),
+        "akp_merkle_tree_device_ptrs": (i32, [vp, pp, pp]),
+        "akp_merkle_tree_gather_paths": (i32, [vp, u64p, sz, u64p, u64p]),
+        "akp_merkle_tree_update_batch": (i32, [vp, u64p, vp, sz, sz]),
+        "akp_merkle_tree_check_update": (i32, [vp, u64, vp, sz, u64p, C.POINTER(i32)]),
+        "akp_merkle_multipath_encode": (i32, [u64p, sz, sz, u32, u64p, u64p, C.POINTER(sz)]),
+        "akp_merkle_multipath_decode": (i32, [u64p, u64p, sz, sz, sz, u32, u64p]),
+        "akp_merkle_verify_multipath_poseidon": (i32, [vp, vp, u64p, u64p, sz, sz, u64p, u64p, u64p, u64p, sz, sz, C.POINTER(i32)]),
+        "akp_merkle_verify_multipath_te": (i32, [vp, vp, u64p, u8p, sz, sz, u64p, u64p, u64p, u64p, sz, sz, C.POINTER(i32)]),
+        "akp_multi_create": (i32, [C.POINTER(i32), i32, pp]),
+        "akp_multi_destroy": (None, [vp]),
+        "akp_multi_size": (i32, [vp]),
+        "akp_multi_ctx": (vp, [vp, i32]),
+        "akp_merkle_build_sharded_poseidon": (i32, [vp, pp, pp, u64p, sz, sz, u64p, u64p, u64p]),
+        "akp_merkle_build_sharded_te": (i32, [vp, pp, pp, u8p, sz, sz, u64p, u64p, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly

@@ -47,9 +47,9 @@ class Commitment:
     def setup(window, seed=0):
         """:44-60 -- 252 doubling powers of one base for the randomness, plus the CRH generators; bases from the
         seeded procedure of params.py (the reference's rng stream is not reproducible)."""
-        from ..params import pedersen_generators
-        rg = pedersen_generators(seed ^ 0x5EED, SCALAR_BITS, 1).reshape(SCALAR_BITS, 2, 4)
-        return Parameters(rg, pedersen_generators(seed, window.WINDOW_SIZE, window.NUM_WINDOWS))
+        from ..params import setup_pedersen_generators
+        rg = setup_pedersen_generators(seed ^ 0x5EED, SCALAR_BITS, 1).reshape(SCALAR_BITS, 2, 4)
+        return Parameters(rg, setup_pedersen_generators(seed, window.WINDOW_SIZE, window.NUM_WINDOWS))
 
     @staticmethod
     def commit(parameters: Parameters, input_: bytes, randomness: int):

@@ -24,8 +24,8 @@ class CRH(_ped._TeCRH):
         if window.WINDOW_SIZE > MAX_CHUNKS_PER_SEGMENT:
             raise ValueError("Bowe-Hopwood-PedersenCRH hash must have a window size resulting in scalars < (p-1)/2, "
                              f"maximum segment size is {MAX_CHUNKS_PER_SEGMENT}")
-        from ..params import bowe_hopwood_generators
-        return Parameters(bowe_hopwood_generators(seed, window.WINDOW_SIZE, window.NUM_WINDOWS))
+        from ..params import setup_bowe_hopwood_generators
+        return Parameters(setup_bowe_hopwood_generators(seed, window.WINDOW_SIZE, window.NUM_WINDOWS))
 
 
 class TwoToOneCRH(_ped.TwoToOneCRH):

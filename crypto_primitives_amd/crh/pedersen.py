@@ -99,8 +99,8 @@ class CRH(_TeCRH):
         """CRHScheme::setup (crh/pedersen/mod.rs:64-74).  The reference draws `C::rand(rng)` bases and
         their doublings (:40-56); its rng stream is not reproducible outside ark-std, so the bases here
         come from a seeded procedure of our own (host big-int, see params.py)."""
-        from ..params import pedersen_generators
-        return Parameters(pedersen_generators(seed, window.WINDOW_SIZE, window.NUM_WINDOWS))
+        from ..params import setup_pedersen_generators
+        return Parameters(setup_pedersen_generators(seed, window.WINDOW_SIZE, window.NUM_WINDOWS))
 
 
 class TwoToOneCRH:

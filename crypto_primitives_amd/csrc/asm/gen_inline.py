@@ -54,10 +54,11 @@ def emit_routine(name, kind, signed=False, terms=1, inplace=False):
             mad("%%[%s%d]" % (M, i), "%%[p%d]" % (k - i))  # signed flavour: [p.] holds -p[.]
         if k < 9:
             if signed:
-                # subtractive reduction: m = acc mod 2^29, acc -= m * p  (p[0] = 1).  Saves the negation; the result is
-                # (ab - mp) / 2^261 in (-2.1p, 1.1p) instead of (ab + mp) / 2^261 in (-1.1p, 2.1p): same magnitude bound
+                # subtractive reduction: m = acc mod 2^29, acc -= m * p  (p[0] = 1).  Subtracting m only clears the low
+                # 29 bits, which the arithmetic shift drops anyway (floor), so the column step is and + shift: no negation,
+                # no add.  The result is (ab - mp) / 2^261 in (-2.1p, 1.1p) instead of (ab + mp) / 2^261 in (-1.1p, 2.1p):
+                # same magnitude bound
                 e("v_and_b32_e32 %%[%s%d], %s, %s" % (M, k, MASK, acclo))
-                mad("%%[%s%d]" % (M, k), "-1")
             else:
                 e("v_sub_u32_e32 %%[%s%d], 0, %s" % (M, k, acclo))
                 e("v_and_b32_e32 %%[%s%d], %s, %%[%s%d]" % (M, k, MASK, M, k))
@@ -114,3 +115,9 @@ print("// signed flavour (Jubjub arithmetic): v_mad_i64_i32 and arithmetic shift
 print(emit_routine("f29_sqr_asm", "sqr", signed=True))
 print(emit_routine("f29_mul_asm", "mul", signed=True))
 print(emit_routine("f29_mulc_asm", "mulc", signed=True))
+print("// signed in-place forms and dot products: the Poseidon kernels run in the signed flavour too (two instructions per")
+print("// reduction column instead of four)")
+print(emit_routine("f29_sqr_ip_asm", "sqr", signed=True, inplace=True))
+print(emit_routine("f29_mul_ip_asm", "mul", signed=True, inplace=True))
+print(emit_routine("f29_dot2_asm", "dot", signed=True, terms=2))
+print(emit_routine("f29_dot3_asm", "dot", signed=True, terms=3))

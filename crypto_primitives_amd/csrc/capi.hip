@@ -46,6 +46,17 @@ extern "C" int32_t akp_device_count(void) {
     return n;
 }
 
+static size_t env_size(const char* name, size_t dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : dflt;
+}
+static u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
+    const char* e = getenv(name);
+    if (!e) return dflt;
+    long v = strtol(e, nullptr, 10);
+    return (v < (long)lo || v > (long)hi) ? dflt : (u32)v;
+}
+
 // ------------------------------------------------------------------------------------------
 // context: device, stream, grow-only scratch slots
 enum { SCR_A = 0, SCR_B, SCR_C, SCR_D, SCR_E, SCR_F, SCR_G, SCR_H, SCR_I, SCR_J, SCR_K, SCR_COUNT };
@@ -54,9 +65,29 @@ struct akp_ctx {
     hipStream_t stream = nullptr;
     void* scratch[SCR_COUNT] = {};
     size_t scratch_bytes[SCR_COUNT] = {};
+    // stream that last used each slot + an event to order the next use on ANOTHER stream behind it: `_dev` entry points
+    // run on the caller's stream while the host-pointer entry points run on `stream` (non-blocking, so no implicit order
+    // with the legacy default stream); without this two calls on different streams would race on the shared scratch
+    hipStream_t slot_stream[SCR_COUNT] = {};
+    bool slot_used[SCR_COUNT] = {};
+    hipEvent_t slot_event[SCR_COUNT] = {};
+    // pinned staging for small host<->device transfers of the tree / proof entry points
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // two more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
+    hipStream_t pipe[2] = {};
 };
-static int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out) {
+// scratch slot `slot` with at least `bytes`, to be used on stream `s`: if the previous use was enqueued on a different
+// stream, `s` first waits for it (event record + stream wait; nothing blocks on the host)
+static int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out, hipStream_t s) {
     if (bytes == 0) bytes = 16;
+    if (c->slot_used[slot] && c->slot_stream[slot] != s) {
+        if (!c->slot_event[slot]) HIP_TRY(hipEventCreateWithFlags(&c->slot_event[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->slot_event[slot], c->slot_stream[slot]));
+        HIP_TRY(hipStreamWaitEvent(s, c->slot_event[slot], 0));
+    }
+    c->slot_used[slot] = true;
+    c->slot_stream[slot] = s;
     if (c->scratch_bytes[slot] < bytes) {
         if (c->scratch[slot]) {
             HIP_TRY(hipDeviceSynchronize());  // work enqueued on other streams may still read it
@@ -90,8 +121,13 @@ extern "C" void akp_ctx_destroy(akp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < SCR_COUNT; ++i)
+    for (int i = 0; i < SCR_COUNT; ++i) {
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+        if (c->slot_event[i]) (void)hipEventDestroy(c->slot_event[i]);
+    }
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int i = 0; i < 2; ++i)
+        if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -104,6 +140,74 @@ extern "C" int32_t akp_ctx_synchronize(akp_ctx* c) {
 // `_dev` entry points use the caller's stream verbatim (NULL = HIP's legacy default stream, which is what
 // torch's default stream is), so event timing and ordering follow the caller's stream semantics.
 static inline hipStream_t pick_stream(akp_ctx*, void* s) { return (hipStream_t)s; }
+
+// ------------------------------------------------------------------------------------------
+// pinned host memory for callers that want the host-pointer entry points to run at PCIe speed: copies from / to
+// pageable memory are staged by the runtime and block the calling thread, pinned (or registered) buffers stream
+// asynchronously in both directions at once.  The entry points accept either kind.
+extern "C" int32_t akp_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(AKP_ERR_BAD_PARAMS, "out is NULL");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return AKP_OK;
+}
+extern "C" int32_t akp_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return AKP_OK;
+}
+extern "C" int32_t akp_host_register(void* p, size_t bytes) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "pointer is NULL");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return AKP_OK;
+}
+extern "C" int32_t akp_host_unregister(void* p) {
+    if (p) HIP_TRY(hipHostUnregister(p));
+    return AKP_OK;
+}
+
+// Chunked host-pointer batch: items are cut into chunks of 2^AKP_HOST_CHUNK_LOG2 (default 2^18); chunk i runs copy-in ->
+// kernel -> copy-out on stream i mod 3 with its own third of the device buffers, so the three stages of consecutive
+// chunks overlap (PCIe is full duplex; the kernel of one chunk hides the copies of its neighbours).  Only for kernels
+// without context scratch of their own (the Poseidon batches).
+struct HostIn {
+    const void* host;
+    size_t bytes_per_item;
+    int slot;
+};
+template <class Launch>
+static int32_t pipelined_batch(akp_ctx* c, size_t n, const HostIn* ins, int n_in, void* host_out, size_t out_bytes_per_item, int out_slot,
+                               Launch launch /* (void* const* d_in, void* d_out, size_t count, hipStream_t) */) {
+    static const size_t chunk_items = (size_t)1 << env_u32("AKP_HOST_CHUNK_LOG2", 18, 10, 30);
+    for (int i = 0; i < 2; ++i)
+        if (!c->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking));
+    hipStream_t st[3] = {c->stream, c->pipe[0], c->pipe[1]};
+    const size_t chunk = std::min(n, chunk_items);
+    const int lanes = n > chunk ? 3 : 1;
+    void* d_in[2] = {nullptr, nullptr};
+    void* d_out = nullptr;
+    for (int k = 0; k < n_in; ++k)
+        if (int32_t rc = ctx_scratch(c, ins[k].slot, lanes * chunk * ins[k].bytes_per_item, &d_in[k], c->stream)) return rc;
+    const bool in_place = out_slot < 0;  // the output overwrites input 0 (permutation)
+    if (!in_place)
+        if (int32_t rc = ctx_scratch(c, out_slot, lanes * chunk * out_bytes_per_item, &d_out, c->stream)) return rc;
+    size_t done = 0;
+    for (size_t ci = 0; done < n; ++ci) {
+        const size_t cnt = std::min(chunk, n - done);
+        const int lane = (int)(ci % lanes);
+        hipStream_t s = st[lane];
+        void* di[2];
+        for (int k = 0; k < n_in; ++k) {
+            di[k] = (char*)d_in[k] + (size_t)lane * chunk * ins[k].bytes_per_item;
+            if (ins[k].bytes_per_item)
+                HIP_TRY(hipMemcpyAsync(di[k], (const char*)ins[k].host + done * ins[k].bytes_per_item, cnt * ins[k].bytes_per_item, hipMemcpyHostToDevice, s));
+        }
+        void* dout = in_place ? di[0] : (char*)d_out + (size_t)lane * chunk * out_bytes_per_item;
+        if (int32_t rc = launch(di, dout, cnt, s)) return rc;
+        HIP_TRY(hipMemcpyAsync((char*)host_out + done * out_bytes_per_item, dout, cnt * out_bytes_per_item, hipMemcpyDeviceToHost, s));
+        done += cnt;
+    }
+    for (int i = 0; i < lanes; ++i) HIP_TRY(hipStreamSynchronize(st[i]));
+    return AKP_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // host field helpers
@@ -506,6 +610,18 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     HIP_TRY(hipGetLastError());
     return AKP_OK;
 }
+// which kernel a batch of n items is routed to (the rule of launch_permute / launch_crh), so that a parity probe can
+// say which kernel it certified.  The returned string is static.
+extern "C" const char* akp_poseidon_kernel_for(const akp_poseidon* p, size_t n, int32_t crh) {
+    if (!p || !p->ctx) return "none";
+    if (p->dims.t == 3 && n > coop_max_items()) {
+        const bool ff = t3_reg_consts(p).scaled == 3u;
+        if (crh) return ff ? "poseidon_crh_t3_kernel<true>" : "poseidon_crh_t3_kernel<false>";
+        return ff ? "poseidon_permute_t3_kernel<true>" : "poseidon_permute_t3_kernel<false>";
+    }
+    if (p->dims.t == 3 || generic_coop(n)) return crh ? "poseidon_crh_coop_kernel" : "poseidon_permute_coop_kernel";
+    return crh ? "poseidon_crh_kernel" : "poseidon_permute_kernel";
+}
 #define NEED_DEV(p, what)                                                                                  \
     do {                                                                                                   \
         if (!(p)) return fail(AKP_ERR_BAD_PARAMS, what ": params is NULL");                                \
@@ -521,15 +637,9 @@ extern "C" int32_t akp_poseidon_permute_batch(akp_poseidon* p, uint64_t* states,
     NEED_DEV(p, "akp_poseidon_permute_batch");
     if (n == 0) return AKP_OK;
     if (!states) return fail(AKP_ERR_BAD_PARAMS, "states is NULL");
-    const size_t bytes = n * p->dims.t * sizeof(Fr);
-    void* d = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, bytes, &d)) return rc;
-    hipStream_t s = p->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, s));
-    if (int32_t rc = launch_permute(p, (Fr*)d, n, s)) return rc;
-    HIP_TRY(hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return AKP_OK;
+    const HostIn in[1] = {{states, p->dims.t * sizeof(Fr), SCR_A}};
+    return pipelined_batch(p->ctx, n, in, 1, states, p->dims.t * sizeof(Fr), -1,
+                           [&](void* const* di, void*, size_t cnt, hipStream_t s) -> int32_t { return launch_permute(p, (Fr*)di[0], cnt, s); });
 }
 extern "C" int32_t akp_poseidon_crh_batch_dev(akp_poseidon* p, const uint64_t* d_inputs, size_t n, size_t k, uint64_t* d_out, void* stream) {
     NEED_DEV(p, "akp_poseidon_crh_batch_dev");
@@ -539,15 +649,10 @@ extern "C" int32_t akp_poseidon_crh_batch(akp_poseidon* p, const uint64_t* input
     NEED_DEV(p, "akp_poseidon_crh_batch");
     if (n == 0) return AKP_OK;
     if (!out || (!inputs && k)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
-    void *din = nullptr, *dout = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * k * sizeof(Fr), &din)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * sizeof(Fr), &dout)) return rc;
-    hipStream_t s = p->ctx->stream;
-    if (k) HIP_TRY(hipMemcpyAsync(din, inputs, n * k * sizeof(Fr), hipMemcpyHostToDevice, s));
-    if (int32_t rc = launch_crh(p, (const Fr*)din, nullptr, k, (Fr*)dout, n, s)) return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return AKP_OK;
+    const HostIn in[1] = {{inputs, k * sizeof(Fr), SCR_A}};
+    return pipelined_batch(p->ctx, n, in, 1, out, sizeof(Fr), SCR_B, [&](void* const* di, void* dout, size_t cnt, hipStream_t s) -> int32_t {
+        return launch_crh(p, (const Fr*)di[0], nullptr, k, (Fr*)dout, cnt, s);
+    });
 }
 extern "C" int32_t akp_poseidon_two_to_one_batch_dev(akp_poseidon* p, const uint64_t* d_left, const uint64_t* d_right, size_t n,
                                                      uint64_t* d_out, void* stream) {
@@ -558,17 +663,10 @@ extern "C" int32_t akp_poseidon_two_to_one_batch(akp_poseidon* p, const uint64_t
     NEED_DEV(p, "akp_poseidon_two_to_one_batch");
     if (n == 0) return AKP_OK;
     if (!left || !right || !out) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
-    void *dl = nullptr, *dr = nullptr, *dout = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * sizeof(Fr), &dl)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * sizeof(Fr), &dr)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * sizeof(Fr), &dout)) return rc;
-    hipStream_t s = p->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(dl, left, n * sizeof(Fr), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dr, right, n * sizeof(Fr), hipMemcpyHostToDevice, s));
-    if (int32_t rc = launch_crh(p, (const Fr*)dl, (const Fr*)dr, 2, (Fr*)dout, n, s)) return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return AKP_OK;
+    const HostIn in[2] = {{left, sizeof(Fr), SCR_A}, {right, sizeof(Fr), SCR_B}};
+    return pipelined_batch(p->ctx, n, in, 2, out, sizeof(Fr), SCR_C, [&](void* const* di, void* dout, size_t cnt, hipStream_t s) -> int32_t {
+        return launch_crh(p, (const Fr*)di[0], (const Fr*)di[1], 2, (Fr*)dout, cnt, s);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -767,16 +865,6 @@ static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == A
 static inline size_t te_input_bits(const akp_te_params* p) {  // max message bits before the reference panics
     return p->kind == AKP_TE_PEDERSEN ? (size_t)p->W * p->N : (size_t)p->W * p->N * 3;
 }
-static size_t env_size(const char* name, size_t dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : dflt;
-}
-static u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
-    const char* e = getenv(name);
-    if (!e) return dflt;
-    long v = strtol(e, nullptr, 10);
-    return (v < (long)lo || v > (long)hi) ? dflt : (u32)v;
-}
 
 extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
     if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
@@ -885,8 +973,8 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         return AKP_OK;
     }
     void *xyz = nullptr, *prefix = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (p->kind == AKP_TE_PEDERSEN)
         hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
@@ -922,8 +1010,8 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     if (!out || (!msgs && msg_len)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
     const size_t fe = te_fe_per_digest(p);
     void *dm = nullptr, *dout = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * msg_len, &dm)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dout)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * msg_len, &dm, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dout, p->ctx->stream)) return rc;
     hipStream_t s = p->ctx->stream;
     if (msg_len) HIP_TRY(hipMemcpyAsync(dm, msgs, n * msg_len, hipMemcpyHostToDevice, s));
     if (int32_t rc = te_crh_dev(p, (const uint8_t*)dm, n, msg_len, (Fr*)dout, s)) return rc;
@@ -938,10 +1026,10 @@ extern "C" int32_t akp_te_two_to_one_batch(akp_te_params* p, const uint8_t* left
     const size_t buflen = ((size_t)p->W * p->N) / 8;  // both schemes size the buffer from pedersen's INPUT_SIZE_BITS
     const size_t fe = te_fe_per_digest(p);
     void *dl = nullptr, *dr = nullptr, *dbuf = nullptr, *dout = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * half_len, &dl)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * half_len, &dr)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * buflen, &dbuf)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * fe * sizeof(Fr), &dout)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * half_len, &dl, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * half_len, &dr, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * buflen, &dbuf, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * fe * sizeof(Fr), &dout, p->ctx->stream)) return rc;
     hipStream_t s = p->ctx->stream;
     if (half_len) {
         HIP_TRY(hipMemcpyAsync(dl, left, n * half_len, hipMemcpyHostToDevice, s));
@@ -964,7 +1052,7 @@ static int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_r
     const u32 fe = te_fe_per_digest(p);
     const size_t used = std::min<size_t>(buflen, (size_t)2 * fe * 32);
     void* dbuf = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * buflen, &dbuf)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * buflen, &dbuf, s)) return rc;
     const size_t work = n * 2 * fe;
     hipLaunchKernelGGL(te_serialize_pairs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, d_left, d_right, fe, buflen, (uint8_t*)dbuf, n);
     HIP_TRY(hipGetLastError());
@@ -981,9 +1069,9 @@ extern "C" int32_t akp_te_compress_batch(akp_te_params* p, const uint64_t* left,
     if (!left || !right || !out) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
     const size_t fe = te_fe_per_digest(p);
     void *dl = nullptr, *dr = nullptr, *dout = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * fe * sizeof(Fr), &dl)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dr)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * fe * sizeof(Fr), &dout)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * fe * sizeof(Fr), &dl, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dr, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * fe * sizeof(Fr), &dout, p->ctx->stream)) return rc;
     hipStream_t s = p->ctx->stream;
     HIP_TRY(hipMemcpyAsync(dl, left, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(dr, right, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
@@ -1017,8 +1105,8 @@ extern "C" int32_t akp_merkle_inner_poseidon(akp_poseidon* two, const uint64_t* 
     if (!leaf_nodes || !non_leaf) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
     akp_ctx* c = two->ctx;
     void *dln = nullptr, *dnl = nullptr;
-    if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dln)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * sizeof(Fr), &dnl)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dln, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * sizeof(Fr), &dnl, c->stream)) return rc;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(dln, leaf_nodes, n * sizeof(Fr), hipMemcpyHostToDevice, s));
     if (int32_t rc = akp_merkle_inner_poseidon_dev(two, (const uint64_t*)dln, n, (uint64_t*)dnl, (void*)s)) return rc;
@@ -1044,9 +1132,9 @@ extern "C" int32_t akp_merkle_build_poseidon(akp_poseidon* leafp, akp_poseidon* 
     if (!leaves && leaf_len) return fail(AKP_ERR_BAD_PARAMS, "leaves is NULL");
     akp_ctx* c = leafp->ctx;
     void *dl = nullptr, *dln = nullptr, *dnl = nullptr;
-    if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len * sizeof(Fr), &dl)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dln)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * sizeof(Fr), &dnl)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len * sizeof(Fr), &dl, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dln, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * sizeof(Fr), &dnl, c->stream)) return rc;
     hipStream_t s = c->stream;
     if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, n * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
     if (int32_t rc = akp_merkle_build_poseidon_dev(leafp, two, (const uint64_t*)dl, n, leaf_len, (uint64_t*)dln, (uint64_t*)dnl, (void*)s)) return rc;
@@ -1078,8 +1166,8 @@ extern "C" int32_t akp_merkle_inner_te(akp_te_params* two, const uint64_t* leaf_
     akp_ctx* c = two->ctx;
     const size_t fe = te_fe_per_digest(two);
     void *dln = nullptr, *dnl = nullptr;
-    if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl, c->stream)) return rc;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(dln, leaf_nodes, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
     if (int32_t rc = akp_merkle_inner_te_dev(two, (const uint64_t*)dln, n, (uint64_t*)dnl, (void*)s)) return rc;
@@ -1109,9 +1197,9 @@ extern "C" int32_t akp_merkle_build_te(akp_te_params* leafp, akp_te_params* two,
     akp_ctx* c = leafp->ctx;
     const size_t fe = te_fe_per_digest(two);
     void *dl = nullptr, *dln = nullptr, *dnl = nullptr;
-    if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len, &dl)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len, &dl, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl, c->stream)) return rc;
     hipStream_t s = c->stream;
     if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, n * leaf_len, hipMemcpyHostToDevice, s));
     if (int32_t rc = akp_merkle_build_te_dev(leafp, two, (const uint8_t*)dl, n, leaf_len, (uint64_t*)dln, (uint64_t*)dnl, (void*)s)) return rc;
@@ -1198,12 +1286,12 @@ static int32_t verify_paths_common(akp_ctx* c, u32 fe, const uint64_t* root, siz
     if (!root || !idx || !sibs || !ok_out || (depth && !auth)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
     const size_t dig = (size_t)fe * sizeof(Fr);
     void *d_cur = nullptr, *d_l = nullptr, *d_r = nullptr, *d_idx = nullptr, *d_sib = nullptr, *d_auth = nullptr, *d_misc = nullptr;
-    if (int32_t rc = ctx_scratch(c, SCR_G, m * dig, &d_cur)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_H, m * dig, &d_l)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_I, m * dig, &d_r)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_G, m * dig, &d_cur, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_H, m * dig, &d_l, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_I, m * dig, &d_r, c->stream)) return rc;
     const size_t idx_bytes = (m * 8 + 15) & ~(size_t)15;  // keep the digests behind the index array 16-byte aligned
-    if (int32_t rc = ctx_scratch(c, SCR_J, idx_bytes + m * dig + dig + m, &d_misc)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_K, std::max<size_t>(m * depth * dig, 16), &d_auth)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_J, idx_bytes + m * dig + dig + m, &d_misc, c->stream)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_K, std::max<size_t>(m * depth * dig, 16), &d_auth, c->stream)) return rc;
     d_idx = d_misc;
     d_sib = (char*)d_misc + idx_bytes;
     void* d_root = (char*)d_sib + m * dig;
@@ -1242,7 +1330,7 @@ extern "C" int32_t akp_merkle_verify_paths_poseidon(akp_poseidon* leafp, akp_pos
         c, 1, root, m, idx, sibs, auth, depth, ok_out,
         [&](Fr* d_cur, hipStream_t s) -> int32_t {
             void* dl = nullptr;
-            if (int32_t rc = ctx_scratch(c, SCR_A, m * leaf_len * sizeof(Fr), &dl)) return rc;
+            if (int32_t rc = ctx_scratch(c, SCR_A, m * leaf_len * sizeof(Fr), &dl, s)) return rc;
             if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
             return launch_crh(leafp, (const Fr*)dl, nullptr, leaf_len, d_cur, m, s);
         },
@@ -1262,9 +1350,12 @@ extern "C" int32_t akp_merkle_verify_paths_te(akp_te_params* leafp, akp_te_param
         c, te_fe_per_digest(two), root, m, idx, sibs, auth, depth, ok_out,
         [&](Fr* d_cur, hipStream_t s) -> int32_t {
             void* dl = nullptr;
-            if (int32_t rc = ctx_scratch(c, SCR_A, m * leaf_len, &dl)) return rc;
+            if (int32_t rc = ctx_scratch(c, SCR_A, m * leaf_len, &dl, s)) return rc;
             if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len, hipMemcpyHostToDevice, s));
             return te_crh_dev(leafp, (const uint8_t*)dl, m, leaf_len, d_cur, s);
         },
         [&](const Fr* l, const Fr* r, Fr* out, hipStream_t s) -> int32_t { return te_compress_dev(two, l, r, m, out, s); });
 }
+
+#include "capi_tree.inc"
+#include "capi_multi.inc"

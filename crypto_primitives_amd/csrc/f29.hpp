@@ -21,8 +21,16 @@
 // Headroom rules (checked in DESIGN.md "F29 bounds"):
 //   FU: 9*A*B + 9*2^58 < 2^64 -> product operands may have limbs < 2^30 (one lazy add each); a 3-term dot
 //       may take state limbs < 2^30 against normalised constants (27 * 2^59 + 9 * 2^58 < 2^64).
-//   FS: 9*A*B + 9*2^58 < 2^63 -> A*B <= 2^59.4: one operand may be a lazy sum/difference (< 2^30), the
-//       other normalised; anything larger goes through f29_weak_norm first.
+//   FS: every column value must stay inside (-2^63, 2^63).  The reduction terms only subtract (>= -8 * 2^58), so the
+//       bound is on the sum of the operand products:
+//       product   9*A*B < 2^63 -> A*B <= 2^59.8: one operand may be a lazy sum/difference (< 2^30), the other
+//                 normalised; anything larger goes through f29_weak_norm first;
+//       square    of an operand with non-negative limbs 0..7 <= 2^30 - 1 and a top limb < 2^26 (|value| < 2^258: a normalised value plus a
+//                 normalised round key): the doubled limbs stay below 2^31, the widest column without the top limb is
+//                 column 7: 8 * (2^30 - 1)^2 + carry (< 7 * 2^31) = 2^63 - 2^31 + small < 2^63; columns 8, 9 have two
+//                 terms with the small top limb;
+//       dot2/dot3 state limbs <= 2^29 + small against normalised constants (27 * 2^58 = 2^62.75): lanes that grow by
+//                 lazy additions are renormalised every round in the signed Poseidon kernels.
 // Wire format <-> internal: one Montgomery product with a constant each way (x*2^256 <-> x*2^261).
 #pragma once
 #include <stdint.h>
@@ -49,6 +57,11 @@ struct F29T<true> {
 };
 typedef F29T<false> FU;
 typedef F29T<true> FS;
+// Flavour of the Poseidon kernels.  Round 2: signed.  Poseidon only adds and multiplies non-negative limbs, but the
+// signed routines reduce subtractively, which costs two instructions per reduction column instead of four (-18
+// instructions per routine, -8 % of a permutation).  Price: half the accumulator headroom, see "Headroom rules".
+#define AKP_PS true
+typedef F29T<AKP_PS> FP;
 
 AKP_HD u32 p29(int i) {
     constexpr u32 P[9] = {0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u};
@@ -125,10 +138,22 @@ AKP_HD F29T<S> f29_weak_norm(const F29T<S>& a) {
 }
 
 // ---- Montgomery reduction tail shared by mul / sqr / dot: columns 0..8 have been folded into m[] ----
-#define AKP_F29_MSTEP()                           \
-    m[k] = (0u - (u32)acc) & AKP_MASK29;          \
-    acc += (W)(u64)m[k];                          \
-    acc >>= 29;
+// Unsigned flavour (additive): m = -acc mod 2^29, acc += m * p (p[0] = 1), result (ab + mp) / 2^261 in [0, 2.1p).
+// Signed flavour (subtractive): m = acc mod 2^29, acc -= m * p; the low 29 bits cancel, so the step is just the
+// arithmetic shift (floor), and the result (ab - mp) / 2^261 lies in (-2.1p, 1.1p) -- same magnitude bound, two
+// instructions per column instead of four.
+#define AKP_F29_MSTEP()                               \
+    if constexpr (S) {                                \
+        m[k] = (u32)acc & AKP_MASK29;                 \
+        acc >>= 29;                                   \
+    } else {                                          \
+        m[k] = (0u - (u32)acc) & AKP_MASK29;          \
+        acc += (W)(u64)m[k];                          \
+        acc >>= 29;                                   \
+    }
+#define AKP_F29_RED(mi, pj)                                  \
+    if constexpr (S) acc -= (W)((u64)(mi) * (u64)(pj));      \
+    else acc += (W)((u64)(mi) * (u64)(pj));
 
 #if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
 // single-accumulator-chain inline assembly for the field routines (generated, asm/gen_inline.py)
@@ -151,7 +176,7 @@ AKP_HD F29T<S> f29_mul(const F29T<S>& a, const F29T<S>& b) {
 #pragma unroll
         for (int i = 0; i <= k; ++i) acc += (W)a.l[i] * (W)b.l[k - i];
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = 0; i < k; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         AKP_F29_MSTEP()
     }
 #pragma unroll
@@ -159,7 +184,7 @@ AKP_HD F29T<S> f29_mul(const F29T<S>& a, const F29T<S>& b) {
 #pragma unroll
         for (int i = k - 8; i < 9; ++i) acc += (W)a.l[i] * (W)b.l[k - i];
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = k - 8; i < 9; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
         acc >>= 29;
     }
@@ -197,7 +222,7 @@ AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
         for (int i = 0; 2 * i < k; ++i) acc += (W)a2[i] * (W)a.l[k - i];
         if ((k & 1) == 0) acc += (W)a.l[k / 2] * (W)a.l[k / 2];
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = 0; i < k; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         AKP_F29_MSTEP()
     }
 #pragma unroll
@@ -206,7 +231,7 @@ AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
         for (int i = k - 8; 2 * i < k; ++i) acc += (W)a2[i] * (W)a.l[k - i];
         if ((k & 1) == 0) acc += (W)a.l[k / 2] * (W)a.l[k / 2];
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = k - 8; i < 9; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
         acc >>= 29;
     }
@@ -215,17 +240,19 @@ AKP_HD F29T<S> f29_sqr(const F29T<S>& a) {
 }
 
 // (a0*b0 + a1*b1 + a2*b2) / 2^261: one reduction for three products (the MDS row of a t = 3 state).
-// FU only: a limbs < 2^30, b limbs < 2^29  =>  27 * 2^59 + 9 * 2^58 + carry < 2^64.
+// FU: a limbs < 2^30, b limbs < 2^29  =>  27 * 2^59 + 9 * 2^58 + carry < 2^64.
+// FS: a limbs <= 2^29 + small, b limbs < 2^29  =>  27 * 2^58 < 2^63.
 // On the device b0..b2 must be wave-uniform (constants): the assembly version takes them in SGPRs.
-AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const FU& a2, const FU& b2) {
+template <bool S>
+AKP_HD F29T<S> f29_dot3(const F29T<S>& a0, const F29T<S>& b0, const F29T<S>& a1, const F29T<S>& b1, const F29T<S>& a2, const F29T<S>& b2) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
     return f29_dot3_asm(a0, b0, a1, b1, a2, b2);
 #endif
-    typedef u32 L;
-    typedef u64 W;
+    typedef typename F29T<S>::L L;
+    typedef typename F29T<S>::W W;
     W acc = 0;
     u32 m[9];
-    FU t;
+    F29T<S> t;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
@@ -235,7 +262,7 @@ AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const
             acc += (W)a2.l[i] * (W)b2.l[k - i];
         }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = 0; i < k; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         AKP_F29_MSTEP()
     }
 #pragma unroll
@@ -247,7 +274,7 @@ AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const
             acc += (W)a2.l[i] * (W)b2.l[k - i];
         }
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = k - 8; i < 9; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
         acc >>= 29;
     }
@@ -256,15 +283,16 @@ AKP_HD FU f29_dot3(const FU& a0, const FU& b0, const FU& a1, const FU& b1, const
 }
 
 // (a0*b0 + a1*b1) / 2^261: two products, one reduction (same operand bounds as f29_dot3)
-AKP_HD FU f29_dot2(const FU& a0, const FU& b0, const FU& a1, const FU& b1) {
+template <bool S>
+AKP_HD F29T<S> f29_dot2(const F29T<S>& a0, const F29T<S>& b0, const F29T<S>& a1, const F29T<S>& b1) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
     return f29_dot2_asm(a0, b0, a1, b1);
 #endif
-    typedef u32 L;
-    typedef u64 W;
+    typedef typename F29T<S>::L L;
+    typedef typename F29T<S>::W W;
     W acc = 0;
     u32 m[9];
-    FU t;
+    F29T<S> t;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
@@ -273,7 +301,7 @@ AKP_HD FU f29_dot2(const FU& a0, const FU& b0, const FU& a1, const FU& b1) {
             acc += (W)a1.l[i] * (W)b1.l[k - i];
         }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = 0; i < k; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         AKP_F29_MSTEP()
     }
 #pragma unroll
@@ -284,7 +312,7 @@ AKP_HD FU f29_dot2(const FU& a0, const FU& b0, const FU& a1, const FU& b1) {
             acc += (W)a1.l[i] * (W)b1.l[k - i];
         }
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (W)((u64)m[i] * (u64)p29(k - i));
+        for (int i = k - 8; i < 9; ++i) { AKP_F29_RED(m[i], p29(k - i)) }
         t.l[k - 9] = (L)((u32)acc & AKP_MASK29);
         acc >>= 29;
     }
@@ -299,14 +327,13 @@ AKP_HD F29T<S> f29_pow_small(const F29T<S>& x, u64 e) {
     int top = 63 - __builtin_clzll(e);
     F29T<S> r = x;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
-    if constexpr (!S) {  // in-place assembly steps: the chain r = r * r, r = r * x needs no register copies
+    // in-place assembly steps: the chain r = r * r, r = r * x needs no register copies
 #pragma unroll 1
-        for (int i = top - 1; i >= 0; --i) {
-            f29_sqr_ip_asm(r);
-            if ((e >> i) & 1) f29_mul_ip_asm(r, x);
-        }
-        return r;
+    for (int i = top - 1; i >= 0; --i) {
+        f29_sqr_ip_asm(r);
+        if ((e >> i) & 1) f29_mul_ip_asm(r, x);
     }
+    return r;
 #endif
 #pragma unroll 1
     for (int i = top - 1; i >= 0; --i) {

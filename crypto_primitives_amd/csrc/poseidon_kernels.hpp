@@ -45,12 +45,12 @@ AKP_HD void store_fr_global(Fr* p, const Fr& v) {
     q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
-AKP_HD FU ldc(const F29Pad* p) { return f29_load_pad<false>(p); }  // wave-uniform address -> scalar loads
+AKP_HD FP ldc(const F29Pad* p) { return f29_load_pad<AKP_PS>(p); }  // wave-uniform address -> scalar loads
 
 // wire-format parameter array -> internal form (run once per parameter set)
 __global__ void poseidon_convert_params_kernel(const Fr* __restrict__ in, F29Pad* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) f29_store_pad(out + i, f29_from_wire<false>(load_fr_global(in + i)));
+    if (i < n) f29_store_pad(out + i, f29_from_wire<AKP_PS>(load_fr_global(in + i)));
 }
 
 // =============================== t == 3: register-resident state ===================================
@@ -59,9 +59,11 @@ __global__ void poseidon_convert_params_kernel(const Fr* __restrict__ in, F29Pad
 // When `sparse` is given the partial rounds run in the algebraically identical sparse form derived on the
 // host (poseidon_opt.hpp): one key add, one S-box, row 0 as a 3-term dot, lanes 1,2 += w_i * s; the full
 // round before the block applies `mpre`, and `ark` already carries the folded key residue.
-// Limb bounds: dot3 / product outputs are normalised (< 2^29); + round key (< 2^29) -> < 2^30, which is what
-// f29_sqr / f29_mul / f29_dot3 admit.  In the sparse block lanes 1,2 grow by < 2^29 per round and are
-// renormalised every second round (dot3 admits lanes < 1.46 * 2^30 next to a normalised lane 0).
+// Limb bounds (signed flavour, f29.hpp "Headroom rules"): dot / product outputs are normalised (<= 2^29 - 1) and
+// f29_weak_norm of a sum of two such values is <= 2^29; + round key (<= 2^29 - 1) -> <= 2^30 - 1, which is what the
+// first squaring of an S-box admits; every later routine of the S-box sees normalised operands.  The linear layers take
+// S-box outputs (normalised) or lanes that were renormalised in the same round: in the sparse block lanes 1,2 grow by
+// < 2^29 per round and are renormalised EVERY round (27 * 2^58 < 2^63; the unsigned flavour of round 1 could wait two).
 struct PoseidonConsts {
     const F29Pad* ark;     // [R][t] round keys (with the residue folded in when sparse != nullptr)
     const F29Pad* mds;     // [t][t]
@@ -84,7 +86,7 @@ typedef PoseidonConsts PoseidonT3Consts;
 // FULLFORM: the constants are in the full form (C.scaled == 3) -- a compile-time switch so that each instantiation
 // carries only the row variants it uses (the kernel has to stay inside the 64 KB instruction cache)
 template <bool FULLFORM>
-AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FU& s0, FU& s1, FU& s2, u32 zero_lanes = 0,
+AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C, FP& s0, FP& s1, FP& s2, u32 zero_lanes = 0,
                                 u32 need_lanes = 7u) {
     const u32 form = FULLFORM ? 3u : (C.scaled == 3u ? 0u : C.scaled);
     const u32 half = D.full_rounds / 2;
@@ -100,6 +102,10 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             else s0 = f29_pow_small(f29_add(s0, ldc(a)), D.alpha);
             s1 = f29_add(s1, ldc(a + 1));
             s2 = f29_add(s2, ldc(a + 2));
+            if (!full) {  // dense partial round: lanes 1,2 enter the row sums without an S-box, bring them back to <= 2^29
+                s1 = f29_weak_norm(s1);
+                s2 = f29_weak_norm(s2);
+            }
             if (full) {
                 if (z & 2u) s1 = ldc(C.sbox0 + 1);
                 else s1 = f29_pow_small(s1, D.alpha);
@@ -114,7 +120,7 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
                 unit0 = unit12 && r + 1 != half;
             }
             const u32 need = (r + 1 == R) ? need_lanes : 7u;
-            FU n0 = s0, n1 = s1, n2 = s2;
+            FP n0 = s0, n1 = s1, n2 = s2;
             if (unit0) {
                 if (need & 1u) n0 = f29_weak_norm(f29_add(s0, f29_dot2(s1, ldc(m + 1), s2, ldc(m + 2))));
             } else if (need & 1u) n0 = f29_dot3(s0, ldc(m + 0), s1, ldc(m + 1), s2, ldc(m + 2));
@@ -131,7 +137,7 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
         } else {
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 6;
-            const FU s = f29_pow_small(f29_add(s0, ldc(sp)), D.alpha);
+            const FP s = f29_pow_small(f29_add(s0, ldc(sp)), D.alpha);
             // the S-box output enters lane 0 with coefficient 1: lane-0 form in all partial rounds but the last, full form
             // in the last one
             if ((form == 1u && j + 1 < D.partial_rounds) || (FULLFORM && j + 1 == D.partial_rounds))
@@ -141,9 +147,9 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             else s1 = f29_add(s1, f29_mulc(s, ldc(sp + 4)));
             s2 = f29_add(s2, f29_mulc(s, ldc(sp + 5)));
             if ((j & 31u) == 31u) {  // lanes 1,2 gain < 2.1p per round and are never reduced mod p: fold them back
-                s1 = f29_mulc(s1, f29_one<false>());  // every 32 rounds so the top limb stays far below 2^32 for any RP
-                s2 = f29_mulc(s2, f29_one<false>());
-            } else if ((j & 1u) || j + 1 == D.partial_rounds) {
+                s1 = f29_mulc(s1, f29_one<AKP_PS>());  // every 32 rounds so the top limb stays far below 2^32 for any RP
+                s2 = f29_mulc(s2, f29_one<AKP_PS>());
+            } else {
                 s1 = f29_weak_norm(s1);
                 s2 = f29_weak_norm(s2);
             }
@@ -152,8 +158,8 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
 }
 // absorb: lane[slot] += input, renormalised so that the following ARK add stays below 2^30.  Value selects per limb
 // (a pointer select on `slot` would force the three lanes into scratch memory).
-AKP_HD void t3_add_slot(FU& s0, FU& s1, FU& s2, u32 slot, const FU& v) {
-    const FU n0 = f29_weak_norm(f29_add(s0, v)), n1 = f29_weak_norm(f29_add(s1, v)), n2 = f29_weak_norm(f29_add(s2, v));
+AKP_HD void t3_add_slot(FP& s0, FP& s1, FP& s2, u32 slot, const FP& v) {
+    const FP n0 = f29_weak_norm(f29_add(s0, v)), n1 = f29_weak_norm(f29_add(s1, v)), n2 = f29_weak_norm(f29_add(s2, v));
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         s0.l[i] = slot == 0 ? n0.l[i] : s0.l[i];
@@ -168,7 +174,7 @@ AKP_HD void t3_add_slot(FU& s0, FU& s1, FU& s2, u32 slot, const FU& v) {
 template <bool FULLFORM>
 AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C, const Fr* __restrict__ in0,
                                const Fr* __restrict__ in1, size_t k, size_t idx) {
-    FU s0 = f29_zero<false>(), s1 = s0, s2 = s0;  // PoseidonSponge::new :223-234
+    FP s0 = f29_zero<AKP_PS>(), s1 = s0, s2 = s0;  // PoseidonSponge::new :223-234
     size_t done = 0;
     do {
         const size_t take = (k - done) < D.rate ? (k - done) : D.rate;
@@ -176,7 +182,7 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
         for (size_t j = 0; j < take; ++j) {
             const size_t e = done + j;
             const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
-            t3_add_slot(s0, s1, s2, D.capacity + (u32)j, FULLFORM ? f29_unpack<false>(load_fr_global(src)) : f29_from_wire<false>(load_fr_global(src)));
+            t3_add_slot(s0, s1, s2, D.capacity + (u32)j, FULLFORM ? f29_unpack<AKP_PS>(load_fr_global(src)) : f29_from_wire<AKP_PS>(load_fr_global(src)));
         }
         // fresh sponge: every lane outside [capacity, capacity + take) is still zero in the first permutation
         const u32 zero_lanes = done == 0 ? (7u & ~(((1u << take) - 1u) << D.capacity)) : 0u;
@@ -187,7 +193,7 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
         // the same way)
     } while (done < k);
     // squeeze_internal(0, 1) :156-186 -- limb-wise selects (an array select would go through scratch)
-    FU out;
+    FP out;
 #pragma unroll
     for (int i = 0; i < 9; ++i) out.l[i] = D.capacity == 0 ? s0.l[i] : (D.capacity == 1 ? s1.l[i] : s2.l[i]);
     if (FULLFORM) return f29_canonical_pack(out);  // the lane already holds x * 2^256
@@ -199,15 +205,15 @@ __global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     Fr* st = states + idx * 3;
-    FU s0, s1, s2;
+    FP s0, s1, s2;
     if (FULLFORM) {  // the full form takes the wire value x * 2^256 as it is
-        s0 = f29_unpack<false>(load_fr_global(st));
-        s1 = f29_unpack<false>(load_fr_global(st + 1));
-        s2 = f29_unpack<false>(load_fr_global(st + 2));
+        s0 = f29_unpack<AKP_PS>(load_fr_global(st));
+        s1 = f29_unpack<AKP_PS>(load_fr_global(st + 1));
+        s2 = f29_unpack<AKP_PS>(load_fr_global(st + 2));
     } else {
-        s0 = f29_from_wire<false>(load_fr_global(st));
-        s1 = f29_from_wire<false>(load_fr_global(st + 1));
-        s2 = f29_from_wire<false>(load_fr_global(st + 2));
+        s0 = f29_from_wire<AKP_PS>(load_fr_global(st));
+        s1 = f29_from_wire<AKP_PS>(load_fr_global(st + 1));
+        s2 = f29_from_wire<AKP_PS>(load_fr_global(st + 2));
     }
     poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2);
     if (FULLFORM) {  // the lanes already hold x * 2^256
@@ -233,13 +239,13 @@ __global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, Po
 template <int BLOCK>
 struct LdsFile29 {
     u32* base;
-    AKP_D FU load(u32 slot) const {
-        FU r;
+    AKP_D FP load(u32 slot) const {
+        FP r;
 #pragma unroll
         for (int i = 0; i < 9; ++i) r.l[i] = base[(slot * 9 + i) * BLOCK + threadIdx.x];
         return r;
     }
-    AKP_D void store(u32 slot, const FU& v) const {
+    AKP_D void store(u32 slot, const FP& v) const {
 #pragma unroll
         for (int i = 0; i < 9; ++i) base[(slot * 9 + i) * BLOCK + threadIdx.x] = v.l[i];
     }
@@ -248,19 +254,19 @@ struct LdsFile29 {
 // sum_j state[src + j] * row[j] over j in [0, T), 3 terms per Montgomery reduction; `first` (if non-null) replaces
 // the lane-0 operand (the freshly S-boxed element of a sparse partial round).  Result weakly normalised.
 template <class File>
-AKP_HD FU poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restrict__ row, const FU* first) {
-    FU acc = f29_zero<false>();
+AKP_HD FP poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restrict__ row, const FP* first) {
+    FP acc = f29_zero<AKP_PS>();
     u32 j = 0;
 #pragma unroll 1
     for (; j + 3 <= T; j += 3) {
-        const FU a0 = (first && j == 0) ? *first : f.load(src + j);
+        const FP a0 = (first && j == 0) ? *first : f.load(src + j);
         acc = f29_add(acc, f29_dot3(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1), f.load(src + j + 2), ldc(row + j + 2)));
     }
     if (j + 2 == T) {  // two terms left: one reduction
-        const FU a0 = (first && j == 0) ? *first : f.load(src + j);
+        const FP a0 = (first && j == 0) ? *first : f.load(src + j);
         acc = f29_add(acc, f29_dot2(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1)));
     } else if (j < T) {
-        const FU a0 = (first && j == 0) ? *first : f.load(src + j);
+        const FP a0 = (first && j == 0) ? *first : f.load(src + j);
         acc = f29_add(acc, f29_mulc(a0, ldc(row + j)));
     }
     return f29_weak_norm(acc);  // <= 6 normalised terms summed: back below 2^29 + 8
@@ -268,22 +274,22 @@ AKP_HD FU poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restri
 // the same sum without term `skip` (full form: that coefficient is 1 and the element is added by the caller).
 // `first` (if non-null) stands for state[0], as above.  Result NOT normalised (the caller adds and normalises).
 template <class File>
-AKP_HD FU poseidon_row_dot_skip(const File& f, u32 T, const F29Pad* __restrict__ row, u32 skip, const FU* first) {
-    FU acc = f29_zero<false>();
+AKP_HD FP poseidon_row_dot_skip(const File& f, u32 T, const F29Pad* __restrict__ row, u32 skip, const FP* first) {
+    FP acc = f29_zero<AKP_PS>();
     u32 c = 0;  // running index over the T - 1 remaining terms
 #pragma unroll 1
     for (; c + 3 <= T - 1; c += 3) {
         const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip), j2 = c + 2 + (c + 2 >= skip);
-        const FU a0 = (first && j0 == 0) ? *first : f.load(j0);
+        const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
         acc = f29_add(acc, f29_dot3(a0, ldc(row + j0), f.load(j1), ldc(row + j1), f.load(j2), ldc(row + j2)));
     }
     if (c + 2 == T - 1) {  // two terms left: one reduction
         const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip);
-        const FU a0 = (first && j0 == 0) ? *first : f.load(j0);
+        const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
         acc = f29_add(acc, f29_dot2(a0, ldc(row + j0), f.load(j1), ldc(row + j1)));
     } else if (c < T - 1) {
         const u32 j0 = c + (c >= skip);
-        const FU a0 = (first && j0 == 0) ? *first : f.load(j0);
+        const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
         acc = f29_add(acc, f29_mulc(a0, ldc(row + j0)));
     }
     return acc;  // <= 6 normalised terms
@@ -299,7 +305,7 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
     const bool opt = C.sparse != nullptr;
-    FU tmp[AKP_POSEIDON_MAX_T];
+    FP tmp[AKP_POSEIDON_MAX_T];
 #pragma unroll 1
     for (u32 r = 0; r < R; ++r) {
         const bool full = (r < half) || (r >= half + D.partial_rounds);
@@ -308,7 +314,9 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
             const F29Pad* arkr = C.ark + (size_t)r * T;
 #pragma unroll 1
             for (u32 e = 0; e < T; ++e) {  // ARK fused with the S-box
-                FU x = f29_add(f.load(e), ldc(arkr + e));
+                // the lane is a weakly normalised sum of row chunks (<= 2^29 + 5): with the key it can pass 2^30 - 1, the
+                // bound of the signed squaring, so one more carry step first (also for lanes that skip the S-box)
+                FP x = f29_weak_norm(f29_add(f.load(e), ldc(arkr + e)));
                 if (e < nsbox) x = f29_pow_small(x, D.alpha);
                 f.store(e, x);
             }
@@ -326,17 +334,17 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
             // sparse partial round, in place: lane 0 <- a00*s + u . lanes;  lane i <- lane i + w_i * s
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
-            const FU sb = f29_pow_small(f29_add(f.load(0), ldc(sp)), D.alpha);
+            const FP sb = f29_pow_small(f29_weak_norm(f29_add(f.load(0), ldc(sp))), D.alpha);
             // full form, last partial round: a00 = 1
-            const FU n0 = (C.scaled == 3u && j + 1 == D.partial_rounds) ? f29_weak_norm(f29_add(sb, poseidon_row_dot_skip(f, T, sp + 1, 0, &sb)))
+            const FP n0 = (C.scaled == 3u && j + 1 == D.partial_rounds) ? f29_weak_norm(f29_add(sb, poseidon_row_dot_skip(f, T, sp + 1, 0, &sb)))
                                                                         : poseidon_row_dot(f, 0, T, sp + 1, &sb);
-            const bool norm = (j & 1u) || j + 1 == D.partial_rounds;  // lanes grow < 2^29 per limb per round (see t3 notes)
-            const bool refold = (j & 31u) == 31u;                       // ... and < 2.1p in value: fold back mod p every 32 rounds
+            const bool norm = true;                // lanes grow < 2^29 per limb per round: renormalise every round (see t3 notes)
+            const bool refold = (j & 31u) == 31u;  // ... and < 2.1p in value: fold back mod p every 32 rounds
 #pragma unroll 1
             for (u32 i = 1; i < T; ++i) {
                 // lane-1 form (scaled == 2): lane 1 takes the S-box output with coefficient 1
-                FU y = (i == 1 && C.scaled >= 2u) ? f29_add(f.load(1), sb) : f29_add(f.load(i), f29_mulc(sb, ldc(sp + T + i)));
-                if (refold) y = f29_mulc(y, f29_one<false>());
+                FP y = (i == 1 && C.scaled >= 2u) ? f29_add(f.load(1), sb) : f29_add(f.load(i), f29_mulc(sb, ldc(sp + T + i)));
+                if (refold) y = f29_mulc(y, f29_one<AKP_PS>());
                 else if (norm) y = f29_weak_norm(y);
                 f.store(i, y);
             }
@@ -348,7 +356,7 @@ template <class File>
 AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const PoseidonConsts& C, const File& f, const Fr* __restrict__ in0,
                             const Fr* __restrict__ in1, size_t k, size_t idx) {
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) f.store(e, f29_zero<false>());
+    for (u32 e = 0; e < D.t; ++e) f.store(e, f29_zero<AKP_PS>());
     size_t done = 0;
     do {
         const size_t take = (k - done) < D.rate ? (k - done) : D.rate;
@@ -359,7 +367,7 @@ AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const PoseidonConsts& C, cons
             const u32 slot = D.capacity + (u32)j;
             // the rate lane holds a weakly normalised MDS output (or zero): keep it that way
             // full form: the lanes hold wire values (x * 2^256), inputs are taken as they are
-            const FU in = C.scaled == 3u ? f29_unpack<false>(load_fr_global(src)) : f29_from_wire<false>(load_fr_global(src));
+            const FP in = C.scaled == 3u ? f29_unpack<AKP_PS>(load_fr_global(src)) : f29_from_wire<AKP_PS>(load_fr_global(src));
             f.store(slot, f29_weak_norm(f29_add(f.load(slot), in)));
         }
         done += take;
@@ -376,7 +384,7 @@ __global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D,
     if (idx >= n) return;  // lanes never exchange data: no barriers anywhere
     Fr* st = states + idx * D.t;
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) f.store(e, C.scaled == 3u ? f29_unpack<false>(load_fr_global(st + e)) : f29_from_wire<false>(load_fr_global(st + e)));
+    for (u32 e = 0; e < D.t; ++e) f.store(e, C.scaled == 3u ? f29_unpack<AKP_PS>(load_fr_global(st + e)) : f29_from_wire<AKP_PS>(load_fr_global(st + e)));
     poseidon_permute_file(D, C, f);
 #pragma unroll 1
     for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, C.scaled == 3u ? f29_canonical_pack(f.load(e)) : f29_to_wire(f.load(e)));
@@ -405,20 +413,20 @@ __global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, Pos
 struct CoopTile {
     u32* base;  // [2][T][9][64]
     u32 T, lane;
-    AKP_D void put(u32 buf, u32 slot, const FU& v) const {
+    AKP_D void put(u32 buf, u32 slot, const FP& v) const {
 #pragma unroll
         for (int i = 0; i < 9; ++i) base[((buf * T + slot) * 9 + i) * 64 + lane] = v.l[i];
     }
-    AKP_D FU get(u32 buf, u32 slot) const {
-        FU v;
+    AKP_D FP get(u32 buf, u32 slot) const {
+        FP v;
 #pragma unroll
         for (int i = 0; i < 9; ++i) v.l[i] = base[((buf * T + slot) * 9 + i) * 64 + lane];
         return v;
     }
 };
 // sum_j published[j] * row[j], three terms per Montgomery reduction; result weakly normalised
-AKP_D FU coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ row) {
-    FU acc = f29_zero<false>();
+AKP_D FP coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ row) {
+    FP acc = f29_zero<AKP_PS>();
     u32 j = 0;
 #pragma unroll 1
     for (; j + 3 <= tile.T; j += 3)
@@ -428,7 +436,7 @@ AKP_D FU coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ 
     return f29_weak_norm(acc);
 }
 // one permutation; x is lane w of the state (weakly normalised in and out); buf is the tile buffer to use next
-AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C, const CoopTile& tile, u32 w, FU& x, u32& buf) {
+AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C, const CoopTile& tile, u32 w, FP& x, u32& buf) {
     const u32 T = D.t;
     const u32 half = D.full_rounds / 2;
     const u32 R = D.full_rounds + D.partial_rounds;
@@ -437,7 +445,7 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
     for (u32 r = 0; r < R; ++r) {
         const bool full = (r < half) || (r >= half + D.partial_rounds);
         if (full || !opt) {
-            x = f29_add(x, ldc(C.ark + (size_t)r * T + w));
+            x = f29_weak_norm(f29_add(x, ldc(C.ark + (size_t)r * T + w)));  // <= 2^29 + small: squaring / row-sum bound
             if (full || w == 0) x = f29_pow_small(x, D.alpha);
             tile.put(buf, w, x);
             __syncthreads();
@@ -447,14 +455,14 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;  // q0, a00, u_1..u_{T-1}, w_1..w_{T-1}
             if (w == 0) {
-                x = f29_pow_small(f29_add(x, ldc(sp)), D.alpha);
+                x = f29_pow_small(f29_weak_norm(f29_add(x, ldc(sp))), D.alpha);
                 tile.put(buf, 0, x);
             } else {
                 tile.put(buf, w, f29_mulc(x, ldc(sp + 1 + w)));
             }
             __syncthreads();
             if (w == 0) {
-                FU acc = (C.scaled == 1u && j + 1 < D.partial_rounds) ? x : f29_mulc(x, ldc(sp + 1));
+                FP acc = (C.scaled == 1u && j + 1 < D.partial_rounds) ? x : f29_mulc(x, ldc(sp + 1));
 #pragma unroll 1
                 for (u32 i = 1; i < T; ++i) {
                     acc = f29_add(acc, tile.get(buf, i));
@@ -463,7 +471,7 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
                 x = f29_weak_norm(acc);
             } else {
                 x = f29_add(x, f29_mulc(tile.get(buf, 0), ldc(sp + T + w)));
-                if ((j & 31u) == 31u) x = f29_mulc(x, f29_one<false>());
+                if ((j & 31u) == 31u) x = f29_mulc(x, f29_one<AKP_PS>());
                 else if ((j & 1u) || j + 1 == D.partial_rounds) x = f29_weak_norm(x);
             }
         }
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(1024) poseidon_permute_coop_kernel(PoseidonDim
     const CoopTile tile{reinterpret_cast<u32*>(smem), D.t, threadIdx.x & 63u};
     const size_t item = (size_t)blockIdx.x * 64 + tile.lane;
     const size_t idx = item < n ? item : n - 1;  // every lane walks all barriers; only valid items are stored
-    FU x = f29_weak_norm(f29_from_wire<false>(load_fr_global(states + idx * D.t + w)));
+    FP x = f29_weak_norm(f29_from_wire<AKP_PS>(load_fr_global(states + idx * D.t + w)));
     u32 buf = 0;
     poseidon_permute_coop(D, C, tile, w, x, buf);
     if (item < n) store_fr_global(states + item * D.t + w, f29_to_wire(x));
@@ -489,7 +497,7 @@ __global__ void __launch_bounds__(1024) poseidon_crh_coop_kernel(PoseidonDims D,
     const CoopTile tile{reinterpret_cast<u32*>(smem), D.t, threadIdx.x & 63u};
     const size_t item = (size_t)blockIdx.x * 64 + tile.lane;
     const size_t idx = item < n ? item : n - 1;
-    FU x = f29_zero<false>();
+    FP x = f29_zero<AKP_PS>();
     u32 buf = 0;
     size_t done = 0;
     do {
@@ -497,7 +505,7 @@ __global__ void __launch_bounds__(1024) poseidon_crh_coop_kernel(PoseidonDims D,
         if (w >= D.capacity && (size_t)(w - D.capacity) < take) {  // absorb_internal :124-153: state[capacity + j] += input
             const size_t e = done + (w - D.capacity);
             const Fr* src = (in1 == nullptr) ? (in0 + idx * k + e) : (e == 0 ? in0 + idx : in1 + idx);
-            x = f29_weak_norm(f29_add(x, f29_from_wire<false>(load_fr_global(src))));
+            x = f29_weak_norm(f29_add(x, f29_from_wire<AKP_PS>(load_fr_global(src))));
         }
         done += take;
         poseidon_permute_coop(D, C, tile, w, x, buf);

@@ -223,10 +223,39 @@ class MultiPath:
         return paths
 
     def verify(self, leaf_hash_params, two_to_one_params, root_hash, leaves) -> bool:
-        """:262-331.  The reference memoises shared nodes in a hash map; here every decoded path is
-        verified in one batched pass (same accept/reject result)."""
+        """:262-331 through akp_merkle_verify_multipath_*: the reference's memoisation (a node shared by several paths
+        is computed once, from the first path that reaches it), one hash launch per level over the distinct nodes."""
+        import ctypes as C
+        cfg = self.config
         leaves = list(leaves)
-        return all(verify_paths(self.config, leaf_hash_params, two_to_one_params, root_hash, self.decode_paths(), leaves))
+        m = len(self.leaf_indexes)
+        assert len(leaves) >= m, "one leaf per index"
+        depth = len(self.auth_paths_suffixes[0])
+        shp = cfg.digest_shape
+        idx = np.array(self.leaf_indexes, dtype=np.uint64)
+        sibs = np.ascontiguousarray(np.stack([np.asarray(x) for x in self.leaf_siblings_hashes]), dtype=np.uint64)
+        pre = np.array(self.auth_paths_prefix_lenghts, dtype=np.uint64)
+        flat = [np.asarray(d, dtype=np.uint64).reshape(shp) for sfx in self.auth_paths_suffixes for d in sfx]
+        suf = np.ascontiguousarray(np.stack(flat), dtype=np.uint64) if flat else np.zeros((0,) + shp, dtype=np.uint64)
+        root = np.ascontiguousarray(root_hash, dtype=np.uint64)
+        ok = C.c_int32(0)
+        if cfg is PoseidonFieldConfig:
+            lv = np.stack([np.ascontiguousarray(x, dtype=np.uint64) for x in leaves[:m]])
+            k = lv.size // (4 * m)
+            check(lib.akp_merkle_verify_multipath_poseidon(leaf_hash_params.handle().h, two_to_one_params.handle().h, root.ctypes.data,
+                                                           lv.ctypes.data, m, k, idx.ctypes.data, sibs.ctypes.data, pre.ctypes.data,
+                                                           suf.ctypes.data if len(flat) else None, len(flat), depth, C.byref(ok)))
+        else:
+            mm, _, L = _ped._as_msgs([bytes(x) if isinstance(x, (bytes, bytearray)) else np.asarray(x, dtype=np.uint8).tobytes() for x in leaves[:m]])
+            check(lib.akp_merkle_verify_multipath_te(leaf_hash_params.handle().h, two_to_one_params.handle().h, root.ctypes.data,
+                                                     mm.ctypes.data if mm.size else None, m, L, idx.ctypes.data, sibs.ctypes.data,
+                                                     pre.ctypes.data, suf.ctypes.data if len(flat) else None, len(flat), depth, C.byref(ok)))
+        return bool(ok.value)
+
+    def verify_each(self, leaf_hash_params, two_to_one_params, root_hash, leaves):
+        """every decoded path verified independently (no memoisation): batched Path::verify over the decoded paths"""
+        leaves = list(leaves)
+        return verify_paths(self.config, leaf_hash_params, two_to_one_params, root_hash, self.decode_paths(), leaves)
 
 
 class MerkleTree:
@@ -382,3 +411,197 @@ class MerkleTree:
         for node in path_bottom_to_top:
             cur = parent(cur)
             self.non_leaf_nodes[cur] = node
+
+
+class GpuMerkleTree:
+    """MerkleTree<P> (:383-726) RESIDENT IN HBM: the akp_merkle_tree handle of include/akp.h.  leaf_nodes / non_leaf_nodes
+    stay on the device; proofs, updates and the root are served from there (what a `GpuMerkleTree<P>` of the Rust shim
+    wraps).  `to_host()` materialises the reference's two vectors as a MerkleTree."""
+
+    def __init__(self, config, leaf_hash_param, two_to_one_hash_param, handle):
+        self.config = config
+        self.leaf_hash_param = leaf_hash_param
+        self.two_to_one_hash_param = two_to_one_hash_param
+        self._h = handle
+        import ctypes as C
+        n, fe, h = C.c_size_t(), C.c_uint32(), C.c_size_t()
+        check(lib.akp_merkle_tree_info(self._h, C.byref(n), C.byref(fe), C.byref(h)))
+        self.n_leaves, self._fe, self._height = n.value, fe.value, h.value
+
+    @staticmethod
+    def _leaf_array(config, leaves):
+        if config is PoseidonFieldConfig:
+            x = np.ascontiguousarray(leaves, dtype=np.uint64)
+            n = x.shape[0]
+            return x, n, (x.size // (4 * n) if n else 0)
+        return _ped._as_msgs(leaves)
+
+    @classmethod
+    def new(cls, config, leaf_hash_param, two_to_one_hash_param, leaves):
+        import ctypes as C
+        x, n, k = cls._leaf_array(config, leaves)
+        h = C.c_void_p()
+        fn = lib.akp_merkle_tree_build_poseidon if config is PoseidonFieldConfig else lib.akp_merkle_tree_build_te
+        check(fn(leaf_hash_param.handle().h, two_to_one_hash_param.handle().h, x.ctypes.data if x.size else None, n, k, C.byref(h)))
+        return cls(config, leaf_hash_param, two_to_one_hash_param, h)
+
+    @classmethod
+    def new_with_leaf_digest(cls, config, leaf_hash_param, two_to_one_hash_param, leaf_digests):
+        import ctypes as C
+        d = np.ascontiguousarray(leaf_digests, dtype=np.uint64).reshape((-1,) + config.digest_shape)
+        h = C.c_void_p()
+        fn = lib.akp_merkle_tree_from_digests_poseidon if config is PoseidonFieldConfig else lib.akp_merkle_tree_from_digests_te
+        check(fn(leaf_hash_param.handle().h, two_to_one_hash_param.handle().h, d.ctypes.data, len(d), C.byref(h)))
+        return cls(config, leaf_hash_param, two_to_one_hash_param, h)
+
+    @classmethod
+    def blank(cls, config, leaf_hash_param, two_to_one_hash_param, height):
+        d = config.default_leaf_digest()
+        return cls.new_with_leaf_digest(config, leaf_hash_param, two_to_one_hash_param, np.stack([d] * (1 << (height - 1))))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.akp_merkle_tree_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def root(self):
+        r = np.empty(self.config.digest_shape, dtype=np.uint64)
+        check(lib.akp_merkle_tree_root(self._h, r.ctypes.data))
+        return r
+
+    def height(self):
+        return self._height
+
+    def to_host(self) -> MerkleTree:
+        shp = self.config.digest_shape
+        ln = np.empty((self.n_leaves,) + shp, dtype=np.uint64)
+        nl = np.empty((self.n_leaves - 1,) + shp, dtype=np.uint64)
+        check(lib.akp_merkle_tree_export(self._h, ln.ctypes.data, nl.ctypes.data))
+        return MerkleTree(self.config, self.leaf_hash_param, self.two_to_one_hash_param, ln, nl)
+
+    def generate_proofs(self, indexes):
+        idx = np.ascontiguousarray(list(indexes), dtype=np.uint64)
+        m, shp, depth = len(idx), self.config.digest_shape, self._height - 2
+        sibs = np.empty((m,) + shp, dtype=np.uint64)
+        auth = np.empty((m, max(depth, 0)) + shp, dtype=np.uint64)
+        check(lib.akp_merkle_tree_gather_paths(self._h, idx.ctypes.data, m, sibs.ctypes.data, auth.ctypes.data if depth > 0 else None))
+        return [Path(self.config, sibs[i], [auth[i, j] for j in range(max(depth, 0))], int(idx[i])) for i in range(m)]
+
+    def generate_proof(self, index) -> Path:
+        return self.generate_proofs([index])[0]
+
+    def generate_multi_proof(self, indexes) -> MultiPath:
+        """:592-625: sorted, de-duplicated indexes; gather on the device, prefix_encode_path through the ABI."""
+        import ctypes as C
+        idxs = sorted(set(int(i) for i in indexes))
+        idx = np.array(idxs, dtype=np.uint64)
+        m, shp, depth = len(idx), self.config.digest_shape, self._height - 2
+        sibs = np.empty((m,) + shp, dtype=np.uint64)
+        auth = np.empty((m, max(depth, 0)) + shp, dtype=np.uint64)
+        check(lib.akp_merkle_tree_gather_paths(self._h, idx.ctypes.data, m, sibs.ctypes.data, auth.ctypes.data if depth > 0 else None))
+        pre = np.zeros(m, dtype=np.uint64)
+        suf = np.empty((m * max(depth, 0),) + shp, dtype=np.uint64)
+        cnt = C.c_size_t(0)
+        check(lib.akp_merkle_multipath_encode(auth.ctypes.data if depth > 0 else None, m, max(depth, 0), self._fe, pre.ctypes.data,
+                                              suf.ctypes.data if depth > 0 else None, C.byref(cnt)))
+        suffixes, o = [], 0
+        for i in range(m):
+            k = max(depth, 0) - int(pre[i])
+            suffixes.append([suf[o + j].copy() for j in range(k)])
+            o += k
+        assert o == cnt.value
+        return MultiPath(self.config, [sibs[i] for i in range(m)], [int(x) for x in pre], suffixes, idxs)
+
+    def update_batch(self, indices, new_leaves):
+        idx = np.ascontiguousarray(list(indices), dtype=np.uint64)
+        x, n, k = self._leaf_array(self.config, new_leaves)
+        assert n == len(idx), "one leaf per index"
+        check(lib.akp_merkle_tree_update_batch(self._h, idx.ctypes.data, x.ctypes.data if x.size else None, n, k))
+
+    def update(self, index, new_leaf):  # :692-702
+        self.update_batch([index], [new_leaf] if self.config is not PoseidonFieldConfig else np.asarray(new_leaf, dtype=np.uint64)[None])
+
+    def check_update(self, index, new_leaf, asserted_new_root) -> bool:  # :707-725
+        import ctypes as C
+        x, _, k = self._leaf_array(self.config, [new_leaf] if self.config is not PoseidonFieldConfig else np.asarray(new_leaf, dtype=np.uint64)[None])
+        root = np.ascontiguousarray(asserted_new_root, dtype=np.uint64)
+        ok = C.c_int32(0)
+        check(lib.akp_merkle_tree_check_update(self._h, int(index), x.ctypes.data if x.size else None, k, root.ctypes.data, C.byref(ok)))
+        return bool(ok.value)
+
+
+class MultiGpu:
+    """akp_multi: the GPUs of one node driven from one process, with the RCCL communicator inside the product library."""
+
+    def __init__(self, device_ids):
+        import ctypes as C
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        check(lib.akp_multi_create(ids, len(device_ids), C.byref(h)))
+        self._h = h
+        self._ctxs = {}
+        self._param_owners = []
+        self.size = lib.akp_multi_size(h)
+
+    def ctx(self, i):
+        from ._lib import Context
+        import ctypes as C
+        if i not in self._ctxs:
+            c = Context.__new__(Context)
+            c.h = C.c_void_p(lib.akp_multi_ctx(self._h, i))
+            c.device_id = None
+            c.close = lambda: None  # owned by the akp_multi handle
+            self._ctxs[i] = c
+        return self._ctxs[i]
+
+    def build_sharded(self, config, leaf_hash_param, two_to_one_hash_param, leaves, want_nodes=True):
+        """MerkleTree::new (:411-523) over all devices: akp_merkle_build_sharded_{poseidon,te}.  Returns
+        (leaf_nodes, non_leaf_nodes, root) in the reference's global heap order (nodes None when want_nodes is False)."""
+        import ctypes as C
+        G = self.size
+        lh = [leaf_hash_param.handle(self.ctx(r)) for r in range(G)]
+        th = [two_to_one_hash_param.handle(self.ctx(r)) for r in range(G)]
+        for cfg in (leaf_hash_param, two_to_one_hash_param):  # destroyed with this object, before their contexts
+            if not any(cfg is c for c in self._param_owners):
+                self._param_owners.append(cfg)
+        la = (C.c_void_p * G)(*[h.h for h in lh])
+        ta = (C.c_void_p * G)(*[h.h for h in th])
+        shp = config.digest_shape
+        if config is PoseidonFieldConfig:
+            x = np.ascontiguousarray(leaves, dtype=np.uint64)
+            n = x.shape[0]
+            k = x.size // (4 * n) if n else 0
+            fn = lib.akp_merkle_build_sharded_poseidon
+        else:
+            x, n, k = _ped._as_msgs(leaves)
+            fn = lib.akp_merkle_build_sharded_te
+        ln = np.empty((n,) + shp, dtype=np.uint64) if want_nodes else None
+        nl = np.empty((max(n - 1, 0),) + shp, dtype=np.uint64) if want_nodes else None
+        root = np.empty(shp, dtype=np.uint64)
+        check(fn(self._h, la, ta, x.ctypes.data if x.size else None, n, k, ln.ctypes.data if want_nodes else None,
+                 nl.ctypes.data if want_nodes else None, root.ctypes.data))
+        return ln, nl, root
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for cfg in self._param_owners:  # parameter handles created on our contexts go first
+                for c in self._ctxs.values():
+                    hobj = cfg._handles.pop(id(c), None)
+                    if hobj is not None:
+                        hobj.__del__()
+            self._param_owners.clear()
+            self._ctxs.clear()
+            lib.akp_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

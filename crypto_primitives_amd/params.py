@@ -2,9 +2,16 @@
 
 The reference's `setup` draws bases with `C::rand(rng)` (crh/pedersen/mod.rs:48-56,
 crh/bowe_hopwood/mod.rs:45-59); that stream depends on ark-std/ark-ec and cannot be reproduced,
-and `Parameters.generators` is a public field, so generators are treated as DATA: here they are
-G_i = k_i * G for SplitMix64-derived scalars k_i, then the per-scheme multiples.  One-off, host-only
-python big-int (the hash evaluation itself never runs here).
+and `Parameters.generators` is a public field, so generators are treated as DATA.  Two seeded procedures:
+
+  * `setup_*_generators` (what `CRH::setup` / `Commitment::setup` use): bases sampled the way ark-ec samples a random
+    twisted-Edwards point -- random y, sign bit, solve for x, clear the cofactor -- so NO discrete-log relation between
+    the bases is known and the hashes are collision resistant / the commitment binding;
+  * `pedersen_generators` / `bowe_hopwood_generators`: G_i = k_i * G for SplitMix64-derived scalars k_i.  Cheap and
+    handy as synthetic benchmark / test data, but the k_i are public, so collisions can be computed: TEST DATA ONLY,
+    never parameters for real use.
+
+One-off, host-only python big-int (the hash evaluation itself never runs here).
 """
 import numpy as np
 
@@ -76,9 +83,59 @@ def _bases(seed, n):
     return out
 
 
-def _generators(seed, window_size, num_windows, doublings_per_step):
+def _sqrt(a):
+    """Tonelli-Shanks in Fq (q - 1 = 2^32 * odd); None for a non-residue"""
+    a %= Q
+    if a == 0:
+        return 0
+    if pow(a, (Q - 1) // 2, Q) != 1:
+        return None
+    s, t = 32, (Q - 1) >> 32
+    z = 2
+    while pow(z, (Q - 1) // 2, Q) == 1:
+        z += 1
+    m, c, tt, r = s, pow(z, t, Q), pow(a, t, Q), pow(a, (t + 1) // 2, Q)
+    while tt != 1:
+        i, u = 0, tt
+        while u != 1:
+            u, i = u * u % Q, i + 1
+        b = pow(c, 1 << (m - i - 1), Q)
+        m, c = i, b * b % Q
+        tt, r = tt * c % Q, r * b % Q
+    return r
+
+
+def _bases_unknown_dlog(seed, n):
+    """ark-ec's `rand` for a twisted-Edwards group, driven by SplitMix64(seed): y uniform, one sign bit,
+    x^2 = (y^2 - 1) / (1 + d y^2) (retry without a root), times the cofactor 8.  Projective points."""
+    g = _splitmix(seed)
+    out = []
+    while len(out) < n:
+        while True:
+            v = 0
+            for i in range(4):
+                v |= next(g) << (64 * i)
+            v &= (1 << 255) - 1
+            if v < Q:
+                break
+        y, greatest = v, next(g) & 1
+        y2 = y * y % Q
+        x = _sqrt((y2 - 1) * pow(1 + _D * y2, -1, Q))
+        if x is None:
+            continue
+        if (x > Q - x) != bool(greatest):
+            x = (Q - x) % Q
+        pt = (x, y, 1)
+        for _ in range(3):
+            pt = _padd(pt, pt)
+        if pt[0] % Q != 0:  # not the identity (0 : 1 : 1)
+            out.append(pt)
+    return out
+
+
+def _generators(seed, window_size, num_windows, doublings_per_step, bases=None):
     pts = []
-    for base in _bases(seed, num_windows):
+    for base in (bases or _bases)(seed, num_windows):
         cur = base
         for _ in range(window_size):
             pts.append(_affine(cur))
@@ -89,10 +146,21 @@ def _generators(seed, window_size, num_windows, doublings_per_step):
 
 
 def pedersen_generators(seed, window_size, num_windows) -> np.ndarray:
-    """generators[i][j] = 2^j * G_i (shape of crh/pedersen/mod.rs:40-56) -> [N, W, 2, 4] wire format."""
+    """TEST / BENCH DATA (known discrete logs): generators[i][j] = 2^j * (k_i G) -> [N, W, 2, 4] wire format."""
     return _generators(seed, window_size, num_windows, 1)
 
 
 def bowe_hopwood_generators(seed, window_size, num_windows) -> np.ndarray:
-    """generators[i][j] = 16^j * G_i (crh/bowe_hopwood/mod.rs:45-59)."""
+    """TEST / BENCH DATA (known discrete logs): generators[i][j] = 16^j * (k_i G)."""
     return _generators(seed, window_size, num_windows, 4)
+
+
+def setup_pedersen_generators(seed, window_size, num_windows) -> np.ndarray:
+    """pedersen::CRH::setup (crh/pedersen/mod.rs:40-56): generators[i][j] = 2^j * G_i, G_i random points with unknown
+    discrete logs (see the module docstring)."""
+    return _generators(seed, window_size, num_windows, 1, _bases_unknown_dlog)
+
+
+def setup_bowe_hopwood_generators(seed, window_size, num_windows) -> np.ndarray:
+    """bowe_hopwood::CRH::setup (crh/bowe_hopwood/mod.rs:45-59): generators[i][j] = 16^j * G_i, G_i as above."""
+    return _generators(seed, window_size, num_windows, 4, _bases_unknown_dlog)

@@ -23,7 +23,11 @@
  *     only enqueue work and never synchronise -- this is the zero-copy path used when inputs are
  *     already resident in HBM (bench.py, torch tensors' data_ptr()).
  *   - Ownership: the caller owns every buffer it passes; the library owns parameter handles and
- *     its scratch.  A context is not thread-safe; distinct contexts are independent.
+ *     its scratch.  A context (and everything created on it) is not thread-safe: calls that share a
+ *     context must be serialised by the caller (the Rust shim keeps one context per thread or a
+ *     mutex); distinct contexts are independent and may be used concurrently.
+ *     Within one context, calls on DIFFERENT streams are ordered by the library where they share
+ *     its scratch (event record + stream wait; nothing blocks on the host).
  *   - Errors mirror the reference: a length the reference would panic on
  *     (crh/pedersen/mod.rs:82-89, crh/bowe_hopwood/mod.rs:121-129) returns AKP_ERR_BAD_LENGTH;
  *     a leaf count that is not a power of two > 1 (merkle_tree/mod.rs:430-433) returns
@@ -44,15 +48,17 @@ extern "C" {
 #define AKP_ERR_BAD_LENGTH 1 /* lib.rs:47-52 Error::IncorrectInputLength / length panics */
 #define AKP_ERR_BAD_PARAMS 2
 #define AKP_ERR_HIP 3
-#define AKP_ERR_RCCL 4 /* reserved: collectives are driven by the host layer (torch.distributed / RCCL) */
+#define AKP_ERR_RCCL 4 /* RCCL could not be loaded / a collective of the multi-device entry points failed */
 #define AKP_ERR_NOT_POW2 5
 
-#define AKP_ABI_VERSION 1
+#define AKP_ABI_VERSION 2
 
 typedef struct akp_ctx akp_ctx;
 typedef struct akp_poseidon akp_poseidon; /* PoseidonConfig<Fr>, sponge/poseidon/mod.rs:27-45 */
 typedef struct akp_te_params akp_te_params; /* pedersen::Parameters / bowe_hopwood::Parameters */
 typedef struct akp_sponge akp_sponge;     /* batch of PoseidonSponge<Fr>, sponge/poseidon/mod.rs:54-63 */
+typedef struct akp_merkle_tree akp_merkle_tree; /* MerkleTree<P> resident in HBM, merkle_tree/mod.rs:383-396 */
+typedef struct akp_multi akp_multi;       /* the GPUs of one node driven from one process + their RCCL communicator */
 
 int32_t akp_abi_version(void);
 const char* akp_last_error(void);
@@ -63,6 +69,16 @@ int32_t akp_device_count(void);
 int32_t akp_ctx_create(int32_t device_id, akp_ctx** out);
 void akp_ctx_destroy(akp_ctx* ctx);
 int32_t akp_ctx_synchronize(akp_ctx* ctx);
+
+/* ---- pinned host memory (optional) ----------------------------------------------------------- */
+/* The host-pointer entry points accept any host memory.  Batches larger than one chunk (2^18 items) are cut
+ * into chunks whose copy-in / kernel / copy-out overlap on three streams; with pageable memory the copies
+ * are staged by the runtime and block the calling thread, with memory from akp_host_alloc (or registered
+ * with akp_host_register) they stream at PCIe speed in both directions at once. */
+int32_t akp_host_alloc(size_t bytes, void** out);
+int32_t akp_host_free(void* p);
+int32_t akp_host_register(void* p, size_t bytes);
+int32_t akp_host_unregister(void* p);
 
 /* ---- field helpers (host side, no device needed) ------------------------------------------ */
 /* canonical little-endian integers (must be < p) <-> Montgomery wire format; n elements */
@@ -102,6 +118,11 @@ int32_t akp_poseidon_two_to_one_batch(akp_poseidon* p, const uint64_t* left, con
                                       uint64_t* out);
 int32_t akp_poseidon_two_to_one_batch_dev(akp_poseidon* p, const uint64_t* d_left, const uint64_t* d_right, size_t n,
                                           uint64_t* d_out, void* stream);
+
+/* name of the kernel a batch of n items is routed to (crh = 0: permutation, 1: CRH / two-to-one / tree level): the
+ * t = 3 register kernels above 2^15 items, the wave-per-lane latency kernels below, the LDS-file kernels for t != 3.
+ * Lets a parity check state which kernel it exercised.  Static string. */
+const char* akp_poseidon_kernel_for(const akp_poseidon* p, size_t n, int32_t crh);
 
 /* ---- batched duplex sponge (CryptographicSponge / FieldBasedCryptographicSponge) ------------ */
 /* `batch` independent PoseidonSponge<Fr> instances that follow the same absorb/squeeze schedule
@@ -199,6 +220,85 @@ int32_t akp_merkle_verify_paths_te(akp_te_params* leaf_params, akp_te_params* tw
                                    const uint8_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indices,
                                    const uint64_t* leaf_sibling_hashes, const uint64_t* auth_paths, size_t depth,
                                    uint8_t* ok_out);
+
+
+/* ---- Merkle tree resident in HBM (MerkleTree<P>, merkle_tree/mod.rs:383-725) ------------------------------------ */
+/* MerkleTree::new (:411-422): the two node vectors stay in device memory (leaf_nodes[n], non_leaf_nodes[n-1] in
+ * heap order); the host asks for what it needs (root, proofs, the vectors).  The parameter handles must outlive
+ * the tree.  leaves: n x leaf_len Fr (Poseidon) / n x leaf_len bytes (Pedersen, Bowe-Hopwood). */
+int32_t akp_merkle_tree_build_poseidon(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* leaves,
+                                       size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
+int32_t akp_merkle_tree_build_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* leaves,
+                                 size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
+/* MerkleTree::new_with_leaf_digest (:424-523); with all-default digests this is MerkleTree::blank (:400-408).
+ * leaf_digests: n_leaves digests (1 Fr; 2 Fr for Pedersen). */
+int32_t akp_merkle_tree_from_digests_poseidon(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params,
+                                              const uint64_t* leaf_digests, size_t n_leaves, akp_merkle_tree** out);
+int32_t akp_merkle_tree_from_digests_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params,
+                                        const uint64_t* leaf_digests, size_t n_leaves, akp_merkle_tree** out);
+void akp_merkle_tree_destroy(akp_merkle_tree* t);
+/* n_leaves, Fr per digest, height() (:531-533); any out pointer may be NULL */
+int32_t akp_merkle_tree_info(const akp_merkle_tree* t, size_t* n_leaves, uint32_t* fe_per_digest, size_t* height);
+/* MerkleTree::root (:526-528) */
+int32_t akp_merkle_tree_root(akp_merkle_tree* t, uint64_t* root_out);
+/* copies of leaf_nodes / non_leaf_nodes (what GpuMerkleTree<P> hands to code that reads the reference's fields);
+ * either may be NULL */
+int32_t akp_merkle_tree_export(akp_merkle_tree* t, uint64_t* leaf_nodes, uint64_t* non_leaf_nodes);
+/* device addresses of the two vectors (valid until the tree is destroyed), for the `_dev` entry points */
+int32_t akp_merkle_tree_device_ptrs(akp_merkle_tree* t, uint64_t** d_leaf_nodes, uint64_t** d_non_leaf_nodes);
+/* MerkleTree::generate_proof (:572-579) for m leaf indices: leaf_sibling_hashes [m], auth_paths [m][log2(n) - 1]
+ * (root side first) */
+int32_t akp_merkle_tree_gather_paths(akp_merkle_tree* t, const uint64_t* leaf_indices, size_t m,
+                                     uint64_t* leaf_sibling_hashes, uint64_t* auth_paths);
+/* MerkleTree::update (:692-702), batched: equal to update(leaf_indices[k], new_leaves[k]) for k = 0..m-1 in order (a
+ * repeated index keeps its last leaf); every level is one hash launch over the distinct touched nodes.  An index out
+ * of range (the reference asserts) is AKP_ERR_BAD_PARAMS and leaves the tree untouched. */
+int32_t akp_merkle_tree_update_batch(akp_merkle_tree* t, const uint64_t* leaf_indices, const void* new_leaves, size_t m,
+                                     size_t leaf_len);
+/* MerkleTree::check_update (:707-725): *ok = 1 and the tree is updated iff the new root equals asserted_new_root;
+ * otherwise *ok = 0 and the tree is unchanged. */
+int32_t akp_merkle_tree_check_update(akp_merkle_tree* t, uint64_t leaf_index, const void* new_leaf, size_t leaf_len,
+                                     const uint64_t* asserted_new_root, int32_t* ok);
+
+/* ---- MultiPath (merkle_tree/mod.rs:215-331, 592-625, 795-817) ------------------------------------------------------ */
+/* prefix_encode_path (:795-805) over m dense auth paths [m][depth] digests (in the order of the sorted, de-duplicated
+ * leaf indexes of generate_multi_proof): prefix_lengths [m], suffixes concatenated (capacity m * depth digests),
+ * *n_suffix_digests = digests written.  Host only. */
+int32_t akp_merkle_multipath_encode(const uint64_t* auth_paths, size_t m, size_t depth, uint32_t fe_per_digest,
+                                    uint64_t* prefix_lengths, uint64_t* suffixes, size_t* n_suffix_digests);
+/* prefix_decode_path (:807-817): the inverse.  Host only. */
+int32_t akp_merkle_multipath_decode(const uint64_t* prefix_lengths, const uint64_t* suffixes, size_t n_suffix_digests, size_t m,
+                                    size_t depth, uint32_t fe_per_digest, uint64_t* auth_paths);
+/* MultiPath::verify (:262-331): leaves in the order of leaf_indexes; depth = auth_paths_suffixes[0].len().  *ok = 1 iff
+ * the paths lead to `root`, with the reference's memoisation (a tree node shared by several paths is computed once,
+ * from the first path that reaches it); each level is one hash launch over the distinct nodes. */
+int32_t akp_merkle_verify_multipath_poseidon(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* root,
+                                             const uint64_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indexes,
+                                             const uint64_t* leaf_siblings_hashes, const uint64_t* prefix_lengths,
+                                             const uint64_t* suffixes, size_t n_suffix_digests, size_t depth, int32_t* ok);
+int32_t akp_merkle_verify_multipath_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint64_t* root,
+                                       const uint8_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indexes,
+                                       const uint64_t* leaf_siblings_hashes, const uint64_t* prefix_lengths,
+                                       const uint64_t* suffixes, size_t n_suffix_digests, size_t depth, int32_t* ok);
+
+/* ---- several GPUs from one process (merkle_tree/mod.rs:411-523 sharded by leaf range) -------- */
+/* akp_ctx_create for n_dev devices (a power of two, distinct ids) + ncclCommInitAll over them.  RCCL is loaded with
+ * dlopen on first use (librccl.so.1; AKP_RCCL_LIB overrides): AKP_ERR_RCCL when it is missing or fails. */
+int32_t akp_multi_create(const int32_t* device_ids, int32_t n_dev, akp_multi** out);
+void akp_multi_destroy(akp_multi* m);
+int32_t akp_multi_size(const akp_multi* m);
+/* context of device slot i (owned by m): create that device's parameter handles on it */
+akp_ctx* akp_multi_ctx(akp_multi* m, int32_t i);
+/* MerkleTree::new over all devices of m: device r hashes leaves [r n/G, (r+1) n/G) into its own sub-tree, ONE
+ * ncclAllGather moves the G sub-roots (xGMI), every device computes the top G-1 nodes.  leaf_params[r] and
+ * two_to_one_params[r] are handles created on akp_multi_ctx(m, r).  Host buffers and outputs exactly as
+ * akp_merkle_build_poseidon / akp_merkle_build_te (global heap order; outputs may be NULL). */
+int32_t akp_merkle_build_sharded_poseidon(akp_multi* m, akp_poseidon* const* leaf_params, akp_poseidon* const* two_to_one_params,
+                                          const uint64_t* leaves, size_t n_leaves, size_t leaf_len, uint64_t* leaf_nodes,
+                                          uint64_t* non_leaf_nodes, uint64_t* root_out);
+int32_t akp_merkle_build_sharded_te(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
+                                    const uint8_t* leaves, size_t n_leaves, size_t leaf_len, uint64_t* leaf_nodes,
+                                    uint64_t* non_leaf_nodes, uint64_t* root_out);
 
 #ifdef __cplusplus
 }

@@ -104,7 +104,8 @@ def fq_serialize(x: int) -> bytes:
 
 # ---- seeded generators: generators are INPUT DATA -----------
 def seeded_bases(seed: int, n: int):
-    """G_i = k_i * G with k_i = SplitMix64-derived scalar mod r (k_i != 0)."""
+    """G_i = k_i * G with k_i = SplitMix64-derived scalar mod r (k_i != 0).  TEST DATA ONLY: the discrete logs between
+    these bases are known, so hashes over them are not collision resistant; `random_bases` is what `setup` uses."""
     rng = SplitMix64(seed)
     out = []
     for _ in range(n):
@@ -115,10 +116,56 @@ def seeded_bases(seed: int, n: int):
     return out
 
 
-def pedersen_generators(seed: int, window_size: int, num_windows: int):
+def fq_sqrt(a: int):
+    """square root in Fq by Tonelli-Shanks (q - 1 = 2^32 * odd), or None for a non-residue"""
+    a %= Q
+    if a == 0:
+        return 0
+    if pow(a, (Q - 1) // 2, Q) != 1:
+        return None
+    s, t = 0, Q - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 2
+    while pow(z, (Q - 1) // 2, Q) == 1:
+        z += 1
+    m, c, tt, r = s, pow(z, t, Q), pow(a, t, Q), pow(a, (t + 1) // 2, Q)
+    while tt != 1:
+        i, u = 0, tt
+        while u != 1:
+            u, i = u * u % Q, i + 1
+        b = pow(c, 1 << (m - i - 1), Q)
+        m, c = i, b * b % Q
+        tt, r = tt * c % Q, r * b % Q
+    return r
+
+
+def random_bases(seed: int, n: int):
+    """Bases with NO known discrete-log relation, the way ark-ec samples `C::rand(rng)` for a twisted-Edwards group
+    (crh/pedersen/mod.rs:50, crh/bowe_hopwood/mod.rs:49): draw y and a sign bit, solve the curve equation for x
+    (x^2 = (y^2 - 1) / (1 + d y^2)), retry when there is no root, clear the cofactor.  The draws come from SplitMix64(seed)
+    (the reference's rng stream is not reproducible), so the result is a public, checkable function of the seed."""
+    rng = SplitMix64(seed)
+    out = []
+    while len(out) < n:
+        y = rng.fr()
+        greatest = rng.next() & 1
+        y2 = y * y % Q
+        x = fq_sqrt((y2 - 1) * pow(1 + D * y2, -1, Q))
+        if x is None:
+            continue
+        if (x > Q - x) != bool(greatest):
+            x = (Q - x) % Q
+        pt = mul((x, y), COFACTOR)
+        if pt != IDENTITY:
+            out.append(pt)
+    return out
+
+
+def pedersen_generators(seed: int, window_size: int, num_windows: int, bases=seeded_bases):
     """shape of crh/pedersen/mod.rs:40-56: generators[i][j] = 2^j * G_i."""
     gens = []
-    for base in seeded_bases(seed, num_windows):
+    for base in bases(seed, num_windows):
         row = []
         cur = base
         for _ in range(window_size):
@@ -128,10 +175,10 @@ def pedersen_generators(seed: int, window_size: int, num_windows: int):
     return gens
 
 
-def bowe_hopwood_generators(seed: int, window_size: int, num_windows: int):
+def bowe_hopwood_generators(seed: int, window_size: int, num_windows: int, bases=seeded_bases):
     """shape of crh/bowe_hopwood/mod.rs:45-59: generators[i][j] = 16^j * G_i."""
     gens = []
-    for base in seeded_bases(seed, num_windows):
+    for base in bases(seed, num_windows):
         row = []
         cur = base
         for _ in range(window_size):

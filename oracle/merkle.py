@@ -136,6 +136,46 @@ class MerkleTree:
                 return False
         return True
 
+    def verify_multi_memo(self, mp, root, leaves):
+        """MultiPath::verify exactly as written (:262-331), INCLUDING its hash look-up table keyed by the node's index in
+        the tree: a node reached by several paths is computed once, from the first of them, and later paths reuse that
+        value without hashing their own children."""
+        tree_height = len(mp["auth_paths_suffixes"][0]) + 2
+        lut = {}
+        prev = list(mp["auth_paths_suffixes"][0])
+        for i, leaf_index in enumerate(mp["leaf_indexes"]):
+            k = mp["auth_paths_prefix_lenghts"][i]
+            auth = (prev[:k] if k else []) + list(mp["auth_paths_suffixes"][i])  # prefix_decode_path :807-817
+            prev = auth
+            claimed = self.leaf_hash(leaves[i])
+            sib = mp["leaf_siblings_hashes"][i]
+            l, r = (claimed, sib) if leaf_index & 1 == 0 else (sib, claimed)
+            index = leaf_index >> 1
+            index_in_tree = parent(convert_index_to_last_level(leaf_index, tree_height))
+            if index_in_tree not in lut:
+                lut[index_in_tree] = self.t_eval(self.convert(l), self.convert(r))
+            cur = lut[index_in_tree]
+            for level in range(len(auth) - 1, -1, -1):
+                l, r = (cur, auth[level]) if index & 1 == 0 else (auth[level], cur)
+                index >>= 1
+                index_in_tree = parent(index_in_tree)
+                if index_in_tree not in lut:
+                    lut[index_in_tree] = self.t_comp(l, r)
+                cur = lut[index_in_tree]
+            if cur != root:
+                return False
+        return True
+
+    def check_update(self, index, new_leaf, asserted_new_root):  # :707-725
+        import copy
+        trial = copy.copy(self)
+        trial.leaf_nodes, trial.non_leaf_nodes = list(self.leaf_nodes), list(self.non_leaf_nodes)
+        trial.update(index, new_leaf)
+        if trial.non_leaf_nodes[0] != asserted_new_root:
+            return False
+        self.leaf_nodes, self.non_leaf_nodes = trial.leaf_nodes, trial.non_leaf_nodes
+        return True
+
     def update(self, index, new_leaf):  # :629-702
         assert index < len(self.leaf_nodes)
         new_hash = self.leaf_hash(new_leaf)

@@ -15,14 +15,14 @@
 using namespace akp;
 
 struct HostFile {
-    FU* slots;
-    FU load(u32 s) const { return slots[s]; }
-    void store(u32 s, const FU& v) const { slots[s] = v; }
+    FP* slots;
+    FP load(u32 s) const { return slots[s]; }
+    void store(u32 s, const FP& v) const { slots[s] = v; }
 };
 // wire-format parameter arrays -> internal form (what poseidon_convert_params_kernel does on the device)
 static std::vector<F29Pad> to29(const Fr* in, size_t n) {
     std::vector<F29Pad> out(n);
-    for (size_t i = 0; i < n; ++i) f29_store_pad(&out[i], f29_from_wire<false>(in[i]));
+    for (size_t i = 0; i < n; ++i) f29_store_pad(&out[i], f29_from_wire<AKP_PS>(in[i]));
     return out;
 }
 // force_generic: 0 = product default (t == 3: register path, else LDS-file path; sparse partial rounds),
@@ -115,7 +115,7 @@ void hh_f29_inv(const Fr* a, const Fr* b, Fr* o) {
 // returns a*b/2^261 mod p canonical for FU (limbs given), and for FS.
 void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int is_signed, Fr* o) {
     if (is_signed) { FS x, y; for (int i = 0; i < 9; ++i) { x.l[i] = (int32_t)al[i]; y.l[i] = (int32_t)bl[i]; }
-        o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); }
+        o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
     else { FU x, y; for (int i = 0; i < 9; ++i) { x.l[i] = al[i]; y.l[i] = bl[i]; }
         o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
 }
@@ -123,15 +123,15 @@ void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int is_signed, Fr* o
 void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
                          Fr* states, size_t n, int force_generic) {
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
-    std::vector<FU> buf(2 * D.t);
+    std::vector<FP> buf(2 * D.t);
     HostFile f{buf.data()};
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
     for (size_t i = 0; i < n; ++i) {
         if (reg_path) {  // the register-resident fast path
-            FU s0 = f29_from_wire<false>(states[i * 3]), s1 = f29_from_wire<false>(states[i * 3 + 1]), s2 = f29_from_wire<false>(states[i * 3 + 2]);
+            FP s0 = f29_from_wire<AKP_PS>(states[i * 3]), s1 = f29_from_wire<AKP_PS>(states[i * 3 + 1]), s2 = f29_from_wire<AKP_PS>(states[i * 3 + 2]);
             if (th->creg.scaled == 3u) {  // as poseidon_permute_t3_kernel<true>: the lanes are the wire values
-                s0 = f29_unpack<false>(states[i * 3]); s1 = f29_unpack<false>(states[i * 3 + 1]); s2 = f29_unpack<false>(states[i * 3 + 2]);
+                s0 = f29_unpack<AKP_PS>(states[i * 3]); s1 = f29_unpack<AKP_PS>(states[i * 3 + 1]); s2 = f29_unpack<AKP_PS>(states[i * 3 + 2]);
                 poseidon_permute_t3<true>(D, th->creg, s0, s1, s2);
                 states[i * 3] = f29_canonical_pack(s0); states[i * 3 + 1] = f29_canonical_pack(s1); states[i * 3 + 2] = f29_canonical_pack(s2);
                 continue;
@@ -141,7 +141,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             continue;
         }
         const bool wire = th->cfile.scaled == 3u;  // as poseidon_permute_kernel
-        for (u32 e = 0; e < D.t; ++e) f.store(e, wire ? f29_unpack<false>(states[i * D.t + e]) : f29_from_wire<false>(states[i * D.t + e]));
+        for (u32 e = 0; e < D.t; ++e) f.store(e, wire ? f29_unpack<AKP_PS>(states[i * D.t + e]) : f29_from_wire<AKP_PS>(states[i * D.t + e]));
         poseidon_permute_file(D, th->cfile, f);
         for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = wire ? f29_canonical_pack(f.load(e)) : f29_to_wire(f.load(e));
     }
@@ -155,7 +155,7 @@ int hh_poseidon_forms(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, u
 void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,
                      const Fr* in0, const Fr* in1, size_t k, Fr* out, size_t n, int force_generic) {
     PoseidonDims D = mk(rf, rp, alpha, rate, cap);
-    std::vector<FU> buf(2 * D.t);
+    std::vector<FP> buf(2 * D.t);
     HostFile f{buf.data()};
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} declared in include/akp.h but not exported"
     # and the python binding declares prototypes for exactly that set
     assert sorted(cpa._lib.DECLARED_SYMBOLS) == syms
-    assert cpa.lib.akp_abi_version() == 1
+    assert cpa.lib.akp_abi_version() == cpa._lib.AKP_ABI_VERSION == 2
 
 
 def test_product_never_imports_oracle():
@@ -34,7 +34,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "crypto_primitives_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".inc")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
                 assert not re.search(r"#\s*include\s*[\"<][^\">]*oracle", txt), f
@@ -118,6 +118,68 @@ def test_seeded_generators_equal_oracle(derived):
     gb = params.bowe_hopwood_generators(0xA5A50005, 3, 2)
     gbo = jj.bowe_hopwood_generators(0xA5A50005, 3, 2)
     assert field.to_ints(gb) == [v for row in gbo for pt in row for v in pt]
+
+
+def test_setup_generators_have_no_known_dlog_and_equal_oracle():
+    """`setup()` must not produce bases k_i * G with public k_i.  The product samples points like ark-ec's
+    `rand` (random y, sign, solve for x, clear the cofactor); the oracle restates the procedure independently."""
+    from crypto_primitives_amd import params, field
+    from oracle import jubjub as jj
+    g = params.setup_pedersen_generators(5, 4, 3)
+    go = jj.pedersen_generators(5, 4, 3, bases=jj.random_bases)
+    assert field.to_ints(g) == [v for row in go for pt in row for v in pt]
+    gb = params.setup_bowe_hopwood_generators(6, 3, 2)
+    gbo = jj.bowe_hopwood_generators(6, 3, 2, bases=jj.random_bases)
+    assert field.to_ints(gb) == [v for row in gbo for pt in row for v in pt]
+    for row in go:
+        assert jj.is_on_curve(row[0]) and jj.mul(row[0], jj.SUBGROUP_ORDER) == jj.IDENTITY and row[0] != jj.IDENTITY  # prime-order subgroup
+        assert row[1] == jj.double(row[0])
+    # not the test-data bases, and not a small multiple of the standard generator
+    assert go[0][0] != jj.pedersen_generators(5, 4, 3)[0][0]
+    assert all(jj.mul(jj.GENERATOR, k) != go[0][0] for k in range(1, 64))
+    r = jj.fq_sqrt(1234567 ** 2 % jj.Q)
+    assert r in (1234567, jj.Q - 1234567) and jj.fq_sqrt(jj.D) is None  # d is a non-square (completeness of the addition law)
+
+
+def test_multipath_encode_decode_host(derived):
+    """prefix_encode_path / prefix_decode_path (merkle_tree/mod.rs:795-817) through the ABI, no GPU"""
+    import ctypes as C
+    import crypto_primitives_amd as cpa
+    rng = np.random.default_rng(3)
+    m, depth = 6, 4
+    auth = rng.integers(0, 1 << 62, size=(m, depth, 4), dtype=np.uint64)
+    auth[1, :2] = auth[0, :2]
+    auth[2] = auth[1]
+    auth[4, :3] = auth[3, :3]
+    pre = np.zeros(m, np.uint64)
+    suf = np.zeros((m * depth, 4), np.uint64)
+    cnt = C.c_size_t()
+    assert cpa.lib.akp_merkle_multipath_encode(auth.ctypes.data, m, depth, 1, pre.ctypes.data, suf.ctypes.data, C.byref(cnt)) == 0
+    assert pre.tolist() == [0, 2, 4, 0, 3, 0] and cnt.value == 4 + 2 + 0 + 4 + 1 + 4
+    back = np.zeros_like(auth)
+    assert cpa.lib.akp_merkle_multipath_decode(pre.ctypes.data, suf.ctypes.data, cnt.value, m, depth, 1, back.ctypes.data) == 0
+    assert np.array_equal(back, auth)
+    assert cpa.lib.akp_merkle_multipath_decode(pre.ctypes.data, suf.ctypes.data, cnt.value - 1, m, depth, 1, back.ctypes.data) == 2
+    pre[0] = 1  # the first path has nothing to share a prefix with
+    assert cpa.lib.akp_merkle_multipath_decode(pre.ctypes.data, suf.ctypes.data, cnt.value, m, depth, 1, back.ctypes.data) == 2
+
+
+def test_multi_device_and_tree_entry_points_fail_loudly_without_gpu():
+    import ctypes as C
+    import crypto_primitives_amd as cpa
+    if cpa.lib.akp_device_count() > 0:
+        pytest.skip("a device is present")
+    ids = (C.c_int32 * 1)(0)
+    h = C.c_void_p()
+    assert cpa.lib.akp_multi_create(ids, 1, C.byref(h)) == cpa._lib.AKP_ERR_HIP
+    cfg = cpa.get_default_poseidon_parameters(2, False)
+    hp = C.c_void_p()
+    cpa._lib.check(cpa.lib.akp_poseidon_default_params(None, 2, 0, C.byref(hp)))
+    leaves = np.zeros((4, 4), np.uint64)
+    t = C.c_void_p()
+    assert cpa.lib.akp_merkle_tree_build_poseidon(hp, hp, leaves.ctypes.data, 4, 1, C.byref(t)) == cpa._lib.AKP_ERR_HIP
+    assert cpa.lib.akp_poseidon_kernel_for(hp, 1 << 20, 0) == b"none"
+    cpa.lib.akp_poseidon_params_destroy(hp)
 
 
 def test_gather_paths_host_matches_oracle_indexing():

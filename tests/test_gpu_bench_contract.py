@@ -1,5 +1,6 @@
-"""bench.py contract on a GPU box: one JSON line with the required keys, also when launched through
-torch.distributed.run (world size 1 exercises the nccl init / barrier / all-gather code path)."""
+"""bench.py contract on a GPU box: one JSON line with the required keys -- single process, under torch.distributed.run
+(world size 1 exercises the nccl init / barrier / all-gather code path), with several ranks sharing the one GPU, and
+self-launched from a plain `python bench.py --gpus 2`."""
 import json
 import os
 import subprocess
@@ -11,6 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline"}
+SMALL = ["--log2-states", "16", "--merkle-log2", "12", "--pedersen-log2", "10", "--bh-merkle-log2", "9", "--sustain-seconds", "0.2",
+         "--sustain-log2-big", "0"]
 
 
 def _check(out):
@@ -18,34 +21,41 @@ def _check(out):
     d = json.loads(line)
     assert REQUIRED <= set(d), REQUIRED - set(d)
     assert d["parity_probe_bit_exact"] is True and d["value"] > 1e6
+    assert d["parity"]["timed_buffer_states_checked"] >= 256  # the probe reads the buffer the timed kernel wrote
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert 0.5 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 2.0
+    assert r["kernel"] == d["parity"]["probe_kernel"] and "static_from" in " ".join(r.keys())
     return d
 
 
 def test_bench_single_process():
-    p = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--log2-states", "16", "--merkle-log2", "12",
-                        "--cpu-seconds", "0.5"], cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5"] + SMALL,
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
     d = _check(p.stdout)
-    assert d["n_gpus"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["n_gpus"] == 1 and d["roofline"]["kernel"] == "poseidon_permute_t3_kernel<true>"  # 2^16 states: the register kernel
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["rate_1_thread"] > 0 and cb["effective_cores"] > 0.5 and cb["cpu_model"]
+    assert d["pedersen"]["sampled_parity_bit_exact"] and d["bh_merkle"]["sampled_parity_bit_exact"] and d["merkle"]["sampled_parity_bit_exact"]
+    assert d["bh_merkle"]["leaves"] == 512 and d["pedersen"]["roofline"]["frac"] > 0
+    assert d["host_path"]["pinned"]["permutations_per_s"] > 0 and d["sustained"]["2^16"]["launches"] >= 8
 
 
 def test_bench_under_torchrun_world1():
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29531", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2-states", "14",
-                        "--merkle-log2", "10", "--bh-merkle-log2", "8", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--master-port", "29531", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"]
+                       + SMALL, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
     d = _check(p.stdout)
-    assert d["n_gpus"] == 1 and "merkle" in d and d["bh_merkle"]["leaves"] == 256
+    assert d["n_gpus"] == 1 and "merkle" in d and d["bh_merkle"]["leaves"] == 512 and d["launch"]["backend"].startswith("nccl")
 
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_multi_rank_code_path_on_one_gpu(world):
     """The N > 1 branch of bench.py (rank env, barriers, MAX-reduced timing, sharded Merkle legs, rank-0 printing) with
     `world` ranks sharing GPU 0 and gloo carrying the collectives (AKP_BENCH_SHARED_GPU=1, a test hook)."""
-    args = ["--steps", "2", "--warmup", "1", "--log2-states", "14", "--merkle-log2", "12", "--bh-merkle-log2", "10", "--no-cpu-baseline"]
+    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"] + SMALL
+    args[args.index("--log2-states") + 1] = "14"
     env = dict(os.environ, AKP_BENCH_SHARED_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                         "127.0.0.1", "--master-port", str(29540 + world), "bench.py", "--gpus", str(world)] + args,
@@ -53,5 +63,24 @@ def test_bench_multi_rank_code_path_on_one_gpu(world):
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
     d = _check(p.stdout)
     assert d["n_gpus"] == world and d["config"]["states_per_gpu"] == 1 << 14 and "cpu_baseline" not in d
-    assert d["merkle"]["leaves"] == 1 << 12 and d["bh_merkle"]["leaves"] == 1 << 10
+    assert d["merkle"]["leaves"] == 1 << 12 and d["bh_merkle"]["leaves"] == world << 9 and d["bh_merkle"]["scaling"] == "weak"
+    assert d["launch"]["ranks"] == world and len(d["launch"]["rank_devices"]) == world
     assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1  # rank 0 only
+
+
+def test_bench_self_launches_ranks_from_plain_python():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start two ranks itself (the driver launched N = 1 that way);
+    here both share GPU 0 through the test hook."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AKP_BENCH_SHARED_GPU"] = "1"
+    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"] + SMALL
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + args, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    d = _check(p.stdout)
+    assert d["n_gpus"] == 2 and d["launch"]["ranks"] == 2
+    # and it refuses when the devices are not there (no hook): 1-GPU box, 2 ranks asked
+    env.pop("AKP_BENCH_SHARED_GPU")
+    import torch
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + args, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode != 0 and "only 1 HIP device" in (p.stderr + p.stdout)

@@ -158,11 +158,11 @@ def test_setup_generators(cpa):
     class W(pedersen.Window):
         WINDOW_SIZE, NUM_WINDOWS = 4, 8
     P = pedersen.CRH.setup(W, seed=5)
-    go = jj.pedersen_generators(5, 4, 8)
+    go = jj.pedersen_generators(5, 4, 8, bases=jj.random_bases)
     assert field.to_ints(P.generators) == [v for row in go for pt in row for v in pt]
     assert tuple(field.to_ints(pedersen.CRH.evaluate(P, bytes([0xff, 1, 2, 3])))) == opd.evaluate(go, 4, 8, bytes([0xff, 1, 2, 3]))
     B = bowe_hopwood.CRH.setup(W, seed=6)
-    gb = jj.bowe_hopwood_generators(6, 4, 8)
+    gb = jj.bowe_hopwood_generators(6, 4, 8, bases=jj.random_bases)
     assert field.to_ints(bowe_hopwood.CRH.evaluate(B, bytes(range(12))))[0] == obh.evaluate(gb, 4, 8, bytes(range(12)))
 
 

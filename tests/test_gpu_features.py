@@ -22,9 +22,8 @@ def test_pedersen_commitment_vs_oracle(cpa):
     class W(pedersen.Window):
         WINDOW_SIZE, NUM_WINDOWS = 4, 16  # 64-bit inputs
     P = cped.Commitment.setup(W, seed=9)
-    g = jj.pedersen_generators(9, 4, 16)
-    rg = [row[0] for row in jj.pedersen_generators(9 ^ 0x5EED, 252, 1)][0:1]
-    rg = jj.pedersen_generators(9 ^ 0x5EED, 252, 1)[0]  # 252 doubling powers of one base
+    g = jj.pedersen_generators(9, 4, 16, bases=jj.random_bases)
+    rg = jj.pedersen_generators(9 ^ 0x5EED, 252, 1, bases=jj.random_bases)[0]  # 252 doubling powers of one base
     assert ints(P.randomness_generator[3]) == list(rg[3])
     rng = ofr.SplitMix64(4)
     msgs = [rng.bytes(8), rng.bytes(8), bytes(8), rng.bytes(5)]

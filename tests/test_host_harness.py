@@ -129,8 +129,25 @@ def test_f29_worst_case_limbs(H):
         va, vb = val(a, True), val(b, True)
         got = ofr.canon_array_to_ints(O)
         assert got[0] == va * vb * Rinv % p
-        if max(abs(val([x], True)) for x in a) <= M29 + 1:  # squares need |limb| <= 2^29.7
+        if max(abs(val([x], True)) for x in a) <= M29 + 1:  # squares of signed limbs need |limb| <= 2^29.7
             assert got[1] == va * va * Rinv % p
+    # the Poseidon kernels run in the signed flavour (round 2): S-box inputs are non-negative with limbs 0..7 <= 2^30 - 1
+    # and a small top limb (normalised value + normalised round key): column 7 of the square reaches 2^63 - 2^31;
+    # the linear layers take limbs <= 2^29 + small against normalised constants (27 * 2^58)
+    T27 = (1 << 26) - 1  # |value| < 2^258
+    for a, b, chk_sqr, chk_dot in [([M30] * 8 + [T27], [M29] * 8 + [T], True, False), ([M30] * 8 + [neg(T27)], [M29] * 8 + [neg(T)], True, False),
+                                   ([M29 + 9] * 8 + [T], [M29] * 8 + [T], True, True), ([M29 + 9] * 8 + [neg(T)], [M29] * 8 + [neg(T)], True, True),
+                                   ([M30] * 8 + [T27], [0] * 9, True, False)]:
+        A, B = np.array(a, np.uint32), np.array(b, np.uint32)
+        O = np.zeros((3, 4), np.uint64)
+        H.hh_f29_raw_mul(P(A), P(B), 1, P(O))
+        va, vb = val(a, True), val(b, True)
+        got = ofr.canon_array_to_ints(O)
+        assert got[0] == va * vb * Rinv % p
+        if chk_sqr:
+            assert got[1] == va * va * Rinv % p
+        if chk_dot:
+            assert got[2] == 3 * va * vb * Rinv % p
 
 
 @pytest.mark.parametrize("generic", [0, 1, 2])  # 0 = t3 sparse (default), 1 = generic LDS-file path, 2 = t3 dense
