@@ -74,8 +74,8 @@ struct akp_ctx {
     // pinned staging for small host<->device transfers of the tree / proof entry points
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
-    // two more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
-    hipStream_t pipe[2] = {};
+    // more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
+    hipStream_t pipe[7] = {};
 };
 // scratch slot `slot` with at least `bytes`, to be used on stream `s`: if the previous use was enqueued on a different
 // stream, `s` first waits for it (event record + stream wait; nothing blocks on the host)
@@ -126,7 +126,7 @@ extern "C" void akp_ctx_destroy(akp_ctx* c) {
         if (c->slot_event[i]) (void)hipEventDestroy(c->slot_event[i]);
     }
     if (c->pinned) (void)hipHostFree(c->pinned);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 7; ++i)
         if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -177,11 +177,14 @@ template <class Launch>
 static int32_t pipelined_batch(akp_ctx* c, size_t n, const HostIn* ins, int n_in, void* host_out, size_t out_bytes_per_item, int out_slot,
                                Launch launch /* (void* const* d_in, void* d_out, size_t count, hipStream_t) */) {
     static const size_t chunk_items = (size_t)1 << env_u32("AKP_HOST_CHUNK_LOG2", 18, 10, 30);
-    for (int i = 0; i < 2; ++i)
+    static const int max_lanes = (int)env_u32("AKP_HOST_LANES", 3, 1, 8);
+    hipStream_t st[8] = {c->stream};
+    for (int i = 0; i + 1 < max_lanes; ++i) {
         if (!c->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking));
-    hipStream_t st[3] = {c->stream, c->pipe[0], c->pipe[1]};
+        st[i + 1] = c->pipe[i];
+    }
     const size_t chunk = std::min(n, chunk_items);
-    const int lanes = n > chunk ? 3 : 1;
+    const int lanes = n > chunk ? max_lanes : 1;
     void* d_in[2] = {nullptr, nullptr};
     void* d_out = nullptr;
     for (int k = 0; k < n_in; ++k)

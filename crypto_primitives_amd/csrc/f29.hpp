@@ -91,6 +91,8 @@ AKP_F29_CONST(f29_k_out, 0x1ffffffeu, 0x0000000fu, 0x00d20080u, 0x096ff400u, 0x0
 AKP_F29_CONST(f29_te_d, 0x0e9ed5e8u, 0x12245679u, 0x002d9f52u, 0x03bb3367u, 0x0d9bfb3du, 0x18ebb3ccu, 0x1c29ceccu, 0x0a7b6020u, 0x0020d725u)
 // 2^522 mod p: plain integer -> internal representation in one product
 AKP_F29_CONST(f29_r2, 0x0a71b3c0u, 0x1d32207eu, 0x1663d999u, 0x1c5abc93u, 0x03b58c44u, 0x0be37438u, 0x0829f771u, 0x1660139eu, 0x0027fd91u)
+AKP_F29_CONST(f29_16p, 0x00000010u, 0x1fffff80u, 0x196ffbffu, 0x14805fffu, 0x180553bdu, 0x00404d0eu, 0x120cce76u, 0x06533afau, 0x073eda75u)
+AKP_F29_CONST(f29_8p, 0x00000008u, 0x1fffffc0u, 0x1cb7fdffu, 0x1a402fffu, 0x0c02a9deu, 0x00202687u, 0x0906673bu, 0x13299d7du, 0x039f6d3au)
 AKP_F29_CONST(f29_4p, 0x00000004u, 0x1fffffe0u, 0x1e5bfeffu, 0x0d2017ffu, 0x160154efu, 0x10101343u, 0x1483339du, 0x0994cebeu, 0x01cfb69du)
 AKP_F29_CONST(f29_2p, 0x00000002u, 0x1ffffff0u, 0x1f2dff7fu, 0x16900bffu, 0x1b00aa77u, 0x180809a1u, 0x0a4199ceu, 0x14ca675fu, 0x00e7db4eu)
 AKP_F29_CONST(f29_p, 0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u)
@@ -373,16 +375,17 @@ template <bool S>
 AKP_HD F29T<S> f29_from_wire(const Fr& w) {
     return f29_mulc(f29_unpack<S>(w), f29_k_in<S>());
 }
-// canonical representative in [0, p) of a value with |v| < 4p (FS) / 0 <= v < 8p (FU), as 8 x u32
-template <bool S>
+// canonical representative in [0, p) of a value with |v| < 4p (FS) / 0 <= v < 8p (FU), as 8 x u32.
+// WIDE: |v| < 16p (FS) / 0 <= v < 32p (FU) -- sums of several reduced terms (the rows of a wide linear layer).
+template <bool S, bool WIDE = false>
 AKP_HD Fr f29_canonical_pack(const F29T<S>& a) {
-    // 1. make non-negative, 2. exact carry propagation, 3. subtract 4p, 2p, p where possible, 4. re-limb
+    // 1. make non-negative, 2. exact carry propagation, 3. subtract 16p, 8p (wide), 4p, 2p, p where possible, 4. re-limb
     int32_t v[9];
     int32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         int32_t x = (int32_t)a.l[i] + c;
-        if (S) x += (int32_t)f29_4p<false>().l[i];
+        if (S) x += (int32_t)(WIDE ? f29_16p<false>().l[i] : f29_4p<false>().l[i]);
         if (i < 8) {
             v[i] = (int32_t)((u32)x & AKP_MASK29);
             c = x >> 29;
@@ -391,8 +394,8 @@ AKP_HD Fr f29_canonical_pack(const F29T<S>& a) {
         }
     }
 #pragma unroll
-    for (int step = 0; step < 3; ++step) {
-        const FU sub = step == 0 ? f29_4p<false>() : (step == 1 ? f29_2p<false>() : f29_p<false>());
+    for (int step = WIDE ? 0 : 2; step < 5; ++step) {
+        const FU sub = step == 0 ? f29_16p<false>() : (step == 1 ? f29_8p<false>() : (step == 2 ? f29_4p<false>() : (step == 3 ? f29_2p<false>() : f29_p<false>())));
         int32_t d[9];
         int32_t bw = 0;
 #pragma unroll

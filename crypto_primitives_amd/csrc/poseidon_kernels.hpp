@@ -253,46 +253,60 @@ struct LdsFile29 {
 // `File` is LdsFile29<BLOCK> on the device; tests/host_harness instantiates it with a plain array.
 // sum_j state[src + j] * row[j] over j in [0, T), 3 terms per Montgomery reduction; `first` (if non-null) replaces
 // the lane-0 operand (the freshly S-boxed element of a sparse partial round).  Result weakly normalised.
+// Sums of several normalised terms in signed 32-bit limbs: at most three terms (3 * 2^29 < 2^31) may be pending, so the
+// running sum is renormalised before a third term is added (`pending` counts the terms since the last carry step).
+#define AKP_ROW_ADD(term)                          \
+    do {                                           \
+        if (pending == 2u) {                       \
+            acc = f29_weak_norm(acc);              \
+            pending = 1u;                          \
+        }                                          \
+        acc = f29_add(acc, (term));                \
+        ++pending;                                 \
+    } while (0)
 template <class File>
 AKP_HD FP poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restrict__ row, const FP* first) {
     FP acc = f29_zero<AKP_PS>();
+    u32 pending = 0;
     u32 j = 0;
 #pragma unroll 1
     for (; j + 3 <= T; j += 3) {
         const FP a0 = (first && j == 0) ? *first : f.load(src + j);
-        acc = f29_add(acc, f29_dot3(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1), f.load(src + j + 2), ldc(row + j + 2)));
+        AKP_ROW_ADD(f29_dot3(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1), f.load(src + j + 2), ldc(row + j + 2)));
     }
     if (j + 2 == T) {  // two terms left: one reduction
         const FP a0 = (first && j == 0) ? *first : f.load(src + j);
-        acc = f29_add(acc, f29_dot2(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1)));
+        AKP_ROW_ADD(f29_dot2(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1)));
     } else if (j < T) {
         const FP a0 = (first && j == 0) ? *first : f.load(src + j);
-        acc = f29_add(acc, f29_mulc(a0, ldc(row + j)));
+        AKP_ROW_ADD(f29_mulc(a0, ldc(row + j)));
     }
-    return f29_weak_norm(acc);  // <= 6 normalised terms summed: back below 2^29 + 8
+    return f29_weak_norm(acc);  // <= 2^29 + 2
 }
 // the same sum without term `skip` (full form: that coefficient is 1 and the element is added by the caller).
-// `first` (if non-null) stands for state[0], as above.  Result NOT normalised (the caller adds and normalises).
+// `first` (if non-null) stands for state[0], as above.  Result NOT normalised: at most two terms pending (<= 2^30 + 2), the
+// caller adds one more and normalises.
 template <class File>
 AKP_HD FP poseidon_row_dot_skip(const File& f, u32 T, const F29Pad* __restrict__ row, u32 skip, const FP* first) {
     FP acc = f29_zero<AKP_PS>();
+    u32 pending = 0;
     u32 c = 0;  // running index over the T - 1 remaining terms
 #pragma unroll 1
     for (; c + 3 <= T - 1; c += 3) {
         const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip), j2 = c + 2 + (c + 2 >= skip);
         const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
-        acc = f29_add(acc, f29_dot3(a0, ldc(row + j0), f.load(j1), ldc(row + j1), f.load(j2), ldc(row + j2)));
+        AKP_ROW_ADD(f29_dot3(a0, ldc(row + j0), f.load(j1), ldc(row + j1), f.load(j2), ldc(row + j2)));
     }
     if (c + 2 == T - 1) {  // two terms left: one reduction
         const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip);
         const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
-        acc = f29_add(acc, f29_dot2(a0, ldc(row + j0), f.load(j1), ldc(row + j1)));
+        AKP_ROW_ADD(f29_dot2(a0, ldc(row + j0), f.load(j1), ldc(row + j1)));
     } else if (c < T - 1) {
         const u32 j0 = c + (c >= skip);
         const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
-        acc = f29_add(acc, f29_mulc(a0, ldc(row + j0)));
+        AKP_ROW_ADD(f29_mulc(a0, ldc(row + j0)));
     }
-    return acc;  // <= 6 normalised terms
+    return acc;
 }
 #define AKP_POSEIDON_MAX_T 16
 // The state occupies slots [0, t) of the file.  Sparse partial rounds update it in place; a dense layer needs all
@@ -373,7 +387,8 @@ AKP_HD Fr poseidon_crh_item(const PoseidonDims& D, const PoseidonConsts& C, cons
         done += take;
         poseidon_permute_file(D, C, f);
     } while (done < k);
-    return C.scaled == 3u ? f29_canonical_pack(f.load(D.capacity)) : f29_to_wire(f.load(D.capacity));
+    // full form: the lane is a row sum of up to six reduced terms (|v| < 16p): the wide canonicalisation
+    return C.scaled == 3u ? f29_canonical_pack<AKP_PS, true>(f.load(D.capacity)) : f29_to_wire(f.load(D.capacity));
 }
 
 template <int BLOCK>
@@ -387,7 +402,7 @@ __global__ void __launch_bounds__(BLOCK) poseidon_permute_kernel(PoseidonDims D,
     for (u32 e = 0; e < D.t; ++e) f.store(e, C.scaled == 3u ? f29_unpack<AKP_PS>(load_fr_global(st + e)) : f29_from_wire<AKP_PS>(load_fr_global(st + e)));
     poseidon_permute_file(D, C, f);
 #pragma unroll 1
-    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, C.scaled == 3u ? f29_canonical_pack(f.load(e)) : f29_to_wire(f.load(e)));
+    for (u32 e = 0; e < D.t; ++e) store_fr_global(st + e, C.scaled == 3u ? f29_canonical_pack<AKP_PS, true>(f.load(e)) : f29_to_wire(f.load(e)));
 }
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, PoseidonConsts C, const Fr* __restrict__ in0,
@@ -427,12 +442,13 @@ struct CoopTile {
 // sum_j published[j] * row[j], three terms per Montgomery reduction; result weakly normalised
 AKP_D FP coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ row) {
     FP acc = f29_zero<AKP_PS>();
+    u32 pending = 0;
     u32 j = 0;
 #pragma unroll 1
     for (; j + 3 <= tile.T; j += 3)
-        acc = f29_add(acc, f29_dot3(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1), tile.get(buf, j + 2), ldc(row + j + 2)));
-    if (j + 2 == tile.T) acc = f29_add(acc, f29_dot2(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1)));
-    else if (j < tile.T) acc = f29_add(acc, f29_mulc(tile.get(buf, j), ldc(row + j)));
+        AKP_ROW_ADD(f29_dot3(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1), tile.get(buf, j + 2), ldc(row + j + 2)));
+    if (j + 2 == tile.T) AKP_ROW_ADD(f29_dot2(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1)));
+    else if (j < tile.T) AKP_ROW_ADD(f29_mulc(tile.get(buf, j), ldc(row + j)));
     return f29_weak_norm(acc);
 }
 // one permutation; x is lane w of the state (weakly normalised in and out); buf is the tile buffer to use next
@@ -463,11 +479,9 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
             __syncthreads();
             if (w == 0) {
                 FP acc = (C.scaled == 1u && j + 1 < D.partial_rounds) ? x : f29_mulc(x, ldc(sp + 1));
+                u32 pending = 1;
 #pragma unroll 1
-                for (u32 i = 1; i < T; ++i) {
-                    acc = f29_add(acc, tile.get(buf, i));
-                    if ((i & 3u) == 3u) acc = f29_weak_norm(acc);  // <= 4 normalised terms between renormalisations
-                }
+                for (u32 i = 1; i < T; ++i) AKP_ROW_ADD(tile.get(buf, i));  // signed limbs: at most three terms pending
                 x = f29_weak_norm(acc);
             } else {
                 x = f29_add(x, f29_mulc(tile.get(buf, 0), ldc(sp + T + w)));

@@ -1,0 +1,119 @@
+//! Per-thread device contexts, the wire-format check and error mapping.
+use crate::ffi;
+use crate::{Error, Fr};
+use ark_ff::{BigInt, PrimeField};
+use ark_std::{cell::RefCell, collections::BTreeMap, string::String, vec::Vec};
+use core::ffi::CStr;
+
+/// `Fr` must be 4 x u64 Montgomery limbs (`Fp(BigInt([u64; 4]), PhantomData)`), byte-identical to the ABI's wire
+/// format.  ark-ff does not promise this layout, so it is asserted once per thread before any pointer cast.
+pub fn layout_check() {
+    assert_eq!(core::mem::size_of::<Fr>(), 32, "ark-ff changed the in-memory layout of Fp256");
+    assert_eq!(core::mem::align_of::<Fr>(), 8);
+    let one = Fr::from(1u64);
+    // R mod p for BLS12-381 Fr
+    assert_eq!((one.0).0, [0x0000_0001_ffff_fffe, 0x5884_b7fa_0003_4802, 0x998c_4fef_ecbc_4ff5, 0x1824_b159_acc5_056f]);
+    // and the library agrees: canonical 1 -> Montgomery through the ABI
+    let canon = [1u64, 0, 0, 0];
+    let mut mont = [0u64; 4];
+    let rc = unsafe { ffi::akp_fr_to_mont(canon.as_ptr(), mont.as_mut_ptr(), 1) };
+    assert!(rc == ffi::AKP_OK && mont == (one.0).0, "libakp.so wire format differs from ark-ff's Fp256");
+    assert_eq!(unsafe { ffi::akp_abi_version() }, ffi::AKP_ABI_VERSION, "libakp.so ABI version mismatch");
+}
+
+#[inline]
+pub fn words(v: &[Fr]) -> *const u64 {
+    v.as_ptr() as *const u64
+}
+#[inline]
+pub fn words_mut(v: &mut [Fr]) -> *mut u64 {
+    v.as_mut_ptr() as *mut u64
+}
+#[inline]
+pub fn fr_from_limbs(l: [u64; 4]) -> Fr {
+    Fr::new_unchecked(BigInt::new(l)) // the limbs are already the Montgomery representation
+}
+
+#[derive(Debug)]
+pub struct AkpError(pub i32, pub String);
+impl core::fmt::Display for AkpError {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        write!(f, "libakp status {}: {}", self.0, self.1)
+    }
+}
+impl ark_std::error::Error for AkpError {}
+
+/// status code -> the reference's `Error` (`lib.rs:47-52`).  `len` is what `IncorrectInputLength` reports.
+pub fn check(rc: i32, len: usize) -> Result<(), Error> {
+    if rc == ffi::AKP_OK {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(ffi::akp_last_error()) }.to_string_lossy().into_owned();
+    match rc {
+        // the reference panics on these lengths (crh/pedersen/mod.rs:82-89, crh/bowe_hopwood/mod.rs:121-129);
+        // Poseidon has no length limit
+        ffi::AKP_ERR_BAD_LENGTH => Err(Error::IncorrectInputLength(len)),
+        // merkle_tree/mod.rs:430-433 asserts: keep the panic so callers see the reference's behaviour
+        ffi::AKP_ERR_NOT_POW2 => panic!("`leaves.len() should be power of two and greater than one"),
+        _ => Err(Error::GenericError(Box::new(AkpError(rc, msg)))),
+    }
+}
+
+/// One context per OS thread + the parameter handles created on it, keyed by a fingerprint of the parameter contents
+/// (the traits hand us `&Parameters` on every call and a handle owns device tables worth tens of MB).
+pub struct ThreadRuntime {
+    pub ctx: *mut ffi::AkpCtx,
+    pub poseidon: BTreeMap<u64, *mut ffi::AkpPoseidon>,
+    pub te: BTreeMap<(i32, u64), *mut ffi::AkpTeParams>,
+}
+impl ThreadRuntime {
+    fn new() -> Self {
+        layout_check();
+        let dev: i32 = std::env::var("AKP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+        let mut ctx = core::ptr::null_mut();
+        let rc = unsafe { ffi::akp_ctx_create(dev, &mut ctx) };
+        assert_eq!(rc, ffi::AKP_OK, "akp_ctx_create({dev}) failed: there is no CPU fallback");
+        Self { ctx, poseidon: BTreeMap::new(), te: BTreeMap::new() }
+    }
+}
+impl Drop for ThreadRuntime {
+    fn drop(&mut self) {
+        unsafe {
+            for (_, h) in self.poseidon.iter() {
+                ffi::akp_poseidon_params_destroy(*h);
+            }
+            for (_, h) in self.te.iter() {
+                ffi::akp_te_params_destroy(*h);
+            }
+            ffi::akp_ctx_destroy(self.ctx);
+        }
+    }
+}
+thread_local! {
+    static RT: RefCell<Option<ThreadRuntime>> = const { RefCell::new(None) };
+}
+/// run `f` with this thread's runtime (created on first use)
+pub fn with_runtime<R>(f: impl FnOnce(&mut ThreadRuntime) -> R) -> R {
+    RT.with(|cell| {
+        let mut slot = cell.borrow_mut();
+        f(slot.get_or_insert_with(ThreadRuntime::new))
+    })
+}
+
+/// FNV-1a over the limbs of field elements (cheap fingerprint for the handle caches)
+pub fn fingerprint<'a>(seed: u64, elems: impl Iterator<Item = &'a Fr>) -> u64 {
+    let mut h = 0xcbf2_9ce4_8422_2325u64 ^ seed;
+    for e in elems {
+        for w in (e.0).0 {
+            h = (h ^ w).wrapping_mul(0x0000_0100_0000_01b3);
+        }
+    }
+    h
+}
+
+/// flatten `Vec<Vec<Fr>>` (ark, mds) row-major
+pub fn flatten(m: &[Vec<Fr>]) -> Vec<Fr> {
+    m.iter().flat_map(|r| r.iter().copied()).collect()
+}
+#[allow(dead_code)]
+fn _assert_prime_field<F: PrimeField>() {}

@@ -143,7 +143,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
         const bool wire = th->cfile.scaled == 3u;  // as poseidon_permute_kernel
         for (u32 e = 0; e < D.t; ++e) f.store(e, wire ? f29_unpack<AKP_PS>(states[i * D.t + e]) : f29_from_wire<AKP_PS>(states[i * D.t + e]));
         poseidon_permute_file(D, th->cfile, f);
-        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = wire ? f29_canonical_pack(f.load(e)) : f29_to_wire(f.load(e));
+        for (u32 e = 0; e < D.t; ++e) states[i * D.t + e] = wire ? f29_canonical_pack<AKP_PS, true>(f.load(e)) : f29_to_wire(f.load(e));
     }
     delete th;
 }

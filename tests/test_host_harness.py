@@ -150,6 +150,23 @@ def test_f29_worst_case_limbs(H):
             assert got[2] == 3 * va * vb * Rinv % p
 
 
+@pytest.mark.parametrize("rate,cap,rf,rp,alpha", [(12, 4, 2, 3, 3), (15, 1, 4, 9, 5), (9, 1, 4, 5, 5)])
+def test_poseidon_wide_states_row_sums(H, rate, cap, rf, rp, alpha):
+    """t = 10, 16: a row of the linear layer is a sum of up to six reduced chunks -- in the signed flavour at most three may
+    be pending in a 32-bit limb (the round-2 GPU run caught an overflow here that no CPU test covered)"""
+    import ctypes as C
+    t = rate + cap
+    mds = [rand_fr(t, 300 + i + t) for i in range(t)]
+    ark = [rand_fr(t, 500 + r) for r in range(rf + rp)]
+    c = po.PoseidonConfig(rf, rp, alpha, ark, mds, rate, cap)
+    A, M = mont([x for r in ark for x in r]), mont([x for r in mds for x in r])
+    sts = [rand_fr(t, 70 + i) for i in range(2)]
+    for generic in (0, 2):
+        S = mont([x for s in sts for x in s])
+        H.hh_poseidon_permute(rf, rp, alpha, rate, cap, P(A), P(M), P(S), 2, generic)
+        assert ints(S) == [x for s in sts for x in po.permute(c, s)], (t, generic)
+
+
 @pytest.mark.parametrize("generic", [0, 1, 2])  # 0 = t3 sparse (default), 1 = generic LDS-file path, 2 = t3 dense
 @pytest.mark.parametrize("rate,weights", [(2, False), (3, False), (8, False), (2, True), (5, True)])
 def test_poseidon_round_code(H, rate, weights, generic):
