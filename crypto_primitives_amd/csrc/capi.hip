@@ -177,7 +177,7 @@ template <class Launch>
 static int32_t pipelined_batch(akp_ctx* c, size_t n, const HostIn* ins, int n_in, void* host_out, size_t out_bytes_per_item, int out_slot,
                                Launch launch /* (void* const* d_in, void* d_out, size_t count, hipStream_t) */) {
     static const size_t chunk_items = (size_t)1 << env_u32("AKP_HOST_CHUNK_LOG2", 18, 10, 30);
-    static const int max_lanes = (int)env_u32("AKP_HOST_LANES", 3, 1, 8);
+    static const int max_lanes = (int)env_u32("AKP_HOST_LANES", 3, 3, 8);  // >= depth + 1 buffers in flight
     hipStream_t st[8] = {c->stream};
     for (int i = 0; i + 1 < max_lanes; ++i) {
         if (!c->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking));
@@ -192,21 +192,32 @@ static int32_t pipelined_batch(akp_ctx* c, size_t n, const HostIn* ins, int n_in
     const bool in_place = out_slot < 0;  // the output overwrites input 0 (permutation)
     if (!in_place)
         if (int32_t rc = ctx_scratch(c, out_slot, lanes * chunk * out_bytes_per_item, &d_out, c->stream)) return rc;
-    size_t done = 0;
-    for (size_t ci = 0; done < n; ++ci) {
-        const size_t cnt = std::min(chunk, n - done);
-        const int lane = (int)(ci % lanes);
-        hipStream_t s = st[lane];
-        void* di[2];
-        for (int k = 0; k < n_in; ++k) {
-            di[k] = (char*)d_in[k] + (size_t)lane * chunk * ins[k].bytes_per_item;
-            if (ins[k].bytes_per_item)
-                HIP_TRY(hipMemcpyAsync(di[k], (const char*)ins[k].host + done * ins[k].bytes_per_item, cnt * ins[k].bytes_per_item, hipMemcpyHostToDevice, s));
+    // Submission order matters: the runtime feeds the copies of all streams to the copy engines in the order they were
+    // issued, and a copy-out that still waits for its kernel blocks the copies queued behind it (measured: rocprofv3
+    // --memory-copy-trace, profiles/r02_s3).  So the copy-out of chunk i is issued only after the copy-in and kernel of
+    // chunk i + 2: by the time the engine reaches it, its kernel has finished.
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    const size_t depth = 2;
+    void* di[2];
+    for (size_t ci = 0; ci < n_chunks + depth; ++ci) {
+        if (ci < n_chunks) {
+            const size_t done = ci * chunk, cnt = std::min(chunk, n - done);
+            const int lane = (int)(ci % lanes);
+            hipStream_t s = st[lane];
+            for (int k = 0; k < n_in; ++k) {
+                di[k] = (char*)d_in[k] + (size_t)lane * chunk * ins[k].bytes_per_item;
+                if (ins[k].bytes_per_item)
+                    HIP_TRY(hipMemcpyAsync(di[k], (const char*)ins[k].host + done * ins[k].bytes_per_item, cnt * ins[k].bytes_per_item, hipMemcpyHostToDevice, s));
+            }
+            void* dout = in_place ? di[0] : (char*)d_out + (size_t)lane * chunk * out_bytes_per_item;
+            if (int32_t rc = launch(di, dout, cnt, s)) return rc;
         }
-        void* dout = in_place ? di[0] : (char*)d_out + (size_t)lane * chunk * out_bytes_per_item;
-        if (int32_t rc = launch(di, dout, cnt, s)) return rc;
-        HIP_TRY(hipMemcpyAsync((char*)host_out + done * out_bytes_per_item, dout, cnt * out_bytes_per_item, hipMemcpyDeviceToHost, s));
-        done += cnt;
+        if (ci >= depth) {
+            const size_t co = ci - depth, done = co * chunk, cnt = std::min(chunk, n - done);
+            const int lane = (int)(co % lanes);
+            const void* dout = in_place ? (char*)d_in[0] + (size_t)lane * chunk * ins[0].bytes_per_item : (char*)d_out + (size_t)lane * chunk * out_bytes_per_item;
+            HIP_TRY(hipMemcpyAsync((char*)host_out + done * out_bytes_per_item, dout, cnt * out_bytes_per_item, hipMemcpyDeviceToHost, st[lane]));
+        }
     }
     for (int i = 0; i < lanes; ++i) HIP_TRY(hipStreamSynchronize(st[i]));
     return AKP_OK;

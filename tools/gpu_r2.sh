@@ -64,7 +64,7 @@ for a, b, k, s in rows:
     print("%9.3f ms  +%7.3f ms  %-14s stream %s" % ((a - t0) / 1e6, (b - a) / 1e6, k, s))
 PY
    ;;
-lanes) for L in 3 4 6 8; do for CH in 15 16 17; do AKP_HOST_LANES=$L AKP_HOST_CHUNK_LOG2=$CH python tools/host_path_probe.py child 20 | sed "s/^/lanes $L /"; done; done 2>&1 | grep -v amdgpu.ids | tee $OUT/host_lanes.txt;;
+lanes) for L in 3 4; do for CH in 16 17 18; do AKP_HOST_LANES=$L AKP_HOST_CHUNK_LOG2=$CH python tools/host_path_probe.py child 20 | sed "s/^/lanes $L /"; done; done 2>&1 | grep -v amdgpu.ids | tee $OUT/host_lanes.txt;;
 avail) rocprofv3 --list-avail 2>/dev/null | grep -i -o "TCC_[A-Z0-9_]*\|MALL[A-Z0-9_]*\|TCP_[A-Z0-9_]*" | sort -u > $OUT/avail_cache_counters.txt; wc -l $OUT/avail_cache_counters.txt;;
 esac; done
 rocm-smi --showclocks --showpower > $OUT/smi_after.txt 2>&1
