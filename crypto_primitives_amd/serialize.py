@@ -7,6 +7,12 @@ pedersen / bowe_hopwood Parameters (crh/pedersen/mod.rs:28-31, crh/bowe_hopwood/
 (merkle_tree/mod.rs:139-156), MultiPath (:239-257).  The byte layouts are inferred from ark-serialize's published
 conventions -- the reference holds no byte-level vectors for them (unpinned, like the digest encoding).
 Host-side glue; field conversions go through the C ABI (field.py).
+
+Both modes of `CanonicalSerialize` are provided (`compress=False / True`): field elements and lengths are identical in
+the two; a twisted-Edwards affine point compresses to y (32 bytes LE) with the sign of x in the top bit of the last
+byte -- set iff x is the lexicographically larger of (x, -x), i.e. x > (p - 1) / 2 (ark-ec's `TEFlags`), possible
+because y < 2^255.  Decompression solves x^2 = (y^2 - 1) / (1 + d y^2) for Jubjub (a = -1) and picks the root the flag
+names.  This, too, is restated from ark-ec's published behaviour and pinned by nothing the reference holds.
 """
 import struct
 
@@ -66,61 +72,111 @@ def deserialize_poseidon_config(b: bytes):
     return PoseidonConfig(rf, rp, alpha, np.stack(ark), np.stack(mds), rate, cap)
 
 
-def serialize_te_parameters(params) -> bytes:
-    """Parameters { generators: Vec<Vec<C>> }, points uncompressed (x || y)."""
+def te_points_bytes(points_wire, compress=False) -> bytes:
+    """affine points [n, 2, 4] (wire format) -> x || y each (uncompressed) or y with the x-sign flag (compressed)"""
+    pts = np.ascontiguousarray(points_wire, dtype=np.uint64).reshape(-1, 2, 4)
+    if not compress:
+        return fr_bytes(pts.reshape(-1, 4))
+    out = bytearray()
+    for x, y in zip(field.to_ints(pts[:, 0]), field.to_ints(pts[:, 1])):
+        b = bytearray(int(y).to_bytes(32, "little"))
+        if x > field.MODULUS - x:  # TEFlags::XIsNegative
+            b[31] |= 0x80
+        out += b
+    return bytes(out)
+
+
+def te_points_from_bytes(b: bytes, n: int, compress=False) -> np.ndarray:
+    """inverse of te_points_bytes -> [n, 2, 4] wire format; raises ValueError on a y with no point on the curve"""
+    if not compress:
+        return fr_from_bytes(b, 2 * n).reshape(n, 2, 4)
+    from .params import _sqrt, _D
+    q = field.MODULUS
+    vals = []
+    for i in range(n):
+        raw = bytearray(b[32 * i: 32 * i + 32])
+        neg = bool(raw[31] & 0x80)
+        raw[31] &= 0x7F
+        y = int.from_bytes(raw, "little")
+        if y >= q:
+            raise ValueError("non-canonical y coordinate")
+        y2 = y * y % q
+        x = _sqrt((y2 - 1) * pow(1 + _D * y2, -1, q))
+        if x is None:
+            raise ValueError("y is not the coordinate of a point of the curve")
+        if (x > q - x) != neg:
+            x = (q - x) % q
+        vals += [x, y]
+    return field.fr(vals).reshape(n, 2, 4)
+
+
+def serialize_te_parameters(params, compress=False) -> bytes:
+    """Parameters { generators: Vec<Vec<C>> }: projective points serialise as their affine form"""
     out = [_u64(params.num_windows)]
     for row in params.generators:
-        out += [_u64(params.window_size), fr_bytes(row.reshape(-1, 4))]
+        out += [_u64(params.window_size), te_points_bytes(row, compress)]
     return b"".join(out)
 
 
-def deserialize_te_parameters(b: bytes, cls):
+def deserialize_te_parameters(b: bytes, cls, compress=False):
     r = _Reader(b)
     rows = []
+    per = 32 if compress else 64
     for _ in range(r.u64()):
         w = r.u64()
-        rows.append(r.fr(2 * w).reshape(w, 2, 4))
+        rows.append(te_points_from_bytes(bytes(r.b[r.o: r.o + per * w]), w, compress))
+        r.o += per * w
     return cls(np.stack(rows))
 
 
-def _digest_bytes(d) -> bytes:
-    return fr_bytes(np.asarray(d, dtype=np.uint64).reshape(-1, 4))
+def _digest_bytes(d, compress=False) -> bytes:
+    d = np.asarray(d, dtype=np.uint64)
+    if compress and d.shape[-2:] == (2, 4):  # an affine point (Pedersen digest)
+        return te_points_bytes(d, True)
+    return fr_bytes(d.reshape(-1, 4))
 
 
-def serialize_path(path) -> bytes:
+def _read_digest(r, config, compress):
+    if config.digest_shape == (2, 4):
+        per = 32 if compress else 64
+        d = te_points_from_bytes(bytes(r.b[r.o: r.o + per]), 1, compress)[0]
+        r.o += per
+        return d
+    return r.fr(1).reshape(config.digest_shape)
+
+
+def serialize_path(path, compress=False) -> bytes:
     """Path { leaf_sibling_hash, auth_path: Vec<InnerDigest>, leaf_index: usize }"""
-    out = [_digest_bytes(path.leaf_sibling_hash), _u64(len(path.auth_path))]
-    out += [_digest_bytes(a) for a in path.auth_path]
+    out = [_digest_bytes(path.leaf_sibling_hash, compress), _u64(len(path.auth_path))]
+    out += [_digest_bytes(a, compress) for a in path.auth_path]
     out.append(_u64(path.leaf_index))
     return b"".join(out)
 
 
-def deserialize_path(b: bytes, config):
+def deserialize_path(b: bytes, config, compress=False):
     from .merkle_tree import Path
-    fe = 2 if config.digest_shape == (2, 4) else 1
     r = _Reader(b)
-    sib = r.fr(fe).reshape(config.digest_shape)
-    auth = [r.fr(fe).reshape(config.digest_shape) for _ in range(r.u64())]
+    sib = _read_digest(r, config, compress)
+    auth = [_read_digest(r, config, compress) for _ in range(r.u64())]
     return Path(config, sib, auth, r.u64())
 
 
-def serialize_multi_path(mp) -> bytes:
+def serialize_multi_path(mp, compress=False) -> bytes:
     """MultiPath { leaf_siblings_hashes, auth_paths_prefix_lenghts, auth_paths_suffixes, leaf_indexes }"""
-    out = [_u64(len(mp.leaf_siblings_hashes))] + [_digest_bytes(d) for d in mp.leaf_siblings_hashes]
+    out = [_u64(len(mp.leaf_siblings_hashes))] + [_digest_bytes(d, compress) for d in mp.leaf_siblings_hashes]
     out += [_u64(len(mp.auth_paths_prefix_lenghts))] + [_u64(v) for v in mp.auth_paths_prefix_lenghts]
     out.append(_u64(len(mp.auth_paths_suffixes)))
     for suf in mp.auth_paths_suffixes:
-        out += [_u64(len(suf))] + [_digest_bytes(d) for d in suf]
+        out += [_u64(len(suf))] + [_digest_bytes(d, compress) for d in suf]
     out += [_u64(len(mp.leaf_indexes))] + [_u64(v) for v in mp.leaf_indexes]
     return b"".join(out)
 
 
-def deserialize_multi_path(b: bytes, config):
+def deserialize_multi_path(b: bytes, config, compress=False):
     from .merkle_tree import MultiPath
-    fe = 2 if config.digest_shape == (2, 4) else 1
     r = _Reader(b)
-    sibs = [r.fr(fe).reshape(config.digest_shape) for _ in range(r.u64())]
+    sibs = [_read_digest(r, config, compress) for _ in range(r.u64())]
     pre = [r.u64() for _ in range(r.u64())]
-    suf = [[r.fr(fe).reshape(config.digest_shape) for _ in range(r.u64())] for _ in range(r.u64())]
+    suf = [[_read_digest(r, config, compress) for _ in range(r.u64())] for _ in range(r.u64())]
     idx = [r.u64() for _ in range(r.u64())]
     return MultiPath(config, sibs, pre, suf, idx)
