@@ -566,6 +566,24 @@ static bool generic_coop(size_t n) {
     }();
     return n <= coop_max;
 }
+// t = 4, 5 (the default rate-3 / rate-4 instances): register-resident kernels for large batches when the parameter set has
+// the full form or the lane-1 form (AKP_POSEIDON_NO_REG_T=1 keeps the LDS-file kernels: the A/B arm)
+static bool reg_t_kernel(const akp_poseidon* p, size_t n, const PoseidonConsts& c) {
+    static const bool enabled = !getenv("AKP_POSEIDON_NO_REG_T");
+    return enabled && (p->dims.t == 4 || p->dims.t == 5) && !generic_coop(n) && (c.scaled == 3u || c.scaled == 2u) && c.sparse != nullptr;
+}
+template <u32 T>
+static void launch_reg_permute(const akp_poseidon* p, const PoseidonConsts& c, Fr* d_states, size_t n, hipStream_t s) {
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (c.scaled == 3u) hipLaunchKernelGGL((poseidon_permute_reg_kernel<T, true>), grid, dim3(256), 0, s, p->dims, c, d_states, n);
+    else hipLaunchKernelGGL((poseidon_permute_reg_kernel<T, false>), grid, dim3(256), 0, s, p->dims, c, d_states, n);
+}
+template <u32 T>
+static void launch_reg_crh(const akp_poseidon* p, const PoseidonConsts& c, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s) {
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (c.scaled == 3u) hipLaunchKernelGGL((poseidon_crh_reg_kernel<T, true>), grid, dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
+    else hipLaunchKernelGGL((poseidon_crh_reg_kernel<T, false>), grid, dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
+}
 static size_t coop_lds(u32 t) {
     const size_t bytes = (size_t)2 * t * 9 * 64 * sizeof(u32);
     if (bytes > 65536) {  // t = 15, 16: above the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU);
@@ -582,6 +600,12 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
         const PoseidonConsts c = t3_reg_consts(p);
         if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_permute_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, d_states, n);
         else hipLaunchKernelGGL(poseidon_permute_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, d_states, n);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
+    if (reg_t_kernel(p, n, file_consts(p))) {
+        if (p->dims.t == 4) launch_reg_permute<4>(p, file_consts(p), d_states, n, s);
+        else launch_reg_permute<5>(p, file_consts(p), d_states, n, s);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -609,6 +633,12 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
+    if (reg_t_kernel(p, n, file_consts(p))) {
+        if (p->dims.t == 4) launch_reg_crh<4>(p, file_consts(p), in0, in1, k, d_out, n, s);
+        else launch_reg_crh<5>(p, file_consts(p), in0, in1, k, d_out, n, s);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
     // small batches (tree tops, single sponges) are bound by the latency of one permutation: one wave per state lane
     if (p->dims.t == 3 || generic_coop(n)) {
         hipLaunchKernelGGL(poseidon_crh_coop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * p->dims.t), coop_lds(p->dims.t), s, p->dims, t3_consts(p), in0, in1, k, d_out, n);
@@ -633,6 +663,7 @@ extern "C" const char* akp_poseidon_kernel_for(const akp_poseidon* p, size_t n, 
         if (crh) return ff ? "poseidon_crh_t3_kernel<true>" : "poseidon_crh_t3_kernel<false>";
         return ff ? "poseidon_permute_t3_kernel<true>" : "poseidon_permute_t3_kernel<false>";
     }
+    if (reg_t_kernel(p, n, file_consts(p))) return crh ? "poseidon_crh_reg_kernel" : "poseidon_permute_reg_kernel";
     if (p->dims.t == 3 || generic_coop(n)) return crh ? "poseidon_crh_coop_kernel" : "poseidon_permute_coop_kernel";
     return crh ? "poseidon_crh_kernel" : "poseidon_permute_kernel";
 }

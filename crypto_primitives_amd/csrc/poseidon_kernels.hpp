@@ -414,6 +414,153 @@ __global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, Pos
     store_fr_global(out + idx, poseidon_crh_item(D, C, f, in0, in1, k, idx));
 }
 
+// =============================== t = 4, 5: register-resident state (round 2) ====================================
+// The default rate-3 / rate-4 instances (alpha = 5, 8 + 56 rounds) spend 56 of 64 rounds in the sparse partial round,
+// which touches fixed lanes: with T a compile-time constant that round is straight-line code on registers.  The eight
+// dense rounds would need T row sums and T S-boxes unrolled (too much code for the 64 KB instruction cache at T = 5),
+// so they keep ONE copy of the S-box and ONE of each row shape and ROTATE the state through position 0 instead:
+//   S-boxes:  T times { S-box on s[0] with key e; rotate s }                       -> s back in order
+//   rows:     T times { row i = sum_k s[k] * m[i][(i + k) mod T]; push into n; rotate s }   (s[0] is lane i: a unit diagonal
+//             is the STATIC operand 0, the coefficients are scalar loads at a uniform, rotating address)
+// 2 * 9 * T register moves per iteration against 350-620 instructions of row arithmetic, in 8 of 64 rounds.
+// Constants: the full form (C.scaled == 3, FF) or the lane-1 form (C.scaled == 2) of poseidon_opt.hpp -- the same arrays
+// the LDS-file kernels read, so the digests are identical to theirs by construction of the same sums.
+template <u32 T>
+AKP_HD void reg_rotate(FP (&s)[T]) {
+    const FP first = s[0];
+#pragma unroll
+    for (u32 k = 0; k + 1 < T; ++k) s[k] = s[k + 1];
+    s[T - 1] = first;
+}
+AKP_HD u32 reg_col(u32 i, u32 k, u32 T) {
+    const u32 c = i + k;
+    return c >= T ? c - T : c;
+}
+// sum_{k = K0}^{T - 1} s[k] * row[(i + k) mod T]: chunks of three terms per reduction, then two or one.  At most two reduced
+// terms are summed (T <= 5), NOT normalised.
+template <u32 T, u32 K0>
+AKP_HD FP reg_row_sum(const FP (&s)[T], const F29Pad* __restrict__ row, u32 i) {
+    constexpr u32 N = T - K0;
+    static_assert(N >= 3 && N <= 5, "register kernels cover t = 4, 5");
+    FP acc = f29_dot3(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)));
+    if constexpr (N == 4) acc = f29_add(acc, f29_mulc(s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T))));
+    if constexpr (N == 5) acc = f29_add(acc, f29_dot2(s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T)), s[K0 + 4], ldc(row + reg_col(i, K0 + 4, T))));
+    return acc;
+}
+template <u32 T, bool FF>
+AKP_HD void poseidon_permute_reg(const PoseidonDims& D, const PoseidonConsts& C, FP (&s)[T], u32 need_lanes = 0xffffu) {
+    const u32 half = D.full_rounds / 2;
+    const u32 R = D.full_rounds + D.partial_rounds;
+#pragma unroll 1
+    for (u32 r = 0; r < R; ++r) {
+        const bool full = (r < half) || (r >= half + D.partial_rounds);
+        if (full) {
+            const F29Pad* arkr = C.ark + (size_t)r * T;
+#pragma unroll 1
+            for (u32 e = 0; e < T; ++e) {  // ARK + S-box, lane e at position 0
+                s[0] = f29_pow_small(f29_weak_norm(f29_add(s[0], ldc(arkr + e))), D.alpha);
+                reg_rotate<T>(s);
+            }
+            const F29Pad* m = FF ? C.mds + (size_t)(r < half ? r : r - D.partial_rounds) * T * T : ((r + 1 == half) ? C.mpre : C.mds);
+            const bool unit_rest = FF && r + 1 != R, unit0 = unit_rest && r + 1 != half;
+            const u32 need = (r + 1 == R) ? need_lanes : 0xffffu;
+            FP n[T];
+#pragma unroll
+            for (u32 k = 0; k < T; ++k) n[k] = s[k];
+#pragma unroll 1
+            for (u32 i = 0; i < T; ++i) {  // row i; s[k] holds lane (i + k) mod T
+                FP v = s[0];
+                if ((need >> i) & 1u) {
+                    if (i == 0 ? unit0 : unit_rest) v = f29_weak_norm(f29_add(s[0], reg_row_sum<T, 1>(s, m + (size_t)i * T, i)));
+                    else v = f29_weak_norm(reg_row_sum<T, 0>(s, m + (size_t)i * T, i));
+                }
+                reg_rotate<T>(n);  // n = (n_1 .. n_{T-1}, new): after T pushes the rows are in order
+                n[T - 1] = v;
+                reg_rotate<T>(s);
+            }
+#pragma unroll
+            for (u32 k = 0; k < T; ++k) s[k] = n[k];
+        } else {
+            // sparse partial round (same schedule as poseidon_permute_file): lane 0 <- a00 * sb + u . lanes,
+            // lane 1 += sb (lane-1 form), lane i += w_i * sb
+            const u32 j = r - half;
+            const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
+            const FP sb = f29_pow_small(f29_weak_norm(f29_add(s[0], ldc(sp))), D.alpha);
+            FP t[T];  // (sb, s_1 .. s_{T-1}): the operands of row 0 against sp[1 .. T]
+            t[0] = sb;
+#pragma unroll
+            for (u32 k = 1; k < T; ++k) t[k] = s[k];
+            const FP n0 = (FF && j + 1 == D.partial_rounds) ? f29_weak_norm(f29_add(sb, reg_row_sum<T, 1>(t, sp + 1, 0)))  // a00 = 1
+                                                            : f29_weak_norm(reg_row_sum<T, 0>(t, sp + 1, 0));
+            const bool refold = (j & 31u) == 31u;  // lanes gain < 2.1p per round: fold back mod p every 32 rounds
+#pragma unroll
+            for (u32 i = 1; i < T; ++i) {
+                FP y = (i == 1) ? f29_add(s[1], sb) : f29_add(s[i], f29_mulc(sb, ldc(sp + T + i)));
+                if (refold) y = f29_mulc(y, f29_one<AKP_PS>());
+                else y = f29_weak_norm(y);
+                s[i] = y;
+            }
+            s[0] = n0;
+        }
+    }
+}
+template <u32 T, bool FF>
+AKP_HD FP reg_load(const Fr* p) {
+    return FF ? f29_unpack<AKP_PS>(load_fr_global(p)) : f29_from_wire<AKP_PS>(load_fr_global(p));
+}
+template <u32 T, bool FF>
+AKP_HD Fr reg_store(const FP& v) {  // full form: a row is up to three reduced terms (|v| < 7p): the wide canonicalisation
+    return FF ? f29_canonical_pack<AKP_PS, true>(v) : f29_to_wire(v);
+}
+// fixed-length sponge CRH on a fresh sponge (same contract as poseidon_crh_item)
+template <u32 T, bool FF>
+AKP_HD Fr poseidon_crh_item_reg(const PoseidonDims& D, const PoseidonConsts& C, const Fr* __restrict__ in0, const Fr* __restrict__ in1, size_t k,
+                                size_t idx) {
+    FP s[T];
+#pragma unroll
+    for (u32 e = 0; e < T; ++e) s[e] = f29_zero<AKP_PS>();
+    size_t done = 0;
+    do {
+        const size_t take = (k - done) < D.rate ? (k - done) : D.rate;
+#pragma unroll
+        for (u32 e = 0; e < T; ++e) {  // absorb_internal :124-153: state[capacity + j] += input j of this block
+            if (e >= D.capacity && (size_t)(e - D.capacity) < take) {
+                const size_t el = done + (e - D.capacity);
+                const Fr* src = (in1 == nullptr) ? (in0 + idx * k + el) : (el == 0 ? in0 + idx : in1 + idx);
+                s[e] = f29_weak_norm(f29_add(s[e], reg_load<T, FF>(src)));
+            }
+        }
+        done += take;
+        // only state[capacity] of the last permutation is squeezed (:156-186)
+        poseidon_permute_reg<T, FF>(D, C, s, done < k ? 0xffffu : (1u << D.capacity));
+    } while (done < k);
+    FP out = s[0];
+#pragma unroll
+    for (u32 e = 1; e < T; ++e)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out.l[i] = D.capacity == e ? s[e].l[i] : out.l[i];
+    return reg_store<T, FF>(out);
+}
+template <u32 T, bool FF>
+__global__ void __launch_bounds__(256) poseidon_permute_reg_kernel(PoseidonDims D, PoseidonConsts C, Fr* states, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    Fr* st = states + idx * T;
+    FP s[T];
+#pragma unroll
+    for (u32 e = 0; e < T; ++e) s[e] = reg_load<T, FF>(st + e);
+    poseidon_permute_reg<T, FF>(D, C, s);
+#pragma unroll
+    for (u32 e = 0; e < T; ++e) store_fr_global(st + e, reg_store<T, FF>(s[e]));
+}
+template <u32 T, bool FF>
+__global__ void __launch_bounds__(256) poseidon_crh_reg_kernel(PoseidonDims D, PoseidonConsts C, const Fr* __restrict__ in0, const Fr* __restrict__ in1,
+                                                              size_t k, Fr* __restrict__ out, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    store_fr_global(out + idx, poseidon_crh_item_reg<T, FF>(D, C, in0, in1, k, idx));
+}
+
 #if defined(__HIPCC__)
 // =============================== any t: one wave per state lane ================================================
 // Workgroup of t waves per 64 items; wave w keeps lane w of the 64 states in registers.  Every round publishes one

@@ -6,6 +6,7 @@
 // (On the host pass fr_mul is the portable multiplier; the inline-asm multiplier is covered by
 // the GPU parity tests.)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <vector>
 #include "../../crypto_primitives_amd/csrc/fr.hpp"
 #include "../../crypto_primitives_amd/csrc/f29.hpp"
@@ -140,6 +141,21 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
             continue;
         }
+        // t = 4, 5 with the full / lane-1 form: the register-resident path (as capi.hip routes large batches)
+        if ((D.t == 4 || D.t == 5) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse) {
+            auto run = [&](auto tag, auto ff) {
+                constexpr u32 T = decltype(tag)::value;
+                constexpr bool FF = decltype(ff)::value;
+                FP s[T];
+                for (u32 e = 0; e < T; ++e) s[e] = reg_load<T, FF>(&states[i * T + e]);
+                poseidon_permute_reg<T, FF>(D, th->cfile, s);
+                for (u32 e = 0; e < T; ++e) states[i * T + e] = reg_store<T, FF>(s[e]);
+            };
+            const bool ff = th->cfile.scaled == 3u;
+            if (D.t == 4) { if (ff) run(std::integral_constant<u32, 4>{}, std::true_type{}); else run(std::integral_constant<u32, 4>{}, std::false_type{}); }
+            else { if (ff) run(std::integral_constant<u32, 5>{}, std::true_type{}); else run(std::integral_constant<u32, 5>{}, std::false_type{}); }
+            continue;
+        }
         const bool wire = th->cfile.scaled == 3u;  // as poseidon_permute_kernel
         for (u32 e = 0; e < D.t; ++e) f.store(e, wire ? f29_unpack<AKP_PS>(states[i * D.t + e]) : f29_from_wire<AKP_PS>(states[i * D.t + e]));
         poseidon_permute_file(D, th->cfile, f);
@@ -159,8 +175,16 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     HostFile f{buf.data()};
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
-    for (size_t i = 0; i < n; ++i)
+    const bool reg45 = (D.t == 4 || D.t == 5) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse;
+    for (size_t i = 0; i < n; ++i) {
+        if (reg45) {
+            const bool ff = th->cfile.scaled == 3u;
+            if (D.t == 4) out[i] = ff ? poseidon_crh_item_reg<4, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<4, false>(D, th->cfile, in0, in1, k, i);
+            else out[i] = ff ? poseidon_crh_item_reg<5, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<5, false>(D, th->cfile, in0, in1, k, i);
+            continue;
+        }
         out[i] = reg_path ? (th->creg.scaled == 3u ? poseidon_crh_item_t3<true>(D, th->creg, in0, in1, k, i) : poseidon_crh_item_t3<false>(D, th->creg, in0, in1, k, i)) : poseidon_crh_item(D, th->cfile, f, in0, in1, k, i);
+    }
     delete th;
 }
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
