@@ -121,3 +121,7 @@ print(emit_routine("f29_sqr_ip_asm", "sqr", signed=True, inplace=True))
 print(emit_routine("f29_mul_ip_asm", "mul", signed=True, inplace=True))
 print(emit_routine("f29_dot2_asm", "dot", signed=True, terms=2))
 print(emit_routine("f29_dot3_asm", "dot", signed=True, terms=3))
+print("// four and five terms under ONE reduction: legal in 64 signed bits because the constants are stored with BALANCED digits")
+print("// (limbs in [-2^28, 2^28), f29_balance): 45 products of < 2^57 stay below 2^62.5")
+print(emit_routine("f29_dot4_asm", "dot", signed=True, terms=4))
+print(emit_routine("f29_dot5_asm", "dot", signed=True, terms=5))

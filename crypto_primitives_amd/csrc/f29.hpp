@@ -29,8 +29,10 @@
 //                 normalised round key): the doubled limbs stay below 2^31, the widest column without the top limb is
 //                 column 7: 8 * (2^30 - 1)^2 + carry (< 7 * 2^31) = 2^63 - 2^31 + small < 2^63; columns 8, 9 have two
 //                 terms with the small top limb;
-//       dot2/dot3 state limbs <= 2^29 + small against normalised constants (27 * 2^58 = 2^62.75): lanes that grow by
-//                 lazy additions are renormalised every round in the signed Poseidon kernels.
+//       dot2..5   Poseidon constants carry balanced digits (f29_balance, |digit| <= 2^28): a product is < 2^57 for a
+//                 normalised state limb, the bound is two-sided (products of either sign, the reduction subtracts up to
+//                 16 * 2^57): 3 terms over lanes with one lazy addition (45 + 16) * 2^57, 4 / 5 terms over normalised
+//                 lanes (36 + 16) / (45 + 16) * 2^57 < 2^63.
 // Wire format <-> internal: one Montgomery product with a constant each way (x*2^256 <-> x*2^261).
 #pragma once
 #include <stdint.h>
@@ -320,6 +322,81 @@ AKP_HD F29T<S> f29_dot2(const F29T<S>& a0, const F29T<S>& b0, const F29T<S>& a1,
     }
     t.l[8] = (L)acc;
     return t;
+}
+
+// Balanced digits for CONSTANTS (round keys, matrix entries): limbs 0..7 in [-2^28, 2^28), same value.  A product of a state
+// limb (<= 2^29 + small) with such a digit is below 2^57 in magnitude, so FOUR or FIVE terms (36 / 45 products per column)
+// fit one signed 64-bit column where normalised digits (< 2^29) allow three -- one Montgomery reduction per row of a t = 4, 5
+// state instead of two.  Applied once when a parameter set is converted (poseidon_convert_params_kernel).
+AKP_HD FS f29_balance(const FS& a) {
+    FS r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int32_t x = a.l[i] + c;                      // |x| < 2^30
+        int32_t lo = (int32_t)((u32)x & AKP_MASK29);  // [0, 2^29)
+        c = x >> 29;
+        if (lo >= (1 << 28)) {
+            lo -= (1 << 29);
+            c += 1;
+        }
+        r.l[i] = lo;
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
+// sum_{k < N} a_k * b_k / 2^261 with one reduction, N = 4, 5.  b_k: balanced constants (wave-uniform on the device).
+template <int N>
+AKP_HD FS f29_dotn_cpp(const FS* const* a, const FS* const* b) {
+    typedef int64_t W;
+    const bool S = true;
+    (void)S;
+    W acc = 0;
+    u32 m[9];
+    FS t;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i)
+#pragma unroll
+            for (int q = 0; q < N; ++q) acc += (W)a[q]->l[i] * (W)b[q]->l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc -= (W)((u64)m[i] * (u64)p29(k - i));
+        m[k] = (u32)acc & AKP_MASK29;
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i)
+#pragma unroll
+            for (int q = 0; q < N; ++q) acc += (W)a[q]->l[i] * (W)b[q]->l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc -= (W)((u64)m[i] * (u64)p29(k - i));
+        t.l[k - 9] = (int32_t)((u32)acc & AKP_MASK29);
+        acc >>= 29;
+    }
+    t.l[8] = (int32_t)acc;
+    return t;
+}
+AKP_HD FS f29_dot4(const FS& a0, const FS& b0, const FS& a1, const FS& b1, const FS& a2, const FS& b2, const FS& a3, const FS& b3) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    return f29_dot4_asm(a0, b0, a1, b1, a2, b2, a3, b3);
+#else
+    const FS* a[4] = {&a0, &a1, &a2, &a3};
+    const FS* b[4] = {&b0, &b1, &b2, &b3};
+    return f29_dotn_cpp<4>(a, b);
+#endif
+}
+AKP_HD FS f29_dot5(const FS& a0, const FS& b0, const FS& a1, const FS& b1, const FS& a2, const FS& b2, const FS& a3, const FS& b3, const FS& a4,
+                   const FS& b4) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AKP_F29_ASM)
+    return f29_dot5_asm(a0, b0, a1, b1, a2, b2, a3, b3, a4, b4);
+#else
+    const FS* a[5] = {&a0, &a1, &a2, &a3, &a4};
+    const FS* b[5] = {&b0, &b1, &b2, &b3, &b4};
+    return f29_dotn_cpp<5>(a, b);
+#endif
 }
 
 // x^e, small public exponent (S-box).  MSB-first from x; equals ark-ff Field::pow for e >= 1.

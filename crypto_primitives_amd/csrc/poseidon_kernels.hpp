@@ -50,7 +50,8 @@ AKP_HD FP ldc(const F29Pad* p) { return f29_load_pad<AKP_PS>(p); }  // wave-unif
 // wire-format parameter array -> internal form (run once per parameter set)
 __global__ void poseidon_convert_params_kernel(const Fr* __restrict__ in, F29Pad* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) f29_store_pad(out + i, f29_from_wire<AKP_PS>(load_fr_global(in + i)));
+    // balanced digits: constants are only ever multiplied or added, and four / five-term row sums rely on |digit| <= 2^28
+    if (i < n) f29_store_pad(out + i, f29_balance(f29_from_wire<AKP_PS>(load_fr_global(in + i))));
 }
 
 // =============================== t == 3: register-resident state ===================================
@@ -59,11 +60,13 @@ __global__ void poseidon_convert_params_kernel(const Fr* __restrict__ in, F29Pad
 // When `sparse` is given the partial rounds run in the algebraically identical sparse form derived on the
 // host (poseidon_opt.hpp): one key add, one S-box, row 0 as a 3-term dot, lanes 1,2 += w_i * s; the full
 // round before the block applies `mpre`, and `ark` already carries the folded key residue.
-// Limb bounds (signed flavour, f29.hpp "Headroom rules"): dot / product outputs are normalised (<= 2^29 - 1) and
-// f29_weak_norm of a sum of two such values is <= 2^29; + round key (<= 2^29 - 1) -> <= 2^30 - 1, which is what the
-// first squaring of an S-box admits; every later routine of the S-box sees normalised operands.  The linear layers take
-// S-box outputs (normalised) or lanes that were renormalised in the same round: in the sparse block lanes 1,2 grow by
-// < 2^29 per round and are renormalised EVERY round (27 * 2^58 < 2^63; the unsigned flavour of round 1 could wait two).
+// Limb bounds (signed flavour, f29.hpp "Headroom rules").  Constants (round keys, matrix entries) carry BALANCED digits,
+// |digit| <= 2^28 (f29_balance).  dot / product outputs are normalised (<= 2^29 - 1), f29_weak_norm of a short sum is
+// <= 2^29 + 2; + round key -> |limb| <= 1.5 * 2^29 + 2: the first squaring of an S-box sees columns of at most
+// 9 * 2.25 * 2^58 = 2^62.3; every later routine of the S-box sees normalised operands.  Linear layers: a state limb
+// (<= 2^30 + 1 after ONE lazy addition) times a balanced digit is < 2^58.01 in magnitude, so the three-term row of the
+// t = 3 kernel over lanes that were renormalised in this or the previous round stays within +-(45 + 16) * 2^57 (products
+// may have either sign now; the reduction subtracts up to 16 * 2^57): lanes 1,2 are renormalised every SECOND round.
 struct PoseidonConsts {
     const F29Pad* ark;     // [R][t] round keys (with the residue folded in when sparse != nullptr)
     const F29Pad* mds;     // [t][t]
@@ -102,10 +105,6 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             else s0 = f29_pow_small(f29_add(s0, ldc(a)), D.alpha);
             s1 = f29_add(s1, ldc(a + 1));
             s2 = f29_add(s2, ldc(a + 2));
-            if (!full) {  // dense partial round: lanes 1,2 enter the row sums without an S-box, bring them back to <= 2^29
-                s1 = f29_weak_norm(s1);
-                s2 = f29_weak_norm(s2);
-            }
             if (full) {
                 if (z & 2u) s1 = ldc(C.sbox0 + 1);
                 else s1 = f29_pow_small(s1, D.alpha);
@@ -149,7 +148,7 @@ AKP_HD void poseidon_permute_t3(const PoseidonDims& D, const PoseidonT3Consts& C
             if ((j & 31u) == 31u) {  // lanes 1,2 gain < 2.1p per round and are never reduced mod p: fold them back
                 s1 = f29_mulc(s1, f29_one<AKP_PS>());  // every 32 rounds so the top limb stays far below 2^32 for any RP
                 s2 = f29_mulc(s2, f29_one<AKP_PS>());
-            } else {
+            } else if ((j & 1u) || j + 1 == D.partial_rounds) {
                 s1 = f29_weak_norm(s1);
                 s2 = f29_weak_norm(s2);
             }
@@ -328,9 +327,8 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
             const F29Pad* arkr = C.ark + (size_t)r * T;
 #pragma unroll 1
             for (u32 e = 0; e < T; ++e) {  // ARK fused with the S-box
-                // the lane is a weakly normalised sum of row chunks (<= 2^29 + 5): with the key it can pass 2^30 - 1, the
-                // bound of the signed squaring, so one more carry step first (also for lanes that skip the S-box)
-                FP x = f29_weak_norm(f29_add(f.load(e), ldc(arkr + e)));
+                // the lane is a weakly normalised row sum (<= 2^29 + 2), the key has balanced digits: |limb| <= 1.5 * 2^29 + 2
+                FP x = f29_add(f.load(e), ldc(arkr + e));
                 if (e < nsbox) x = f29_pow_small(x, D.alpha);
                 f.store(e, x);
             }
@@ -348,11 +346,13 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
             // sparse partial round, in place: lane 0 <- a00*s + u . lanes;  lane i <- lane i + w_i * s
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
-            const FP sb = f29_pow_small(f29_weak_norm(f29_add(f.load(0), ldc(sp))), D.alpha);
+            const FP sb = f29_pow_small(f29_add(f.load(0), ldc(sp)), D.alpha);
             // full form, last partial round: a00 = 1
             const FP n0 = (C.scaled == 3u && j + 1 == D.partial_rounds) ? f29_weak_norm(f29_add(sb, poseidon_row_dot_skip(f, T, sp + 1, 0, &sb)))
                                                                         : poseidon_row_dot(f, 0, T, sp + 1, &sb);
-            const bool norm = true;                // lanes grow < 2^29 per limb per round: renormalise every round (see t3 notes)
+            // lanes grow < 2^29 per limb per round; a row chunk may consist of three such lanes, and with signed products the
+            // column bound is two-sided (27 * 2^58 + 8 * 2^58 > 2^63 for lazy lanes): renormalise every round
+            const bool norm = true;
             const bool refold = (j & 31u) == 31u;  // ... and < 2.1p in value: fold back mod p every 32 rounds
 #pragma unroll 1
             for (u32 i = 1; i < T; ++i) {
@@ -436,16 +436,20 @@ AKP_HD u32 reg_col(u32 i, u32 k, u32 T) {
     const u32 c = i + k;
     return c >= T ? c - T : c;
 }
-// sum_{k = K0}^{T - 1} s[k] * row[(i + k) mod T]: chunks of three terms per reduction, then two or one.  At most two reduced
-// terms are summed (T <= 5), NOT normalised.
+// sum_{k = K0}^{T - 1} s[k] * row[(i + k) mod T]: three to five terms under one Montgomery reduction.  Normalised output.
 template <u32 T, u32 K0>
 AKP_HD FP reg_row_sum(const FP (&s)[T], const F29Pad* __restrict__ row, u32 i) {
     constexpr u32 N = T - K0;
     static_assert(N >= 3 && N <= 5, "register kernels cover t = 4, 5");
-    FP acc = f29_dot3(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)));
-    if constexpr (N == 4) acc = f29_add(acc, f29_mulc(s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T))));
-    if constexpr (N == 5) acc = f29_add(acc, f29_dot2(s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T)), s[K0 + 4], ldc(row + reg_col(i, K0 + 4, T))));
-    return acc;
+    // the constants carry balanced digits (f29_balance), so up to five terms share ONE reduction
+    if constexpr (N == 3)
+        return f29_dot3(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)));
+    else if constexpr (N == 4)
+        return f29_dot4(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)),
+                        s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T)));
+    else
+        return f29_dot5(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)),
+                        s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T)), s[K0 + 4], ldc(row + reg_col(i, K0 + 4, T)));
 }
 template <u32 T, bool FF>
 AKP_HD void poseidon_permute_reg(const PoseidonDims& D, const PoseidonConsts& C, FP (&s)[T], u32 need_lanes = 0xffffu) {
@@ -458,7 +462,7 @@ AKP_HD void poseidon_permute_reg(const PoseidonDims& D, const PoseidonConsts& C,
             const F29Pad* arkr = C.ark + (size_t)r * T;
 #pragma unroll 1
             for (u32 e = 0; e < T; ++e) {  // ARK + S-box, lane e at position 0
-                s[0] = f29_pow_small(f29_weak_norm(f29_add(s[0], ldc(arkr + e))), D.alpha);
+                s[0] = f29_pow_small(f29_add(s[0], ldc(arkr + e)), D.alpha);
                 reg_rotate<T>(s);
             }
             const F29Pad* m = FF ? C.mds + (size_t)(r < half ? r : r - D.partial_rounds) * T * T : ((r + 1 == half) ? C.mpre : C.mds);
@@ -472,7 +476,7 @@ AKP_HD void poseidon_permute_reg(const PoseidonDims& D, const PoseidonConsts& C,
                 FP v = s[0];
                 if ((need >> i) & 1u) {
                     if (i == 0 ? unit0 : unit_rest) v = f29_weak_norm(f29_add(s[0], reg_row_sum<T, 1>(s, m + (size_t)i * T, i)));
-                    else v = f29_weak_norm(reg_row_sum<T, 0>(s, m + (size_t)i * T, i));
+                    else v = reg_row_sum<T, 0>(s, m + (size_t)i * T, i);  // one reduction: already normalised
                 }
                 reg_rotate<T>(n);  // n = (n_1 .. n_{T-1}, new): after T pushes the rows are in order
                 n[T - 1] = v;
@@ -485,19 +489,19 @@ AKP_HD void poseidon_permute_reg(const PoseidonDims& D, const PoseidonConsts& C,
             // lane 1 += sb (lane-1 form), lane i += w_i * sb
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;
-            const FP sb = f29_pow_small(f29_weak_norm(f29_add(s[0], ldc(sp))), D.alpha);
+            const FP sb = f29_pow_small(f29_add(s[0], ldc(sp)), D.alpha);
             FP t[T];  // (sb, s_1 .. s_{T-1}): the operands of row 0 against sp[1 .. T]
             t[0] = sb;
 #pragma unroll
             for (u32 k = 1; k < T; ++k) t[k] = s[k];
             const FP n0 = (FF && j + 1 == D.partial_rounds) ? f29_weak_norm(f29_add(sb, reg_row_sum<T, 1>(t, sp + 1, 0)))  // a00 = 1
-                                                            : f29_weak_norm(reg_row_sum<T, 0>(t, sp + 1, 0));
+                                                            : reg_row_sum<T, 0>(t, sp + 1, 0);
             const bool refold = (j & 31u) == 31u;  // lanes gain < 2.1p per round: fold back mod p every 32 rounds
 #pragma unroll
             for (u32 i = 1; i < T; ++i) {
                 FP y = (i == 1) ? f29_add(s[1], sb) : f29_add(s[i], f29_mulc(sb, ldc(sp + T + i)));
                 if (refold) y = f29_mulc(y, f29_one<AKP_PS>());
-                else y = f29_weak_norm(y);
+                else y = f29_weak_norm(y);  // every round: four / five terms share a column (36 / 45 products + 16 for the reduction)
                 s[i] = y;
             }
             s[0] = n0;
@@ -509,7 +513,7 @@ AKP_HD FP reg_load(const Fr* p) {
     return FF ? f29_unpack<AKP_PS>(load_fr_global(p)) : f29_from_wire<AKP_PS>(load_fr_global(p));
 }
 template <u32 T, bool FF>
-AKP_HD Fr reg_store(const FP& v) {  // full form: a row is up to three reduced terms (|v| < 7p): the wide canonicalisation
+AKP_HD Fr reg_store(const FP& v) {  // full form: the wide canonicalisation is kept for safety (a last-round row is one reduced term)
     return FF ? f29_canonical_pack<AKP_PS, true>(v) : f29_to_wire(v);
 }
 // fixed-length sponge CRH on a fresh sponge (same contract as poseidon_crh_item)
@@ -608,7 +612,7 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
     for (u32 r = 0; r < R; ++r) {
         const bool full = (r < half) || (r >= half + D.partial_rounds);
         if (full || !opt) {
-            x = f29_weak_norm(f29_add(x, ldc(C.ark + (size_t)r * T + w)));  // <= 2^29 + small: squaring / row-sum bound
+            x = f29_add(x, ldc(C.ark + (size_t)r * T + w));  // balanced key digits: |limb| <= 1.5 * 2^29 + small
             if (full || w == 0) x = f29_pow_small(x, D.alpha);
             tile.put(buf, w, x);
             __syncthreads();
@@ -618,7 +622,7 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
             const u32 j = r - half;
             const F29Pad* sp = C.sparse + (size_t)j * 2 * T;  // q0, a00, u_1..u_{T-1}, w_1..w_{T-1}
             if (w == 0) {
-                x = f29_pow_small(f29_weak_norm(f29_add(x, ldc(sp))), D.alpha);
+                x = f29_pow_small(f29_add(x, ldc(sp)), D.alpha);
                 tile.put(buf, 0, x);
             } else {
                 tile.put(buf, w, f29_mulc(x, ldc(sp + 1 + w)));

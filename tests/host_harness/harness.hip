@@ -23,7 +23,7 @@ struct HostFile {
 // wire-format parameter arrays -> internal form (what poseidon_convert_params_kernel does on the device)
 static std::vector<F29Pad> to29(const Fr* in, size_t n) {
     std::vector<F29Pad> out(n);
-    for (size_t i = 0; i < n; ++i) f29_store_pad(&out[i], f29_from_wire<AKP_PS>(in[i]));
+    for (size_t i = 0; i < n; ++i) f29_store_pad(&out[i], f29_balance(f29_from_wire<AKP_PS>(in[i])));  // as poseidon_convert_params_kernel
     return out;
 }
 // force_generic: 0 = product default (t == 3: register path, else LDS-file path; sparse partial rounds),
@@ -119,6 +119,20 @@ void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int is_signed, Fr* o
         o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
     else { FU x, y; for (int i = 0; i < 9; ++i) { x.l[i] = al[i]; y.l[i] = bl[i]; }
         o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
+}
+
+// four / five-term dot products at their limb bounds (state limbs <= 2^29 + 2, balanced constant digits |d| <= 2^28), and the
+// digit balancing itself: out = [dot4(x,y,...), dot5(x,y,...), canonical(balance(y))]
+void hh_f29_dotn(const uint32_t* al, const uint32_t* bl, Fr* o) {
+    FS x, y;
+    for (int i = 0; i < 9; ++i) { x.l[i] = (int32_t)al[i]; y.l[i] = (int32_t)bl[i]; }
+    o[0] = f29_canonical_pack<true, true>(f29_dot4(x, y, x, y, x, y, x, y));
+    o[1] = f29_canonical_pack<true, true>(f29_dot5(x, y, x, y, x, y, x, y, x, y));
+    const FS b = f29_balance(y);
+    bool ok = true;
+    for (int i = 0; i < 8; ++i) ok = ok && b.l[i] >= -(1 << 28) && b.l[i] < (1 << 28);
+    o[2] = f29_canonical_pack<true, true>(b);
+    o[3] = Fr{{ok ? 1u : 0u, 0, 0, 0, 0, 0, 0, 0}};
 }
 
 void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, uint32_t cap, const Fr* ark, const Fr* mds,

@@ -150,6 +150,35 @@ def test_f29_worst_case_limbs(H):
             assert got[2] == 3 * va * vb * Rinv % p
 
 
+def test_f29_dot4_dot5_and_balanced_digits(H):
+    """round 2: four / five terms under one reduction.  Legal because constants carry balanced digits (|d| <= 2^28): the
+    column bound is two-sided, (36 | 45) * 2^57 for the products + 16 * 2^57 for the reduction < 2^63."""
+    p = ofr.P
+    Rinv = pow(1 << 261, -1, p)
+    neg = lambda x: (1 << 32) - x
+
+    def val(l):
+        return sum((int(x) - (1 << 32) if x >= (1 << 31) else int(x)) << (29 * i) for i, x in enumerate(l))
+    S = (1 << 29) + 2      # weakly normalised state limb
+    Dp, Dn = (1 << 28) - 1, neg(1 << 28)  # extreme balanced digits
+    T = 1 << 24
+    for a, b in [([S] * 8 + [T], [Dn] * 8 + [neg(T)]), ([S] * 8 + [T], [Dp] * 8 + [T]), ([S] * 8 + [neg(T)], [Dn, Dp] * 4 + [3]),
+                 ([0] * 9, [Dn] * 8 + [1]), ([S] * 8 + [T], [0] * 9)]:
+        A, B = np.array(a, np.uint32), np.array(b, np.uint32)
+        O = np.zeros((4, 4), np.uint64)
+        H.hh_f29_dotn(P(A), P(B), P(O))
+        got = ofr.canon_array_to_ints(O)
+        va, vb = val(a), val(b)
+        assert got[0] == 4 * va * vb * Rinv % p and got[1] == 5 * va * vb * Rinv % p
+        assert got[2] == vb % p and got[3] == 1  # balancing keeps the value, digits land in [-2^28, 2^28)
+    # balancing of ordinary normalised digits (0 .. 2^29 - 1), including the carry chain through 2^28 .. 2^29 - 1 everywhere
+    for b in [[(1 << 29) - 1] * 8 + [5], [1 << 28] * 8 + [0], [(1 << 28) - 1] * 8 + [7], [0x1234567, 0x1fffffff, 0, 0x10000000, 0xfffffff, 1, 0x1fffffff, 0x1fffffff, 9]]:
+        O = np.zeros((4, 4), np.uint64)
+        H.hh_f29_dotn(P(np.zeros(9, np.uint32)), P(np.array(b, np.uint32)), P(O))
+        got = ofr.canon_array_to_ints(O)
+        assert got[2] == val(b) % p and got[3] == 1
+
+
 @pytest.mark.parametrize("rate,cap,rf,rp,alpha", [(12, 4, 2, 3, 3), (15, 1, 4, 9, 5), (9, 1, 4, 5, 5)])
 def test_poseidon_wide_states_row_sums(H, rate, cap, rf, rp, alpha):
     """t = 10, 16: a row of the linear layer is a sum of up to six reduced chunks -- in the signed flavour at most three may
