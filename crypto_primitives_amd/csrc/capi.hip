@@ -76,6 +76,7 @@ struct akp_ctx {
     size_t pinned_bytes = 0;
     // more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
     hipStream_t pipe[7] = {};
+    hipEvent_t chunk_event[8] = {};  // copy-stream -> compute-stream hand-over of leaf chunks (host_tree_build)
 };
 // scratch slot `slot` with at least `bytes`, to be used on stream `s`: if the previous use was enqueued on a different
 // stream, `s` first waits for it (event record + stream wait; nothing blocks on the host)
@@ -125,6 +126,8 @@ extern "C" void akp_ctx_destroy(akp_ctx* c) {
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
         if (c->slot_event[i]) (void)hipEventDestroy(c->slot_event[i]);
     }
+    for (int i = 0; i < 8; ++i)
+        if (c->chunk_event[i]) (void)hipEventDestroy(c->chunk_event[i]);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (int i = 0; i < 7; ++i)
         if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
@@ -1131,6 +1134,45 @@ extern "C" int32_t akp_te_compress_batch(akp_te_params* p, const uint64_t* left,
 // heap-ordered non_leaf array starts at 2^l - 1.
 static inline bool pow2_gt1(size_t n) { return n > 1 && (n & (n - 1)) == 0; }
 
+
+// MerkleTree::new from host leaves: the copy-in of leaf chunk i + 1 (copy stream) overlaps the leaf hashing of chunk i
+// (context stream); the inner levels follow on the context stream while the copy stream already returns the leaf digests;
+// the inner nodes go back last.  hash_leaves(d_chunk, first_leaf, count, stream), inner(stream).
+template <class HashLeaves, class Inner>
+static int32_t host_tree_build(akp_ctx* c, const void* leaves, size_t n, size_t leaf_bytes, size_t dig_bytes, void* d_leaves, void* d_ln, void* d_nl,
+                               void* h_ln, void* h_nl, void* h_root, HashLeaves hash_leaves, Inner inner) {
+    static const size_t chunk_items = (size_t)1 << env_u32("AKP_TREE_CHUNK_LOG2", 20, 12, 30);
+    if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i)
+        if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
+    hipStream_t comp = c->stream, copy = c->pipe[0];
+    // the scratch regions were acquired for the context stream: let the copy stream start behind whatever used them last
+    HIP_TRY(hipEventRecord(c->chunk_event[7], comp));
+    HIP_TRY(hipStreamWaitEvent(copy, c->chunk_event[7], 0));
+    size_t ci = 0;
+    for (size_t done = 0; done < n; done += chunk_items, ++ci) {
+        const size_t cnt = std::min(chunk_items, n - done);
+        if (leaf_bytes) {
+            HIP_TRY(hipMemcpyAsync((char*)d_leaves + done * leaf_bytes, (const char*)leaves + done * leaf_bytes, cnt * leaf_bytes, hipMemcpyHostToDevice, copy));
+            hipEvent_t e = c->chunk_event[ci % 6];
+            HIP_TRY(hipEventRecord(e, copy));
+            HIP_TRY(hipStreamWaitEvent(comp, e, 0));
+        }
+        if (int32_t rc = hash_leaves((const char*)d_leaves + done * leaf_bytes, done, cnt, comp)) return rc;
+    }
+    if (h_ln) {  // leaf digests are final: copy them out while the inner levels run
+        HIP_TRY(hipEventRecord(c->chunk_event[6], comp));
+        HIP_TRY(hipStreamWaitEvent(copy, c->chunk_event[6], 0));
+        HIP_TRY(hipMemcpyAsync(h_ln, d_ln, n * dig_bytes, hipMemcpyDeviceToHost, copy));
+    }
+    if (int32_t rc = inner(comp)) return rc;
+    if (h_nl) HIP_TRY(hipMemcpyAsync(h_nl, d_nl, (n - 1) * dig_bytes, hipMemcpyDeviceToHost, comp));
+    if (h_root) HIP_TRY(hipMemcpyAsync(h_root, d_nl, dig_bytes, hipMemcpyDeviceToHost, comp));
+    HIP_TRY(hipStreamSynchronize(copy));
+    HIP_TRY(hipStreamSynchronize(comp));
+    return AKP_OK;
+}
+
 extern "C" int32_t akp_merkle_inner_poseidon_dev(akp_poseidon* two, const uint64_t* d_leaf_nodes, size_t n, uint64_t* d_non_leaf, void* stream) {
     NEED_DEV(two, "akp_merkle_inner_poseidon_dev");
     if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
@@ -1180,14 +1222,13 @@ extern "C" int32_t akp_merkle_build_poseidon(akp_poseidon* leafp, akp_poseidon* 
     if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len * sizeof(Fr), &dl, c->stream)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dln, c->stream)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * sizeof(Fr), &dnl, c->stream)) return rc;
-    hipStream_t s = c->stream;
-    if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, n * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
-    if (int32_t rc = akp_merkle_build_poseidon_dev(leafp, two, (const uint64_t*)dl, n, leaf_len, (uint64_t*)dln, (uint64_t*)dnl, (void*)s)) return rc;
-    if (leaf_nodes) HIP_TRY(hipMemcpyAsync(leaf_nodes, dln, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    if (non_leaf) HIP_TRY(hipMemcpyAsync(non_leaf, dnl, (n - 1) * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, dnl, sizeof(Fr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return AKP_OK;
+    if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "leaf and two-to-one parameters belong to different contexts");
+    return host_tree_build(
+        c, leaves, n, leaf_len * sizeof(Fr), sizeof(Fr), dl, dln, dnl, leaf_nodes, non_leaf, root_out,
+        [&](const void* d_chunk, size_t first, size_t cnt, hipStream_t s) -> int32_t {
+            return launch_crh(leafp, (const Fr*)d_chunk, nullptr, leaf_len, (Fr*)dln + first, cnt, s);  // :417-419
+        },
+        [&](hipStream_t s) -> int32_t { return akp_merkle_inner_poseidon_dev(two, (const uint64_t*)dln, n, (uint64_t*)dnl, (void*)s); });
 }
 
 extern "C" int32_t akp_merkle_inner_te_dev(akp_te_params* two, const uint64_t* d_leaf_nodes, size_t n, uint64_t* d_non_leaf, void* stream) {
@@ -1245,14 +1286,13 @@ extern "C" int32_t akp_merkle_build_te(akp_te_params* leafp, akp_te_params* two,
     if (int32_t rc = ctx_scratch(c, SCR_A, n * leaf_len, &dl, c->stream)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln, c->stream)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl, c->stream)) return rc;
-    hipStream_t s = c->stream;
-    if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, n * leaf_len, hipMemcpyHostToDevice, s));
-    if (int32_t rc = akp_merkle_build_te_dev(leafp, two, (const uint8_t*)dl, n, leaf_len, (uint64_t*)dln, (uint64_t*)dnl, (void*)s)) return rc;
-    if (leaf_nodes) HIP_TRY(hipMemcpyAsync(leaf_nodes, dln, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    if (non_leaf) HIP_TRY(hipMemcpyAsync(non_leaf, dnl, (n - 1) * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, dnl, fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return AKP_OK;
+    if (leafp->kind != two->kind || leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "leaf / two-to-one parameters mismatch");
+    return host_tree_build(
+        c, leaves, n, leaf_len, fe * sizeof(Fr), dl, dln, dnl, leaf_nodes, non_leaf, root_out,
+        [&](const void* d_chunk, size_t first, size_t cnt, hipStream_t s) -> int32_t {
+            return te_crh_dev(leafp, (const uint8_t*)d_chunk, cnt, leaf_len, (Fr*)dln + first * fe, s);
+        },
+        [&](hipStream_t s) -> int32_t { return akp_merkle_inner_te_dev(two, (const uint64_t*)dln, n, (uint64_t*)dnl, (void*)s); });
 }
 
 // ------------------------------------------------------------------------------------------
