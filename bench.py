@@ -62,16 +62,31 @@ def free_port():
 
 
 def gpu_clock_mhz(index=0):
-    """current shader clock from sysfs (the line pp_dpm_sclk marks with '*'); None when unreadable"""
+    """current shader clock: the level pp_dpm_sclk marks with '*' (highest over the cards that expose one -- a box may list an
+    idle integrated device first), else `rocm-smi --showclocks --json`; None when unreadable"""
+    best = None
     try:
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        txt = open(cards[min(index, len(cards) - 1)]).read()
-        for line in txt.splitlines():
-            if line.strip().endswith("*"):
-                return float(line.split(":")[1].strip().split("M")[0])
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            for line in open(path).read().splitlines():
+                if line.strip().endswith("*"):
+                    v = float(line.split(":")[1].strip().split("M")[0])
+                    best = v if best is None else max(best, v)
     except Exception:
         pass
-    return None
+    if best is not None and best > 200.0:
+        return best
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+        vals = []
+        for card in json.loads(out).values():
+            for k, v in card.items():
+                if "sclk" in k.lower() and "(" in str(v):
+                    vals.append(float(str(v).split("(")[1].split("M")[0]))
+        if vals:
+            return max(vals + ([best] if best else []))
+    except Exception:
+        pass
+    return best
 
 
 def cpu_info():
