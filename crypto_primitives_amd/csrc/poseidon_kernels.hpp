@@ -250,8 +250,8 @@ struct LdsFile29 {
     }
 };
 // `File` is LdsFile29<BLOCK> on the device; tests/host_harness instantiates it with a plain array.
-// sum_j state[src + j] * row[j] over j in [0, T), 3 terms per Montgomery reduction; `first` (if non-null) replaces
-// the lane-0 operand (the freshly S-boxed element of a sparse partial round).  Result weakly normalised.
+// Row sums of the wide kernels: sum_j state[src + j] * row[j] over j in [0, T); `first` (if non-null) replaces the lane-0
+// operand (the freshly S-boxed element of a sparse partial round).  poseidon_row_dot returns a weakly normalised value.
 // Sums of several normalised terms in signed 32-bit limbs: at most three terms (3 * 2^29 < 2^31) may be pending, so the
 // running sum is renormalised before a third term is added (`pending` counts the terms since the last carry step).
 #define AKP_ROW_ADD(term)                          \
@@ -263,49 +263,41 @@ struct LdsFile29 {
         acc = f29_add(acc, (term));                \
         ++pending;                                 \
     } while (0)
-template <class File>
-AKP_HD FP poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restrict__ row, const FP* first) {
+// sum_{k < count} get(k) * coefficient co(k): chunks of FIVE terms per Montgomery reduction (balanced constant digits, f29.hpp),
+// then one routine for the 4 / 3 / 2 / 1 terms left.  Operands must be normalised lanes (<= 2^29 + 2): (45 + 16) * 2^57 < 2^63.
+// Returns the running sum with at most two reduced terms pending (NOT normalised).
+template <class Get, class Co>
+AKP_HD FP poseidon_terms_sum(u32 count, Get get, Co co) {
     FP acc = f29_zero<AKP_PS>();
     u32 pending = 0;
-    u32 j = 0;
+    u32 k = 0;
 #pragma unroll 1
-    for (; j + 3 <= T; j += 3) {
-        const FP a0 = (first && j == 0) ? *first : f.load(src + j);
-        AKP_ROW_ADD(f29_dot3(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1), f.load(src + j + 2), ldc(row + j + 2)));
-    }
-    if (j + 2 == T) {  // two terms left: one reduction
-        const FP a0 = (first && j == 0) ? *first : f.load(src + j);
-        AKP_ROW_ADD(f29_dot2(a0, ldc(row + j), f.load(src + j + 1), ldc(row + j + 1)));
-    } else if (j < T) {
-        const FP a0 = (first && j == 0) ? *first : f.load(src + j);
-        AKP_ROW_ADD(f29_mulc(a0, ldc(row + j)));
-    }
-    return f29_weak_norm(acc);  // <= 2^29 + 2
+    for (; k + 5 <= count; k += 5)
+        AKP_ROW_ADD(f29_dot5(get(k), ldc(co(k)), get(k + 1), ldc(co(k + 1)), get(k + 2), ldc(co(k + 2)), get(k + 3), ldc(co(k + 3)), get(k + 4), ldc(co(k + 4))));
+    const u32 left = count - k;
+    if (left == 4) AKP_ROW_ADD(f29_dot4(get(k), ldc(co(k)), get(k + 1), ldc(co(k + 1)), get(k + 2), ldc(co(k + 2)), get(k + 3), ldc(co(k + 3))));
+    else if (left == 3) AKP_ROW_ADD(f29_dot3(get(k), ldc(co(k)), get(k + 1), ldc(co(k + 1)), get(k + 2), ldc(co(k + 2))));
+    else if (left == 2) AKP_ROW_ADD(f29_dot2(get(k), ldc(co(k)), get(k + 1), ldc(co(k + 1))));
+    else if (left == 1) AKP_ROW_ADD(f29_mulc(get(k), ldc(co(k))));
+    return acc;
+}
+template <class File>
+AKP_HD FP poseidon_row_dot(const File& f, u32 src, u32 T, const F29Pad* __restrict__ row, const FP* first) {
+    return f29_weak_norm(poseidon_terms_sum(
+        T, [&](u32 k) -> FP { return (first && k == 0) ? *first : f.load(src + k); }, [&](u32 k) { return row + k; }));  // <= 2^29 + 2
 }
 // the same sum without term `skip` (full form: that coefficient is 1 and the element is added by the caller).
 // `first` (if non-null) stands for state[0], as above.  Result NOT normalised: at most two terms pending (<= 2^30 + 2), the
 // caller adds one more and normalises.
 template <class File>
 AKP_HD FP poseidon_row_dot_skip(const File& f, u32 T, const F29Pad* __restrict__ row, u32 skip, const FP* first) {
-    FP acc = f29_zero<AKP_PS>();
-    u32 pending = 0;
-    u32 c = 0;  // running index over the T - 1 remaining terms
-#pragma unroll 1
-    for (; c + 3 <= T - 1; c += 3) {
-        const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip), j2 = c + 2 + (c + 2 >= skip);
-        const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
-        AKP_ROW_ADD(f29_dot3(a0, ldc(row + j0), f.load(j1), ldc(row + j1), f.load(j2), ldc(row + j2)));
-    }
-    if (c + 2 == T - 1) {  // two terms left: one reduction
-        const u32 j0 = c + (c >= skip), j1 = c + 1 + (c + 1 >= skip);
-        const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
-        AKP_ROW_ADD(f29_dot2(a0, ldc(row + j0), f.load(j1), ldc(row + j1)));
-    } else if (c < T - 1) {
-        const u32 j0 = c + (c >= skip);
-        const FP a0 = (first && j0 == 0) ? *first : f.load(j0);
-        AKP_ROW_ADD(f29_mulc(a0, ldc(row + j0)));
-    }
-    return acc;
+    return poseidon_terms_sum(
+        T - 1,
+        [&](u32 c) -> FP {
+            const u32 j = c + (c >= skip);
+            return (first && j == 0) ? *first : f.load(j);
+        },
+        [&](u32 c) { return row + (c + (c >= skip)); });
 }
 #define AKP_POSEIDON_MAX_T 16
 // The state occupies slots [0, t) of the file.  Sparse partial rounds update it in place; a dense layer needs all
@@ -330,6 +322,7 @@ AKP_HD void poseidon_permute_file(const PoseidonDims& D, const PoseidonConsts& C
                 // the lane is a weakly normalised row sum (<= 2^29 + 2), the key has balanced digits: |limb| <= 1.5 * 2^29 + 2
                 FP x = f29_add(f.load(e), ldc(arkr + e));
                 if (e < nsbox) x = f29_pow_small(x, D.alpha);
+                else x = f29_weak_norm(x);  // dense partial round: the lane enters a five-term chunk as it is
                 f.store(e, x);
             }
             const bool ff = C.scaled == 3u;  // full form: one matrix per full round, unit diagonal where flagged
@@ -592,15 +585,8 @@ struct CoopTile {
 };
 // sum_j published[j] * row[j], three terms per Montgomery reduction; result weakly normalised
 AKP_D FP coop_row_dot(const CoopTile& tile, u32 buf, const F29Pad* __restrict__ row) {
-    FP acc = f29_zero<AKP_PS>();
-    u32 pending = 0;
-    u32 j = 0;
-#pragma unroll 1
-    for (; j + 3 <= tile.T; j += 3)
-        AKP_ROW_ADD(f29_dot3(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1), tile.get(buf, j + 2), ldc(row + j + 2)));
-    if (j + 2 == tile.T) AKP_ROW_ADD(f29_dot2(tile.get(buf, j), ldc(row + j), tile.get(buf, j + 1), ldc(row + j + 1)));
-    else if (j < tile.T) AKP_ROW_ADD(f29_mulc(tile.get(buf, j), ldc(row + j)));
-    return f29_weak_norm(acc);
+    return f29_weak_norm(poseidon_terms_sum(
+        tile.T, [&](u32 k) -> FP { return tile.get(buf, k); }, [&](u32 k) { return row + k; }));
 }
 // one permutation; x is lane w of the state (weakly normalised in and out); buf is the tile buffer to use next
 AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C, const CoopTile& tile, u32 w, FP& x, u32& buf) {
@@ -614,6 +600,7 @@ AKP_D void poseidon_permute_coop(const PoseidonDims& D, const PoseidonConsts& C,
         if (full || !opt) {
             x = f29_add(x, ldc(C.ark + (size_t)r * T + w));  // balanced key digits: |limb| <= 1.5 * 2^29 + small
             if (full || w == 0) x = f29_pow_small(x, D.alpha);
+            else x = f29_weak_norm(x);  // dense partial round: published as it is into five-term chunks
             tile.put(buf, w, x);
             __syncthreads();
             const F29Pad* m = ((opt && r + 1 == half) ? C.mpre : C.mds) + (size_t)w * T;
