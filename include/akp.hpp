@@ -283,4 +283,62 @@ class MerkleTree {  // merkle_tree::MerkleTree<P> (:383-726)
     size_t height_ = 0;
 };
 
+// MerkleTree<P> kept in HBM (akp_merkle_tree_*): what the Rust shim's GpuMerkleTree<P> wraps.  Poseidon field config.
+class GpuMerkleTree {
+  public:
+    using Digest = FrWire;
+    // MerkleTree::new (:411-422)
+    GpuMerkleTree(const PoseidonConfig& leaf_params, const PoseidonConfig& two_params, const std::vector<FrWire>& leaves, size_t leaf_len)
+        : leaf_(&leaf_params), two_(&two_params), leaf_len_(leaf_len) {
+        check(akp_merkle_tree_build_poseidon(leaf_params.get(), two_params.get(), leaves.empty() ? nullptr : leaves[0].data(),
+                                             leaf_len ? leaves.size() / leaf_len : 0, leaf_len, &h_));
+        uint32_t fe = 0;
+        check(akp_merkle_tree_info(h_, &n_, &fe, &height_));
+    }
+    ~GpuMerkleTree() { akp_merkle_tree_destroy(h_); }
+    GpuMerkleTree(const GpuMerkleTree&) = delete;
+    GpuMerkleTree& operator=(const GpuMerkleTree&) = delete;
+    Digest root() const {  // :526-528
+        Digest r;
+        check(akp_merkle_tree_root(h_, r.data()));
+        return r;
+    }
+    size_t height() const { return height_; }  // :531-533
+    // generate_proof (:572-579), many leaves per call
+    std::vector<Path<PoseidonFieldConfig>> generate_proofs(const std::vector<uint64_t>& indexes) const {
+        const size_t m = indexes.size(), depth = height_ - 2;
+        std::vector<FrWire> sib(m), auth(m * depth);
+        check(akp_merkle_tree_gather_paths(h_, indexes.data(), m, m ? sib[0].data() : nullptr, (m && depth) ? auth[0].data() : nullptr));
+        std::vector<Path<PoseidonFieldConfig>> out(m);
+        for (size_t i = 0; i < m; ++i) {
+            out[i].leaf_index = (size_t)indexes[i];
+            out[i].leaf_sibling_hash = sib[i];
+            out[i].auth_path.assign(auth.begin() + i * depth, auth.begin() + (i + 1) * depth);
+        }
+        return out;
+    }
+    // update (:692-702), batched: (index, leaf) pairs applied in order, one launch per level
+    void update_batch(const std::vector<uint64_t>& indexes, const std::vector<FrWire>& new_leaves) {
+        check(akp_merkle_tree_update_batch(h_, indexes.data(), new_leaves.empty() ? nullptr : new_leaves[0].data(), indexes.size(), leaf_len_));
+    }
+    // check_update (:707-725)
+    bool check_update(uint64_t index, const std::vector<FrWire>& new_leaf, const Digest& asserted_new_root) {
+        int32_t ok = 0;
+        check(akp_merkle_tree_check_update(h_, index, new_leaf.empty() ? nullptr : new_leaf[0].data(), leaf_len_, asserted_new_root.data(), &ok));
+        return ok == 1;
+    }
+    // the reference's two vectors (heap order)
+    void export_nodes(std::vector<Digest>& leaf_nodes, std::vector<Digest>& non_leaf_nodes) const {
+        leaf_nodes.resize(n_);
+        non_leaf_nodes.resize(n_ - 1);
+        check(akp_merkle_tree_export(h_, leaf_nodes[0].data(), non_leaf_nodes[0].data()));
+    }
+
+  private:
+    const PoseidonConfig* leaf_;
+    const PoseidonConfig* two_;
+    size_t leaf_len_ = 0, n_ = 0, height_ = 0;
+    akp_merkle_tree* h_ = nullptr;
+};
+
 }  // namespace akp

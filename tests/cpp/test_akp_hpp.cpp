@@ -95,6 +95,29 @@ int main(int argc, char** argv) {
     // power-of-two assertion -> Error code 5
     try { MerkleTree<PoseidonFieldConfig>::new_(cfg, cfg, std::vector<FrWire>(leaves.begin(), leaves.begin() + 3), 1); REQUIRE(false); }
     catch (const Error& e) { REQUIRE(e.code == AKP_ERR_NOT_POW2); }
+    // the HBM-resident tree: same root and nodes, proofs from the device, batched update == rebuilt tree, check_update
+    {
+        GpuMerkleTree gt(cfg, cfg, leaves, 1);
+        REQUIRE(gt.height() == 4 && gt.root() == root);
+        std::vector<FrWire> ln, nl;
+        gt.export_nodes(ln, nl);
+        REQUIRE(ln == tree.leaf_nodes() && nl == tree.non_leaf_nodes());
+        auto proofs = gt.generate_proofs({0, 5, 7});
+        REQUIRE(proofs.size() == 3 && proofs[1].auth_path == tree.generate_proof(5).auth_path && proofs[1].leaf_sibling_hash == tree.generate_proof(5).leaf_sibling_hash);
+        REQUIRE(proofs[2].verify(cfg, cfg, root, {leaves[7]}));
+        std::vector<FrWire> upd = {fr_from_u64(100), fr_from_u64(101)};
+        gt.update_batch({2, 6}, upd);
+        std::vector<FrWire> leaves2 = leaves;
+        leaves2[2] = upd[0];
+        leaves2[6] = upd[1];
+        auto tree2 = MerkleTree<PoseidonFieldConfig>::new_(cfg, cfg, leaves2, 1);
+        REQUIRE(gt.root() == tree2.root());
+        REQUIRE(!gt.check_update(0, {fr_from_u64(7)}, root) && gt.root() == tree2.root());
+        leaves2[0] = fr_from_u64(7);
+        auto tree3 = MerkleTree<PoseidonFieldConfig>::new_(cfg, cfg, leaves2, 1);
+        REQUIRE(gt.check_update(0, {fr_from_u64(7)}, tree3.root()) && gt.root() == tree3.root());
+        try { gt.update_batch({8}, {fr_from_u64(1)}); REQUIRE(false); } catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_PARAMS); }
+    }
     // reference returns None for rate 9
     try { PoseidonConfig::get_default_poseidon_parameters(ctx, 9, false); REQUIRE(false); } catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_PARAMS); }
     if (argc > 1 && te_cases(ctx, argv[1]) != 0) return 1;
