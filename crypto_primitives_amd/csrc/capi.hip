@@ -906,8 +906,9 @@ struct akp_te_params {
     u32 n_gen = 0;             // W * N flat generators
     u32 digit_bits = 0;        // Pedersen: table digit width D (1..8)
     u32 group = 1;             // Bowe-Hopwood: chunks per table step (1..4)
-    NielsPad* d_lut = nullptr;   // Pedersen: [ceil(n_gen/D)][2^D]; BH: triples [n_gen/3][256] (group 3) or singles
-    NielsPad* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]
+    NielsPad* d_lut = nullptr;   // Pedersen: [ceil(n_gen/D)][2^D] (signed-subset table: [ceil(n_gen/D)][2^(D-1)]); BH: group table
+    NielsPad* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]; Pedersen signed-subset: cprefix [n_digits + 1]
+    bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
 };
 static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN ? 2u : 1u; }
 static inline size_t te_input_bits(const akp_te_params* p) {  // max message bits before the reference panics
@@ -931,18 +932,53 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
     if (kind == AKP_TE_PEDERSEN) {
-        // digit width: 13 bits (4x256: 79 steps, 93 MB table, served from the 256 MB Infinity Cache) unless the table
-        // would exceed 192 MB; AKP_PEDERSEN_DIGIT_BITS overrides (1..14).  Measured 2^20 x 128 B on MI355X:
-        // D = 4: 73 M/s, 8: 151, 10: 177, 12: 199, 13: 209, 14: 220 (175 MB table).
-        u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 13, 1, 14);
-        while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > ((size_t)192 << 20)) --D;
-        p->digit_bits = D;
-        const size_t entries = ((n_gen + D - 1) / D) << D;
-        if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, D, (u32)entries, p->d_lut);
-            e = hipGetLastError();
+        // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
+        // stores 2^(D-1) entries per digit, so D = 14 costs what D = 13 costs in the plain table: 4x256 is 74 steps (87 MB).
+        // AKP_PEDERSEN_PLAIN=1 keeps the plain table (the A/B arm, and the fallback for generators outside the subgroup).
+        NielsPad* d_half = nullptr;
+        u32* d_bad = nullptr;
+        u32 bad = 1;
+        if (!getenv("AKP_PEDERSEN_PLAIN")) {
+            if (e == hipSuccess) e = hipMalloc(&d_half, n_gen * sizeof(NielsPad));
+            if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(u32));
+            if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_halve_generators, dim3((unsigned)((n_gen + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, d_half, d_bad);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
+        if (e == hipSuccess && bad == 0) {
+            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 14, 2, 15);
+            while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(NielsPad) > ((size_t)192 << 20)) --D;
+            p->digit_bits = D;
+            p->signed_subset = true;
+            const size_t n_digits = (n_gen + D - 1) / D, entries = n_digits << (D - 1);
+            e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(NielsPad));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_build_pedersen_slut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_half, (u32)n_gen, D, (u32)entries, p->d_lut);
+                hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half, (u32)n_gen, D, (u32)n_digits, p->d_lut1);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        } else if (e == hipSuccess) {
+            // plain table.  digit width: 13 bits (4x256: 79 steps, 93 MB table, served from the 256 MB Infinity Cache) unless the table
+            // would exceed 192 MB; AKP_PEDERSEN_DIGIT_BITS overrides (1..14).  Measured 2^20 x 128 B on MI355X:
+            // D = 4: 73 M/s, 8: 151, 10: 177, 12: 199, 13: 209, 14: 220 (175 MB table; round 2: 13 beats 14, profiles/r02_s8).
+            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 13, 1, 14);
+            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > ((size_t)192 << 20)) --D;
+            p->digit_bits = D;
+            const size_t entries = ((n_gen + D - 1) / D) << D;
+            e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, D, (u32)entries, p->d_lut);
+                e = hipGetLastError();
+            }
+        }
+        if (d_half) (void)hipFree(d_half);
+        if (d_bad) (void)hipFree(d_bad);
     } else {
         u32 G = env_u32("AKP_BH_GROUP", 4, 1, 4);
         while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(NielsPad) > ((size_t)192 << 20))) --G;
@@ -1013,7 +1049,9 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     static const size_t split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
     if (n <= split_max) {
         const unsigned sgrid = (unsigned)((n + 63) / 64);
-        if (p->kind == AKP_TE_PEDERSEN)
+        if (p->kind == AKP_TE_PEDERSEN && p->signed_subset)
+            hipLaunchKernelGGL(te_crh_small_kernel<2>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, d_out, n);
+        else if (p->kind == AKP_TE_PEDERSEN)
             hipLaunchKernelGGL(te_crh_small_kernel<0>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, d_out, n);
         else
             hipLaunchKernelGGL(te_crh_small_kernel<1>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->group, groups, steps, d_out, n);
@@ -1024,7 +1062,9 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
     const unsigned grid = (unsigned)((n + 255) / 256);
-    if (p->kind == AKP_TE_PEDERSEN)
+    if (p->kind == AKP_TE_PEDERSEN && p->signed_subset)
+        hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
+    else if (p->kind == AKP_TE_PEDERSEN)
         hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
     else
         hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->group, groups, steps, (F29Pad*)xyz, n);

@@ -160,6 +160,75 @@ __global__ void te_build_bh_lutg(const Fr* __restrict__ gens_affine, u32 G, u32 
     store_niels(lut + idx, te_bh_lutg_entry(gens_affine, G, idx));
 }
 
+// ---- Pedersen, signed-subset table (round 2) ----------------------------------------------------
+// A digit of D message bits selects a SUBSET sum of D generators.  With H_g = G_g / 2 (the half of a point of the odd-order
+// subgroup: ((r + 1) / 2) * G_g) the subset sum is   sum_b v_b G_b = sum_b H_b + sum_b (2 v_b - 1) H_b = C_u + S_u(v),
+// and S_u(~v) = -S_u(v): only the 2^(D-1) entries whose top bit is set are stored, the other half is their negation (swap
+// the Niels components).  For the same table size the digit is one bit wider: 74 steps instead of 79 for 4x256.  The
+// constants C_u of the windows a message of n_steps digits touches are summed once per possible n_steps (`cprefix`) and are
+// what the sum starts from.  Needs every generator in the prime-order subgroup (what setup produces: ark-ec's `rand`
+// clears the cofactor); te_halve_generators checks 2 H == G and the host falls back to the plain table otherwise.
+AKP_HD u32 te_half_order_bit(u32 i) {  // bit i of (r + 1) / 2, r = order of the prime subgroup of Jubjub
+    constexpr u32 K[8] = {0x6b7b965cu, 0x684b872fu, 0xe6640841u, 0x53341049u, 0x809a1d80u, 0x83339d80u, 0x3299d7d4u, 0x073eda75u};
+    return (K[i >> 5] >> (i & 31u)) & 1u;
+}
+// H = G / 2 as a table entry; false when G is not in the prime-order subgroup (2 H != G)
+AKP_HD bool te_half_generator(const Fr* __restrict__ gens_affine, size_t g, Niels& out) {
+    const FS x = f29_from_wire<true>(load_fr_g(gens_affine + 2 * g)), y = f29_from_wire<true>(load_fr_g(gens_affine + 2 * g + 1));
+    const Niels gn = niels_from_affine(x, y);
+    Ext acc = ext_identity();
+#pragma unroll 1
+    for (int i = 250; i >= 0; --i) {  // (r + 1) / 2 has 251 bits
+        acc = te_add_ext(acc, acc);
+        if (te_half_order_bit((u32)i)) acc = te_madd(acc, gn);
+    }
+    const Ext dbl = te_add_ext(acc, acc);  // must be G: X = x Z, Y = y Z
+    const Fr lx = f29_to_wire(dbl.X), rx = f29_to_wire(f29_mul(x, dbl.Z)), ly = f29_to_wire(dbl.Y), ry = f29_to_wire(f29_mul(y, dbl.Z));
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) same = same && lx.l[i] == rx.l[i] && ly.l[i] == ry.l[i];
+    out = niels_of_ext(acc);
+    return same;
+}
+__global__ void te_halve_generators(const Fr* __restrict__ gens_affine, u32 n_gen, NielsPad* __restrict__ half, u32* __restrict__ not_in_subgroup) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_gen) return;
+    Niels h;
+    if (!te_half_generator(gens_affine, g, h)) atomicAdd(not_in_subgroup, 1u);
+    store_niels(half + g, h);
+}
+// entry v' in [0, 2^(D-1)) of digit u: S_u(v) for v = v' | 2^(D-1):  sum_b (v_b ? +H : -H)[uD + b] over the generators present
+AKP_HD Niels te_pedersen_slut_entry(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 idx) {
+    const u32 u = idx >> (D - 1u), v = (idx & ((1u << (D - 1u)) - 1u)) | (1u << (D - 1u));
+    Ext acc = ext_identity();
+#pragma unroll 1
+    for (u32 b = 0; b < D; ++b) {
+        const u32 g = u * D + b;
+        if (g >= n_gen) break;
+        const Niels h = load_niels(half + g);
+        acc = te_madd(acc, ((v >> b) & 1u) ? h : niels_neg(h));
+    }
+    return niels_of_ext(acc);
+}
+__global__ void te_build_pedersen_slut(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_entries, NielsPad* __restrict__ lut) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_entries) return;
+    store_niels(lut + idx, te_pedersen_slut_entry(half, n_gen, D, idx));
+}
+// cprefix[k] = sum of H_g over the generators of digits 0 .. k-1 (k = 0: the identity)
+AKP_HD Niels te_pedersen_cprefix_entry(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 k) {
+    const u32 upto = (k * D < n_gen) ? k * D : n_gen;
+    Ext acc = ext_identity();
+#pragma unroll 1
+    for (u32 g = 0; g < upto; ++g) acc = te_madd(acc, load_niels(half + g));
+    return niels_of_ext(acc);
+}
+__global__ void te_build_pedersen_cprefix(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_digits, NielsPad* __restrict__ cprefix) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_digits) return;
+    store_niels(cprefix + k, te_pedersen_cprefix_entry(half, n_gen, D, k));
+}
+
 // ---- message bit access -----------------------------------------------------------------------
 // bits [o, o+w) (w <= 16) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
 // bits past the end read as zero (Pedersen zero padding :91-99 / Bowe-Hopwood chunk padding :131-138).
@@ -177,12 +246,20 @@ AKP_HD u32 msg_bits(const uint8_t* __restrict__ msg, size_t len, size_t o, u32 w
 //  kind 0 (Pedersen): digit = msg_bits(u*D, D), entry lut[u << D | digit].
 //  kind 1 (Bowe-Hopwood): steps [0, n_groups) are groups of D (= G) chunks from lut (2^(3G-1) entries each),
 //                         negated by s_0; steps [n_groups, n_steps) are the left-over single chunks from lut1.
+//  kind 2 (Pedersen, signed-subset table): lut[u << (D-1) | ...]; lut1 is the cprefix table the sum starts from.
 template <int KIND>
 AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
                            size_t msg_len, u32 D, u32 n_groups, u32 u) {
     if (KIND == 0) {
         const u32 digit = msg_bits(msg, msg_len, (size_t)u * D, D);
         return load_niels(lut + (((size_t)u << D) | digit));
+    }
+    if (KIND == 2) {  // signed-subset table: top bit set -> entry as stored, clear -> the entry of the complement, negated
+        const u32 digit = msg_bits(msg, msg_len, (size_t)u * D, D);
+        const u32 half_mask = (1u << (D - 1u)) - 1u;
+        const bool top = (digit >> (D - 1u)) & 1u;
+        const Niels q = load_niels(lut + (((size_t)u << (D - 1u)) | ((top ? digit : ~digit) & half_mask)));
+        return top ? q : niels_neg(q);
     }
     const u32 G = D;  // chunks per group step
     if (u < n_groups) {
@@ -205,14 +282,22 @@ AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __r
 template <int KIND>
 AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
                               size_t msg_len, u32 D, u32 n_groups, u32 n_steps) {
-    if (n_steps == 0) return ext_identity();
     // Two steps per iteration with two entry buffers: the entry of step u+1 is fetched before the ~2000-instruction
     // addition that consumes the entry of step u, and no register copies are needed to rotate the buffers.
-    // Step 0 is not an addition: the sum starts as the first entry itself.
-    Ext acc = ext_from_niels(te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 0));
-    if (n_steps == 1) return acc;
-    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 1);
-    u32 u = 1;
+    // The sum starts as a table entry (no addition): the first step's entry, or (kind 2) the constant cprefix[n_steps].
+    Ext acc;
+    u32 u;
+    if (KIND == 2) {
+        acc = ext_from_niels(load_niels(lut1 + n_steps));
+        u = 0;
+        if (n_steps == 0) return acc;
+    } else {
+        if (n_steps == 0) return ext_identity();
+        acc = ext_from_niels(te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, 0));
+        u = 1;
+        if (n_steps == 1) return acc;
+    }
+    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, u);
 #pragma unroll 1
     for (; u + 2 <= n_steps; u += 2) {
         const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, u + 1);
@@ -227,12 +312,20 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
 template <int KIND>
 AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
                                  size_t msg_len, u32 D, u32 n_groups, u32 n_steps, u32 first, u32 stride) {
-    if (first >= n_steps) return ext_identity();
-    Ext acc = ext_from_niels(te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, first));  // first term: no addition
-    if (first + stride >= n_steps) return acc;
-    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, first + stride);
+    Ext acc;
+    u32 start;
+    if (KIND == 2 && first == 0) {  // the partial sum that starts at step 0 also carries the constant of the signed table
+        acc = ext_from_niels(load_niels(lut1 + n_steps));
+        start = 0;
+    } else {
+        if (first >= n_steps) return ext_identity();
+        acc = ext_from_niels(te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, first));  // first term: no addition
+        start = first + stride;
+    }
+    if (start >= n_steps) return acc;
+    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, start);
 #pragma unroll 1
-    for (u32 u = first + stride; u < n_steps; u += stride) {
+    for (u32 u = start; u < n_steps; u += stride) {
         const u32 nxt = (u + stride < n_steps) ? u + stride : u;
         const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, nxt);  // fetched ahead of the addition
         acc = te_madd(acc, q0);
@@ -273,7 +366,7 @@ AKP_HD void te_finalize_lane(const F29Pad* __restrict__ xyz, F29Pad* __restrict_
         const size_t e = l + k * lanes;
         const FS zi = f29_mul(inv, f29_load_pad<true>(prefix + e));
         inv = f29_mul(inv, f29_load_pad<true>(xyz + e * 3 + 2));
-        if (KIND == 0) {
+        if (KIND != 1) {
             store_fr_g(out + e * 2, f29_to_wire(f29_mul(f29_load_pad<true>(xyz + e * 3), zi)));
             store_fr_g(out + e * 2 + 1, f29_to_wire(f29_mul(f29_load_pad<true>(xyz + e * 3 + 1), zi)));
         } else {
@@ -332,7 +425,7 @@ __global__ void __launch_bounds__(64 * AKP_TE_SPLIT) te_crh_small_kernel(const N
     }
     if (j != 0 || item >= n) return;
     const FS zi = f29_inv(acc.Z);  // Z != 0 always (complete formulas)
-    if (KIND == 0) {
+    if (KIND != 1) {
         store_fr_g(out + item * 2, f29_to_wire(f29_mul(acc.X, zi)));
         store_fr_g(out + item * 2 + 1, f29_to_wire(f29_mul(acc.Y, zi)));
     } else {

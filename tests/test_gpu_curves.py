@@ -187,9 +187,33 @@ def test_table_variants_agree(cpa):
                     assert tuple(ints(dp[i])) == opd.evaluate(g, 5, 13, bytes(m[i]))
                     assert ints(db[i])[0] == obh.evaluate(gb, 7, 5, bytes(mb[i]))
             assert np.array_equal(dp, ref_p) and np.array_equal(db, ref_b), (D, grp)
+        # the plain table (round 1) as A/B arm of the signed-subset table, at several digit widths
+        os.environ["AKP_PEDERSEN_PLAIN"] = "1"
+        for D in (13, 5, 1):
+            os.environ["AKP_PEDERSEN_DIGIT_BITS"] = str(D)
+            assert np.array_equal(pedersen.CRH.evaluate_batch(pedersen.Parameters(gens_array(g)), m), ref_p), ("plain", D)
     finally:
         os.environ.pop("AKP_PEDERSEN_DIGIT_BITS", None)
         os.environ.pop("AKP_BH_GROUP", None)
+        os.environ.pop("AKP_PEDERSEN_PLAIN", None)
+
+
+def test_pedersen_generators_outside_the_prime_subgroup(cpa):
+    """`Parameters.generators` is a public field: the points need not lie in the prime-order subgroup.  The signed-subset
+    table halves the generators, which only exists for odd order; such parameter sets must fall back to the plain table and
+    still hash like the oracle (whose group law is complete on the whole curve)."""
+    from crypto_primitives_amd.crh import pedersen
+    g = jj.pedersen_generators(91, 4, 8)
+    t2 = (0, jj.Q - 1)  # the point of order 2
+    g[3][1] = jj.add(g[3][1], t2)
+    g[7][0] = t2
+    assert jj.mul(g[3][1], jj.SUBGROUP_ORDER) != jj.IDENTITY
+    P = pedersen.Parameters(gens_array(g))
+    for n in (5, 20000):  # split kernel and accumulate + finalize
+        m = _msgs(n, 4, 17 + n)
+        got = pedersen.CRH.evaluate_batch(P, m)
+        for i in list(range(0, n, max(1, n // 7))) + [n - 1]:
+            assert tuple(ints(got[i])) == opd.evaluate(g, 4, 8, bytes(m[i])), (n, i)
 
 
 # ---- two device paths: accumulate + shared-inversion finalize (large batches) and the 8-wave split kernel

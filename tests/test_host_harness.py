@@ -26,6 +26,8 @@ def H():
     h.hh_te_build_lut.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     h.hh_te_crh.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
     h.hh_te_crh_split.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    h.hh_te_in_subgroup.argtypes = [vp]
+    h.hh_te_in_subgroup.restype = C.c_int
     h.hh_te_serialize_pairs.argtypes = [vp, vp, C.c_uint32, C.c_size_t, vp, C.c_size_t]
     h.hh_fr_pow.argtypes = [vp, C.c_uint64, vp]
     return h
@@ -243,6 +245,49 @@ def test_pedersen_table_path(H, W, N, D):
             out2 = np.zeros_like(out)
             H.hh_te_crh_split(0, P(lut), None, P(m), n, L, D, 0, _pedersen_steps(n_gen, D, L), split, P(out2))
             assert np.array_equal(out2, out), (W, N, D, L, split)
+
+
+@pytest.mark.parametrize("W,N,D", [(8, 20, 8), (6, 10, 8), (6, 10, 5), (3, 7, 8), (3, 7, 2), (5, 13, 7), (4, 16, 9)])
+def test_pedersen_signed_subset_table(H, W, N, D):
+    """round 2: the signed-subset table (half the entries per digit, sum starts from cprefix[n_steps]) gives the same digests
+    as the oracle for every message length -- including lengths that leave whole digits unused or end inside a digit -- in
+    the one-lane-per-item form and in the split form of the small-batch kernel"""
+    g = jj.pedersen_generators(13, W, N)
+    G = gens_array(g)
+    n_gen = W * N
+    n_digits = (n_gen + D - 1) // D
+    lut = np.zeros((n_digits << (D - 1), 36), np.uint32)
+    cpre = np.zeros((n_digits + 1, 36), np.uint32)
+    H.hh_te_build_lut(2, P(G), W, N, D, 1, P(lut), P(cpre))
+    for L in sorted({W * N // 8, 1, 0, 2, max(W * N // 8 - 3, 0), W * N // 16}):
+        n = 6
+        m = np.frombuffer(ofr.SplitMix64(7 * L + W).bytes(max(L, 1) * n), dtype=np.uint8).copy()
+        if L:
+            m[:L] = 0        # an all-zero message: the identity (every digit takes the negated complement entry)
+            m[L:2 * L] = 255  # all ones
+        out = np.zeros((n, 2, 4), np.uint64)
+        steps = _pedersen_steps(n_gen, D, L)
+        H.hh_te_crh(2, P(lut), P(cpre), P(m), n, L, D, 0, steps, 2, P(out))
+        for i in range(n):
+            assert tuple(ints(out[i])) == pd.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, D, L, i)
+        for split in (8, 2):
+            out2 = np.zeros_like(out)
+            H.hh_te_crh_split(2, P(lut), P(cpre), P(m), n, L, D, 0, steps, split, P(out2))
+            assert np.array_equal(out2, out), (W, N, D, L, split)
+
+
+def test_subgroup_check_of_the_signed_table(H):
+    """the signed-subset table needs generators of odd order: 2 * (G / 2) == G holds exactly for the prime-order subgroup"""
+    ok = gens_array([[jj.mul(jj.GENERATOR, 5)]])
+    assert H.hh_te_in_subgroup(P(ok)) == 1
+    assert H.hh_te_in_subgroup(P(gens_array([[jj.IDENTITY]]))) == 1
+    # a point with a cofactor component: (0, -1) has order 2; order-2 point + subgroup point has order 2r
+    t2 = (0, jj.Q - 1)
+    assert jj.is_on_curve(t2) and jj.add(t2, t2) == jj.IDENTITY
+    bad = jj.add(jj.mul(jj.GENERATOR, 9), t2)
+    assert jj.mul(bad, jj.SUBGROUP_ORDER) != jj.IDENTITY
+    assert H.hh_te_in_subgroup(P(gens_array([[bad]]))) == 0
+    assert H.hh_te_in_subgroup(P(gens_array([[t2]]))) == 0
 
 
 @pytest.mark.parametrize("W,N,group", [(63, 9, 1), (5, 3, 3), (5, 3, 1), (7, 2, 3), (63, 1, 3), (5, 3, 4), (7, 3, 2), (6, 2, 4)])

@@ -68,7 +68,7 @@ lanes) for L in 3 4; do for CH in 16 17 18; do AKP_HOST_LANES=$L AKP_HOST_CHUNK_
 rates) echo "== generic rates (register kernels for t = 4, 5 vs the LDS-file arm) =="
    (python tools/gpu_rates2.py; AKP_POSEIDON_NO_REG_T=1 python tools/gpu_rates2.py) 2>&1 | grep -v amdgpu.ids | tee $OUT/generic_rates.txt;;
 digits) echo "== Pedersen table digit width =="
-   (for D in 12 13 14; do AKP_PEDERSEN_DIGIT_BITS=$D python tools/gpu_pedersen_digits.py; done) 2>&1 | grep -v amdgpu.ids | tee $OUT/pedersen_digits.txt;;
+   (for D in 13 14 15; do AKP_PEDERSEN_DIGIT_BITS=$D python tools/gpu_pedersen_digits.py; done; AKP_PEDERSEN_PLAIN=1 AKP_PEDERSEN_DIGIT_BITS=13 python tools/gpu_pedersen_digits.py) 2>&1 | grep -v amdgpu.ids | tee $OUT/pedersen_digits.txt;;
 avail) rocprofv3 --list-avail 2>/dev/null | grep -i -o "TCC_[A-Z0-9_]*\|MALL[A-Z0-9_]*\|TCP_[A-Z0-9_]*" | sort -u > $OUT/avail_cache_counters.txt; wc -l $OUT/avail_cache_counters.txt;;
 esac; done
 rocm-smi --showclocks --showpower > $OUT/smi_after.txt 2>&1
