@@ -933,7 +933,8 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
     if (kind == AKP_TE_PEDERSEN) {
         // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
-        // stores 2^(D-1) entries per digit, so D = 14 costs what D = 13 costs in the plain table: 4x256 is 74 steps (87 MB).
+        // stores 2^(D-1) entries per digit.  Default D = 15: 4x256 is 69 steps over a 163 MB table.  Measured on MI355X, 2^20 x 128 B
+        // (profiles/r02_s9): signed D = 13 / 14 / 15: 2.70 / 2.75 / 2.88e8 hashes/s; plain table D = 13: 2.56e8.
         // AKP_PEDERSEN_PLAIN=1 keeps the plain table (the A/B arm, and the fallback for generators outside the subgroup).
         NielsPad* d_half = nullptr;
         u32* d_bad = nullptr;
@@ -950,7 +951,7 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
         if (e == hipSuccess && bad == 0) {
-            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 14, 2, 15);
+            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 15, 2, 15);
             while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(NielsPad) > ((size_t)192 << 20)) --D;
             p->digit_bits = D;
             p->signed_subset = true;
