@@ -304,10 +304,11 @@ def main():
                     "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<0> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
                                  "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": 192.0 * npd / kavg / 1e9 / HBM_PEAK_GBS,
-                                 "table_bytes_gathered_per_hash": 79 * 144, "gather_over_algorithmic": 79 * 144 / 192.0,
-                                 "valu": {"table_steps_per_hash": 79, "field_products_per_step": 7,
-                                          "note": "VALU-issue bound like the permutation: 79 mixed additions of 7 products; the "
-                                                  "93 MB table is gathered through L2 / Infinity Cache (counters: profiles/r02_*)"}}}
+                                 "table_bytes_gathered_per_hash": 69 * 144, "gather_over_algorithmic": 69 * 144 / 192.0,
+                                 "valu": {"table_steps_per_hash": 69, "field_products_per_step": 7,
+                                          "note": "VALU-issue bound like the permutation: 69 mixed additions of 7 products (signed-subset "
+                                                  "table, 15-bit digits); the 163 MB table is gathered through L2 / Infinity Cache "
+                                                  "(counters: profiles/r02_s2/pmc_counters_te.txt for the 13-bit plain table)"}}}
         if rank == 0:
             from oracle import cref
             cur = cref.CurveParams(4, 256, gens)
