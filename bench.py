@@ -145,6 +145,7 @@ def main():
                     help="Bowe-Hopwood 63x9 tree: leaves PER GPU (BASELINE config 5 is 2^23 per GPU on 8 GPUs; 0 disables)")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of each sustained loop (0 disables)")
     ap.add_argument("--sustain-log2-big", type=int, default=24, help="second sustained size (0 disables)")
+    ap.add_argument("--settle-launches", type=int, default=120, help="untimed launches before the W warm-up steps (clock ramp)")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -384,6 +385,11 @@ def main():
         parity["bit_exact"] = bool(np.array_equal(got, exp))
         if not parity["bit_exact"]:
             raise SystemExit("parity probe FAILED: the timed kernel's output differs from the oracle")
+    # the oracle check above left the GPU idle for ~0.1 s and the clocks drop within milliseconds: settle them with untimed
+    # launches (like the side legs, outside W and K) so that the W + K steps measure the steady state, not the ramp
+    for _ in range(args.settle_launches):
+        step()
+    torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -492,6 +498,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: batched Poseidon permutation, BLS12-381 Fr, t=3 rate=2 alpha=17 RF=8 RP=31 "
                                "(default Grain-LFSR parameters), 2^%d states per GPU, in place in HBM" % args.log2_states,
                    "states_per_gpu": n, "parallelism": "shard%d (no data-path collective)" % world},
+        "settle_launches_before_warmup": args.settle_launches,
         "launch": {"ranks": world, "backend": None if not dist else ("gloo (shared-GPU test hook)" if shared_gpu else "nccl (RCCL)"),
                    "rank_devices": rank_devices},
         "parity_probe_bit_exact": parity["bit_exact"],
