@@ -156,7 +156,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             continue;
         }
         // t = 4, 5 with the full / lane-1 form: the register-resident path (as capi.hip routes large batches)
-        if ((D.t == 4 || D.t == 5) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse) {
+        if ((D.t >= 4 && D.t <= 6) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse) {
             auto run = [&](auto tag, auto ff) {
                 constexpr u32 T = decltype(tag)::value;
                 constexpr bool FF = decltype(ff)::value;
@@ -167,7 +167,8 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             };
             const bool ff = th->cfile.scaled == 3u;
             if (D.t == 4) { if (ff) run(std::integral_constant<u32, 4>{}, std::true_type{}); else run(std::integral_constant<u32, 4>{}, std::false_type{}); }
-            else { if (ff) run(std::integral_constant<u32, 5>{}, std::true_type{}); else run(std::integral_constant<u32, 5>{}, std::false_type{}); }
+            else if (D.t == 5) { if (ff) run(std::integral_constant<u32, 5>{}, std::true_type{}); else run(std::integral_constant<u32, 5>{}, std::false_type{}); }
+            else { if (ff) run(std::integral_constant<u32, 6>{}, std::true_type{}); else run(std::integral_constant<u32, 6>{}, std::false_type{}); }
             continue;
         }
         const bool wire = th->cfile.scaled == 3u;  // as poseidon_permute_kernel
@@ -189,12 +190,13 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     HostFile f{buf.data()};
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
-    const bool reg45 = (D.t == 4 || D.t == 5) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse;
+    const bool reg45 = (D.t >= 4 && D.t <= 6) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse;
     for (size_t i = 0; i < n; ++i) {
         if (reg45) {
             const bool ff = th->cfile.scaled == 3u;
             if (D.t == 4) out[i] = ff ? poseidon_crh_item_reg<4, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<4, false>(D, th->cfile, in0, in1, k, i);
-            else out[i] = ff ? poseidon_crh_item_reg<5, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<5, false>(D, th->cfile, in0, in1, k, i);
+            else if (D.t == 5) out[i] = ff ? poseidon_crh_item_reg<5, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<5, false>(D, th->cfile, in0, in1, k, i);
+            else out[i] = ff ? poseidon_crh_item_reg<6, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<6, false>(D, th->cfile, in0, in1, k, i);
             continue;
         }
         out[i] = reg_path ? (th->creg.scaled == 3u ? poseidon_crh_item_t3<true>(D, th->creg, in0, in1, k, i) : poseidon_crh_item_t3<false>(D, th->creg, in0, in1, k, i)) : poseidon_crh_item(D, th->cfile, f, in0, in1, k, i);
