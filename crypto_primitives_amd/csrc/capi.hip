@@ -569,11 +569,11 @@ static bool generic_coop(size_t n) {
     }();
     return n <= coop_max;
 }
-// t = 4, 5, 6 (the default rate-3 / rate-4 / rate-5 instances): register-resident kernels for large batches when the parameter set has
+// t = 4 .. 9 (the default rate-3 .. rate-8 instances): register-resident kernels for large batches when the parameter set has
 // the full form or the lane-1 form (AKP_POSEIDON_NO_REG_T=1 keeps the LDS-file kernels: the A/B arm)
 static bool reg_t_kernel(const akp_poseidon* p, size_t n, const PoseidonConsts& c) {
     static const bool enabled = !getenv("AKP_POSEIDON_NO_REG_T");
-    return enabled && (p->dims.t >= 4 && p->dims.t <= 6) && !generic_coop(n) && (c.scaled == 3u || c.scaled == 2u) && c.sparse != nullptr;
+    return enabled && (p->dims.t >= 4 && p->dims.t <= 9) && !generic_coop(n) && (c.scaled == 3u || c.scaled == 2u) && c.sparse != nullptr;
 }
 template <u32 T>
 static void launch_reg_permute(const akp_poseidon* p, const PoseidonConsts& c, Fr* d_states, size_t n, hipStream_t s) {
@@ -607,9 +607,14 @@ static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream
         return AKP_OK;
     }
     if (reg_t_kernel(p, n, file_consts(p))) {
-        if (p->dims.t == 4) launch_reg_permute<4>(p, file_consts(p), d_states, n, s);
-        else if (p->dims.t == 5) launch_reg_permute<5>(p, file_consts(p), d_states, n, s);
-        else launch_reg_permute<6>(p, file_consts(p), d_states, n, s);
+        switch (p->dims.t) {
+            case 4: launch_reg_permute<4>(p, file_consts(p), d_states, n, s); break;
+            case 5: launch_reg_permute<5>(p, file_consts(p), d_states, n, s); break;
+            case 6: launch_reg_permute<6>(p, file_consts(p), d_states, n, s); break;
+            case 7: launch_reg_permute<7>(p, file_consts(p), d_states, n, s); break;
+            case 8: launch_reg_permute<8>(p, file_consts(p), d_states, n, s); break;
+            default: launch_reg_permute<9>(p, file_consts(p), d_states, n, s); break;
+        }
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -638,9 +643,14 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
         return AKP_OK;
     }
     if (reg_t_kernel(p, n, file_consts(p))) {
-        if (p->dims.t == 4) launch_reg_crh<4>(p, file_consts(p), in0, in1, k, d_out, n, s);
-        else if (p->dims.t == 5) launch_reg_crh<5>(p, file_consts(p), in0, in1, k, d_out, n, s);
-        else launch_reg_crh<6>(p, file_consts(p), in0, in1, k, d_out, n, s);
+        switch (p->dims.t) {
+            case 4: launch_reg_crh<4>(p, file_consts(p), in0, in1, k, d_out, n, s); break;
+            case 5: launch_reg_crh<5>(p, file_consts(p), in0, in1, k, d_out, n, s); break;
+            case 6: launch_reg_crh<6>(p, file_consts(p), in0, in1, k, d_out, n, s); break;
+            case 7: launch_reg_crh<7>(p, file_consts(p), in0, in1, k, d_out, n, s); break;
+            case 8: launch_reg_crh<8>(p, file_consts(p), in0, in1, k, d_out, n, s); break;
+            default: launch_reg_crh<9>(p, file_consts(p), in0, in1, k, d_out, n, s); break;
+        }
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(BLOCK) poseidon_crh_kernel(PoseidonDims D, Pos
     store_fr_global(out + idx, poseidon_crh_item(D, C, f, in0, in1, k, idx));
 }
 
-// =============================== t = 4, 5, 6: register-resident state (round 2) =================================
+// =============================== t = 4 .. 9: register-resident state (round 2) ==================================
 // The default rate-3 / rate-4 instances (alpha = 5, 8 + 56 rounds) spend 56 of 64 rounds in the sparse partial round,
 // which touches fixed lanes: with T a compile-time constant that round is straight-line code on registers.  The eight
 // dense rounds would need T row sums and T S-boxes unrolled (too much code for the 64 KB instruction cache at T = 5),
@@ -433,21 +433,21 @@ AKP_HD u32 reg_col(u32 i, u32 k, u32 T) {
 template <u32 T, u32 K0>
 AKP_HD FP reg_row_sum(const FP (&s)[T], const F29Pad* __restrict__ row, u32 i) {
     constexpr u32 N = T - K0;
-    static_assert(N >= 3 && N <= 6, "register kernels cover t = 4, 5, 6");
-    // the constants carry balanced digits (f29_balance), so up to five terms share ONE reduction
-    if constexpr (N == 3)
-        return f29_dot3(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)));
-    else if constexpr (N == 4)
-        return f29_dot4(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)),
-                        s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T)));
-    else if constexpr (N == 5)
-        return f29_dot5(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2], ldc(row + reg_col(i, K0 + 2, T)),
-                        s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T)), s[K0 + 4], ldc(row + reg_col(i, K0 + 4, T)));
-    else  // six terms: five under one reduction + one product, carried back to <= 2^29 + 1
-        return f29_weak_norm(f29_add(f29_dot5(s[K0], ldc(row + reg_col(i, K0, T)), s[K0 + 1], ldc(row + reg_col(i, K0 + 1, T)), s[K0 + 2],
-                                              ldc(row + reg_col(i, K0 + 2, T)), s[K0 + 3], ldc(row + reg_col(i, K0 + 3, T)), s[K0 + 4],
-                                              ldc(row + reg_col(i, K0 + 4, T))),
-                                     f29_mulc(s[K0 + 5], ldc(row + reg_col(i, K0 + 5, T)))));
+    static_assert(N >= 3 && N <= 9, "register kernels cover t = 4 .. 9");
+    // the constants carry balanced digits (f29_balance), so up to five terms share ONE reduction; six to nine terms are five + the
+    // rest under a second reduction, and the two-term sum is carried back to <= 2^29 + 1
+#define AKP_RS(k) s[K0 + (k)], ldc(row + reg_col(i, K0 + (k), T))
+    if constexpr (N == 3) return f29_dot3(AKP_RS(0), AKP_RS(1), AKP_RS(2));
+    else if constexpr (N == 4) return f29_dot4(AKP_RS(0), AKP_RS(1), AKP_RS(2), AKP_RS(3));
+    else if constexpr (N == 5) return f29_dot5(AKP_RS(0), AKP_RS(1), AKP_RS(2), AKP_RS(3), AKP_RS(4));
+    else {
+        const FP head = f29_dot5(AKP_RS(0), AKP_RS(1), AKP_RS(2), AKP_RS(3), AKP_RS(4));
+        if constexpr (N == 6) return f29_weak_norm(f29_add(head, f29_mulc(AKP_RS(5))));
+        else if constexpr (N == 7) return f29_weak_norm(f29_add(head, f29_dot2(AKP_RS(5), AKP_RS(6))));
+        else if constexpr (N == 8) return f29_weak_norm(f29_add(head, f29_dot3(AKP_RS(5), AKP_RS(6), AKP_RS(7))));
+        else return f29_weak_norm(f29_add(head, f29_dot4(AKP_RS(5), AKP_RS(6), AKP_RS(7), AKP_RS(8))));
+    }
+#undef AKP_RS
 }
 template <u32 T, bool FF>
 AKP_HD void poseidon_permute_reg(const PoseidonDims& D, const PoseidonConsts& C, FP (&s)[T], u32 need_lanes = 0xffffu) {

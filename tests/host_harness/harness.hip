@@ -156,7 +156,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             continue;
         }
         // t = 4, 5 with the full / lane-1 form: the register-resident path (as capi.hip routes large batches)
-        if ((D.t >= 4 && D.t <= 6) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse) {
+        if ((D.t >= 4 && D.t <= 9) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse) {
             auto run = [&](auto tag, auto ff) {
                 constexpr u32 T = decltype(tag)::value;
                 constexpr bool FF = decltype(ff)::value;
@@ -166,9 +166,11 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
                 for (u32 e = 0; e < T; ++e) states[i * T + e] = reg_store<T, FF>(s[e]);
             };
             const bool ff = th->cfile.scaled == 3u;
-            if (D.t == 4) { if (ff) run(std::integral_constant<u32, 4>{}, std::true_type{}); else run(std::integral_constant<u32, 4>{}, std::false_type{}); }
-            else if (D.t == 5) { if (ff) run(std::integral_constant<u32, 5>{}, std::true_type{}); else run(std::integral_constant<u32, 5>{}, std::false_type{}); }
-            else { if (ff) run(std::integral_constant<u32, 6>{}, std::true_type{}); else run(std::integral_constant<u32, 6>{}, std::false_type{}); }
+            switch (D.t) {
+#define AKP_RUN(TT) case TT: if (ff) run(std::integral_constant<u32, TT>{}, std::true_type{}); else run(std::integral_constant<u32, TT>{}, std::false_type{}); break;
+                AKP_RUN(4) AKP_RUN(5) AKP_RUN(6) AKP_RUN(7) AKP_RUN(8) AKP_RUN(9)
+#undef AKP_RUN
+            }
             continue;
         }
         const bool wire = th->cfile.scaled == 3u;  // as poseidon_permute_kernel
@@ -190,13 +192,15 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     HostFile f{buf.data()};
     T3Host* th = new T3Host(D.t, rf, rp, alpha, ark, mds, force_generic != 2);
     const bool reg_path = D.t == 3 && force_generic != 1;
-    const bool reg45 = (D.t >= 4 && D.t <= 6) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse;
+    const bool reg45 = (D.t >= 4 && D.t <= 9) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse;
     for (size_t i = 0; i < n; ++i) {
         if (reg45) {
             const bool ff = th->cfile.scaled == 3u;
-            if (D.t == 4) out[i] = ff ? poseidon_crh_item_reg<4, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<4, false>(D, th->cfile, in0, in1, k, i);
-            else if (D.t == 5) out[i] = ff ? poseidon_crh_item_reg<5, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<5, false>(D, th->cfile, in0, in1, k, i);
-            else out[i] = ff ? poseidon_crh_item_reg<6, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<6, false>(D, th->cfile, in0, in1, k, i);
+            switch (D.t) {
+#define AKP_RUN(TT) case TT: out[i] = ff ? poseidon_crh_item_reg<TT, true>(D, th->cfile, in0, in1, k, i) : poseidon_crh_item_reg<TT, false>(D, th->cfile, in0, in1, k, i); break;
+                AKP_RUN(4) AKP_RUN(5) AKP_RUN(6) AKP_RUN(7) AKP_RUN(8) AKP_RUN(9)
+#undef AKP_RUN
+            }
             continue;
         }
         out[i] = reg_path ? (th->creg.scaled == 3u ? poseidon_crh_item_t3<true>(D, th->creg, in0, in1, k, i) : poseidon_crh_item_t3<false>(D, th->creg, in0, in1, k, i)) : poseidon_crh_item(D, th->cfile, f, in0, in1, k, i);
