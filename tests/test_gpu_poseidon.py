@@ -264,15 +264,19 @@ def test_generic_kernel_on_custom_t(cpa, shape):
         assert np.array_equal(got, exp), (shape, k)
 
 
-@pytest.mark.parametrize("coop_max", ["0", "1000000000"])
-def test_generic_kernels_both_ways(cpa, coop_max):
-    """the same checks with every batch forced through the LDS-file kernels (0) / the wave-per-lane kernels (10^9),
-    in a fresh process (the switch is read once)"""
+@pytest.mark.parametrize("coop_max,no_reg", [("0", ""), ("0", "1"), ("1000000000", "")])
+def test_generic_kernels_both_ways(cpa, coop_max, no_reg):
+    """the same checks with every batch forced through the one-lane-per-item kernels (0: register-resident for t = 4 .. 9,
+    LDS-file otherwise; with AKP_POSEIDON_NO_REG_T=1 the LDS-file kernels for every t) / the wave-per-lane kernels (10^9),
+    in a fresh process (the switches are read once)"""
     import os, subprocess, sys
     here = os.path.abspath(__file__)
+    env = dict(os.environ, AKP_POSEIDON_GENERIC_COOP_MAX=coop_max)
+    if no_reg:
+        env["AKP_POSEIDON_NO_REG_T"] = no_reg
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                         "test_generic_kernel_on_custom_t or test_crh_other_rates or test_permute_all_default_configs"],
-                       env=dict(os.environ, AKP_POSEIDON_GENERIC_COOP_MAX=coop_max), capture_output=True, text=True, timeout=900,
+                       env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
