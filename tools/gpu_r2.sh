@@ -69,6 +69,10 @@ rates) echo "== generic rates (register kernels for t = 4, 5 vs the LDS-file arm
    (python tools/gpu_rates2.py; AKP_POSEIDON_NO_REG_T=1 python tools/gpu_rates2.py) 2>&1 | grep -v amdgpu.ids | tee $OUT/generic_rates.txt;;
 digits) echo "== Pedersen table digit width =="
    (for D in 13 14 15; do AKP_PEDERSEN_DIGIT_BITS=$D python tools/gpu_pedersen_digits.py; done; AKP_PEDERSEN_PLAIN=1 AKP_PEDERSEN_DIGIT_BITS=13 python tools/gpu_pedersen_digits.py) 2>&1 | grep -v amdgpu.ids | tee $OUT/pedersen_digits.txt;;
+latency) echo "== small-batch latencies =="
+   (AKP_POSEIDON_COOP_MAX=0 python tools/gpu_coop.py; AKP_POSEIDON_COOP_MAX=1000000000 python tools/gpu_coop.py) 2>&1 | grep -v amdgpu.ids > $OUT/latency_poseidon_t3.txt; tail -25 $OUT/latency_poseidon_t3.txt
+   python tools/gpu_te_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/latency_te.txt; tail -20 $OUT/latency_te.txt;;
+benchall) echo "== bench_all =="; timeout 900 python tools/bench_all.py --cpu-seconds 1 > $OUT/bench_all.jsonl 2> $OUT/bench_all.err; cut -c1-230 $OUT/bench_all.jsonl; tail -3 $OUT/bench_all.err;;
 avail) rocprofv3 --list-avail 2>/dev/null | grep -i -o "TCC_[A-Z0-9_]*\|MALL[A-Z0-9_]*\|TCP_[A-Z0-9_]*" | sort -u > $OUT/avail_cache_counters.txt; wc -l $OUT/avail_cache_counters.txt;;
 esac; done
 rocm-smi --showclocks --showpower > $OUT/smi_after.txt 2>&1
