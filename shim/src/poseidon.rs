@@ -4,9 +4,7 @@ use crate::runtime::{check, fingerprint, flatten, fr_from_limbs, with_runtime, w
 use crate::{ffi, Error, Fr};
 use ark_crypto_primitives::crh::{CRHScheme, TwoToOneCRHScheme};
 use ark_crypto_primitives::sponge::poseidon::PoseidonConfig;
-use ark_crypto_primitives::sponge::{
-    Absorb, CryptographicSponge, DuplexSpongeMode, FieldBasedCryptographicSponge, FieldElementSize, SpongeExt,
-};
+use ark_crypto_primitives::sponge::{Absorb, CryptographicSponge, DuplexSpongeMode, FieldBasedCryptographicSponge, SpongeExt};
 use ark_ff::{BigInteger, PrimeField, Zero};
 use ark_std::{borrow::Borrow, rand::Rng, vec::Vec};
 
@@ -178,13 +176,8 @@ impl FieldBasedCryptographicSponge<Fr> for GpuPoseidonSponge {
         check(unsafe { ffi::akp_sponge_squeeze(self.h, words_mut(&mut out), num_elements) }, num_elements).expect("akp_sponge_squeeze");
         out
     }
-    fn squeeze_native_field_elements_with_sizes(&mut self, sizes: &[FieldElementSize]) -> Vec<Fr> {
-        if sizes.iter().all(|s| *s == FieldElementSize::Full) {
-            self.squeeze_native_field_elements(sizes.len())
-        } else {
-            ark_crypto_primitives::sponge::squeeze_field_elements_with_sizes_default_impl(self, sizes)
-        }
-    }
+    // squeeze_native_field_elements_with_sizes: the trait's default (sponge/mod.rs:162-178) -- full sizes go through
+    // squeeze_native_field_elements above, truncated sizes through squeeze_bits.
 }
 impl SpongeExt for GpuPoseidonSponge {
     type State = GpuPoseidonSpongeState;

@@ -72,7 +72,78 @@ static int worker(int seed, std::vector<Fr>* digests) {  // what a rayon worker 
     return 0;
 }
 
-int main() {
+// te.rs + merkle.rs (byte trees): records written by tests/test_shim_sequence.py -- u32 kind, W, N, msg_len; N*W affine
+// generators (8 u64 each); one message; its expected digest from the oracle (8 or 4 u64).
+static int te_section(akp_ctx* ctx, const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    REQUIRE(f != nullptr);
+    uint32_t hdr[4];
+    int cases = 0;
+    while (std::fread(hdr, sizeof hdr, 1, f) == 1) {
+        const uint32_t kind = hdr[0], W = hdr[1], N = hdr[2], L = hdr[3];
+        const size_t fe = kind == AKP_TE_PEDERSEN ? 2 : 1;
+        std::vector<uint64_t> gens((size_t)W * N * 8), want(fe * 4);
+        std::vector<uint8_t> msg(L);
+        REQUIRE(std::fread(gens.data(), 8, gens.size(), f) == gens.size());
+        REQUIRE(L == 0 || std::fread(msg.data(), 1, L, f) == L);
+        REQUIRE(std::fread(want.data(), 8, want.size(), f) == want.size());
+        akp_te_params* p = nullptr;
+        OKC(akp_te_params_create(ctx, (int32_t)kind, W, N, gens.data(), &p));  // te_handle(): generators normalised to affine x || y
+        // CRHScheme::evaluate (one item) == the oracle's digest == the same message inside a batch
+        std::vector<uint64_t> one(fe * 4), many(5 * fe * 4);
+        OKC(akp_te_crh_batch(p, msg.data(), 1, L, one.data()));
+        REQUIRE(one == want);
+        std::vector<uint8_t> batch(5 * (size_t)L);
+        for (size_t i = 0; i < batch.size(); ++i) batch[i] = (uint8_t)splitmix();
+        if (L) std::memcpy(&batch[2 * (size_t)L], msg.data(), L);
+        OKC(akp_te_crh_batch(p, batch.data(), 5, L, many.data()));
+        REQUIRE(std::memcmp(&many[2 * fe * 4], want.data(), fe * 32) == 0);
+        // the reference panics on an oversized input: status 1 -> Error::IncorrectInputLength in the shim
+        const size_t max_bytes = (kind == AKP_TE_PEDERSEN ? (size_t)W * N : (size_t)W * N * 3) / 8;
+        std::vector<uint8_t> big(max_bytes + 1);
+        REQUIRE(akp_te_crh_batch(p, big.data(), 1, big.size(), one.data()) == AKP_ERR_BAD_LENGTH);
+        // TwoToOneCRHScheme::compress(l, r) on two digests == evaluate on their uncompressed serialisations: build a 4-leaf
+        // byte tree (GpuMerkleTree<PedersenByteConfig / BoweHopwoodByteConfig>) and recompute its root by hand
+        const size_t leaf_len = L < 4 ? 4 : (L > 32 ? 32 : L);
+        if (leaf_len * 8 <= (kind == AKP_TE_PEDERSEN ? (size_t)W * N : (size_t)W * N * 3) && (size_t)W * N / 8 >= 2 * fe * 32) {
+            std::vector<uint8_t> leaves(4 * leaf_len);
+            for (auto& b : leaves) b = (uint8_t)splitmix();
+            akp_merkle_tree* t = nullptr;
+            OKC(akp_merkle_tree_build_te(p, p, leaves.data(), 4, leaf_len, &t));
+            std::vector<uint64_t> ln(4 * fe * 4), nl(3 * fe * 4), d(4 * fe * 4), lvl(2 * fe * 4), root(fe * 4);
+            OKC(akp_merkle_tree_export(t, ln.data(), nl.data()));
+            OKC(akp_te_crh_batch(p, leaves.data(), 4, leaf_len, d.data()));
+            REQUIRE(ln == d);
+            std::vector<uint64_t> left = {d.begin(), d.begin() + fe * 4}, right = {d.begin() + fe * 4, d.begin() + 2 * fe * 4};
+            std::vector<uint64_t> l2 = {d.begin() + 2 * fe * 4, d.begin() + 3 * fe * 4}, r2 = {d.begin() + 3 * fe * 4, d.end()};
+            OKC(akp_te_compress_batch(p, left.data(), right.data(), 1, &lvl[0]));
+            OKC(akp_te_compress_batch(p, l2.data(), r2.data(), 1, &lvl[fe * 4]));
+            OKC(akp_te_compress_batch(p, &lvl[0], &lvl[fe * 4], 1, root.data()));
+            REQUIRE(std::memcmp(&nl[fe * 4], lvl.data(), 2 * fe * 32) == 0 && std::memcmp(nl.data(), root.data(), fe * 32) == 0);
+            // update + proof round trip on the byte tree
+            uint64_t idx = 2;
+            std::vector<uint8_t> nleaf(leaf_len, 0x5a);
+            OKC(akp_merkle_tree_update_batch(t, &idx, nleaf.data(), 1, leaf_len));
+            std::memcpy(&leaves[2 * leaf_len], nleaf.data(), leaf_len);
+            std::vector<uint64_t> nl2(3 * fe * 4), root2(fe * 4), sib(fe * 4), auth(fe * 4);
+            OKC(akp_merkle_build_te(p, p, leaves.data(), 4, leaf_len, nullptr, nl2.data(), root2.data()));
+            OKC(akp_merkle_tree_root(t, root.data()));
+            REQUIRE(root == root2);
+            OKC(akp_merkle_tree_gather_paths(t, &idx, 1, sib.data(), auth.data()));
+            uint8_t ok = 0;
+            OKC(akp_merkle_verify_paths_te(p, p, root.data(), nleaf.data(), 1, leaf_len, &idx, sib.data(), auth.data(), 1, &ok));
+            REQUIRE(ok == 1);
+            akp_merkle_tree_destroy(t);
+        }
+        akp_te_params_destroy(p);
+        ++cases;
+    }
+    std::fclose(f);
+    std::printf("te cases %d\n", cases);
+    return 0;
+}
+
+int main(int argc, char** argv) {
     if (akp_device_count() < 1) { std::fprintf(stderr, "no HIP device\n"); return 2; }
     Runtime rt;
     if (rt.init()) return 1;
@@ -235,8 +306,8 @@ int main() {
         akp_merkle_tree_destroy(t);
     }
 
-    // ---- te.rs: Bowe-Hopwood over generators read from the case file is covered by test_akp_hpp; here the per-item /
-    //      batch agreement and the TwoToOne buffer rule with generators derived on the device side of the ABI ----------
+    // ---- te.rs + byte-tree configurations of merkle.rs ------------------------------------------------------------------
+    if (argc > 1 && te_section(rt.ctx, argv[1]) != 0) return 1;
     std::printf("OK\n");
     return 0;
 }
