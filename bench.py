@@ -269,6 +269,25 @@ def main():
             merkle["sampled_parity_bit_exact"] = bool(ok)
             if not ok:
                 raise SystemExit("Merkle leg: sampled nodes differ from the oracle")
+        # the same tree through the C ABI's single-process multi-device entry point (what a Rust host calls): all visible GPUs
+        # (a power of two), leaves in host memory, RCCL all-gather of the sub-roots inside libakp.so.  PCIe-inclusive.  Only when
+        # this is the one process of the run; any failure is reported, not fatal (n_dev > 1 cannot be tested on a one-GPU box).
+        if world == 1 and not shared_gpu and os.environ.get("AKP_BENCH_NO_MULTI") != "1":
+            try:
+                g = 1
+                while g * 2 <= min(torch.cuda.device_count(), 8):
+                    g *= 2
+                mg = cpa.MultiGpu(list(range(g)))
+                mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves[: 1 << 16], want_nodes=False)  # handles, scratch, RCCL warm-up
+                mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
+                m0 = time.perf_counter()
+                _, _, mroot = mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
+                merkle["one_process_c_abi"] = {"entry_point": "akp_merkle_build_sharded_poseidon", "devices": g, "seconds": time.perf_counter() - m0,
+                                                "includes": "copy-in of the leaves over PCIe", "collective": "ncclAllGather of %d sub-roots" % g,
+                                                "root_matches": bool(np.array_equal(np.asarray(mroot).reshape(-1), np.asarray(res["root"]).reshape(-1)))}
+                mg.close()
+            except Exception as exc:  # pragma: no cover
+                merkle["one_process_c_abi"] = {"error": repr(exc)[:300]}
         del d_leaves, res, backend
 
     # ---- BASELINE config 4: Pedersen 4x256 over Jubjub, 2^k x 128 B per GPU ------------------------------------------
