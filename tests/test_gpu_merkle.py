@@ -256,3 +256,49 @@ def test_update_batch_equals_sequential_updates(cpa):
     t2 = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves[:2])
     t2.update_batch([1], new[:1])
     assert np.array_equal(t2.root(), cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, np.stack([leaves[0], new[0]])).root())
+
+
+def test_largest_batches_2pow26(cpa):
+    """the upper end of the BASELINE size range (2^26): a batched permutation over 2^26 states and a Poseidon tree over 2^26
+    leaves, both resident in HBM (6 GiB of states; 2 + 2 + 2 GiB of leaves and nodes), checked through size-independent
+    properties: the input repeats a 2^20 block 64 times, so every block of the permutation output must equal the first one
+    (itself sampled against the oracle), and the 64 nodes of tree level 6 must all equal the root of the 2^20-leaf tree."""
+    import torch
+    from crypto_primitives_amd import field
+    from crypto_primitives_amd._lib import lib, check
+    c = cpa.get_default_poseidon_parameters(2, False)
+    ora = cref_poseidon(po.get_default_poseidon_parameters(2, False))
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(dev).total_memory < (40 << 30):
+        pytest.skip("needs ~16 GiB of device memory")
+    h = c.handle(cpa.default_context(0))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    blk, reps = 1 << 20, 64
+    n = blk * reps
+    host = field.random_fr(blk * 3, seed=0xA5A50026).reshape(blk, 3, 4)
+    st = torch.from_numpy(host.view(np.int64)).to(dev).repeat(reps, 1, 1)
+    check(lib.akp_poseidon_permute_batch_dev(h.h, st.data_ptr(), n, stream))
+    torch.cuda.synchronize()
+    first = st[:blk]
+    for r in (1, 17, 63):
+        assert torch.equal(st[r * blk:(r + 1) * blk], first), r
+    si = np.unique(np.concatenate([np.arange(64), np.linspace(0, blk - 1, 193).astype(np.int64)]))
+    assert np.array_equal(first.cpu().numpy().view(np.uint64)[si], ora.permute_batch(np.ascontiguousarray(host[si]), threads=8).reshape(len(si), 3, 4))
+    del st, first
+    leaves_blk = torch.from_numpy(host[:, :1].copy().view(np.int64)).to(dev)
+    leaves = leaves_blk.repeat(reps, 1, 1)
+    ln = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    nl = torch.empty((n - 1, 4), dtype=torch.int64, device=dev)
+    check(lib.akp_merkle_build_poseidon_dev(h.h, h.h, leaves.data_ptr(), n, 1, ln.data_ptr(), nl.data_ptr(), stream))
+    ln_b = torch.empty((blk, 4), dtype=torch.int64, device=dev)
+    nl_b = torch.empty((blk - 1, 4), dtype=torch.int64, device=dev)
+    check(lib.akp_merkle_build_poseidon_dev(h.h, h.h, leaves_blk.data_ptr(), blk, 1, ln_b.data_ptr(), nl_b.data_ptr(), stream))
+    torch.cuda.synchronize()
+    level6 = nl[63:127]  # global level 6 = the roots of the 64 sub-trees of 2^20 leaves
+    assert torch.equal(level6, nl_b[0:1].expand(64, 4))
+    assert torch.equal(nl[127:127 + 128][0::2], nl_b[1:2].expand(64, 4))  # level 7: left children
+    top = nl[:63].cpu().numpy().view(np.uint64)
+    lvl = level6.cpu().numpy().view(np.uint64)
+    for width in (32, 16, 8, 4, 2, 1):  # the top six levels recomputed by the oracle from level 6
+        lvl = ora.two_to_one_batch(np.ascontiguousarray(lvl[0::2]), np.ascontiguousarray(lvl[1::2]), threads=4)
+        assert np.array_equal(top[width - 1: 2 * width - 1], lvl), width
