@@ -23,4 +23,10 @@ Pinning status (see DESIGN.md "Oracle"):
     dependencies).  They are pinned structurally: group-law identities,
     scalar-multiplication form of the hash, the generator-independent known
     answers that follow from the reference code, and proof round trips.
+    Since round 2 the Jubjub GROUP LAW underneath them is pinned at value
+    level by the one absolute vector of the un-vendored curve dependency,
+    ark-ed-on-bls12-381's test_scalar_multiplication (f1 * f2 * g), kept in
+    tests/golden/jubjub_upstream_kat.json: a Pedersen hash over one window
+    of generators 2^j * g IS that scalar multiplication.  Bit order, padding,
+    the Bowe-Hopwood chunk encoding and the byte encodings stay unpinned.
 """

@@ -2,7 +2,8 @@
 
 Follows crh/bowe_hopwood/mod.rs:114-186 (evaluate), :202-239 (TwoToOneCRH),
 :81-101 (window bound).  Output = x-coordinate (canonical int).
-PARITY UNPINNED at value level; see oracle/__init__.py.
+PARITY UNPINNED at value level as far as the reference goes; the group law underneath is pinned by the upstream curve
+crate's scalar-multiplication vector (tests/golden/jubjub_upstream_kat.json); see oracle/__init__.py.
 """
 from . import jubjub as jj
 from .pedersen import bytes_to_bits, InputLengthPanic

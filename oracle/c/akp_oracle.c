@@ -22,7 +22,7 @@
  *
  * Pinning: Poseidon functions are pinned by the reference KATs through
  * tests/test_oracle_c.py (C == python oracle == reference constants).  Pedersen /
- * Bowe-Hopwood / Merkle digests are PARITY UNPINNED at value level (no absolute vectors
+ * Bowe-Hopwood / Merkle digests are PARITY UNPINNED at value level as far as the reference goes (no absolute vectors
  * exist in the reference); they are checked against the python big-int oracle and
  * structural identities.
  *

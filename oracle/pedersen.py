@@ -2,8 +2,9 @@
 
 Follows crh/pedersen/mod.rs:76-129 (evaluate), :158-197 (TwoToOneCRH),
 :200-209 (bytes_to_bits).  Generators are `generators[i][j]` affine tuples.
-PARITY UNPINNED at value level (no absolute vectors in the reference); see
-oracle/__init__.py.
+PARITY UNPINNED at value level as far as the reference goes (it holds no absolute vectors); the group law
+underneath is pinned by the upstream curve crate's scalar-multiplication vector
+(tests/golden/jubjub_upstream_kat.json, tests/test_oracle_curves.py); see oracle/__init__.py.
 """
 from . import jubjub as jj
 

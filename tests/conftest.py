@@ -31,3 +31,12 @@ def derived():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "derived_vectors.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def jubjub_kat():
+    """value-level known answer for the Jubjub group law from the upstream curve crate's own test (see the file's `source`)"""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "jubjub_upstream_kat.json")) as f:
+        d = json.load(f)
+    return {"f1": int(d["f1"]), "f2": int(d["f2"]), "g": tuple(int(v) for v in d["g"]), "f1f2g": tuple(int(v) for v in d["f1f2g"])}

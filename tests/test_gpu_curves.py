@@ -198,6 +198,37 @@ def test_table_variants_agree(cpa):
         os.environ.pop("AKP_PEDERSEN_PLAIN", None)
 
 
+def test_upstream_jubjub_kat_on_the_gpu(cpa, jubjub_kat):
+    """the Pedersen kernels (table build from the caller's generators, mixed additions, shared inversion, wire encoding of the
+    coordinates) reproduce ark-ed-on-bls12-381's scalar-multiplication vector: one window of 256 generators 2^j * g -- computed
+    by the PRODUCT's host code, not by the oracle -- evaluates (f1 * f2) * g of the upstream test.  Both table kinds, both
+    device paths."""
+    import os
+    from crypto_primitives_amd import params as cparams, field
+    from crypto_primitives_amd.crh import pedersen
+    k = jubjub_kat
+    scalar = (k["f1"] * k["f2"]) % jj.SUBGROUP_ORDER
+    pts, cur = [], (k["g"][0], k["g"][1], 1)
+    for _ in range(256):
+        pts.append(cparams._affine(cur))
+        cur = cparams._padd(cur, cur)
+    gens = field.fr([c for pt in pts for c in pt]).reshape(1, 256, 2, 4)
+    msg = np.frombuffer(scalar.to_bytes(32, "little"), dtype=np.uint8)
+    try:
+        for plain in ("", "1"):
+            if plain:
+                os.environ["AKP_PEDERSEN_PLAIN"] = plain
+            P = pedersen.Parameters(gens)
+            assert tuple(ints(pedersen.CRH.evaluate(P, bytes(msg)))) == k["f1f2g"], plain
+            batch = np.tile(msg, (20000, 1))  # accumulate + finalize kernels
+            batch[1:, 0] ^= np.arange(1, 20000, dtype=np.uint64).astype(np.uint8)  # other scalars around it; row 0 stays the KAT
+            got = pedersen.CRH.evaluate_batch(P, batch)
+            assert tuple(ints(got[0])) == k["f1f2g"], plain
+            assert tuple(ints(got[256])) == k["f1f2g"]  # 256 & 0xff == 0: the same scalar again
+    finally:
+        os.environ.pop("AKP_PEDERSEN_PLAIN", None)
+
+
 def test_pedersen_generators_outside_the_prime_subgroup(cpa):
     """`Parameters.generators` is a public field: the points need not lie in the prime-order subgroup.  The signed-subset
     table halves the generators, which only exists for odd order; such parameter sets must fall back to the plain table and

@@ -276,6 +276,30 @@ def test_pedersen_signed_subset_table(H, W, N, D):
             assert np.array_equal(out2, out), (W, N, D, L, split)
 
 
+def test_upstream_jubjub_kat_through_the_device_functions(H, jubjub_kat):
+    """the product's table construction + accumulation + finalisation (the __host__ __device__ functions the kernels wrap), both
+    table kinds, reproduce ark-ed-on-bls12-381's scalar-multiplication vector (tests/golden/jubjub_upstream_kat.json)"""
+    k = jubjub_kat
+    scalar = (k["f1"] * k["f2"]) % jj.SUBGROUP_ORDER
+    gens = [[k["g"]]]
+    for _ in range(255):
+        gens[0].append(jj.double(gens[0][-1]))
+    G = gens_array(gens)
+    m = np.frombuffer(scalar.to_bytes(32, "little"), dtype=np.uint8).copy()
+    W, N, D = 256, 1, 8
+    lut = np.zeros((32 << D, 36), np.uint32)
+    H.hh_te_build_lut(0, P(G), W, N, D, 1, P(lut), None)
+    out = np.zeros((1, 2, 4), np.uint64)
+    H.hh_te_crh(0, P(lut), None, P(m), 1, 32, D, 0, 32, 1, P(out))
+    assert tuple(ints(out[0])) == k["f1f2g"]
+    slut = np.zeros((32 << (D - 1), 36), np.uint32)
+    cpre = np.zeros((33, 36), np.uint32)
+    H.hh_te_build_lut(2, P(G), W, N, D, 1, P(slut), P(cpre))
+    out2 = np.zeros((1, 2, 4), np.uint64)
+    H.hh_te_crh(2, P(slut), P(cpre), P(m), 1, 32, D, 0, 32, 1, P(out2))
+    assert tuple(ints(out2[0])) == k["f1f2g"]
+
+
 def test_subgroup_check_of_the_signed_table(H):
     """the signed-subset table needs generators of odd order: 2 * (G / 2) == G holds exactly for the prime-order subgroup"""
     ok = gens_array([[jj.mul(jj.GENERATOR, 5)]])
