@@ -133,6 +133,35 @@ def measure_hbm_copy(torch, dev, nbytes=1 << 30, reps=10):
         return None
 
 
+def one_process_leg(log2_leaves):
+    """Child process of the Merkle leg: the same 2^k-leaf Poseidon tree through the C ABI's single-process multi-device
+    entry point (what a Rust host calls): all visible GPUs (a power of two, at most 8), leaves in pageable host memory,
+    one host thread per device, RCCL all-gather of the sub-roots inside libakp.so.  PCIe-inclusive.  Prints one JSON line."""
+    import numpy as np
+    import torch
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import field
+    g = 1
+    while g * 2 <= min(torch.cuda.device_count(), 8):
+        g *= 2
+    total = 1 << log2_leaves
+    cfg = cpa.get_default_poseidon_parameters(2, False)
+    leaves = field.random_fr(total, seed=0xA5A50003).reshape(total, 1, 4)
+    mg = cpa.MultiGpu(list(range(g)))
+    mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves[: 1 << 16], want_nodes=False)  # handles, scratch, RCCL warm-up
+    mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
+    secs = []
+    for _ in range(3):
+        m0 = time.perf_counter()
+        _, _, mroot = mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
+        secs.append(time.perf_counter() - m0)
+    mg.close()
+    print(json.dumps({"entry_point": "akp_merkle_build_sharded_poseidon", "devices": g, "seconds": min(secs), "seconds_all": secs,
+                      "includes": "copy-in of the leaves from pageable memory over PCIe (one host thread per device)",
+                      "collective": "ncclAllGather of %d sub-roots" % g, "root_limb0": int(np.asarray(mroot).reshape(-1)[0])}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,7 +178,10 @@ def main():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-process-leg", type=int, default=0, help=argparse.SUPPRESS)  # internal: child process of the Merkle leg
     args = ap.parse_args()
+    if args.one_process_leg:
+        return one_process_leg(args.one_process_leg)
 
     # test hook (tests/test_gpu_bench_contract.py): AKP_BENCH_SHARED_GPU=1 puts every rank on GPU 0 and carries the
     # collectives over gloo, so the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
@@ -273,19 +305,20 @@ def main():
         # (a power of two), leaves in host memory, RCCL all-gather of the sub-roots inside libakp.so.  PCIe-inclusive.  Only when
         # this is the one process of the run; any failure is reported, not fatal (n_dev > 1 cannot be tested on a one-GPU box).
         if world == 1 and not shared_gpu and os.environ.get("AKP_BENCH_NO_MULTI") != "1":
+            # in a child process with a time limit: a first-ever n_dev > 1 RCCL bring-up must not be able to take the headline
+            # measurement down with it (a crash or a hang there is reported here, nothing else)
+            cmd = [sys.executable, os.path.abspath(__file__), "--one-process-leg", str(args.merkle_log2)]
             try:
-                g = 1
-                while g * 2 <= min(torch.cuda.device_count(), 8):
-                    g *= 2
-                mg = cpa.MultiGpu(list(range(g)))
-                mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves[: 1 << 16], want_nodes=False)  # handles, scratch, RCCL warm-up
-                mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
-                m0 = time.perf_counter()
-                _, _, mroot = mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
-                merkle["one_process_c_abi"] = {"entry_point": "akp_merkle_build_sharded_poseidon", "devices": g, "seconds": time.perf_counter() - m0,
-                                                "includes": "copy-in of the leaves over PCIe", "collective": "ncclAllGather of %d sub-roots" % g,
-                                                "root_matches": bool(np.array_equal(np.asarray(mroot).reshape(-1), np.asarray(res["root"]).reshape(-1)))}
-                mg.close()
+                cp = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                if cp.returncode == 0 and line:
+                    leg = json.loads(line[-1])
+                    leg["root_matches"] = leg.pop("root_limb0", None) == merkle["root_limb0"]
+                    merkle["one_process_c_abi"] = leg
+                else:
+                    merkle["one_process_c_abi"] = {"error": "exit %d: %s" % (cp.returncode, (cp.stderr or cp.stdout)[-300:])}
+            except subprocess.TimeoutExpired:  # pragma: no cover
+                merkle["one_process_c_abi"] = {"error": "no result within 300 s (child process stopped)"}
             except Exception as exc:  # pragma: no cover
                 merkle["one_process_c_abi"] = {"error": repr(exc)[:300]}
         del d_leaves, res, backend
