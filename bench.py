@@ -89,6 +89,18 @@ def gpu_clock_mhz(index=0):
     return best
 
 
+def gpu_power_w():
+    """average socket power of the busiest card, watts (hwmon power1_average, microwatts); None when unreadable"""
+    best = None
+    try:
+        for path in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"):
+            v = float(open(path).read().strip()) / 1e6
+            best = v if best is None else max(best, v)
+    except Exception:
+        pass
+    return best
+
+
 def cpu_info():
     model = None
     try:
@@ -357,11 +369,22 @@ def main():
                     "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<0> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
                                  "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": 192.0 * npd / kavg / 1e9 / HBM_PEAK_GBS,
-                                 "table_bytes_gathered_per_hash": 69 * 144, "gather_over_algorithmic": 69 * 144 / 192.0,
+                                 "table_bytes_gathered_per_hash": 69 * 128, "gather_over_algorithmic": 69 * 128 / 192.0,
                                  "valu": {"table_steps_per_hash": 69, "field_products_per_step": 7,
                                           "note": "VALU-issue bound like the permutation: 69 mixed additions of 7 products (signed-subset "
-                                                  "table, 15-bit digits); the 163 MB table is gathered through L2 / Infinity Cache "
+                                                  "table, 15-bit digits); the 145 MB table (one 128-byte line per entry) is gathered through L2 / Infinity Cache "
                                                   "(counters: profiles/r02_s2/pmc_counters_te.txt for the 13-bit plain table)"}}}
+        if args.sustain_seconds > 0:  # clock / power under the gather-heavy kernel (the permutation's figures are in `sustained`)
+            count = int(min(2000, max(8, 0.5 * args.sustain_seconds / max(kavg, 1e-4))))
+            torch.cuda.synchronize(dev)
+            s0 = time.perf_counter()
+            for _ in range(count):
+                ped_step()
+            time.sleep(min(0.25, 0.25 * count * kavg))  # sample while the queue is still draining
+            cmid, wmid = gpu_clock_mhz(local_rank), gpu_power_w()
+            torch.cuda.synchronize(dev)
+            ssec = time.perf_counter() - s0
+            pedersen["sustained"] = {"launches": count, "seconds": ssec, "hashes_per_s": npd * count / ssec, "sclk_mhz_during": cmid, "power_w_during": wmid}
         if rank == 0:
             from oracle import cref
             cur = cref.CurveParams(4, 256, gens)
@@ -481,13 +504,13 @@ def main():
                 a.record()
                 check(lib.akp_poseidon_permute_batch_dev(ph.h, buf.data_ptr(), ns, stream))
                 b.record()
-            cmid = gpu_clock_mhz(local_rank)
+            cmid, wmid = gpu_clock_mhz(local_rank), gpu_power_w()
             torch.cuda.synchronize(dev)
             secs = time.perf_counter() - s0
             ms = sorted(a.elapsed_time(b) for a, b in evs)
             sustained["2^%d" % lg] = {"launches": count, "seconds": secs, "permutations_per_s": ns * count / secs,
                                       "launch_ms_min": ms[0], "launch_ms_median": ms[len(ms) // 2], "launch_ms_max": ms[-1],
-                                      "sclk_mhz_before": c0, "sclk_mhz_during": cmid, "sclk_mhz_after": gpu_clock_mhz(local_rank)}
+                                      "sclk_mhz_before": c0, "sclk_mhz_during": cmid, "sclk_mhz_after": gpu_clock_mhz(local_rank), "power_w_during": wmid}
             if buf is not d_states:
                 del buf
 

@@ -17,7 +17,7 @@
 // so one step is a 7-product mixed addition (madd-2008-hwcd-3, a = -1, complete on Jubjub because d is a
 // non-square; every coordinate comes out scaled by 1/4, which the projective form absorbs and which
 // removes the doubling of Z).  One message per lane; the tables (tens of MB) live in L2 / the 256 MB Infinity
-// Cache -- per step a wavefront gathers 64 x 144 B (the entry of step u+1 is fetched before the addition of step u)
+// Cache -- per step a wavefront gathers 64 x 128 B (the entry of step u+1 is fetched before the addition of step u)
 // against ~1900 VALU instructions, so the path stays integer-ALU bound.
 // Arithmetic: signed lazy radix-2^29 form (f29.hpp, FS): subtraction is limb-wise, no reduction anywhere.
 // The projective -> affine conversion (crh/pedersen/mod.rs:128, bowe_hopwood/mod.rs:185) is one field
@@ -36,8 +36,11 @@ AKP_F29_CONST(f29_inv2, 0x1fffffddu, 0x00000117u, 0x0e5b08c0u, 0x05272e00u, 0x17
 struct Niels {
     FS ypx, ymx, dxy;  // (y + x)/2, (y - x)/2, d*x*y   -- normalised
 };
-struct NielsPad {
-    F29Pad ypx, ymx, dxy;  // 144 B table entry
+// Table entry: the 27 limbs back to back in ONE 128-byte cache line (w[0..8] = (y+x)/2, w[9..17] = (y-x)/2, w[18..26] = dxy,
+// 5 dwords of padding): a lane's entry is two 64-byte L2 sectors and seven 16-byte loads.  (Round 1-2 layout: three
+// 48-byte padded elements = 144 B, 3.3 sectors and twelve loads per entry; the gather was 19 % of the Pedersen kernel.)
+struct alignas(128) NielsPad {
+    u32 w[32];
 };
 struct Ext {
     FS X, Y, Z, T;  // x = X/Z, y = Y/Z, T = XY/Z  -- normalised (product outputs)
@@ -90,12 +93,32 @@ AKP_HD void store_fr_g(Fr* p, const Fr& v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 AKP_HD Niels load_niels(const NielsPad* p) {
-    return Niels{f29_load_pad<true>(&p->ypx), f29_load_pad<true>(&p->ymx), f29_load_pad<true>(&p->dxy)};
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5], v6 = q[6];
+    const u32 w[28] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y,
+                       v3.z, v3.w, v4.x, v4.y, v4.z, v4.w, v5.x, v5.y, v5.z, v5.w, v6.x, v6.y, v6.z, v6.w};
+    Niels r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.ypx.l[i] = (int32_t)w[i];
+        r.ymx.l[i] = (int32_t)w[9 + i];
+        r.dxy.l[i] = (int32_t)w[18 + i];
+    }
+    return r;
 }
 AKP_HD void store_niels(NielsPad* p, const Niels& n) {
-    f29_store_pad(&p->ypx, n.ypx);
-    f29_store_pad(&p->ymx, n.ymx);
-    f29_store_pad(&p->dxy, n.dxy);
+    u32 w[32];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        w[i] = (u32)n.ypx.l[i];
+        w[9 + i] = (u32)n.ymx.l[i];
+        w[18 + i] = (u32)n.dxy.l[i];
+    }
+#pragma unroll
+    for (int i = 27; i < 32; ++i) w[i] = 0;
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 AKP_HD Niels niels_of_ext(const Ext& acc) {  // affine point of acc, as a table entry
     const FS zi = f29_inv(acc.Z);
@@ -240,51 +263,238 @@ AKP_HD u32 msg_bits(const uint8_t* __restrict__ msg, size_t len, size_t o, u32 w
     if (byte + 2 < len) v |= (u32)msg[byte + 2] << 16;
     return (v >> (o & 7)) & ((1u << w) - 1u);
 }
+// The same in two halves for the software pipeline of te_accumulate_item: msg_load3 only issues the three byte loads
+// (unconditionally, from addresses clamped into the message, so that nothing waits for them here), msg_combine masks the
+// bytes that lie past the end and extracts the bits -- it runs one curve addition later.
+struct MsgRaw {
+    u32 b0, b1, b2;
+};
+AKP_HD MsgRaw msg_load3(const uint8_t* __restrict__ msg, size_t len, size_t o) {
+    if (len == 0) return MsgRaw{0u, 0u, 0u};
+    const size_t byte = o >> 3, top = len - 1;
+    return MsgRaw{msg[byte < top ? byte : top], msg[byte + 1 < top ? byte + 1 : top], msg[byte + 2 < top ? byte + 2 : top]};
+}
+AKP_HD u32 msg_combine(const MsgRaw& r, size_t len, size_t o, u32 w) {
+    const size_t byte = o >> 3;
+    const u32 m0 = 0u - (u32)(byte < len), m1 = 0u - (u32)(byte + 1 < len), m2 = 0u - (u32)(byte + 2 < len);
+    const u32 v = (r.b0 & m0) | ((r.b1 & m1) << 8) | ((r.b2 & m2) << 16);
+    return (v >> (o & 7)) & ((1u << w) - 1u);
+}
 
 // ---- accumulate: one message per lane ------------------------------------------------------------
-// Table entry of step u for this message.
+// A step is split into three stages so that no load is consumed in the stage that issues it (the compiler places the
+// wait where the first use is, in program order):
+//   te_step_bits   message bits of the step (up to three byte loads)
+//   te_step_fetch  table index from those bits, the 128-byte entry load, and the sign of the step -- nothing is computed
+//                  on the loaded limbs
+//   niels_apply    branch-free negation of the entry (swap y+x / y-x, negate dxy), at the point of use
 //  kind 0 (Pedersen): digit = msg_bits(u*D, D), entry lut[u << D | digit].
 //  kind 1 (Bowe-Hopwood): steps [0, n_groups) are groups of D (= G) chunks from lut (2^(3G-1) entries each),
 //                         negated by s_0; steps [n_groups, n_steps) are the left-over single chunks from lut1.
 //  kind 2 (Pedersen, signed-subset table): lut[u << (D-1) | ...]; lut1 is the cprefix table the sum starts from.
-template <int KIND>
-AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
-                           size_t msg_len, u32 D, u32 n_groups, u32 u) {
-    if (KIND == 0) {
-        const u32 digit = msg_bits(msg, msg_len, (size_t)u * D, D);
-        return load_niels(lut + (((size_t)u << D) | digit));
+struct NielsSel {
+    Niels q;  // the entry as stored
+    u32 neg;  // 1: the step adds -q
+};
+AKP_HD Niels niels_apply(const NielsSel& s) {
+    const int32_t m = -(int32_t)(s.neg & 1u);  // 0 or all ones
+    Niels r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int32_t sw = (s.q.ypx.l[i] ^ s.q.ymx.l[i]) & m;
+        r.ypx.l[i] = s.q.ypx.l[i] ^ sw;
+        r.ymx.l[i] = s.q.ymx.l[i] ^ sw;
+        r.dxy.l[i] = (s.q.dxy.l[i] ^ m) - m;
     }
-    if (KIND == 2) {  // signed-subset table: top bit set -> entry as stored, clear -> the entry of the complement, negated
-        const u32 digit = msg_bits(msg, msg_len, (size_t)u * D, D);
-        const u32 half_mask = (1u << (D - 1u)) - 1u;
-        const bool top = (digit >> (D - 1u)) & 1u;
-        const Niels q = load_niels(lut + (((size_t)u << (D - 1u)) | ((top ? digit : ~digit) & half_mask)));
-        return top ? q : niels_neg(q);
+    return r;
+}
+// bit offset and width of step u's message bits
+template <int KIND>
+AKP_HD size_t te_step_offset(u32 D, u32 n_groups, u32 u, u32* width) {
+    if (KIND != 1) {
+        *width = D;
+        return (size_t)u * D;
     }
     const u32 G = D;  // chunks per group step
     if (u < n_groups) {
-        const u32 b = msg_bits(msg, msg_len, (size_t)u * 3u * G, 3u * G);
-        const u32 s0 = (b >> 2) & 1u;
-        u32 idx = b & 3u;
+        *width = 3u * G;
+        return (size_t)u * 3u * G;
+    }
+    *width = 3u;
+    return (size_t)(G * n_groups + (u - n_groups)) * 3u;
+}
+// P + (-1)^neg Q without touching the entry's limbs (they are consumed by the products as loaded): for -Q the roles of
+// Y - X and Y + X are exchanged, and e and c change sign:
+//   a* = (neg ? Y + X : Y - X) * ymx,  b* = (neg ? Y - X : Y + X) * ypx,  e = +-(b* - a*),  h = b* + a*,  c = +-T * dxy
+// SEL = false: plain P + Q.  `hook(stage, value)` is called after the products a*, b*, c, X3 (stages 0..3) with the
+// product just computed, so that a caller can hang the loads of the next step between the products (te_fetch_piece);
+// te_accumulate_item does not: the burst before the addition measured faster (see there).
+template <bool SEL, class Hook>
+AKP_HD Ext te_madd_hooked(const Ext& p, const Niels& q, u32 neg, Hook&& hook) {
+    const int32_t m = -(int32_t)(neg & 1u);  // 0 or all ones
+    FS d = f29_sub(p.Y, p.X), t = f29_add(p.Y, p.X);
+    if (SEL) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int32_t sw = (d.l[i] ^ t.l[i]) & m;
+            d.l[i] ^= sw;
+            t.l[i] ^= sw;
+        }
+    }
+    const FS a = f29_mul(d, q.ymx);
+    hook(0, a);
+    const FS b = f29_mul(t, q.ypx);
+    hook(1, b);
+    FS c = f29_mul(p.T, q.dxy);
+    hook(2, c);
+    FS e = f29_sub(b, a);
+    if (SEL) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            c.l[i] = (c.l[i] ^ m) - m;
+            e.l[i] = (e.l[i] ^ m) - m;
+        }
+    }
+    const FS f = f29_sub(p.Z, c), g = f29_weak_norm(f29_add(p.Z, c)), h = f29_add(b, a);
+    Ext r;
+    r.X = f29_mul(e, f);
+    hook(3, r.X);
+    r.Y = f29_mul(g, h);
+    r.Z = f29_mul(f, g);
+    r.T = f29_mul(e, h);
+    return r;
+}
+struct NoHook {
+    AKP_HD void operator()(int, const FS&) const {}
+};
+AKP_HD Ext te_madd_sel(const Ext& p, const NielsSel& s) { return te_madd_hooked<true>(p, s.q, s.neg, NoHook()); }
+
+// A table entry on its way in: address, sign of the step, and the seven 16-byte pieces of the 128-byte line.
+struct NielsFetch {
+    const NielsPad* base;  // lut or lut1 (kept as it is: a pointer that went through an asm statement would lose its
+    u32 idx;               // address space and turn the loads into flat loads), entry index
+    u32 neg;
+    uint4 v[7];
+};
+// issue the load of piece k -- not before `after` (a product of the running addition) has been computed
+AKP_HD void te_fetch_piece(NielsFetch& f, int k, const FS& after) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(f.idx) : "v"(after.l[8]));
+#else
+    (void)after;
+#endif
+    f.v[k] = reinterpret_cast<const uint4*>(f.base + f.idx)[k];
+}
+AKP_HD void te_fetch_all(NielsFetch& f) {
+    const uint4* q = reinterpret_cast<const uint4*>(f.base + f.idx);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) f.v[k] = q[k];
+}
+AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
+    const u32 w[28] = {f.v[0].x, f.v[0].y, f.v[0].z, f.v[0].w, f.v[1].x, f.v[1].y, f.v[1].z, f.v[1].w, f.v[2].x, f.v[2].y,
+                       f.v[2].z, f.v[2].w, f.v[3].x, f.v[3].y, f.v[3].z, f.v[3].w, f.v[4].x, f.v[4].y, f.v[4].z, f.v[4].w,
+                       f.v[5].x, f.v[5].y, f.v[5].z, f.v[5].w, f.v[6].x, f.v[6].y, f.v[6].z, f.v[6].w};
+    Niels r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.ypx.l[i] = (int32_t)w[i];
+        r.ymx.l[i] = (int32_t)w[9 + i];
+        r.dxy.l[i] = (int32_t)w[18 + i];
+    }
+    return r;
+}
+template <int KIND>
+AKP_HD MsgRaw te_step_bits(const uint8_t* __restrict__ msg, size_t msg_len, u32 D, u32 n_groups, u32 u) {
+    u32 w;
+    return msg_load3(msg, msg_len, te_step_offset<KIND>(D, n_groups, u, &w));
+}
+template <int KIND>
+AKP_HD NielsSel te_step_fetch(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const MsgRaw& raw, size_t msg_len, u32 D,
+                              u32 n_groups, u32 u) {
+    u32 width;
+    const size_t off = te_step_offset<KIND>(D, n_groups, u, &width);
+    const u32 bits = msg_combine(raw, msg_len, off, width);
+    if (KIND == 0) return NielsSel{load_niels(lut + (((size_t)u << D) | bits)), 0u};
+    if (KIND == 2) {  // signed-subset table: top bit set -> entry as stored, clear -> the entry of the complement, negated
+        const u32 half_mask = (1u << (D - 1u)) - 1u;
+        const u32 top = (bits >> (D - 1u)) & 1u;
+        return NielsSel{load_niels(lut + (((size_t)u << (D - 1u)) | ((top ? bits : ~bits) & half_mask))), top ^ 1u};
+    }
+    const u32 G = D;
+    if (u < n_groups) {
+        const u32 s0 = (bits >> 2) & 1u;
+        u32 idx = bits & 3u;
 #pragma unroll 1
         for (u32 i = 1; i < G; ++i) {
-            idx |= ((b >> (3u * i)) & 3u) << (2u * i);
-            idx |= (((b >> (3u * i + 2u)) & 1u) ^ s0) << (2u * G + i - 1u);
+            idx |= ((bits >> (3u * i)) & 3u) << (2u * i);
+            idx |= (((bits >> (3u * i + 2u)) & 1u) ^ s0) << (2u * G + i - 1u);
         }
-        const Niels q = load_niels(lut + ((size_t)u << (3u * G - 1u)) + idx);
-        return s0 ? niels_neg(q) : q;
+        return NielsSel{load_niels(lut + ((size_t)u << (3u * G - 1u)) + idx), s0};
     }
     const u32 c = G * n_groups + (u - n_groups);
-    const u32 bits = msg_bits(msg, msg_len, (size_t)c * 3u, 3u);
-    const Niels q = load_niels(lut1 + (size_t)c * 4u + (bits & 3u));
-    return (bits & 4u) ? niels_neg(q) : q;
+    return NielsSel{load_niels(lut1 + (size_t)c * 4u + (bits & 3u)), (bits >> 2) & 1u};
+}
+// the same index computation without the load: address of the entry and sign of the step
+template <int KIND>
+AKP_HD void te_step_address(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const MsgRaw& raw, size_t msg_len, u32 D,
+                            u32 n_groups, u32 u, NielsFetch& f) {
+    u32 width;
+    const size_t off = te_step_offset<KIND>(D, n_groups, u, &width);
+    const u32 bits = msg_combine(raw, msg_len, off, width);
+    f.base = lut;
+    if (KIND == 0) {
+        f.idx = (u << D) | bits;
+        f.neg = 0u;
+    } else if (KIND == 2) {
+        const u32 half_mask = (1u << (D - 1u)) - 1u;
+        const u32 top = (bits >> (D - 1u)) & 1u;
+        f.idx = (u << (D - 1u)) | ((top ? bits : ~bits) & half_mask);
+        f.neg = top ^ 1u;
+    } else {
+        const u32 G = D;
+        if (u < n_groups) {
+            const u32 s0 = (bits >> 2) & 1u;
+            u32 idx = bits & 3u;
+#pragma unroll 1
+            for (u32 i = 1; i < G; ++i) {
+                idx |= ((bits >> (3u * i)) & 3u) << (2u * i);
+                idx |= (((bits >> (3u * i + 2u)) & 1u) ^ s0) << (2u * G + i - 1u);
+            }
+            f.idx = (u << (3u * G - 1u)) + idx;
+            f.neg = s0;
+        } else {
+            const u32 c = G * n_groups + (u - n_groups);
+            f.base = lut1;
+            f.idx = c * 4u + (bits & 3u);
+            f.neg = (bits >> 2) & 1u;
+        }
+    }
+}
+template <int KIND>
+AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
+                           size_t msg_len, u32 D, u32 n_groups, u32 u) {
+    return niels_apply(te_step_fetch<KIND>(lut, lut1, te_step_bits<KIND>(msg, msg_len, D, n_groups, u), msg_len, D, n_groups, u));
+}
+// Scheduling fence of the pipeline: the loaded message bytes may not be touched before the addition that was issued after
+// them has produced `after` (the scheduler would otherwise hoist the cheap bit extraction -- and with it the wait for the
+// loads -- above the addition).  Emits no instruction.
+AKP_HD void te_consume_after(MsgRaw& r, const Ext& after) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(r.b0), "+v"(r.b1), "+v"(r.b2) : "v"(after.X.l[8]), "v"(after.Y.l[8]), "v"(after.Z.l[8]), "v"(after.T.l[8]));
+#else
+    (void)r;
+    (void)after;
+#endif
 }
 template <int KIND>
 AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
                               size_t msg_len, u32 D, u32 n_groups, u32 n_steps) {
-    // Two steps per iteration with two entry buffers: the entry of step u+1 is fetched before the ~2000-instruction
-    // addition that consumes the entry of step u, and no register copies are needed to rotate the buffers.
-    // The sum starts as a table entry (no addition): the first step's entry, or (kind 2) the constant cprefix[n_steps].
+    // Software pipeline, two steps per iteration (two entry buffers, no register copies to rotate them).  Before the
+    // addition of step u starts, the seven pieces of step u + 1's table line and the message bytes of step u + 2 are
+    // requested; they are consumed one whole addition (~1400 instructions) later.  (Spreading the loads over the products
+    // of the addition through te_madd_hooked's hook was measured slower than this burst: 3.51 vs 3.36 ms for 2^20 Pedersen
+    // hashes, profiles/r02_s21.)  The sum starts as a table entry (no addition): the first step's entry, or (kind 2)
+    // cprefix[n_steps].
     Ext acc;
     u32 u;
     if (KIND == 2) {
@@ -297,15 +507,26 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
         u = 1;
         if (n_steps == 1) return acc;
     }
-    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, u);
+    const u32 last = n_steps - 1u;
+    NielsFetch f0, f1;
+    te_step_address<KIND>(lut, lut1, te_step_bits<KIND>(msg, msg_len, D, n_groups, u), msg_len, D, n_groups, u, f0);
+    te_fetch_all(f0);
+    MsgRaw nb = te_step_bits<KIND>(msg, msg_len, D, n_groups, u + 1 <= last ? u + 1 : last);
 #pragma unroll 1
     for (; u + 2 <= n_steps; u += 2) {
-        const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, u + 1);
-        acc = te_madd(acc, q0);
-        q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, (u + 2 < n_steps) ? u + 2 : u + 1);
-        acc = te_madd(acc, q1);
+        const u32 u2 = u + 2 <= last ? u + 2 : last, u3 = u + 3 <= last ? u + 3 : last;
+        te_step_address<KIND>(lut, lut1, nb, msg_len, D, n_groups, u + 1, f1);  // u + 1 <= last here
+        te_fetch_all(f1);
+        nb = te_step_bits<KIND>(msg, msg_len, D, n_groups, u2);
+        acc = te_madd_hooked<KIND != 0>(acc, niels_of_fetch(f0), f0.neg, NoHook());
+        te_consume_after(nb, acc);
+        te_step_address<KIND>(lut, lut1, nb, msg_len, D, n_groups, u2, f0);
+        te_fetch_all(f0);
+        nb = te_step_bits<KIND>(msg, msg_len, D, n_groups, u3);
+        acc = te_madd_hooked<KIND != 0>(acc, niels_of_fetch(f1), f1.neg, NoHook());
+        te_consume_after(nb, acc);
     }
-    if (u < n_steps) acc = te_madd(acc, q0);
+    if (u < n_steps) acc = te_madd_hooked<KIND != 0>(acc, niels_of_fetch(f0), f0.neg, NoHook());
     return acc;
 }
 // partial sum over steps first, first + stride, ... (the whole message for first = 0, stride = 1)
@@ -323,19 +544,22 @@ AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPa
         start = first + stride;
     }
     if (start >= n_steps) return acc;
-    Niels q0 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, start);
+    NielsSel q0 = te_step_fetch<KIND>(lut, lut1, te_step_bits<KIND>(msg, msg_len, D, n_groups, start), msg_len, D, n_groups, start);
 #pragma unroll 1
     for (u32 u = start; u < n_steps; u += stride) {
         const u32 nxt = (u + stride < n_steps) ? u + stride : u;
-        const Niels q1 = te_step_entry<KIND>(lut, lut1, msg, msg_len, D, n_groups, nxt);  // fetched ahead of the addition
-        acc = te_madd(acc, q0);
+        const NielsSel q1 = te_step_fetch<KIND>(lut, lut1, te_step_bits<KIND>(msg, msg_len, D, n_groups, nxt), msg_len, D, n_groups, nxt);  // fetched ahead of the addition
+        acc = te_madd(acc, niels_apply(q0));
         q0 = q1;
     }
     return acc;
 }
 // writes the extended-coordinate sum (X, Y, Z), internal form, to xyz[idx*3 ..]
+#ifndef AKP_TE_MIN_WAVES
+#define AKP_TE_MIN_WAVES 4  // waves per SIMD the register allocation must allow: <= 128 VGPRs (the signed-table kernel then keeps 21 loop-invariant values in scratch, stored and reloaded once outside the loop).  Build-time A/B: make EXTRA=-DAKP_TE_MIN_WAVES=1
+#endif
 template <int KIND>
-__global__ void __launch_bounds__(256) te_accumulate_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
+__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
                                                            const uint8_t* __restrict__ msgs, size_t msg_len, u32 D, u32 n_groups,
                                                            u32 n_steps, F29Pad* __restrict__ xyz, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
