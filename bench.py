@@ -364,15 +364,18 @@ def main():
         psec = max_over_ranks(time.perf_counter() - p0)
         kms = sorted(a.elapsed_time(b) for a, b in evs)
         kavg = sum(kms) / len(kms) / 1e3
+        pinfo = hP.info(128)
+        psteps = pinfo["steps"]
         pedersen = {"config": "BASELINE configs[3]: pedersen::CRH, Jubjub, window 4x256, 128-byte messages", "messages_per_gpu": npd,
                     "hashes_per_s": npd * world * reps / psec, "ms_per_batch": psec / reps * 1e3,
-                    "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<0> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
+                    "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<2> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
                                  "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": 192.0 * npd / kavg / 1e9 / HBM_PEAK_GBS,
-                                 "table_bytes_gathered_per_hash": 69 * 128, "gather_over_algorithmic": 69 * 128 / 192.0,
-                                 "valu": {"table_steps_per_hash": 69, "field_products_per_step": 7,
-                                          "note": "VALU-issue bound like the permutation: 69 mixed additions of 7 products (signed-subset "
-                                                  "table, 15-bit digits); the 145 MB table (one 128-byte line per entry) is gathered through L2 / Infinity Cache "
+                                 "table_bytes_gathered_per_hash": psteps * 128, "gather_over_algorithmic": psteps * 128 / 192.0,
+                                 "table": pinfo,
+                                 "valu": {"table_steps_per_hash": psteps, "field_products_per_step": 7,
+                                          "note": "VALU-issue bound like the permutation: one mixed addition of 7 products per table step "
+                                                  "(signed-subset table); one 128-byte line per entry, gathered through L2 / Infinity Cache / HBM "
                                                   "(counters: profiles/r02_s2/pmc_counters_te.txt for the 13-bit plain table)"}}}
         if args.sustain_seconds > 0:  # clock / power under the gather-heavy kernel (the permutation's figures are in `sustained`)
             count = int(min(2000, max(8, 0.5 * args.sustain_seconds / max(kavg, 1e-4))))
@@ -426,7 +429,9 @@ def main():
                      "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<1> + te_finalize_kernel<1> + te_serialize_pairs_kernel per level",
                                   "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                  "valu": {"table_steps": "23 per leaf (21 quads + 2 singles), 49 per inner node (46 + 3)", "field_products_per_step": 7}}}
+                                  "table": B.handle(ctx).info(32),
+                                  "valu": {"table_steps_per_leaf_hash": B.handle(ctx).info(32)["steps"], "table_steps_per_inner_node": B.handle(ctx).info(70)["steps"],
+                                           "field_products_per_step": 7}}}
         if rank == 0:
             from oracle import cref
             cur = cref.CurveParams(63, 9, gens)

@@ -84,6 +84,7 @@ def _load():
         "akp_sponge_set_state": (i32, [vp, u64p, i32, u32]),
         "akp_te_params_create": (i32, [vp, i32, u32, u32, u64p, pp]),
         "akp_te_params_destroy": (None, [vp]),
+        "akp_te_params_info": (i32, [vp, vp, vp, vp, sz, vp]),
         "akp_te_crh_batch": (i32, [vp, u8p, sz, sz, u64p]),
         "akp_te_crh_batch_dev": (i32, [vp, u8p, sz, sz, u64p, vp]),
         "akp_te_two_to_one_batch": (i32, [vp, u8p, u8p, sz, sz, u64p]),

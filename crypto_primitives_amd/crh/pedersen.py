@@ -44,6 +44,13 @@ class _TeHandle:
     def __init__(self, h, ctx):
         self.h, self.ctx = h, ctx
 
+    def info(self, msg_len=0):
+        """tuning facts of the device tables (akp_te_params_info): digit width / chunks per step, signed-subset flag,
+        table bytes, table steps of a msg_len-byte input"""
+        d, sg, tb, st = C.c_uint32(), C.c_int32(), C.c_size_t(), C.c_uint32()
+        check(lib.akp_te_params_info(self.h, C.byref(d), C.byref(sg), C.byref(tb), msg_len, C.byref(st)))
+        return {"digit_bits_or_group": d.value, "signed_subset": bool(sg.value), "table_bytes": tb.value, "steps": st.value}
+
     def __del__(self):
         try:
             if self.h:

@@ -911,6 +911,16 @@ extern "C" int32_t akp_sponge_set_state(akp_sponge* s, const uint64_t* state, in
 
 // ------------------------------------------------------------------------------------------
 // Pedersen / Bowe-Hopwood
+// largest precomputed table, bytes: the digit width / chunk grouping is reduced until the table fits.  Pedersen: 320 MiB
+// admits 16-bit digits for the 4 x 256 window of BASELINE config 4 (64 steps x 2^15 entries x 128 B = 268 MB; measured on
+// MI355X, 2^20 x 128 B: 15 bits / 145 MB 3.37 ms, 16 bits 3.25 ms, 17 bits / 512 MB 3.28 ms -- past the 256 MiB Infinity
+// Cache the gather costs what the shorter sum saves).  Bowe-Hopwood: 256 MiB admits groups of five chunks for the 63 x 9
+// window of config 5 (113 groups x 2^14 entries x 128 B = 237 MB, of which the 64-byte inputs of a tree touch the first
+// 73 MB; 2.16 -> 1.78 ms per 2^20 two-to-one hashes against groups of four).  AKP_TE_TABLE_MB overrides both (A/B runs).
+static size_t te_table_cap(bool bowe_hopwood = false) {
+    static const u32 forced = env_u32("AKP_TE_TABLE_MB", 0, 0, 8192);
+    return (size_t)(forced ? forced : (bowe_hopwood ? 256u : 320u)) << 20;
+}
 struct akp_te_params {
     akp_ctx* ctx = nullptr;
     int kind = 0;
@@ -963,8 +973,8 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
         if (e == hipSuccess && bad == 0) {
-            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 15, 2, 15);
-            while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(NielsPad) > ((size_t)192 << 20)) --D;
+            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 16, 2, 17);
+            while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(NielsPad) > te_table_cap()) --D;
             p->digit_bits = D;
             p->signed_subset = true;
             const size_t n_digits = (n_gen + D - 1) / D, entries = n_digits << (D - 1);
@@ -981,7 +991,7 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             // would exceed 192 MB; AKP_PEDERSEN_DIGIT_BITS overrides (1..14).  Measured 2^20 x 128 B on MI355X:
             // D = 4: 73 M/s, 8: 151, 10: 177, 12: 199, 13: 209, 14: 220 (175 MB table; round 2: 13 beats 14, profiles/r02_s8).
             u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 13, 1, 14);
-            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > ((size_t)192 << 20)) --D;
+            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > te_table_cap()) --D;
             p->digit_bits = D;
             const size_t entries = ((n_gen + D - 1) / D) << D;
             e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
@@ -993,8 +1003,8 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
         if (d_half) (void)hipFree(d_half);
         if (d_bad) (void)hipFree(d_bad);
     } else {
-        u32 G = env_u32("AKP_BH_GROUP", 4, 1, 4);
-        while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(NielsPad) > ((size_t)192 << 20))) --G;
+        u32 G = env_u32("AKP_BH_GROUP", 5, 1, 5);
+        while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(NielsPad) > te_table_cap(true))) --G;
         p->group = G;
         if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(NielsPad));
         if (e == hipSuccess) {
@@ -1049,6 +1059,29 @@ static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32*
         *n_groups = 0;
         *n_steps = (u32)chunks;
     }
+}
+extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset, size_t* table_bytes, size_t msg_len,
+                                      uint32_t* steps) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_info: params is NULL");
+    const bool ped = p->kind == AKP_TE_PEDERSEN;
+    if (digit_bits_or_group) *digit_bits_or_group = ped ? p->digit_bits : p->group;
+    if (signed_subset) *signed_subset = ped && p->signed_subset ? 1 : 0;
+    if (table_bytes) {
+        size_t entries;
+        if (ped) {
+            const size_t n_digits = (p->n_gen + p->digit_bits - 1) / p->digit_bits;
+            entries = p->signed_subset ? (n_digits << (p->digit_bits - 1)) + n_digits + 1 : n_digits << p->digit_bits;
+        } else {
+            entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)(p->n_gen / p->group) << (3 * p->group - 1)) : 0);
+        }
+        *table_bytes = entries * sizeof(NielsPad);
+    }
+    if (steps) {
+        u32 g = 0, st = 0;
+        te_steps(p, msg_len, &g, &st);
+        *steps = st;
+    }
+    return AKP_OK;
 }
 // accumulate + finalize on device buffers.  scratch: SCR_E (xyz), SCR_F (prefix)
 static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s) {

@@ -556,7 +556,7 @@ AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPa
 }
 // writes the extended-coordinate sum (X, Y, Z), internal form, to xyz[idx*3 ..]
 #ifndef AKP_TE_MIN_WAVES
-#define AKP_TE_MIN_WAVES 4  // waves per SIMD the register allocation must allow: <= 128 VGPRs (the signed-table kernel then keeps 21 loop-invariant values in scratch, stored and reloaded once outside the loop).  Build-time A/B: make EXTRA=-DAKP_TE_MIN_WAVES=1
+#define AKP_TE_MIN_WAVES 1  // waves per SIMD the register allocation must allow.  4 (<= 128 VGPRs; the signed-table kernel then keeps 21 loop-invariant values in scratch) measured the same as 1 (155 VGPRs, 3 waves): profiles/r02_s23.  Build-time A/B: make EXTRA=-DAKP_TE_MIN_WAVES=4
 #endif
 template <int KIND>
 __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,

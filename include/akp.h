@@ -149,6 +149,11 @@ int32_t akp_sponge_set_state(akp_sponge* s, const uint64_t* state, int32_t mode,
 int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
                              const uint64_t* generators_affine, akp_te_params** out);
 void akp_te_params_destroy(akp_te_params* p);
+/* Tuning facts of a handle (any pointer may be NULL): digit width of the Pedersen table / chunks per table step of the
+ * Bowe-Hopwood table, whether the Pedersen table is the signed-subset one, bytes of precomputed tables in HBM, and the
+ * number of table steps (curve additions + 1) an input of msg_len bytes takes. */
+int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset,
+                           size_t* table_bytes, size_t msg_len, uint32_t* steps);
 /* pedersen::CRH::evaluate (crh/pedersen/mod.rs:76-129) / bowe_hopwood::CRH::evaluate
  * (crh/bowe_hopwood/mod.rs:114-186): n messages of msg_len bytes each ->
  * n digests (2 Fr for Pedersen, 1 Fr for Bowe-Hopwood). */

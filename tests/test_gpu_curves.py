@@ -177,7 +177,7 @@ def test_table_variants_agree(cpa):
     mb = _msgs(40, 13, 6)
     ref_p = ref_b = None
     try:
-        for D, grp in ((12, 4), (8, 3), (4, 1), (7, 2), (1, 1), (3, 3), (13, 4)):
+        for D, grp in ((12, 4), (8, 3), (4, 1), (7, 2), (1, 1), (3, 3), (13, 4), (15, 5)):
             os.environ["AKP_PEDERSEN_DIGIT_BITS"], os.environ["AKP_BH_GROUP"] = str(D), str(grp)
             dp = pedersen.CRH.evaluate_batch(pedersen.Parameters(gens_array(g)), m)
             db = bowe_hopwood.CRH.evaluate_batch(bowe_hopwood.Parameters(gens_array(gb)), mb)
@@ -287,3 +287,17 @@ def test_split_kernel_disabled_matches(cpa, ped, bhp, tmp_path):
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, AKP_TE_SPLIT_MAX="0"), timeout=600)
     assert np.array_equal(np.load(tmp_path / "op.npy"), pedersen.CRH.evaluate_batch(P, mp))
     assert np.array_equal(np.load(tmp_path / "ob.npy"), bowe_hopwood.CRH.evaluate_batch(B, mb))
+
+
+def test_table_info_of_the_baseline_windows(cpa):
+    """akp_te_params_info: the shapes bench.py quotes -- Pedersen 4x256 with 16-bit signed digits (64 steps, one 128-byte
+    line per entry), Bowe-Hopwood 63x9 with five chunks per step (18 steps per 32-byte leaf, 39 per 70-byte inner node)"""
+    from crypto_primitives_amd import params as cparams
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    hp = pedersen.Parameters(cparams.pedersen_generators(0xA5A50004, 4, 256)).handle()
+    i = hp.info(128)
+    assert i == {"digit_bits_or_group": 16, "signed_subset": True, "table_bytes": ((64 << 15) + 65) * 128, "steps": 64}
+    assert hp.info(32)["steps"] == 16 and hp.info(0)["steps"] == 0
+    hb = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)).handle()
+    assert hb.info(32) == {"digit_bits_or_group": 5, "signed_subset": False, "table_bytes": (567 * 4 + (113 << 14)) * 128, "steps": 18}
+    assert hb.info(70)["steps"] == 39 and hb.info(64)["steps"] == 35

@@ -314,7 +314,7 @@ def test_subgroup_check_of_the_signed_table(H):
     assert H.hh_te_in_subgroup(P(gens_array([[t2]]))) == 0
 
 
-@pytest.mark.parametrize("W,N,group", [(63, 9, 1), (5, 3, 3), (5, 3, 1), (7, 2, 3), (63, 1, 3), (5, 3, 4), (7, 3, 2), (6, 2, 4)])
+@pytest.mark.parametrize("W,N,group", [(63, 9, 1), (5, 3, 3), (5, 3, 1), (7, 2, 3), (63, 1, 3), (5, 3, 4), (7, 3, 2), (6, 2, 4), (6, 2, 5), (7, 3, 5)])
 def test_bowe_hopwood_table_path(H, W, N, group):
     g = jj.bowe_hopwood_generators(12, W, N)
     G = gens_array(g)

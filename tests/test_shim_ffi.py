@@ -20,7 +20,7 @@ def test_ffi_prototypes_equal_header_symbols_and_library_exports():
     protos = sorted(re.findall(r"pub fn (akp_[a-z0-9_]+)\(", rs))
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "akp.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(akp_[a-z0-9_]+)\s*\(", hdr)))
-    assert protos == syms and len(protos) >= 70
+    assert protos == syms and len(protos) >= 71
     L = C.CDLL(cpa.LIB_PATH)
     for s in protos:
         assert hasattr(L, s), s
