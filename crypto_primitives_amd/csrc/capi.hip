@@ -1115,8 +1115,11 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     else
         hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->group, groups, steps, (F29Pad*)xyz, n);
     HIP_TRY(hipGetLastError());
-    // share one inversion among up to 64 messages per lane, but keep >= 64K lanes busy when n allows
-    size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / 65536));
+    // share one inversion among up to 64 messages per lane, but keep `target` lanes busy when n allows.  Measured at 2^20
+    // Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K / 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 /
+    // 3.29 / 3.46 ms for accumulate + finalize (two boxes): one wave per SIMD it is.  AKP_TE_FINALIZE_LANES for A/B runs.
+    static const size_t target = (size_t)env_u32("AKP_TE_FINALIZE_LANES", 65536, 64, 1u << 24);
+    size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / target));
     size_t lanes = (n + chain - 1) / chain;
     const unsigned fgrid = (unsigned)((lanes + 255) / 256);
     if (p->kind == AKP_TE_PEDERSEN)
