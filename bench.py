@@ -430,7 +430,10 @@ def main():
                                   "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                   "table": B.handle(ctx).info(32),
-                                  "valu": {"table_steps_per_leaf_hash": B.handle(ctx).info(32)["steps"], "table_steps_per_inner_node": B.handle(ctx).info(70)["steps"],
+                                  "valu": {"table_steps_per_leaf_hash": B.handle(ctx).info(32)["steps"],
+                                           "table_steps_per_inner_node": B.handle(ctx).info(64)["steps"] + 1,
+                                           "inner_node_note": "64 bytes of digests in a 70-byte buffer: the table steps of the 64 data bytes + one constant "
+                                                              "entry for the zero-padded tail (a zero chunk adds +g); %d steps if the padding is walked" % B.handle(ctx).info(70)["steps"],
                                            "field_products_per_step": 7}}}
         if rank == 0:
             from oracle import cref

@@ -930,6 +930,8 @@ struct akp_te_params {
     u32 group = 1;             // Bowe-Hopwood: chunks per table step (1..4)
     NielsPad* d_lut = nullptr;   // Pedersen: [ceil(n_gen/D)][2^D] (signed-subset table: [ceil(n_gen/D)][2^(D-1)]); BH: group table
     NielsPad* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]; Pedersen signed-subset: cprefix [n_digits + 1]
+    NielsPad* d_tail = nullptr;  // BH: sum of G[c] over the zero-padded tail chunks [tail_from, tail_to) of the last compress shape
+    u32 tail_from = 0, tail_to = 0;
     bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
 };
 static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN ? 2u : 1u; }
@@ -1037,6 +1039,7 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
     (void)hipDeviceSynchronize();
     if (p->d_lut) (void)hipFree(p->d_lut);
     if (p->d_lut1) (void)hipFree(p->d_lut1);
+    if (p->d_tail) (void)hipFree(p->d_tail);
     delete p;
 }
 
@@ -1084,23 +1087,48 @@ extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bi
     return AKP_OK;
 }
 // accumulate + finalize on device buffers.  scratch: SCR_E (xyz), SCR_F (prefix)
-static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s) {
+// `data_len` <= msg_len: the bytes [data_len, msg_len) of every message are known to be zero (the padding of a two-to-one
+// buffer, crh/bowe_hopwood/mod.rs:219-224) and are not read.  Pedersen: zero bits select nothing, the sum simply stops
+// earlier.  Bowe-Hopwood: a zero chunk still adds +g (:167), so the chunks that lie wholly in the padding contribute the
+// CONSTANT sum of their generators: one table entry (computed once per shape, te_bh_tail_kernel) added at the end instead
+// of one table step per five chunks -- a 63 x 9 inner node (64 bytes of digests in a 70-byte buffer) takes 35 + 1 steps
+// instead of 39.
+static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len = (size_t)-1) {
     if (msg_len * 8 > te_input_bits(p))
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
     if (n == 0) return AKP_OK;
     if (n > ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32", n);
+    const bool tail_on = env_u32("AKP_BH_ZERO_TAIL", 1, 0, 1) != 0;  // 0: walk the padding chunk by chunk (A/B arm; read per call)
+    if (data_len > msg_len || !tail_on) data_len = msg_len;
     u32 groups = 0, steps = 0;
-    te_steps(p, msg_len, &groups, &steps);
+    te_steps(p, data_len, &groups, &steps);
+    const NielsPad* tail = nullptr;
+    if (p->kind == AKP_TE_BOWE_HOPWOOD && data_len < msg_len) {
+        const u32 from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, p->n_gen), to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3, p->n_gen);
+        if (from < to) {
+            if (!p->d_tail) HIP_TRY(hipMalloc(&p->d_tail, sizeof(NielsPad)));
+            if (p->tail_from != from || p->tail_to != to) {  // stream-ordered: later launches on other streams go through ctx_scratch-style events below
+                HIP_TRY(hipStreamSynchronize(s));           // an earlier shape's constant may still be in use (rare: one shape per parameter set)
+                hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, s, p->d_lut1, from, to, p->d_tail);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(s));
+                p->tail_from = from;
+                p->tail_to = to;
+            }
+            tail = p->d_tail;
+        }
+    }
+    const size_t stride = msg_len;
     // small batches (tree tops) are bound by the latency of one message: split each one over AKP_TE_SPLIT waves
     static const size_t split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
     if (n <= split_max) {
         const unsigned sgrid = (unsigned)((n + 63) / 64);
         if (p->kind == AKP_TE_PEDERSEN && p->signed_subset)
-            hipLaunchKernelGGL(te_crh_small_kernel<2>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, d_out, n);
+            hipLaunchKernelGGL(te_crh_small_kernel<2>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
         else if (p->kind == AKP_TE_PEDERSEN)
-            hipLaunchKernelGGL(te_crh_small_kernel<0>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, d_out, n);
+            hipLaunchKernelGGL(te_crh_small_kernel<0>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
         else
-            hipLaunchKernelGGL(te_crh_small_kernel<1>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->group, groups, steps, d_out, n);
+            hipLaunchKernelGGL(te_crh_small_kernel<1>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->group, groups, steps, tail, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -1109,11 +1137,11 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (p->kind == AKP_TE_PEDERSEN && p->signed_subset)
-        hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
     else if (p->kind == AKP_TE_PEDERSEN)
-        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->digit_bits, groups, steps, (F29Pad*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
     else
-        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, msg_len, p->group, groups, steps, (F29Pad*)xyz, n);
+        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->group, groups, steps, tail, (F29Pad*)xyz, n);
     HIP_TRY(hipGetLastError());
     // share one inversion among up to 64 messages per lane, but keep `target` lanes busy when n allows.  Measured at 2^20
     // Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K / 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 /
@@ -1193,12 +1221,13 @@ static int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_r
     const size_t work = n * 2 * fe;
     hipLaunchKernelGGL(te_serialize_pairs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, d_left, d_right, fe, buflen, (uint8_t*)dbuf, n);
     HIP_TRY(hipGetLastError());
-    if (used < buflen) {
+    const bool tail_on = env_u32("AKP_BH_ZERO_TAIL", 1, 0, 1) != 0;
+    if (used < buflen && !tail_on) {  // with the zero-tail shortcut the padding bytes are never read
         const size_t tw = n * (buflen - used);
         hipLaunchKernelGGL(te_zero_tail_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, s, (uint8_t*)dbuf, buflen, used, n);
         HIP_TRY(hipGetLastError());
     }
-    return te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, d_out, s);
+    return te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, d_out, s, used);
 }
 extern "C" int32_t akp_te_compress_batch(akp_te_params* p, const uint64_t* left, const uint64_t* right, size_t n, uint64_t* out) {
     NEED_TE(p, "akp_te_compress_batch");

@@ -558,16 +558,28 @@ AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPa
 #ifndef AKP_TE_MIN_WAVES
 #define AKP_TE_MIN_WAVES 1  // waves per SIMD the register allocation must allow.  4 (<= 128 VGPRs; the signed-table kernel then keeps 21 loop-invariant values in scratch) measured the same as 1 (155 VGPRs, 3 waves): profiles/r02_s23.  Build-time A/B: make EXTRA=-DAKP_TE_MIN_WAVES=4
 #endif
+// `stride`: bytes between consecutive messages (>= msg_len; the bytes past msg_len are never read).  `tail` (may be null):
+// one more table entry every sum ends with -- the constant contribution of a zero-padded Bowe-Hopwood tail (a zero chunk
+// selects +g, crh/bowe_hopwood/mod.rs:167), see te_crh_dev.
 template <int KIND>
 __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
-                                                           const uint8_t* __restrict__ msgs, size_t msg_len, u32 D, u32 n_groups,
-                                                           u32 n_steps, F29Pad* __restrict__ xyz, size_t n) {
+                                                           const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
+                                                           u32 n_steps, const NielsPad* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const Ext acc = te_accumulate_item<KIND>(lut, lut1, msgs + idx * msg_len, msg_len, D, n_groups, n_steps);
+    Ext acc = te_accumulate_item<KIND>(lut, lut1, msgs + idx * stride, msg_len, D, n_groups, n_steps);
+    if (tail) acc = te_madd(acc, load_niels(tail));
     f29_store_pad(xyz + idx * 3, acc.X);
     f29_store_pad(xyz + idx * 3 + 1, acc.Y);
     f29_store_pad(xyz + idx * 3 + 2, acc.Z);
+}
+// sum of the single-chunk entries 1 * G[c], c in [from, to): the constant of a zero tail (one thread; once per parameter set)
+__global__ void te_bh_tail_kernel(const NielsPad* __restrict__ lut1, u32 from, u32 to, NielsPad* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Ext acc = ext_from_niels(load_niels(lut1 + (size_t)from * 4u));
+#pragma unroll 1
+    for (u32 c = from + 1; c < to; ++c) acc = te_madd(acc, load_niels(lut1 + (size_t)c * 4u));
+    store_niels(out, niels_of_ext(acc));
 }
 
 // ---- projective -> affine with shared inversions ---------------------------------------------------
@@ -615,14 +627,16 @@ __global__ void __launch_bounds__(256) te_finalize_kernel(const F29Pad* __restri
 #define AKP_TE_SPLIT 8
 template <int KIND>
 __global__ void __launch_bounds__(64 * AKP_TE_SPLIT) te_crh_small_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
-                                                                        const uint8_t* __restrict__ msgs, size_t msg_len, u32 D,
-                                                                        u32 n_groups, u32 n_steps, Fr* __restrict__ out, size_t n) {
+                                                                        const uint8_t* __restrict__ msgs, size_t msg_len, size_t msg_stride, u32 D,
+                                                                        u32 n_groups, u32 n_steps, const NielsPad* __restrict__ tail,
+                                                                        Fr* __restrict__ out, size_t n) {
     __shared__ u32 part[AKP_TE_SPLIT - 1][36][64];
     const u32 j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u32 lane = threadIdx.x & 63u;
     const size_t item = (size_t)blockIdx.x * 64 + lane;
     const size_t idx = item < n ? item : n - 1;
-    Ext acc = te_accumulate_strided<KIND>(lut, lut1, msgs + idx * msg_len, msg_len, D, n_groups, n_steps, j, AKP_TE_SPLIT);
+    Ext acc = te_accumulate_strided<KIND>(lut, lut1, msgs + idx * msg_stride, msg_len, D, n_groups, n_steps, j, AKP_TE_SPLIT);
+    if (tail && j == AKP_TE_SPLIT - 1) acc = te_madd(acc, load_niels(tail));  // the wave with the fewest steps takes the constant
 #pragma unroll 1
     for (u32 stride = 1; stride < AKP_TE_SPLIT; stride <<= 1) {
         if ((j & (2 * stride - 1)) == stride) {  // each wave j > 0 publishes exactly once, in slot j - 1

@@ -301,3 +301,30 @@ def test_table_info_of_the_baseline_windows(cpa):
     hb = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)).handle()
     assert hb.info(32) == {"digit_bits_or_group": 5, "signed_subset": False, "table_bytes": (567 * 4 + (113 << 14)) * 128, "steps": 18}
     assert hb.info(70)["steps"] == 39 and hb.info(64)["steps"] == 35
+
+
+@pytest.mark.parametrize("W,N", [(63, 9), (40, 14), (63, 13), (30, 19)])
+def test_bowe_hopwood_compress_zero_tail_constant(cpa, W, N):
+    """TwoToOneCRH::compress of two 32-byte digests in a (W*N)/8-byte buffer: the chunks that lie wholly in the zero
+    padding are replaced by one constant table entry (a zero chunk adds +g, crh/bowe_hopwood/mod.rs:167).  Against the oracle
+    (which walks every chunk), with the shortcut on and off, through the latency kernel (n <= 2^14) and the table kernels."""
+    import os
+    from crypto_primitives_amd.crh import bowe_hopwood
+    from crypto_primitives_amd import field
+    g = jj.bowe_hopwood_generators(300 + W, W, N)
+    B = bowe_hopwood.Parameters(gens_array(g))
+    assert (W * N) // 8 > 64  # there is a padded tail
+    rng = np.random.default_rng(W * 100 + N)
+    for n in (5, 20000):
+        l = field.random_fr(n, seed=W + n).reshape(n, 1, 4)
+        r = field.random_fr(n, seed=N + n).reshape(n, 1, 4)
+        got = bowe_hopwood.TwoToOneCRH.compress_batch(B, l, r)
+        pick = rng.integers(0, n, size=4)
+        for i in pick:
+            li, ri = field.to_ints(l[i])[0], field.to_ints(r[i])[0]
+            assert ints(got[i])[0] == obh.two_to_one_compress(g, W, N, li, ri), (W, N, n, int(i))
+        try:
+            os.environ["AKP_BH_ZERO_TAIL"] = "0"
+            assert np.array_equal(bowe_hopwood.TwoToOneCRH.compress_batch(B, l, r), got)
+        finally:
+            os.environ.pop("AKP_BH_ZERO_TAIL", None)
