@@ -155,6 +155,20 @@ class TeParameters {  // pedersen::Parameters / bowe_hopwood::Parameters { gener
     ~TeParameters() { akp_te_params_destroy(h_); }
     TeParameters(const TeParameters&) = delete;
     akp_te_params* get() const { return h_; }
+    // tuning facts of the device tables (akp_te_params_info)
+    struct Info {
+        uint32_t digit_bits_or_group = 0;
+        bool signed_subset = false;
+        size_t table_bytes = 0;
+        uint32_t steps = 0;
+    };
+    Info info(size_t msg_len = 0) const {
+        Info i;
+        int32_t sg = 0;
+        check(akp_te_params_info(h_, &i.digit_bits_or_group, &sg, &i.table_bytes, msg_len, &i.steps));
+        i.signed_subset = sg != 0;
+        return i;
+    }
     uint32_t window_size, num_windows;
 
   private:
