@@ -376,7 +376,7 @@ def main():
                                  "valu": {"table_steps_per_hash": psteps, "field_products_per_step": 7,
                                           "note": "VALU-issue bound like the permutation: one mixed addition of 7 products per table step "
                                                   "(signed-subset table); one 128-byte line per entry, gathered through L2 / Infinity Cache / HBM "
-                                                  "(counters: profiles/r02_s2/pmc_counters_te.txt for the 13-bit plain table)"}}}
+                                                  "(counters: profiles/r02_s26/pmc_counters_te.txt; gather share: profiles/r02_s19/te_gather_probe.txt, r02_s24)"}}}
         if args.sustain_seconds > 0:  # clock / power under the gather-heavy kernel (the permutation's figures are in `sustained`)
             count = int(min(2000, max(8, 0.5 * args.sustain_seconds / max(kavg, 1e-4))))
             torch.cuda.synchronize(dev)

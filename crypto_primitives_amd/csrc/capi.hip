@@ -977,10 +977,17 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
         if (e == hipSuccess && bad == 0) {
             u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 16, 2, 17);
             while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(NielsPad) > te_table_cap()) --D;
+            size_t n_digits = (n_gen + D - 1) / D, entries = n_digits << (D - 1);
+            e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            while (e == hipErrorOutOfMemory && D > 8) {  // a crowded device: a narrower digit needs half the table
+                (void)hipGetLastError();
+                --D;
+                n_digits = (n_gen + D - 1) / D;
+                entries = n_digits << (D - 1);
+                e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            }
             p->digit_bits = D;
             p->signed_subset = true;
-            const size_t n_digits = (n_gen + D - 1) / D, entries = n_digits << (D - 1);
-            e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
             if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(NielsPad));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_pedersen_slut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_half, (u32)n_gen, D, (u32)entries, p->d_lut);
@@ -1014,8 +1021,15 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             e = hipGetLastError();
         }
         if (G > 1) {
-            const size_t entries = (n_gen / G) << (3 * G - 1);
+            size_t entries = (n_gen / G) << (3 * G - 1);
             if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            while (e == hipErrorOutOfMemory && G > 2) {  // a crowded device: a smaller group needs an eighth of the table
+                (void)hipGetLastError();
+                --G;
+                p->group = G;
+                entries = (n_gen / G) << (3 * G - 1);
+                e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            }
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_bh_lutg, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, G, (u32)entries, p->d_lut);
                 e = hipGetLastError();
