@@ -543,7 +543,9 @@ def main():
             for _ in range(reps):
                 check(lib.akp_poseidon_permute_batch(ph.h, ptr, n))
             hs = (time.perf_counter() - h0) / reps
-            host_path[label] = {"permutations_per_s": n / hs, "ms_per_batch": hs * 1e3, "GBps_each_direction": 96.0 * n / hs / 1e9}
+            host_path[label] = {"permutations_per_s": n / hs, "ms_per_batch": hs * 1e3, "GBps_each_direction": 96.0 * n / hs / 1e9,
+                                "mode": "zero copy: the kernel addresses the pinned buffer over PCIe" if label == "pinned"
+                                        else "chunked copy-in / kernel / copy-out on three streams (runtime-staged copies)"}
             if label == "pinned":
                 check(lib.akp_host_free(pp))
         if args.merkle_log2:

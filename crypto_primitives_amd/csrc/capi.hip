@@ -176,9 +176,53 @@ struct HostIn {
     size_t bytes_per_item;
     int slot;
 };
+// Device alias of a host buffer the GPU can address directly -- memory from akp_host_alloc / hipHostMalloc or a range
+// registered with akp_host_register / hipHostRegister -- or nullptr for ordinary pageable memory.
+static void* device_alias(const void* host, size_t bytes) {
+    if (!host || bytes == 0) return nullptr;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: not an error for the caller
+        return nullptr;
+    }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) == hipSuccess) {
+        if ((const char*)a.devicePointer + bytes > (const char*)base + size) return nullptr;  // only part of the buffer is pinned
+    } else {
+        (void)hipGetLastError();
+    }
+    return a.devicePointer;
+}
 template <class Launch>
 static int32_t pipelined_batch(akp_ctx* c, size_t n, const HostIn* ins, int n_in, void* host_out, size_t out_bytes_per_item, int out_slot,
                                Launch launch /* (void* const* d_in, void* d_out, size_t count, hipStream_t) */) {
+    // Zero copy: when every buffer is pinned / registered host memory the kernels read and write it in place over PCIe.
+    // Each item is read once and written once, the kernels are compute-bound, and loads and stores of different waves use
+    // both directions of the link at the same time -- which the copy engines of this platform do not (opposite copies
+    // mostly serialise, profiles/r02_s3): 2^20 permutations 3.79 -> 3.00 ms, 2^22 11.2 -> 10.2 ms (profiles/r02_s33).
+    // AKP_HOST_ZERO_COPY=0 keeps the copy pipeline (A/B arm).
+    static const bool zero_copy = env_u32("AKP_HOST_ZERO_COPY", 1, 0, 1) != 0;
+    if (zero_copy && n) {
+        void* di[2] = {nullptr, nullptr};
+        bool all = true;
+        for (int k = 0; k < n_in && all; ++k) {
+            if (ins[k].bytes_per_item == 0) continue;
+            di[k] = device_alias(ins[k].host, n * ins[k].bytes_per_item);
+            all = di[k] != nullptr;
+        }
+        void* dout = nullptr;
+        if (all) {
+            dout = out_slot < 0 ? di[0] : device_alias(host_out, n * out_bytes_per_item);
+            all = dout != nullptr;
+        }
+        if (all) {
+            if (int32_t rc = launch(di, dout, n, c->stream)) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return AKP_OK;
+        }
+    }
     static const size_t chunk_items = (size_t)1 << env_u32("AKP_HOST_CHUNK_LOG2", 18, 10, 30);
     static const int max_lanes = (int)env_u32("AKP_HOST_LANES", 3, 3, 8);  // >= depth + 1 buffers in flight
     hipStream_t st[8] = {c->stream};

@@ -71,10 +71,12 @@ void akp_ctx_destroy(akp_ctx* ctx);
 int32_t akp_ctx_synchronize(akp_ctx* ctx);
 
 /* ---- pinned host memory (optional) ----------------------------------------------------------- */
-/* The host-pointer entry points accept any host memory.  Batches larger than one chunk (2^18 items) are cut
- * into chunks whose copy-in / kernel / copy-out overlap on three streams; with pageable memory the copies
- * are staged by the runtime and block the calling thread, with memory from akp_host_alloc (or registered
- * with akp_host_register) they stream at PCIe speed in both directions at once. */
+/* The host-pointer entry points accept any host memory.  Pageable memory: batches larger than one chunk
+ * (2^18 items) are cut into chunks whose copy-in / kernel / copy-out overlap on three streams (the copies are
+ * staged by the runtime).  Memory from akp_host_alloc, or registered with akp_host_register, is addressed by the
+ * Poseidon batch kernels DIRECTLY (zero copy: every item is read once and written once over PCIe, both directions
+ * at the same time) when all buffers of a call are of that kind.  Register a buffer as a whole: the runtime rejects
+ * copies that straddle registered and unregistered memory. */
 int32_t akp_host_alloc(size_t bytes, void** out);
 int32_t akp_host_free(void* p);
 int32_t akp_host_register(void* p, size_t bytes);
