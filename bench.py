@@ -548,6 +548,21 @@ def main():
                                         else "chunked copy-in / kernel / copy-out on three streams (runtime-staged copies)"}
             if label == "pinned":
                 check(lib.akp_host_free(pp))
+        if args.pedersen_log2:  # config 4 through the host-pointer entry point: 128 B in, 64 B out per hash
+            from crypto_primitives_amd import params as cparams2
+            from crypto_primitives_amd.crh import pedersen as cped2
+            nph = 1 << args.pedersen_log2
+            hPh = cped2.Parameters(cparams2.pedersen_generators(0xA5A50004, 4, 256)).handle(ctx)
+            hm = np.random.default_rng(0xA5A50014).integers(0, 256, size=(nph, 128), dtype=np.uint8)
+            ho = np.empty((nph, 8), dtype=np.uint64)
+            check(lib.akp_te_crh_batch(hPh.h, hm.ctypes.data, nph, 128, ho.ctypes.data))
+            reps = 3
+            h0 = time.perf_counter()
+            for _ in range(reps):
+                check(lib.akp_te_crh_batch(hPh.h, hm.ctypes.data, nph, 128, ho.ctypes.data))
+            hs = (time.perf_counter() - h0) / reps
+            host_path["pedersen_pageable"] = {"hashes_per_s": nph / hs, "ms_per_batch": hs * 1e3, "GBps_in": 128.0 * nph / hs / 1e9, "GBps_out": 64.0 * nph / hs / 1e9,
+                                              "mode": "double-buffered chunks of 2^17 messages: copy-in / kernels / copy-out on three streams"}
         if args.merkle_log2:
             ntree = 1 << min(args.merkle_log2, 22)
             lv = field.random_fr(ntree, seed=0xA5A50013).reshape(ntree, 1, 4)

@@ -1232,14 +1232,60 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     if (n == 0) return AKP_OK;
     if (!out || (!msgs && msg_len)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
     const size_t fe = te_fe_per_digest(p);
+    akp_ctx* c = p->ctx;
     void *dm = nullptr, *dout = nullptr;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * msg_len, &dm, p->ctx->stream)) return rc;
-    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dout, p->ctx->stream)) return rc;
-    hipStream_t s = p->ctx->stream;
-    if (msg_len) HIP_TRY(hipMemcpyAsync(dm, msgs, n * msg_len, hipMemcpyHostToDevice, s));
-    if (int32_t rc = te_crh_dev(p, (const uint8_t*)dm, n, msg_len, (Fr*)dout, s)) return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    hipStream_t s = c->stream;
+    // Large batches: chunks of 2^AKP_TE_HOST_CHUNK_LOG2 messages (default 2^17), double-buffered -- the copy-in of chunk
+    // i + 1 and the copy-out of chunk i - 1 run on their own streams under the kernels of chunk i (a 4x256 Pedersen hash
+    // moves 128 B in and 64 B out for 3 us of kernel time per 1000 hashes: serial copies would double the call).
+    static const size_t chunk = (size_t)1 << env_u32("AKP_TE_HOST_CHUNK_LOG2", 17, 10, 30);
+    if (n <= chunk || msg_len == 0) {
+        if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
+        if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dout, s)) return rc;
+        if (msg_len) HIP_TRY(hipMemcpyAsync(dm, msgs, n * msg_len, hipMemcpyHostToDevice, s));
+        if (int32_t rc = te_crh_dev(p, (const uint8_t*)dm, n, msg_len, (Fr*)dout, s)) return rc;
+        HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return AKP_OK;
+    }
+    const size_t dig = fe * sizeof(Fr);
+    if (int32_t rc = ctx_scratch(c, SCR_A, 2 * chunk * msg_len, &dm, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, 2 * chunk * dig, &dout, s)) return rc;
+    for (int i = 0; i < 2; ++i)
+        if (!c->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i)
+        if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
+    hipStream_t cin = c->pipe[0], cout = c->pipe[1];
+    hipEvent_t *in_done = c->chunk_event, *comp_done = c->chunk_event + 2, *out_done = c->chunk_event + 4;
+    HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the copy streams start behind whatever used the scratch last
+    HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));
+    HIP_TRY(hipStreamWaitEvent(cout, c->chunk_event[7], 0));
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    for (size_t ci = 0; ci <= n_chunks; ++ci) {
+        if (ci < n_chunks) {
+            const size_t done = ci * chunk, cnt = std::min(chunk, n - done);
+            const int b = (int)(ci & 1);
+            uint8_t* d_in = (uint8_t*)dm + (size_t)b * chunk * msg_len;
+            Fr* d_o = (Fr*)((char*)dout + (size_t)b * chunk * dig);
+            if (ci >= 2) HIP_TRY(hipStreamWaitEvent(cin, comp_done[b], 0));  // the kernels of chunk ci - 2 have read this half
+            HIP_TRY(hipMemcpyAsync(d_in, msgs + done * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
+            HIP_TRY(hipEventRecord(in_done[b], cin));
+            HIP_TRY(hipStreamWaitEvent(s, in_done[b], 0));
+            if (ci >= 2) HIP_TRY(hipStreamWaitEvent(s, out_done[b], 0));  // the copy-out of chunk ci - 2 has drained this half
+            if (int32_t rc = te_crh_dev(p, d_in, cnt, msg_len, d_o, s)) return rc;
+            HIP_TRY(hipEventRecord(comp_done[b], s));
+        }
+        if (ci >= 1) {  // issued after the copy-in of the next chunk: the copy engines serve the queues in issue order
+            const size_t co = ci - 1, done = co * chunk, cnt = std::min(chunk, n - done);
+            const int b = (int)(co & 1);
+            HIP_TRY(hipStreamWaitEvent(cout, comp_done[b], 0));
+            HIP_TRY(hipMemcpyAsync((char*)out + done * dig, (char*)dout + (size_t)b * chunk * dig, cnt * dig, hipMemcpyDeviceToHost, cout));
+            HIP_TRY(hipEventRecord(out_done[b], cout));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(cin));
     HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize(cout));
     return AKP_OK;
 }
 extern "C" int32_t akp_te_two_to_one_batch(akp_te_params* p, const uint8_t* left, const uint8_t* right, size_t n, size_t half_len, uint64_t* out) {

@@ -328,3 +328,24 @@ def test_bowe_hopwood_compress_zero_tail_constant(cpa, W, N):
             assert np.array_equal(bowe_hopwood.TwoToOneCRH.compress_batch(B, l, r), got)
         finally:
             os.environ.pop("AKP_BH_ZERO_TAIL", None)
+
+
+def test_host_batches_larger_than_one_chunk(cpa, ped, bhp):
+    """akp_te_crh_batch cuts large host batches into double-buffered chunks (copy-in / kernels / copy-out overlap): three
+    chunks and a ragged tail, sampled against the C oracle, whole batch against the device-pointer path"""
+    import torch
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    n = (1 << 17) * 3 + 777
+    for (P, g, Cc), L, crh, fe in ((ped, 128, pedersen.CRH, 2), (bhp, 45, bowe_hopwood.CRH, 1)):
+        m = np.random.default_rng(4242 + L).integers(0, 256, size=(n, L), dtype=np.uint8)
+        got = crh.evaluate_batch(P, m)
+        samp = np.unique(np.concatenate([np.arange(0, 40), np.arange((1 << 17) - 20, (1 << 17) + 20), np.arange(2 * (1 << 17) - 20, 2 * (1 << 17) + 20),
+                                         np.arange(n - 40, n)]))
+        ms = np.ascontiguousarray(m[samp])
+        exp = Cc.pedersen_crh_batch(ms, len(samp), L, threads=8) if fe == 2 else Cc.bh_crh_batch(ms, len(samp), L, threads=8)
+        assert np.array_equal(np.asarray(got)[samp].reshape(len(samp), -1), np.asarray(exp).reshape(len(samp), -1))
+        d_m = torch.from_numpy(m).cuda()
+        d_o = torch.empty((n, fe * 4), dtype=torch.int64, device="cuda")
+        cpa._lib.check(cpa.lib.akp_te_crh_batch_dev(P.handle().h, d_m.data_ptr(), n, L, d_o.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_o.cpu().numpy().view(np.uint64).reshape(n, -1), np.asarray(got).reshape(n, -1))
