@@ -470,14 +470,17 @@ def main():
             raise SystemExit("parity probe FAILED: the timed kernel's output differs from the oracle")
     # the oracle check above left the GPU idle for ~0.1 s and the clocks drop within milliseconds: settle them with untimed
     # launches (like the side legs, outside W and K) so that the W + K steps measure the steady state, not the ramp
+    # (everything the timed region needs is prepared BEFORE the settle launches: reading the clock can cost a `rocm-smi`
+    # subprocess -- hundreds of ms of idle device right before t0 would hand the first timed steps a ramping clock)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for _ in range(8):
+        step()
+    clk0 = gpu_clock_mhz(local_rank)  # sampled while launches are in flight
     for _ in range(args.settle_launches):
         step()
-    torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    clk0 = gpu_clock_mhz(local_rank)
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
