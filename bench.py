@@ -45,7 +45,7 @@ MODMUL_PER_PERM_REF = 626        # reference-shaped count
 # HBM bytes per permutation from PMC passes of an earlier session (NOT measured in this run; see `static_from`):
 # (2 * 49 579.75 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B)
 PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49579.75 + 98304.0) * 1024 / (1 << 20)
-PMC_TRAFFIC_SOURCE = "profiles/r02_s7/pmc_counters_poseidon.txt"
+PMC_TRAFFIC_SOURCE = "profiles/r02_s26/pmc_counters_poseidon.txt"
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
 MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
 # (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:
@@ -620,8 +620,8 @@ def main():
                               "v_mad_per_s": MADS_PER_PERM * n / kern_avg_s,
                               "v_mad_peak_per_s": VALU_PEAK_WAVE_INSTR * 64,
                               "frac_of_mad_issue_peak": MADS_PER_PERM * n / kern_avg_s / (VALU_PEAK_WAVE_INSTR * 64),
-                              "valu_instructions_per_permutation": 74752, "valu_busy_percent": 94.6,
-                              "valu_counters_static_from": "profiles/r02_s7/pmc_counters_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy; NOT measured in this run)"}},
+                              "valu_instructions_per_permutation": 74752, "valu_busy_percent": 97.4,
+                              "valu_counters_static_from": "profiles/r02_s26/pmc_counters_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy; NOT measured in this run)"}},
     }
     for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("host_path", host_path)):
         if leg:
