@@ -59,7 +59,7 @@ static u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
 
 // ------------------------------------------------------------------------------------------
 // context: device, stream, grow-only scratch slots
-enum { SCR_A = 0, SCR_B, SCR_C, SCR_D, SCR_E, SCR_F, SCR_G, SCR_H, SCR_I, SCR_J, SCR_K, SCR_COUNT };
+enum { SCR_A = 0, SCR_B, SCR_C, SCR_D, SCR_E, SCR_F, SCR_G, SCR_H, SCR_I, SCR_J, SCR_K, SCR_L, SCR_COUNT };
 struct akp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1176,7 +1176,16 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
             tail = p->d_tail;
         }
     }
-    const size_t stride = msg_len;
+    size_t stride = msg_len;
+    if (data_len > 0 && data_len < 4) {  // the kernels fetch message bits with one 32-bit load: pad 1..3-byte messages to four bytes
+        void* pad = nullptr;
+        if (int32_t rc = ctx_scratch(p->ctx, SCR_L, n * 4, &pad, s)) return rc;
+        hipLaunchKernelGGL(te_pad4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_msgs, stride, (u32)data_len, (uint8_t*)pad, n);
+        HIP_TRY(hipGetLastError());
+        d_msgs = (const uint8_t*)pad;
+        stride = 4;
+        data_len = 4;  // three zero bytes at most: they select nothing (Pedersen) / lie past the steps counted above (Bowe-Hopwood)
+    }
     // small batches (tree tops) are bound by the latency of one message: split each one over AKP_TE_SPLIT waves
     static const size_t split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
     if (n <= split_max) {

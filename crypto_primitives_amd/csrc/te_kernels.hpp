@@ -263,22 +263,37 @@ AKP_HD u32 msg_bits(const uint8_t* __restrict__ msg, size_t len, size_t o, u32 w
     if (byte + 2 < len) v |= (u32)msg[byte + 2] << 16;
     return (v >> (o & 7)) & ((1u << w) - 1u);
 }
-// The same in two halves for the software pipeline of te_accumulate_item: msg_load3 only issues the three byte loads
-// (unconditionally, from addresses clamped into the message, so that nothing waits for them here), msg_combine masks the
-// bytes that lie past the end and extracts the bits -- it runs one curve addition later.
+// The same in two halves for the software pipeline of te_accumulate_item: msg_load issues ONE unconditional, unaligned
+// 32-bit load that covers the window (so that nothing waits for it here), msg_combine extracts the bits -- it runs one
+// curve addition later.  The load address is pulled back so that the four bytes end inside the message (messages of
+// fewer than four bytes are padded by the host, te_crh_dev); a window of w <= 17 bits starting at bit (o & 7) of its first
+// byte fits the 32 bits, and when the address was pulled back the window reaches past the end of the message, where the
+// bits are zero -- exactly what the right shift of the 32-bit word shifts in.
 struct MsgRaw {
-    u32 b0, b1, b2;
+    u32 word;
 };
-AKP_HD MsgRaw msg_load3(const uint8_t* __restrict__ msg, size_t len, size_t o) {
-    if (len == 0) return MsgRaw{0u, 0u, 0u};
-    const size_t byte = o >> 3, top = len - 1;
-    return MsgRaw{msg[byte < top ? byte : top], msg[byte + 1 < top ? byte + 1 : top], msg[byte + 2 < top ? byte + 2 : top]};
+AKP_HD size_t msg_word_addr(size_t len, size_t o) {
+    if (len < 4) return 0;  // host harness only (the device never sees such a length)
+    const size_t byte = o >> 3, last = len - 4;
+    return byte < last ? byte : last;
+}
+AKP_HD MsgRaw msg_load(const uint8_t* __restrict__ msg, size_t len, size_t o) {
+    if (len == 0) return MsgRaw{0u};
+    u32 v;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (len < 4) {  // tests/host_harness calls the per-item code with any length; te_crh_dev pads such messages for the device
+        v = 0;
+        for (size_t k = 0; k < len; ++k) v |= (u32)msg[k] << (8 * k);
+        return MsgRaw{v};
+    }
+#endif
+    __builtin_memcpy(&v, msg + msg_word_addr(len, o), 4);
+    return MsgRaw{v};
 }
 AKP_HD u32 msg_combine(const MsgRaw& r, size_t len, size_t o, u32 w) {
-    const size_t byte = o >> 3;
-    const u32 m0 = 0u - (u32)(byte < len), m1 = 0u - (u32)(byte + 1 < len), m2 = 0u - (u32)(byte + 2 < len);
-    const u32 v = (r.b0 & m0) | ((r.b1 & m1) << 8) | ((r.b2 & m2) << 16);
-    return (v >> (o & 7)) & ((1u << w) - 1u);
+    if (len == 0 || o >= len * 8) return 0u;
+    const u32 shift = (u32)(o - 8 * msg_word_addr(len, o));  // 0..7, or up to 31 next to the end of the message
+    return (r.word >> shift) & ((1u << w) - 1u);
 }
 
 // ---- accumulate: one message per lane ------------------------------------------------------------
@@ -406,7 +421,7 @@ AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
 template <int KIND>
 AKP_HD MsgRaw te_step_bits(const uint8_t* __restrict__ msg, size_t msg_len, u32 D, u32 n_groups, u32 u) {
     u32 w;
-    return msg_load3(msg, msg_len, te_step_offset<KIND>(D, n_groups, u, &w));
+    return msg_load(msg, msg_len, te_step_offset<KIND>(D, n_groups, u, &w));
 }
 template <int KIND>
 AKP_HD NielsSel te_step_fetch(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const MsgRaw& raw, size_t msg_len, u32 D,
@@ -480,7 +495,7 @@ AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __r
 // loads -- above the addition).  Emits no instruction.
 AKP_HD void te_consume_after(MsgRaw& r, const Ext& after) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(r.b0), "+v"(r.b1), "+v"(r.b2) : "v"(after.X.l[8]), "v"(after.Y.l[8]), "v"(after.Z.l[8]), "v"(after.T.l[8]));
+    asm volatile("" : "+v"(r.word) : "v"(after.X.l[8]), "v"(after.Y.l[8]), "v"(after.Z.l[8]), "v"(after.T.l[8]));
 #else
     (void)r;
     (void)after;
@@ -711,6 +726,14 @@ __global__ void te_serialize_pairs_kernel(const Fr* __restrict__ left, const Fr*
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * 2 * (size_t)fe_per_digest) return;
     te_serialize_pair_fe(left, right, fe_per_digest, buflen, buf, t);
+}
+// messages of 1..3 bytes, zero-padded to four (the accumulate kernels read message bits with one 32-bit load)
+__global__ void te_pad4_kernel(const uint8_t* __restrict__ msgs, size_t stride, u32 len, uint8_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 v = 0;
+    for (u32 k = 0; k < len; ++k) v |= (u32)msgs[i * stride + k] << (8u * k);
+    reinterpret_cast<u32*>(out)[i] = v;
 }
 __global__ void te_zero_tail_kernel(uint8_t* __restrict__ buf, size_t buflen, size_t used, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
