@@ -1318,7 +1318,8 @@ extern "C" int32_t akp_te_two_to_one_batch(akp_te_params* p, const uint8_t* left
         hipLaunchKernelGGL(te_concat_bytes_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (const uint8_t*)dl, (const uint8_t*)dr, half_len, buflen, (uint8_t*)dbuf, n);
         HIP_TRY(hipGetLastError());
     }
-    if (int32_t rc = te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, (Fr*)dout, s)) return rc;
+    // the buffer past left || right is zero padding: te_crh_dev skips it (Pedersen) or adds its constant (Bowe-Hopwood)
+    if (int32_t rc = te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, (Fr*)dout, s, std::min(buflen, 2 * half_len))) return rc;
     HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return AKP_OK;

@@ -349,3 +349,17 @@ def test_host_batches_larger_than_one_chunk(cpa, ped, bhp):
         cpa._lib.check(cpa.lib.akp_te_crh_batch_dev(P.handle().h, d_m.data_ptr(), n, L, d_o.data_ptr(), torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert np.array_equal(d_o.cpu().numpy().view(np.uint64).reshape(n, -1), np.asarray(got).reshape(n, -1))
+
+
+@pytest.mark.parametrize("half", [0, 1, 2, 10, 31, 35, 40])
+def test_bowe_hopwood_two_to_one_short_halves(cpa, bhp, half):
+    """TwoToOneCRH::evaluate with halves shorter than half the buffer: the zero padding past left || right is a constant
+    (all-zero chunks add +g each); 1- and 2-byte data goes through the 4-byte padding of the message loads; 40 + 40 bytes
+    are zip-truncated to the 70-byte buffer (no padding at all)"""
+    from crypto_primitives_amd.crh import bowe_hopwood
+    B, gb, _ = bhp
+    n = 6
+    l, r = _msgs(n, half, 900 + half), _msgs(n, half, 901 + half)
+    got = bowe_hopwood.TwoToOneCRH.evaluate_batch(B, l, r)
+    for i in range(n):
+        assert ints(got[i])[0] == obh.two_to_one_evaluate(gb, 63, 9, bytes(l[i]), bytes(r[i])), (half, i)
