@@ -40,6 +40,7 @@ for name, P, L, fe in (("pedersen 4x256, 128 B", cped.Parameters(cparams.pederse
     rnd = torch.from_numpy(rng.integers(0, 256, size=(n, L), dtype=np.uint8)).to(dev)
     same = rnd[:1].repeat(n, 1).contiguous()
     few = rnd[:64].repeat(n // 64, 1).contiguous()  # 64 distinct messages: one per lane, the same in every wave
-    for label, m in (("random messages", rnd), ("64 distinct messages", few), ("one message", same)):
+    oct8 = rnd[:8].repeat_interleave(8, dim=0).repeat(n // 64, 1).contiguous()  # 8 distinct per wave: lanes 8j .. 8j+7 share one
+    for label, m in (("random messages", rnd), ("64 distinct messages", few), ("8 distinct per wave", oct8), ("one message", same)):
         ms = timed(lambda: check(lib.akp_te_crh_batch_dev(h.h, m.data_ptr(), n, L, out.data_ptr(), st)))
         print("%-26s %-22s %.3f ms  %.4g hashes/s" % (name, label, ms, n / ms * 1e3))
