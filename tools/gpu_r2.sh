@@ -12,6 +12,10 @@ test)  echo "== pytest gpu =="; timeout 1500 python -m pytest tests -m gpu -q > 
 smoke) echo "== smoke =="; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log;;
 bench) echo "== bench =="; timeout 900 python bench.py > $OUT/bench.log 2> $OUT/bench.err; tail -c 6000 $OUT/bench.log; tail -5 $OUT/bench.err;;
 bench2) echo "== bench --gpus 2 (shared GPU hook) =="; AKP_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 2 --no-cpu-baseline --no-host-path --merkle-log2 20 --bh-merkle-log2 16 --sustain-seconds 0 > $OUT/bench2.log 2> $OUT/bench2.err; tail -c 1500 $OUT/bench2.log; tail -5 $OUT/bench2.err;;
+benchprof) echo "== rocprofv3 --kernel-trace --stats of bench.py itself =="
+   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/benchprof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-path --sustain-seconds 0 > $OUT/benchprof_bench.log 2> $OUT/benchprof.err); tail -c 300 $OUT/benchprof_bench.log
+   F=$(find $OUT/benchprof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/rocprof_kernel_stats_bench_py.csv && head -12 $OUT/rocprof_kernel_stats_bench_py.csv | cut -c1-200
+   find $OUT/benchprof -name "*kernel_trace.csv" -delete;;
 stats) echo "== rocprofv3 kernel stats =="
    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- python $GRAFT_REPO_ROOT/tools/prof_driver.py > $OUT/stats.log 2>&1); tail -2 $OUT/stats.log
    F=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/rocprof_kernel_stats.csv && head -30 $OUT/rocprof_kernel_stats.csv
