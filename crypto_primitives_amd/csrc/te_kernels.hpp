@@ -255,15 +255,7 @@ __global__ void te_build_pedersen_cprefix(const NielsPad* __restrict__ half, u32
 // ---- message bit access -----------------------------------------------------------------------
 // bits [o, o+w) (w <= 16) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
 // bits past the end read as zero (Pedersen zero padding :91-99 / Bowe-Hopwood chunk padding :131-138).
-AKP_HD u32 msg_bits(const uint8_t* __restrict__ msg, size_t len, size_t o, u32 w) {
-    const size_t byte = o >> 3;
-    u32 v = 0;
-    if (byte < len) v = msg[byte];
-    if (byte + 1 < len) v |= (u32)msg[byte + 1] << 8;
-    if (byte + 2 < len) v |= (u32)msg[byte + 2] << 16;
-    return (v >> (o & 7)) & ((1u << w) - 1u);
-}
-// The same in two halves for the software pipeline of te_accumulate_item: msg_load issues ONE unconditional, unaligned
+// Done in two halves for the software pipeline of te_accumulate_item: msg_load issues ONE unconditional, unaligned
 // 32-bit load that covers the window (so that nothing waits for it here), msg_combine extracts the bits -- it runs one
 // curve addition later.  The load address is pulled back so that the four bytes end inside the message (messages of
 // fewer than four bytes are padded by the host, te_crh_dev); a window of w <= 17 bits starting at bit (o & 7) of its first
@@ -303,7 +295,7 @@ AKP_HD u32 msg_combine(const MsgRaw& r, size_t len, size_t o, u32 w) {
 //   te_step_fetch  table index from those bits, the 128-byte entry load, and the sign of the step -- nothing is computed
 //                  on the loaded limbs
 //   niels_apply    branch-free negation of the entry (swap y+x / y-x, negate dxy), at the point of use
-//  kind 0 (Pedersen): digit = msg_bits(u*D, D), entry lut[u << D | digit].
+//  kind 0 (Pedersen): digit = message bits [u*D, u*D + D), entry lut[u << D | digit].
 //  kind 1 (Bowe-Hopwood): steps [0, n_groups) are groups of D (= G) chunks from lut (2^(3G-1) entries each),
 //                         negated by s_0; steps [n_groups, n_steps) are the left-over single chunks from lut1.
 //  kind 2 (Pedersen, signed-subset table): lut[u << (D-1) | ...]; lut1 is the cprefix table the sum starts from.
@@ -341,11 +333,9 @@ AKP_HD size_t te_step_offset(u32 D, u32 n_groups, u32 u, u32* width) {
 // P + (-1)^neg Q without touching the entry's limbs (they are consumed by the products as loaded): for -Q the roles of
 // Y - X and Y + X are exchanged, and e and c change sign:
 //   a* = (neg ? Y + X : Y - X) * ymx,  b* = (neg ? Y - X : Y + X) * ypx,  e = +-(b* - a*),  h = b* + a*,  c = +-T * dxy
-// SEL = false: plain P + Q.  `hook(stage, value)` is called after the products a*, b*, c, X3 (stages 0..3) with the
-// product just computed, so that a caller can hang the loads of the next step between the products (te_fetch_piece);
-// te_accumulate_item does not: the burst before the addition measured faster (see there).
-template <bool SEL, class Hook>
-AKP_HD Ext te_madd_hooked(const Ext& p, const Niels& q, u32 neg, Hook&& hook) {
+// SEL = false: plain P + Q.
+template <bool SEL>
+AKP_HD Ext te_madd_signed(const Ext& p, const Niels& q, u32 neg) {
     const int32_t m = -(int32_t)(neg & 1u);  // 0 or all ones
     FS d = f29_sub(p.Y, p.X), t = f29_add(p.Y, p.X);
     if (SEL) {
@@ -357,11 +347,8 @@ AKP_HD Ext te_madd_hooked(const Ext& p, const Niels& q, u32 neg, Hook&& hook) {
         }
     }
     const FS a = f29_mul(d, q.ymx);
-    hook(0, a);
     const FS b = f29_mul(t, q.ypx);
-    hook(1, b);
     FS c = f29_mul(p.T, q.dxy);
-    hook(2, c);
     FS e = f29_sub(b, a);
     if (SEL) {
 #pragma unroll
@@ -373,17 +360,11 @@ AKP_HD Ext te_madd_hooked(const Ext& p, const Niels& q, u32 neg, Hook&& hook) {
     const FS f = f29_sub(p.Z, c), g = f29_weak_norm(f29_add(p.Z, c)), h = f29_add(b, a);
     Ext r;
     r.X = f29_mul(e, f);
-    hook(3, r.X);
     r.Y = f29_mul(g, h);
     r.Z = f29_mul(f, g);
     r.T = f29_mul(e, h);
     return r;
 }
-struct NoHook {
-    AKP_HD void operator()(int, const FS&) const {}
-};
-AKP_HD Ext te_madd_sel(const Ext& p, const NielsSel& s) { return te_madd_hooked<true>(p, s.q, s.neg, NoHook()); }
-
 // A table entry on its way in: address, sign of the step, and the seven 16-byte pieces of the 128-byte line.
 struct NielsFetch {
     const NielsPad* base;  // lut or lut1 (kept as it is: a pointer that went through an asm statement would lose its
@@ -391,15 +372,6 @@ struct NielsFetch {
     u32 neg;
     uint4 v[7];
 };
-// issue the load of piece k -- not before `after` (a product of the running addition) has been computed
-AKP_HD void te_fetch_piece(NielsFetch& f, int k, const FS& after) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(f.idx) : "v"(after.l[8]));
-#else
-    (void)after;
-#endif
-    f.v[k] = reinterpret_cast<const uint4*>(f.base + f.idx)[k];
-}
 AKP_HD void te_fetch_all(NielsFetch& f) {
     const uint4* q = reinterpret_cast<const uint4*>(f.base + f.idx);
 #pragma unroll
@@ -507,8 +479,7 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
     // Software pipeline, two steps per iteration (two entry buffers, no register copies to rotate them).  Before the
     // addition of step u starts, the seven pieces of step u + 1's table line and the message bytes of step u + 2 are
     // requested; they are consumed one whole addition (~1400 instructions) later.  (Spreading the loads over the products
-    // of the addition through te_madd_hooked's hook was measured slower than this burst: 3.51 vs 3.36 ms for 2^20 Pedersen
-    // hashes, profiles/r02_s21.)  The sum starts as a table entry (no addition): the first step's entry, or (kind 2)
+    // of the addition was measured slower than this burst: 3.51 vs 3.36 ms for 2^20 Pedersen hashes, profiles/r02_s24.)  The sum starts as a table entry (no addition): the first step's entry, or (kind 2)
     // cprefix[n_steps].
     Ext acc;
     u32 u;
@@ -533,15 +504,15 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
         te_step_address<KIND>(lut, lut1, nb, msg_len, D, n_groups, u + 1, f1);  // u + 1 <= last here
         te_fetch_all(f1);
         nb = te_step_bits<KIND>(msg, msg_len, D, n_groups, u2);
-        acc = te_madd_hooked<KIND != 0>(acc, niels_of_fetch(f0), f0.neg, NoHook());
+        acc = te_madd_signed<KIND != 0>(acc, niels_of_fetch(f0), f0.neg);
         te_consume_after(nb, acc);
         te_step_address<KIND>(lut, lut1, nb, msg_len, D, n_groups, u2, f0);
         te_fetch_all(f0);
         nb = te_step_bits<KIND>(msg, msg_len, D, n_groups, u3);
-        acc = te_madd_hooked<KIND != 0>(acc, niels_of_fetch(f1), f1.neg, NoHook());
+        acc = te_madd_signed<KIND != 0>(acc, niels_of_fetch(f1), f1.neg);
         te_consume_after(nb, acc);
     }
-    if (u < n_steps) acc = te_madd_hooked<KIND != 0>(acc, niels_of_fetch(f0), f0.neg, NoHook());
+    if (u < n_steps) acc = te_madd_signed<KIND != 0>(acc, niels_of_fetch(f0), f0.neg);
     return acc;
 }
 // partial sum over steps first, first + stride, ... (the whole message for first = 0, stride = 1)
