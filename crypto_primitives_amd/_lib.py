@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AKP_LIB", os.path.join(_HERE, "lib", "libakp.so"))
 
 AKP_OK, AKP_ERR_BAD_LENGTH, AKP_ERR_BAD_PARAMS, AKP_ERR_HIP, AKP_ERR_RCCL, AKP_ERR_NOT_POW2 = 0, 1, 2, 3, 4, 5
 AKP_ABI_VERSION = 2
-TE_PEDERSEN, TE_BOWE_HOPWOOD = 0, 1
+TE_PEDERSEN, TE_BOWE_HOPWOOD, TE_PEDERSEN_X = 0, 1, 2
 
 
 class AkpError(RuntimeError):

@@ -978,15 +978,17 @@ struct akp_te_params {
     u32 tail_from = 0, tail_to = 0;
     bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
 };
+// Pedersen arithmetic (subset-sum tables over W * N generators): the plain hash and the one composed with TECompressor
+static inline bool te_is_pedersen(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN || p->kind == AKP_TE_PEDERSEN_X; }
 static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN ? 2u : 1u; }
 static inline size_t te_input_bits(const akp_te_params* p) {  // max message bits before the reference panics
-    return p->kind == AKP_TE_PEDERSEN ? (size_t)p->W * p->N : (size_t)p->W * p->N * 3;
+    return te_is_pedersen(p) ? (size_t)p->W * p->N : (size_t)p->W * p->N * 3;
 }
 
 extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
     if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
     if (!out || !gens) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
-    if (kind != AKP_TE_PEDERSEN && kind != AKP_TE_BOWE_HOPWOOD) return fail(AKP_ERR_BAD_PARAMS, "unknown kind %d", kind);
+    if (kind != AKP_TE_PEDERSEN && kind != AKP_TE_BOWE_HOPWOOD && kind != AKP_TE_PEDERSEN_X) return fail(AKP_ERR_BAD_PARAMS, "unknown kind %d", kind);
     if (W == 0 || N == 0) return fail(AKP_ERR_BAD_PARAMS, "empty window");
     if (kind == AKP_TE_BOWE_HOPWOOD && W > 63) return fail(AKP_ERR_BAD_PARAMS, "Bowe-Hopwood window size %u > 63 (bowe_hopwood/mod.rs:81-101)", W);
     const size_t n_gen = (size_t)W * N;
@@ -999,7 +1001,7 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     Fr* d_g = nullptr;
     hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
-    if (kind == AKP_TE_PEDERSEN) {
+    if (kind == AKP_TE_PEDERSEN || kind == AKP_TE_PEDERSEN_X) {
         // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
         // stores 2^(D-1) entries per digit.  Default D = 15: 4x256 is 69 steps over a 163 MB table.  Measured on MI355X, 2^20 x 128 B
         // (profiles/r02_s9): signed D = 13 / 14 / 15: 2.70 / 2.75 / 2.88e8 hashes/s; plain table D = 13: 2.56e8.
@@ -1106,7 +1108,7 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
 // left-over singles.
 static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32* n_steps) {
     const size_t bits = msg_len * 8;
-    if (p->kind == AKP_TE_PEDERSEN) {
+    if (te_is_pedersen(p)) {
         const size_t used = std::min<size_t>(bits, p->n_gen);
         *n_groups = 0;
         *n_steps = (u32)((used + p->digit_bits - 1) / p->digit_bits);
@@ -1124,7 +1126,7 @@ static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32*
 extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset, size_t* table_bytes, size_t msg_len,
                                       uint32_t* steps) {
     if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_info: params is NULL");
-    const bool ped = p->kind == AKP_TE_PEDERSEN;
+    const bool ped = te_is_pedersen(p);
     if (digit_bits_or_group) *digit_bits_or_group = ped ? p->digit_bits : p->group;
     if (signed_subset) *signed_subset = ped && p->signed_subset ? 1 : 0;
     if (table_bytes) {
@@ -1190,12 +1192,16 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     static const size_t split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
     if (n <= split_max) {
         const unsigned sgrid = (unsigned)((n + 63) / 64);
-        if (p->kind == AKP_TE_PEDERSEN && p->signed_subset)
-            hipLaunchKernelGGL(te_crh_small_kernel<2>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
-        else if (p->kind == AKP_TE_PEDERSEN)
-            hipLaunchKernelGGL(te_crh_small_kernel<0>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
-        else
-            hipLaunchKernelGGL(te_crh_small_kernel<1>, dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->group, groups, steps, tail, d_out, n);
+        const bool xy = p->kind == AKP_TE_PEDERSEN;  // digest = (x, y); otherwise x only
+        if (te_is_pedersen(p) && p->signed_subset) {
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<2, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+            else hipLaunchKernelGGL((te_crh_small_kernel<2, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+        } else if (te_is_pedersen(p)) {
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<0, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+            else hipLaunchKernelGGL((te_crh_small_kernel<0, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+        } else {
+            hipLaunchKernelGGL((te_crh_small_kernel<1, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->group, groups, steps, tail, d_out, n);
+        }
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -1203,9 +1209,9 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
     const unsigned grid = (unsigned)((n + 255) / 256);
-    if (p->kind == AKP_TE_PEDERSEN && p->signed_subset)
+    if (te_is_pedersen(p) && p->signed_subset)
         hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
-    else if (p->kind == AKP_TE_PEDERSEN)
+    else if (te_is_pedersen(p))
         hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
     else
         hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->group, groups, steps, tail, (F29Pad*)xyz, n);

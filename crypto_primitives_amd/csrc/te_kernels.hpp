@@ -611,7 +611,8 @@ __global__ void __launch_bounds__(256) te_finalize_kernel(const F29Pad* __restri
 // inversion.  Depth ceil(steps/S) mixed additions + log2(S) full additions instead of `steps` mixed additions, and
 // one launch instead of two.
 #define AKP_TE_SPLIT 8
-template <int KIND>
+// KIND: table kind (as te_accumulate_kernel); XONLY: digest = x coordinate (Bowe-Hopwood, Pedersen with TECompressor)
+template <int KIND, bool XONLY>
 __global__ void __launch_bounds__(64 * AKP_TE_SPLIT) te_crh_small_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
                                                                         const uint8_t* __restrict__ msgs, size_t msg_len, size_t msg_stride, u32 D,
                                                                         u32 n_groups, u32 n_steps, const NielsPad* __restrict__ tail,
@@ -649,7 +650,7 @@ __global__ void __launch_bounds__(64 * AKP_TE_SPLIT) te_crh_small_kernel(const N
     }
     if (j != 0 || item >= n) return;
     const FS zi = f29_inv(acc.Z);  // Z != 0 always (complete formulas)
-    if (KIND != 1) {
+    if (!XONLY) {
         store_fr_g(out + item * 2, f29_to_wire(f29_mul(acc.X, zi)));
         store_fr_g(out + item * 2 + 1, f29_to_wire(f29_mul(acc.Y, zi)));
     } else {

@@ -10,7 +10,7 @@ Config objects bundle what the reference's `Config` trait (:83-122) fixes at typ
 import numpy as np
 
 from ._lib import lib, check, NotPowerOfTwo
-from .crh import poseidon as _pos, pedersen as _ped, bowe_hopwood as _bh
+from .crh import poseidon as _pos, pedersen as _ped, bowe_hopwood as _bh, injective_map as _inj
 
 
 # ---- Config implementations ---------------------------------------------------------------------
@@ -125,6 +125,14 @@ class PedersenByteConfig(_ByteConfig):
 class BoweHopwoodByteConfig(_ByteConfig):
     LeafHash = _bh.CRH
     TwoToOneHash = _bh.TwoToOneCRH
+    digest_shape = (4,)
+
+
+class PedersenXByteConfig(_ByteConfig):
+    """JubJubMerkleTreeParams of merkle_tree/tests/constraints.rs: LeafHash = PedersenCRHCompressor<JubJub, TECompressor, W>,
+    TwoToOneHash = PedersenTwoToOneCRHCompressor<...>, digests = Fq, ByteDigestConverter"""
+    LeafHash = _inj.PedersenCRHCompressor
+    TwoToOneHash = _inj.PedersenTwoToOneCRHCompressor
     digest_shape = (4,)
 
 

@@ -144,6 +144,10 @@ int32_t akp_sponge_set_state(akp_sponge* s, const uint64_t* state, int32_t mode,
 /* ---- Pedersen / Bowe-Hopwood over Jubjub (ark_ed_on_bls12_381) -------------------------------- */
 #define AKP_TE_PEDERSEN 0     /* crh/pedersen/mod.rs: digest = affine point x||y (2 Fr) */
 #define AKP_TE_BOWE_HOPWOOD 1 /* crh/bowe_hopwood/mod.rs: digest = x coordinate (1 Fr) */
+#define AKP_TE_PEDERSEN_X 2   /* crh/injective_map/mod.rs:16-108: PedersenCRHCompressor / PedersenTwoToOneCRHCompressor with
+                               * TECompressor -- the Pedersen hash followed by the injective map (x, y) -> x: digest = 1 Fr;
+                               * compress serialises the two x coordinates (64 bytes) into the (W*N)/8-byte buffer.  The
+                               * leaf / two-to-one hashes of the reference's R1CS Merkle tests (merkle_tree/tests/constraints.rs). */
 /* Parameters { generators } (crh/pedersen/mod.rs:28-31, crh/bowe_hopwood/mod.rs:33-37):
  * generators is [num_windows][window_size] affine points (x||y, Fr wire format), used verbatim
  * (no assumption that generators[i][j] is a multiple of generators[i][0]).

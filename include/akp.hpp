@@ -228,6 +228,33 @@ struct TwoToOneCRH {  // :189-240
     }
 };
 }  // namespace bowe_hopwood
+namespace injective_map {  // crh/injective_map/mod.rs:16-108 with TECompressor: digest = x coordinate of the Pedersen hash
+using Parameters = TeParameters<AKP_TE_PEDERSEN_X>;
+struct PedersenCRHCompressor {  // :33-62
+    using Output = FrWire;
+    static std::vector<Output> evaluate_batch(const Parameters& p, const std::vector<uint8_t>& msgs, size_t msg_len) {
+        const size_t n = msg_len ? msgs.size() / msg_len : 1;
+        std::vector<Output> out(n);
+        check(akp_te_crh_batch(p.get(), msgs.data(), n, msg_len, out[0].data()));
+        return out;
+    }
+    static Output evaluate(const Parameters& p, const std::vector<uint8_t>& input) { return evaluate_batch(p, input, input.size())[0]; }
+};
+struct PedersenTwoToOneCRHCompressor {  // :64-108
+    using Output = FrWire;
+    static Output evaluate(const Parameters& p, const std::vector<uint8_t>& l, const std::vector<uint8_t>& r) {
+        if (l.size() != r.size()) throw Error(AKP_ERR_BAD_LENGTH, "left and right input should be of equal length");
+        Output out;
+        check(akp_te_two_to_one_batch(p.get(), l.data(), r.data(), 1, l.size(), out.data()));
+        return out;
+    }
+    static Output compress(const Parameters& p, const Output& l, const Output& r) {
+        Output out;
+        check(akp_te_compress_batch(p.get(), l.data(), r.data(), 1, out.data()));
+        return out;
+    }
+};
+}  // namespace injective_map
 
 // ---- MerkleTree (merkle_tree/mod.rs) -----------------------------------------------------------------------
 // Config for Leaf = [Fr], poseidon CRH + TwoToOneCRH, IdentityDigestConverter (merkle_tree/tests/mod.rs:198-206)

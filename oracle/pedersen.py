@@ -53,3 +53,19 @@ def two_to_one_compress(generators, window_size, num_windows, left_pt, right_pt)
     """pedersen/mod.rs:187-197: evaluate(uncompressed(left), uncompressed(right))."""
     return two_to_one_evaluate(generators, window_size, num_windows,
                                jj.serialize_uncompressed(left_pt), jj.serialize_uncompressed(right_pt))
+
+
+# ---- crh/injective_map/mod.rs:16-108: Pedersen followed by TECompressor (affine point -> x) --------------------------
+def compressor_evaluate(generators, window_size, num_windows, message: bytes) -> int:
+    """PedersenCRHCompressor::evaluate (:54-62): injective_map(pedersen::CRH::evaluate) = its x coordinate (:24-31)"""
+    return evaluate(generators, window_size, num_windows, message)[0]
+
+
+def compressor_two_to_one_evaluate(generators, window_size, num_windows, left: bytes, right: bytes) -> int:
+    """PedersenTwoToOneCRHCompressor::evaluate (:81-94)"""
+    return two_to_one_evaluate(generators, window_size, num_windows, left, right)[0]
+
+
+def compressor_two_to_one_compress(generators, window_size, num_windows, left_x: int, right_x: int) -> int:
+    """:96-107: evaluate on to_uncompressed_bytes!(x) of both Fq digests (32 bytes little-endian canonical each)"""
+    return compressor_two_to_one_evaluate(generators, window_size, num_windows, jj.fq_serialize(left_x), jj.fq_serialize(right_x))

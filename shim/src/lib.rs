@@ -9,7 +9,8 @@
 //! * [`poseidon::CRH`], [`poseidon::TwoToOneCRH`] -- `CRHScheme` / `TwoToOneCRHScheme` for Poseidon over BLS12-381 Fr
 //! * [`poseidon::GpuPoseidonSponge`] -- `CryptographicSponge + FieldBasedCryptographicSponge<Fr> + SpongeExt`
 //! * [`te::PedersenCRH`], [`te::PedersenTwoToOneCRH`], [`te::BoweHopwoodCRH`], [`te::BoweHopwoodTwoToOneCRH`]
-//!   over Jubjub (`ark_ed_on_bls12_381`)
+//!   over Jubjub (`ark_ed_on_bls12_381`); [`te::PedersenCRHCompressor`], [`te::PedersenTwoToOneCRHCompressor`] = the Pedersen
+//!   hashes composed with `TECompressor` (`crh/injective_map/mod.rs`)
 //! * [`merkle::GpuMerkleTree`] -- `MerkleTree<P>` resident on the device (new / blank / root / generate_proof /
 //!   generate_multi_proof / update / check_update), plus `into_reference_vectors` for code that reads the
 //!   reference's `leaf_nodes` / `non_leaf_nodes`.

@@ -168,6 +168,44 @@ impl<W: Window> GpuConfig for BoweHopwoodByteConfig<W> {
     }
 }
 
+/// Pedersen byte tree with `TECompressor` digests (`JubJubMerkleTreeParams` of `merkle_tree/tests/constraints.rs`):
+/// leaf hash `PedersenCRHCompressor`, two-to-one `PedersenTwoToOneCRHCompressor`, Fq digests, `ByteDigestConverter`
+pub struct PedersenXByteConfig<W: Window>(PhantomData<W>);
+impl<W: Window> Config for PedersenXByteConfig<W> {
+    type Leaf = [u8];
+    type LeafDigest = Fr;
+    type LeafInnerDigestConverter = ark_crypto_primitives::merkle_tree::ByteDigestConverter<Fr>;
+    type InnerDigest = Fr;
+    type LeafHash = te::PedersenCRHCompressor<W>;
+    type TwoToOneHash = te::PedersenTwoToOneCRHCompressor<W>;
+}
+impl<W: Window> GpuConfig for PedersenXByteConfig<W> {
+    const FE_PER_DIGEST: usize = 1;
+    fn build(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, leaves: &[&[u8]]) -> Result<*mut ffi::AkpMerkleTree, Error> {
+        let (flat, l) = bytes_flat(leaves);
+        let mut t = core::ptr::null_mut();
+        check(unsafe { ffi::akp_merkle_tree_build_te(te::pedersen_x_handle(leaf)?, te::pedersen_x_handle(two)?, flat.as_ptr(), leaves.len(), l, &mut t) }, l)?;
+        Ok(t)
+    }
+    fn from_digests(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, digests: &[Fr]) -> Result<*mut ffi::AkpMerkleTree, Error> {
+        let mut t = core::ptr::null_mut();
+        check(unsafe { ffi::akp_merkle_tree_from_digests_te(te::pedersen_x_handle(leaf)?, te::pedersen_x_handle(two)?, words(digests), digests.len(), &mut t) }, 0)?;
+        Ok(t)
+    }
+    fn encode_leaves(leaves: &[&[u8]]) -> (Vec<u8>, usize) {
+        bytes_flat(leaves)
+    }
+    fn leaf_digest(w: &[u64]) -> Fr {
+        fr_of(w)
+    }
+    fn inner_digest(w: &[u64]) -> Fr {
+        fr_of(w)
+    }
+    fn inner_words(d: &Fr) -> Vec<u64> {
+        (d.0).0.to_vec()
+    }
+}
+
 /// `MerkleTree<P>` with `leaf_nodes` / `non_leaf_nodes` in device memory.
 ///
 /// Not `Sync`: the handle belongs to the context of the thread that built it (see [`crate::runtime`]).

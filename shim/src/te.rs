@@ -1,5 +1,6 @@
 //! Pedersen and Bowe-Hopwood CRH over Jubjub (`ark_ed_on_bls12_381`) on the GPU
-//! (`crh/pedersen/mod.rs:23-209`, `crh/bowe_hopwood/mod.rs:31-240`).
+//! (`crh/pedersen/mod.rs:23-209`, `crh/bowe_hopwood/mod.rs:31-240`) and the Pedersen hashes composed with `TECompressor`
+//! (`crh/injective_map/mod.rs:16-108`).
 use crate::runtime::{check, fingerprint, fr_from_limbs, with_runtime, words};
 use crate::{ffi, Error, Fr};
 use ark_crypto_primitives::crh::{bowe_hopwood, pedersen, CRHScheme, TwoToOneCRHScheme};
@@ -146,8 +147,60 @@ impl<W: pedersen::Window> TwoToOneCRHScheme for BoweHopwoodTwoToOneCRH<W> {
     }
 }
 
+/// `PedersenCRHCompressor<EdwardsProjective, TECompressor, W>` (`crh/injective_map/mod.rs:33-62`): the Pedersen hash followed
+/// by the injective map (x, y) -> x.  Runs as the library's third kind (`AKP_TE_PEDERSEN_X`): Pedersen tables, x-only output.
+pub struct PedersenCRHCompressor<W: pedersen::Window>(PhantomData<W>);
+impl<W: pedersen::Window> PedersenCRHCompressor<W> {
+    pub fn evaluate_batch(parameters: &pedersen::Parameters<EdwardsProjective>, msgs: &[u8], msg_len: usize) -> Result<Vec<Fr>, Error> {
+        let n = if msg_len == 0 { 1 } else { msgs.len() / msg_len };
+        let w = crh_words(te_handle(ffi::AKP_TE_PEDERSEN_X, &parameters.generators)?, 1, msgs, n, msg_len)?;
+        Ok(w.chunks_exact(4).map(|c| fr_from_limbs([c[0], c[1], c[2], c[3]])).collect())
+    }
+}
+impl<W: pedersen::Window> CRHScheme for PedersenCRHCompressor<W> {
+    type Input = [u8];
+    type Output = Fr; // TECompressor::Output = <EdwardsConfig as CurveConfig>::BaseField (:21-22)
+    type Parameters = pedersen::Parameters<EdwardsProjective>;
+
+    fn setup<R: Rng>(rng: &mut R) -> Result<Self::Parameters, Error> {
+        pedersen::CRH::<EdwardsProjective, W>::setup(rng) // :47-52
+    }
+    fn evaluate<T: Borrow<Self::Input>>(parameters: &Self::Parameters, input: T) -> Result<Self::Output, Error> {
+        let input = input.borrow();
+        assert!(input.len() * 8 <= W::WINDOW_SIZE * W::NUM_WINDOWS, "incorrect input length {:?} for window params {:?}✕{:?}", input.len(), W::WINDOW_SIZE, W::NUM_WINDOWS);
+        assert_eq!(parameters.generators.len(), W::NUM_WINDOWS);
+        Ok(Self::evaluate_batch(parameters, input, input.len())?[0])
+    }
+}
+/// `PedersenTwoToOneCRHCompressor<EdwardsProjective, TECompressor, W>` (`crh/injective_map/mod.rs:64-108`)
+pub struct PedersenTwoToOneCRHCompressor<W: pedersen::Window>(PhantomData<W>);
+impl<W: pedersen::Window> TwoToOneCRHScheme for PedersenTwoToOneCRHCompressor<W> {
+    type Input = [u8];
+    type Output = Fr;
+    type Parameters = pedersen::Parameters<EdwardsProjective>;
+
+    fn setup<R: Rng>(rng: &mut R) -> Result<Self::Parameters, Error> {
+        pedersen::CRH::<EdwardsProjective, W>::setup(rng) // :76-78
+    }
+    fn evaluate<T: Borrow<Self::Input>>(parameters: &Self::Parameters, left_input: T, right_input: T) -> Result<Self::Output, Error> {
+        let (l, r) = (left_input.borrow(), right_input.borrow());
+        assert_eq!(l.len(), r.len(), "left and right input should be of equal length");
+        let w = two_to_one_words(te_handle(ffi::AKP_TE_PEDERSEN_X, &parameters.generators)?, 1, l, r)?;
+        Ok(fr_from_limbs([w[0], w[1], w[2], w[3]]))
+    }
+    fn compress<T: Borrow<Self::Output>>(parameters: &Self::Parameters, left_input: T, right_input: T) -> Result<Self::Output, Error> {
+        let (mut l, mut r) = (Vec::new(), Vec::new()); // :96-107 to_uncompressed_bytes!
+        left_input.borrow().serialize_uncompressed(&mut l).map_err(Error::SerializationError)?;
+        right_input.borrow().serialize_uncompressed(&mut r).map_err(Error::SerializationError)?;
+        Self::evaluate(parameters, l, r)
+    }
+}
+
 pub(crate) fn pedersen_handle(p: &pedersen::Parameters<EdwardsProjective>) -> Result<*mut ffi::AkpTeParams, Error> {
     te_handle(ffi::AKP_TE_PEDERSEN, &p.generators)
+}
+pub(crate) fn pedersen_x_handle(p: &pedersen::Parameters<EdwardsProjective>) -> Result<*mut ffi::AkpTeParams, Error> {
+    te_handle(ffi::AKP_TE_PEDERSEN_X, &p.generators)
 }
 pub(crate) fn bowe_hopwood_handle(p: &bowe_hopwood::Parameters<EdwardsConfig>) -> Result<*mut ffi::AkpTeParams, Error> {
     te_handle(ffi::AKP_TE_BOWE_HOPWOOD, &p.generators)

@@ -40,6 +40,17 @@ static int te_cases(const Context& ctx, const char* path) {
             catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_LENGTH); }  // the reference panics (:82-89)
             auto batch = pedersen::CRH::evaluate_batch(P, std::vector<uint8_t>(msg), L);
             REQUIRE(batch.size() == 1 && batch[0].x == want.x);
+            // crh/injective_map/mod.rs: PedersenCRHCompressor with TECompressor = x of the same hash; compress of two Fq
+            // digests = evaluate on their 32-byte canonical serialisations
+            injective_map::Parameters X(ctx, W, N, gens);
+            REQUIRE(injective_map::PedersenCRHCompressor::evaluate(X, msg) == want.x);
+            if ((size_t)W * N >= 512) {
+                const FrWire cx = fr_to_canonical({want.x})[0];
+                std::vector<uint8_t> ser(32);
+                std::memcpy(ser.data(), cx.data(), 32);
+                REQUIRE(injective_map::PedersenTwoToOneCRHCompressor::compress(X, want.x, want.x) ==
+                        injective_map::PedersenTwoToOneCRHCompressor::evaluate(X, ser, ser));
+            }
         } else {
             FrWire want;
             REQUIRE(std::fread(&want, sizeof want, 1, f) == 1);

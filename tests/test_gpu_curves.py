@@ -363,3 +363,35 @@ def test_bowe_hopwood_two_to_one_short_halves(cpa, bhp, half):
     got = bowe_hopwood.TwoToOneCRH.evaluate_batch(B, l, r)
     for i in range(n):
         assert ints(got[i])[0] == obh.two_to_one_evaluate(gb, 63, 9, bytes(l[i]), bytes(r[i])), (half, i)
+
+
+def test_pedersen_compressor_injective_map(cpa, ped):
+    """crh/injective_map/mod.rs:16-108: PedersenCRHCompressor / PedersenTwoToOneCRHCompressor with TECompressor = x of the
+    Pedersen hash; compress = evaluate on the 32-byte LE serialisations of the two Fq digests (zero padding behind them).
+    Against the python oracle, the (x, y) kernels, and across the latency / table kernel switch."""
+    from crypto_primitives_amd.crh import pedersen, injective_map as inj
+    from crypto_primitives_amd import field
+    P, g, Cc = ped
+    X = inj.Parameters(gens_array(g))
+    m = _msgs(6, 100, 77)
+    got = inj.PedersenCRHCompressor.evaluate_batch(X, m)
+    for i in range(6):
+        assert ints(got[i])[0] == opd.compressor_evaluate(g, 4, 256, bytes(m[i]))
+    assert np.array_equal(got, inj.TECompressor.injective_map(pedersen.CRH.evaluate_batch(P, m)))
+    l, r = _msgs(5, 30, 78), _msgs(5, 30, 79)
+    got2 = inj.PedersenTwoToOneCRHCompressor.evaluate_batch(X, l, r)
+    for i in range(5):
+        assert ints(got2[i])[0] == opd.compressor_two_to_one_evaluate(g, 4, 256, bytes(l[i]), bytes(r[i]))
+    dl, dr = got[:3], got[3:6]
+    cmp_ = inj.PedersenTwoToOneCRHCompressor.compress_batch(X, dl, dr)
+    for i in range(3):
+        assert ints(cmp_[i])[0] == opd.compressor_two_to_one_compress(g, 4, 256, ints(dl[i])[0], ints(dr[i])[0])
+    # table kernels (n > 2^14) against the C oracle: x of the Pedersen digest
+    n = 20000
+    mm = np.random.default_rng(5).integers(0, 256, size=(n, 128), dtype=np.uint8)
+    big = inj.PedersenCRHCompressor.evaluate_batch(X, mm)
+    samp = np.arange(0, n, 997)
+    exp = np.asarray(Cc.pedersen_crh_batch(np.ascontiguousarray(mm[samp]), len(samp), 128, threads=8)).reshape(len(samp), 2, 4)[:, 0]
+    assert np.array_equal(big[samp], exp)
+    # 64 bytes of data in the 128-byte buffer: half the table steps
+    assert X.handle().info(64)["steps"] * 2 == X.handle().info(128)["steps"]

@@ -302,3 +302,47 @@ def test_largest_batches_2pow26(cpa):
     for width in (32, 16, 8, 4, 2, 1):  # the top six levels recomputed by the oracle from level 6
         lvl = ora.two_to_one_batch(np.ascontiguousarray(lvl[0::2]), np.ascontiguousarray(lvl[1::2]), threads=4)
         assert np.array_equal(top[width - 1: 2 * width - 1], lvl), width
+
+
+def test_pedersen_compressor_tree(cpa):
+    """JubJubMerkleTreeParams of merkle_tree/tests/constraints.rs: leaf hash PedersenCRHCompressor<JubJub, TECompressor,
+    Window4x256>, two-to-one PedersenTwoToOneCRHCompressor, Fq digests, ByteDigestConverter.  Small tree against the generic
+    python oracle (oracle/merkle.py over oracle/pedersen.py), a 512-leaf tree level by level against the C oracle; proofs,
+    multi-proof and update through the generic machinery."""
+    from crypto_primitives_amd.crh import injective_map as inj
+    from crypto_primitives_amd import field
+    from oracle import merkle as omk, pedersen as opd
+    g = jj.pedersen_generators(0xA5A50004, 4, 256)
+    X = inj.Parameters(gens_array(g))
+    C = cref.CurveParams(4, 256, gens_array(g))
+    lv = _byte_leaves(8, 30, 4321)
+    t = cpa.MerkleTree.new(cpa.PedersenXByteConfig, X, X, lv)
+    ot = omk.MerkleTree(lambda leaf: opd.compressor_evaluate(g, 4, 256, bytes(leaf)),
+                        lambda a, b: opd.compressor_two_to_one_evaluate(g, 4, 256, a, b),
+                        lambda a, b: opd.compressor_two_to_one_compress(g, 4, 256, a, b),
+                        jj.fq_serialize, leaves=[bytes(x) for x in lv])
+    assert [field.to_ints(x)[0] for x in t.leaf_nodes] == list(ot.leaf_nodes)
+    assert [field.to_ints(x)[0] for x in t.non_leaf_nodes] == list(ot.non_leaf_nodes)
+    n = 512
+    lv = _byte_leaves(n, 32, 4322)
+    t = cpa.MerkleTree.new(cpa.PedersenXByteConfig, X, X, lv)
+    ln = np.asarray(C.pedersen_crh_batch(np.ascontiguousarray(lv), n, 32, threads=8)).reshape(n, 2, 4)[:, 0]
+    assert np.array_equal(t.leaf_nodes, ln)
+    child = ln
+    for width in (256, 128, 64, 32, 16, 8, 4, 2, 1):
+        buf = np.zeros((width, 128), np.uint8)
+        pairs = cref.from_mont(np.ascontiguousarray(child)).view(np.uint8).reshape(width, 64)
+        buf[:, :64] = pairs
+        exp = np.asarray(C.pedersen_crh_batch(buf, width, 128, threads=8)).reshape(width, 2, 4)[:, 0]
+        assert np.array_equal(t.non_leaf_nodes[width - 1: 2 * width - 1], exp), width
+        child = exp
+    root = t.root()
+    assert all(t.generate_proof(i).verify(X, X, root, bytes(lv[i])) for i in (0, 1, 255, 511))
+    assert not t.generate_proof(3).verify(X, X, root, bytes(lv[4]))
+    mp = t.generate_multi_proof([0, 1, 2, 3, 100, 101])
+    assert mp.verify(X, X, root, [bytes(lv[i]) for i in (0, 1, 2, 3, 100, 101)])
+    t.update(9, bytes(lv[10])); lv[9] = lv[10]
+    assert np.array_equal(t.non_leaf_nodes, cpa.MerkleTree.new(cpa.PedersenXByteConfig, X, X, lv).non_leaf_nodes)
+    # HBM-resident handle with the same configuration
+    gt = cpa.GpuMerkleTree.new(cpa.PedersenXByteConfig, X, X, lv)
+    assert np.array_equal(np.asarray(gt.root()).reshape(-1), np.asarray(t.root()).reshape(-1))

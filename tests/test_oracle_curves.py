@@ -128,3 +128,18 @@ def test_merkle_structure_python_oracle():
         assert t.verify(t.generate_proof(i), t.root(), leaves[i])
     with pytest.raises(AssertionError):
         merkle.MerkleTree(t.leaf_hash, t.t_eval, t.t_comp, t.convert, leaves=leaves[:3])
+
+
+def test_injective_map_compressor_is_x_of_pedersen():
+    """crh/injective_map/mod.rs:24-31,54-62,81-107: TECompressor keeps x; compress serialises the two Fq digests (32 bytes
+    LE canonical each) and evaluates"""
+    g = jj.pedersen_generators(11, 4, 256)
+    m = bytes(range(40))
+    opd = pd
+    pt = opd.evaluate(g, 4, 256, m)
+    assert opd.compressor_evaluate(g, 4, 256, m) == pt[0]
+    l, r = bytes(range(20)), bytes(range(20, 40))
+    assert opd.compressor_two_to_one_evaluate(g, 4, 256, l, r) == opd.two_to_one_evaluate(g, 4, 256, l, r)[0]
+    a, b = 12345, jj.Q - 2
+    want = opd.evaluate(g, 4, 256, a.to_bytes(32, "little") + b.to_bytes(32, "little") + bytes(64))[0]
+    assert opd.compressor_two_to_one_compress(g, 4, 256, a, b) == want
