@@ -156,7 +156,60 @@ class PoseidonSponge:
         check(lib.akp_sponge_squeeze(self.h, out.ctypes.data, n))
         return out[0] if self.batch == 1 else out
 
-    squeeze_field_elements = squeeze_native_field_elements  # same field: identity field_cast (:309-320)
+    # ---- sized / foreign-field squeezes: host logic over squeeze_bits (sponge/mod.rs:28-100,164-179; poseidon :293-322) ----
+    FULL = None  # FieldElementSize::Full; an int n stands for FieldElementSize::Truncated(n)
+
+    @staticmethod
+    def _size_num_bits(size, modulus):
+        """FieldElementSize::num_bits (sponge/mod.rs:38-48)"""
+        if size is None:
+            return modulus.bit_length() - 1
+        if size > modulus.bit_length():
+            raise ValueError("num_bits is greater than the capacity of the field.")
+        return int(size)
+
+    def _squeeze_with_sizes_default(self, sizes, modulus):
+        """squeeze_field_elements_with_sizes_default_impl (sponge/mod.rs:57-100): one squeeze_bits for all elements, each
+        element = its bits little-endian, reduced mod the target modulus.  Returns python ints [batch][len(sizes)]."""
+        if not sizes:
+            return [] if self.batch == 1 else [[] for _ in range(self.batch)]
+        nb = [self._size_num_bits(sz, modulus) for sz in sizes]
+        bits = self.squeeze_bits(sum(nb))
+        rows = [bits] if self.batch == 1 else bits
+        out = []
+        for row in rows:
+            vals, pos = [], 0
+            for n in nb:
+                w = np.asarray(row[pos:pos + n], dtype=np.uint8)
+                pos += n
+                vals.append(int.from_bytes(np.packbits(w, bitorder="little").tobytes(), "little") % modulus)
+            out.append(vals)
+        return out[0] if self.batch == 1 else out
+
+    def squeeze_native_field_elements_with_sizes(self, sizes):
+        """FieldBasedCryptographicSponge::squeeze_native_field_elements_with_sizes (sponge/mod.rs:164-179): all `Full`
+        -> the plain native squeeze; otherwise bits.  Wire-format array [batch, n, 4] (or [n, 4])."""
+        sizes = list(sizes)
+        if all(sz is None for sz in sizes):
+            return self.squeeze_native_field_elements(len(sizes))
+        vals = self._squeeze_with_sizes_default(sizes, field.MODULUS)
+        if self.batch == 1:
+            return field.fr(vals).reshape(len(sizes), 4)
+        return np.stack([field.fr(v).reshape(len(sizes), 4) for v in vals])
+
+    def squeeze_field_elements_with_sizes(self, sizes, modulus=None):
+        """CryptographicSponge::squeeze_field_elements_with_sizes::<F2> (sponge/poseidon/mod.rs:293-308).  `modulus` None or
+        p: F2 is the native field (wire-format array); any other prime: python ints reduced mod it."""
+        if modulus is None or modulus == field.MODULUS:
+            return self.squeeze_native_field_elements_with_sizes(sizes)
+        return self._squeeze_with_sizes_default(list(sizes), int(modulus))
+
+    def squeeze_field_elements(self, n: int, modulus=None):
+        """squeeze_field_elements::<F2> (:310-322): the native squeeze for F2 = Fr (identity field_cast), else n `Full`-sized
+        elements of the foreign field through the bit path"""
+        if modulus is None or modulus == field.MODULUS:
+            return self.squeeze_native_field_elements(n)
+        return self.squeeze_field_elements_with_sizes([None] * n, modulus)
 
     def squeeze_bytes(self, num_bytes: int):
         usable = (field.MODULUS.bit_length() - 1) // 8  # :260

@@ -234,6 +234,53 @@ class PoseidonSponge:
         return out[:num_bits]
 
 
+# ---- sized squeezes (sponge/mod.rs:28-100, sponge/poseidon/mod.rs:293-322) ----------------------------------------
+FULL = None  # FieldElementSize::Full; an int n stands for FieldElementSize::Truncated(n)
+
+
+def size_num_bits(size, modulus):  # FieldElementSize::num_bits (:38-48)
+    if size is FULL:
+        return modulus.bit_length() - 1
+    if size > modulus.bit_length():
+        raise ValueError("num_bits is greater than the capacity of the field.")
+    return size
+
+
+def squeeze_field_elements_with_sizes_default_impl(sp, sizes, modulus):  # sponge/mod.rs:57-100
+    if not sizes:
+        return []
+    nb = [size_num_bits(sz, modulus) for sz in sizes]
+    bits = sp.squeeze_bits(sum(nb))
+    out, pos = [], 0
+    for n in nb:
+        window = bits[pos:pos + n]
+        pos += n
+        by = bytearray((n + 7) // 8)
+        for i, b in enumerate(window):
+            if b:
+                by[i // 8] |= 1 << (i % 8)
+        out.append(int.from_bytes(bytes(by), "little") % modulus)  # from_le_bytes_mod_order
+    return out
+
+
+def squeeze_native_field_elements_with_sizes(sp, sizes):  # sponge/mod.rs:164-179
+    if all(sz is FULL for sz in sizes):
+        return sp.squeeze_native_field_elements(len(sizes))
+    return squeeze_field_elements_with_sizes_default_impl(sp, sizes, sp.p)
+
+
+def squeeze_field_elements_with_sizes(sp, sizes, modulus=None):  # sponge/poseidon/mod.rs:293-308
+    if modulus is None or modulus == sp.p:  # same characteristic: the native path + identity field_cast
+        return squeeze_native_field_elements_with_sizes(sp, sizes)
+    return squeeze_field_elements_with_sizes_default_impl(sp, sizes, modulus)
+
+
+def squeeze_field_elements(sp, n, modulus=None):  # :310-322
+    if modulus is None or modulus == sp.p:
+        return sp.squeeze_native_field_elements(n)
+    return squeeze_field_elements_with_sizes(sp, [FULL] * n, modulus)
+
+
 def bytes_to_field_elements(data: bytes, p=P):
     """sponge/absorb.rs:124-143 (`Absorb for [u8]`): u64 LE length || bytes, 31-byte LE chunks (ark-ff
     `ToConstraintField<F> for [u8]`; external crate, restated from its published behaviour -- unpinned)."""

@@ -219,3 +219,34 @@ def test_sharded_build_real_backends_multi_rank(cpa, world):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     for k in range(world):
         assert "rank %d ok" % k in r.stdout
+
+
+def test_sponge_sized_and_foreign_field_squeezes(cpa):
+    """CryptographicSponge::squeeze_field_elements_with_sizes / squeeze_field_elements::<F2> and
+    FieldBasedCryptographicSponge::squeeze_native_field_elements_with_sizes (sponge/mod.rs:57-100,164-179,
+    sponge/poseidon/mod.rs:293-322) on the device sponge against the oracle, single sponge and a batch"""
+    from crypto_primitives_amd import field
+    c = cpa.get_default_poseidon_parameters(2, False)
+    o = po.get_default_poseidon_parameters(2, False)
+    FULL = cpa.PoseidonSponge.FULL
+    sizes = [FULL, 100, 7, FULL, 253]
+    a, b = cpa.PoseidonSponge(c), po.PoseidonSponge(o)
+    a.absorb(field.fr([5, 6, 7])); b.absorb([5, 6, 7])
+    assert field.to_ints(a.squeeze_field_elements_with_sizes(sizes)) == po.squeeze_field_elements_with_sizes(b, sizes)
+    assert field.to_ints(a.squeeze_native_field_elements_with_sizes([FULL, FULL])) == po.squeeze_native_field_elements_with_sizes(b, [po.FULL, po.FULL])
+    q = 0xe7db4ea6533afa906673b0101343b00a6682093ccc81082d0970e5ed6f72cb7  # Jubjub's scalar field: a real "F2"
+    assert a.squeeze_field_elements(3, modulus=q) == po.squeeze_field_elements(b, 3, modulus=q)
+    assert a.squeeze_field_elements_with_sizes([64, FULL], modulus=q) == po.squeeze_field_elements_with_sizes(b, [64, po.FULL], modulus=q)
+    assert field.to_ints(a.squeeze_field_elements(2)) == b.squeeze_native_field_elements(2)
+    with pytest.raises(ValueError):
+        a.squeeze_field_elements_with_sizes([256])
+    # a batch of three sponges with different inputs
+    A = cpa.PoseidonSponge(c, batch=3)
+    ins = [[1, 2], [3, 4], [5, 6]]
+    A.absorb(np.stack([field.fr(x) for x in ins]))
+    got = A.squeeze_field_elements_with_sizes([FULL, 33])
+    fq = A.squeeze_field_elements(1, modulus=q)
+    for k in range(3):
+        B = po.PoseidonSponge(o); B.absorb(ins[k])
+        assert field.to_ints(got[k]) == po.squeeze_field_elements_with_sizes(B, [po.FULL, 33])
+        assert fq[k] == po.squeeze_field_elements(B, 1, modulus=q)

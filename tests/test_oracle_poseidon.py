@@ -94,3 +94,35 @@ def test_sponge_cross_fuzz_c_vs_python():
                 continue
             got = ints(P.sponge_script(ops, mont(inputs) if inputs else [], n_out))
             assert got == exp
+
+
+def test_sized_squeezes_follow_the_reference_rules():
+    """sponge/mod.rs:28-100,164-179 and sponge/poseidon/mod.rs:293-322: all-`Full` native sizes = the plain native squeeze;
+    otherwise ONE squeeze_bits for all elements (Full = MODULUS_BIT_SIZE - 1 bits), little-endian, reduced mod the target
+    field; a foreign field always takes the bit path; oversize truncations panic"""
+    cfg = po.get_default_poseidon_parameters(2, False)
+
+    def fresh():
+        sp = po.PoseidonSponge(cfg)
+        sp.absorb([5, 6, 7])
+        return sp
+    a, b = fresh(), fresh()
+    assert po.squeeze_field_elements_with_sizes(a, [po.FULL] * 3) == b.squeeze_native_field_elements(3)
+    a, b = fresh(), fresh()
+    got = po.squeeze_field_elements_with_sizes(a, [po.FULL, 100, 7])
+    bits = b.squeeze_bits(254 + 100 + 7)
+
+    def val(w):
+        return sum(int(x) << i for i, x in enumerate(w))
+    assert got == [val(bits[:254]) % po.P, val(bits[254:354]), val(bits[354:361])]
+    assert got[1] < (1 << 100) and got[2] < (1 << 7)
+    q = (1 << 61) - 1
+    a, b = fresh(), fresh()
+    f = po.squeeze_field_elements(a, 2, modulus=q)
+    bits = b.squeeze_bits(2 * 60)
+    assert f == [val(bits[:60]) % q, val(bits[60:120]) % q]
+    a, b = fresh(), fresh()
+    assert po.squeeze_field_elements(a, 2) == b.squeeze_native_field_elements(2)
+    with pytest.raises(ValueError):
+        po.squeeze_field_elements_with_sizes(fresh(), [256])
+    assert po.squeeze_field_elements_with_sizes(fresh(), []) == []
