@@ -120,7 +120,16 @@ class PoseidonSponge:
             pass
 
     def absorb(self, elems):
-        """elems: wire-format array [batch, k, 4] (or [k, 4] when batch == 1)."""
+        """CryptographicSponge::absorb (sponge/poseidon/mod.rs:236-257).  elems: wire-format array [batch, k, 4] (or [k, 4]
+        when batch == 1), or an `absorb.Absorbable` (every sponge of the batch absorbs its encoding; an empty encoding is a
+        no-op, :238-240)."""
+        from .absorb import Absorbable
+        if isinstance(elems, Absorbable):
+            vals = elems.to_sponge_field_elements()
+            if not vals:
+                return
+            el = field.fr(vals)
+            elems = np.broadcast_to(el, (self.batch,) + el.shape).copy()
         e = np.ascontiguousarray(elems, dtype=np.uint64)
         k = e.size // (4 * self.batch)
         assert e.size == self.batch * k * 4
@@ -139,6 +148,11 @@ class PoseidonSponge:
         """absorb(&data) for a byte slice; every sponge of the batch absorbs the same bytes."""
         el = self.bytes_to_field_elements(data)
         self.absorb(np.broadcast_to(el, (self.batch,) + el.shape).copy())
+
+    def absorb_all(self, *items):
+        """absorb! (sponge/absorb.rs:348-356): each item absorbed on its own, in order"""
+        for it in items:
+            self.absorb(it)
 
     def clone(self):
         """`Clone` (the reference sponge is a value type)."""
