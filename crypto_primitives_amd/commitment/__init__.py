@@ -1,2 +1,2 @@
-"""commitment layer (reference: crypto-primitives/src/commitment/): Pedersen commitment on the GPU table kernel."""
-from . import pedersen  # noqa: F401
+"""commitment layer (reference: crypto-primitives/src/commitment/): Pedersen commitment on the GPU table kernel, and its composition with TECompressor (commitment/injective_map)."""
+from . import pedersen, injective_map  # noqa: F401

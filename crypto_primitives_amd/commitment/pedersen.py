@@ -58,6 +58,11 @@ class Commitment:
     @staticmethod
     def commit_batch(parameters: Parameters, inputs, randomness):
         """inputs: equal-length byte strings; randomness: python ints (Randomness<C>(ScalarField))."""
+        return _ped.CRH.evaluate_batch(parameters.flat(), Commitment.encode_batch(parameters, inputs, randomness))
+
+    @staticmethod
+    def encode_batch(parameters: Parameters, inputs, randomness):
+        """the messages pad(input) || r (little-endian) the table kernel is evaluated on, with the reference's length checks"""
         m, n, L = _ped._as_msgs(inputs)
         bits = parameters.window_size * parameters.num_windows
         if L > bits:  # :70-72 (the reference compares the BYTE length with W*N here)
@@ -71,4 +76,4 @@ class Commitment:
             r = int(r)
             assert 0 <= r < SCALAR_MODULUS
             buf[i, padded:] = np.frombuffer(r.to_bytes(32, "little"), dtype=np.uint8)
-        return _ped.CRH.evaluate_batch(parameters.flat(), buf)
+        return buf

@@ -36,6 +36,12 @@ def test_pedersen_commitment_vs_oracle(cpa):
     assert tuple(ints(cped.Commitment.commit(P, bytes(8), 77))) == jj.mul(rg[0], 77)
     with pytest.raises(cpa.IncorrectInputLength):
         cped.Commitment.commit(P, bytes(9), 1)
+    # commitment/injective_map/mod.rs:12-45: PedersenCommCompressor with TECompressor = x of the commitment
+    from crypto_primitives_amd.commitment import injective_map as cinj
+    gx = cinj.PedersenCommCompressor.commit_batch(P, msgs[:3], rs[:3])
+    for i in range(3):
+        assert ints(gx[i])[0] == ocm.commit(g, rg, 4, 16, msgs[i], rs[i])[0]
+    assert ints(cinj.PedersenCommCompressor.commit(P, msgs[3], rs[3]))[0] == ocm.commit(g, rg, 4, 16, msgs[3], rs[3])[0]
 
 
 def test_serialization_roundtrips(cpa):
