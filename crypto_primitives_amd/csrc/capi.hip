@@ -640,13 +640,21 @@ static size_t coop_lds(u32 t) {
     }
     return bytes;
 }
+// Resident waves per SIMD of the t = 3 register kernels.  Their 78-81 VGPRs would allow six; a dynamic-LDS request of
+// 160 KiB / w per workgroup caps it at w workgroups per CU (one wave of each per SIMD).  Four measured 0.5-1 % faster than
+// six at every batch size (profiles/r02_s46) and makes the 4096 workgroups of a 2^20-state launch exactly four rounds.
+// AKP_POSEIDON_T3_WAVES (3..6, 6 = no cap) for A/B runs.
+static unsigned t3_lds_cap() {
+    static const unsigned w = env_u32("AKP_POSEIDON_T3_WAVES", 4, 3, 6);
+    return w >= 6 ? 0u : ((160u * 1024u / w) & ~1023u);
+}
 static int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
         const PoseidonConsts c = t3_reg_consts(p);
-        if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_permute_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, d_states, n);
-        else hipLaunchKernelGGL(poseidon_permute_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, d_states, n);
+        if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_permute_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims, c, d_states, n);
+        else hipLaunchKernelGGL(poseidon_permute_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims, c, d_states, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
@@ -681,8 +689,8 @@ static int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t 
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
         const PoseidonConsts c = t3_reg_consts(p);
-        if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_crh_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
-        else hipLaunchKernelGGL(poseidon_crh_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->dims, c, in0, in1, k, d_out, n);
+        if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_crh_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims, c, in0, in1, k, d_out, n);
+        else hipLaunchKernelGGL(poseidon_crh_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims, c, in0, in1, k, d_out, n);
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     }
