@@ -16,6 +16,7 @@ class Parameters(_ped.Parameters):
 class CRH(_ped._TeCRH):
     """bowe_hopwood::CRH<EdwardsConfig, W>: Input = [u8], Output = Fq."""
     _FE = 1
+    _KIND = TE_BOWE_HOPWOOD
 
     @staticmethod
     def setup(window, seed=0):

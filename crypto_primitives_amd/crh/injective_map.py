@@ -28,6 +28,7 @@ class TECompressor:
 class PedersenCRHCompressor(_ped._TeCRH):
     """PedersenCRHCompressor<JubJub, TECompressor, W> (:33-62): Input = [u8], Output = Fq."""
     _FE = 1
+    _KIND = TE_PEDERSEN_X
 
     @staticmethod
     def setup(window, seed=0):

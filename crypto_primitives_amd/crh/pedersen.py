@@ -29,20 +29,38 @@ class Parameters:
         self.window_size, self.num_windows = window_size, num_windows
         self._handles = {}
 
-    def handle(self, ctx=None):
+    def handle(self, ctx=None, kind=None):
+        """device tables of these generators for one kernel kind (default: the kind of this Parameters class).  In the
+        reference pedersen::Parameters serve both pedersen::CRH and the TECompressor types (injective_map/mod.rs:45,77), so
+        the CRH class -- not the parameter object -- decides the digest width: callers go through `te_handle`."""
         ctx = ctx or default_context()
-        key = id(ctx)
+        kind = self._KIND if kind is None else kind
+        key = (id(ctx), kind)
         if key not in self._handles:
             h = C.c_void_p()
-            check(lib.akp_te_params_create(ctx.h, self._KIND, self.window_size, self.num_windows,
+            check(lib.akp_te_params_create(ctx.h, kind, self.window_size, self.num_windows,
                                            self.generators.ctypes.data, C.byref(h)))
-            self._handles[key] = _TeHandle(h, ctx)
+            self._handles[key] = _TeHandle(h, ctx, kind)
         return self._handles[key]
 
 
+def te_handle(parameters, crh_cls, ctx=None):
+    """the handle a CRH class must use with `parameters`: the kernel kind (and with it the number of Fr the library writes
+    per digest) is the CLASS's, so the output buffers sized from `crh_cls._FE` always match what libakp writes.  Pedersen
+    parameters may serve either Pedersen flavour (x||y or x only); mixing Pedersen and Bowe-Hopwood parameter types is the
+    type error the reference's generics rule out."""
+    kind = crh_cls._KIND
+    if (kind == TE_BOWE_HOPWOOD) != (parameters._KIND == TE_BOWE_HOPWOOD):
+        raise TypeError("%s cannot be evaluated with %s.%s" % (crh_cls.__name__, type(parameters).__module__, type(parameters).__name__))
+    h = parameters.handle(ctx, kind=kind)
+    assert h.fe_per_digest == crh_cls._FE, "digest width of the handle and of the CRH class disagree"
+    return h
+
+
 class _TeHandle:
-    def __init__(self, h, ctx):
-        self.h, self.ctx = h, ctx
+    def __init__(self, h, ctx, kind=TE_PEDERSEN):
+        self.h, self.ctx, self.kind = h, ctx, kind
+        self.fe_per_digest = 2 if kind == TE_PEDERSEN else 1  # what libakp writes per digest (te_fe_per_digest, capi)
 
     def info(self, msg_len=0):
         """tuning facts of the device tables (akp_te_params_info): digit width / chunks per step, signed-subset flag,
@@ -76,6 +94,7 @@ def _as_msgs(msgs, n=None, msg_len=None):
 
 class _TeCRH:
     _FE = 2  # field elements per digest
+    _KIND = TE_PEDERSEN  # kernel kind (AKP_TE_*): fixes the digest width on the library side
 
     @classmethod
     def _check_window(cls, W, parameters):
@@ -94,7 +113,7 @@ class _TeCRH:
         cls._check_window(window, parameters)
         m, n, L = _as_msgs(msgs)
         out = np.empty((n, cls._FE, 4), dtype=np.uint64)
-        check(lib.akp_te_crh_batch(parameters.handle().h, m.ctypes.data if m.size else None, n, L, out.ctypes.data))
+        check(lib.akp_te_crh_batch(te_handle(parameters, cls).h, m.ctypes.data if m.size else None, n, L, out.ctypes.data))
         return out if cls._FE == 2 else out.reshape(n, 4)
 
 
@@ -130,7 +149,7 @@ class TwoToOneCRH:
         assert (n, L) == (n2, L2), "left and right input should be of equal length"
         fe = cls._crh._FE
         out = np.empty((n, fe, 4), dtype=np.uint64)
-        check(lib.akp_te_two_to_one_batch(parameters.handle().h, l.ctypes.data if l.size else None,
+        check(lib.akp_te_two_to_one_batch(te_handle(parameters, cls._crh).h, l.ctypes.data if l.size else None,
                                           r.ctypes.data if r.size else None, n, L, out.ctypes.data))
         return out if fe == 2 else out.reshape(n, 4)
 
@@ -148,5 +167,5 @@ class TwoToOneCRH:
         l = np.ascontiguousarray(left, dtype=np.uint64).reshape(-1, fe, 4)
         r = np.ascontiguousarray(right, dtype=np.uint64).reshape(-1, fe, 4)
         out = np.empty_like(l)
-        check(lib.akp_te_compress_batch(parameters.handle().h, l.ctypes.data, r.ctypes.data, l.shape[0], out.ctypes.data))
+        check(lib.akp_te_compress_batch(te_handle(parameters, cls._crh).h, l.ctypes.data, r.ctypes.data, l.shape[0], out.ctypes.data))
         return out if fe == 2 else out.reshape(-1, 4)

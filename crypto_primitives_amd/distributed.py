@@ -146,7 +146,9 @@ class GpuTeBackend:
         self.leaf_h = leaf_params.handle(self.ctx)
         self.two_h = two_params.handle(self.ctx)
         self.two_params = two_params
-        self.fe = 2 if two_params._KIND == 0 else 1
+        if self.leaf_h.fe_per_digest != self.two_h.fe_per_digest:
+            raise TypeError("leaf and two-to-one parameters produce digests of different widths")
+        self.fe = self.two_h.fe_per_digest  # what libakp writes per node for this handle kind
 
     def comm_device(self):
         return self.device
@@ -177,7 +179,8 @@ class GpuTeBackend:
         return top
 
     def two_to_one_compress(self, left, right):
-        from .crh import pedersen, bowe_hopwood
-        cls = pedersen.TwoToOneCRH if self.fe == 2 else bowe_hopwood.TwoToOneCRH
+        from .crh import pedersen, bowe_hopwood, injective_map
+        from ._lib import TE_PEDERSEN, TE_BOWE_HOPWOOD
+        cls = {TE_PEDERSEN: pedersen.TwoToOneCRH, TE_BOWE_HOPWOOD: bowe_hopwood.TwoToOneCRH}.get(self.two_h.kind, injective_map.PedersenTwoToOneCRHCompressor)
         out = cls.compress_batch(self.two_params, np.ascontiguousarray(left), np.ascontiguousarray(right))
         return np.ascontiguousarray(out).reshape(len(out), -1)

@@ -66,6 +66,16 @@ class PoseidonFieldConfig:
         return ok
 
 
+def _leaf_handle(config, params, ctx=None):
+    """handle of the LEAF hash parameters as this config's LeafHash class uses them (the class fixes the kernel kind and with
+    it the Fr per digest libakp writes -- crh/pedersen.py te_handle)"""
+    return params.handle(ctx) if config is PoseidonFieldConfig else _ped.te_handle(params, config.LeafHash, ctx)
+
+
+def _two_handle(config, params, ctx=None):
+    return params.handle(ctx) if config is PoseidonFieldConfig else _ped.te_handle(params, config.TwoToOneHash._crh, ctx)
+
+
 class _ByteConfig:
     """Leaf = [u8], ByteDigestConverter (:67-78): digests are serialised uncompressed before the
     two-to-one hash (config shape merkle_tree/tests/mod.rs:24-33)."""
@@ -76,7 +86,7 @@ class _ByteConfig:
         fe = cls.LeafHash._FE
         leaf_nodes = np.empty((n, fe, 4), dtype=np.uint64)
         non_leaf = np.empty((max(n - 1, 0), fe, 4), dtype=np.uint64)
-        check(lib.akp_merkle_build_te(leaf_params.handle().h, two_params.handle().h, m.ctypes.data if m.size else None,
+        check(lib.akp_merkle_build_te(_leaf_handle(cls, leaf_params).h, _two_handle(cls, two_params).h, m.ctypes.data if m.size else None,
                                       n, L, leaf_nodes.ctypes.data, non_leaf.ctypes.data, None))
         shp = cls.digest_shape
         return leaf_nodes.reshape((n,) + shp), non_leaf.reshape((max(n - 1, 0),) + shp)
@@ -85,7 +95,7 @@ class _ByteConfig:
     def build_inner(cls, two_params, leaf_digests):
         ln = np.ascontiguousarray(leaf_digests, dtype=np.uint64).reshape((-1,) + cls.digest_shape)
         non_leaf = np.empty((max(len(ln) - 1, 0),) + cls.digest_shape, dtype=np.uint64)
-        check(lib.akp_merkle_inner_te(two_params.handle().h, ln.ctypes.data, len(ln), non_leaf.ctypes.data))
+        check(lib.akp_merkle_inner_te(_two_handle(cls, two_params).h, ln.ctypes.data, len(ln), non_leaf.ctypes.data))
         return ln, non_leaf
 
     @classmethod
@@ -111,7 +121,7 @@ class _ByteConfig:
     def verify_abi(cls, leaf_params, two_params, root, leaves, idx, sibs, auth, depth):
         mm, m, L = _ped._as_msgs(leaves)
         ok = np.zeros(m, dtype=np.uint8)
-        check(lib.akp_merkle_verify_paths_te(leaf_params.handle().h, two_params.handle().h, root.ctypes.data, mm.ctypes.data if mm.size else None,
+        check(lib.akp_merkle_verify_paths_te(_leaf_handle(cls, leaf_params).h, _two_handle(cls, two_params).h, root.ctypes.data, mm.ctypes.data if mm.size else None,
                                              m, L, idx.ctypes.data, sibs.ctypes.data, auth.ctypes.data if depth else None, depth, ok.ctypes.data))
         return ok
 
@@ -255,7 +265,7 @@ class MultiPath:
                                                            suf.ctypes.data if len(flat) else None, len(flat), depth, C.byref(ok)))
         else:
             mm, _, L = _ped._as_msgs([bytes(x) if isinstance(x, (bytes, bytearray)) else np.asarray(x, dtype=np.uint8).tobytes() for x in leaves[:m]])
-            check(lib.akp_merkle_verify_multipath_te(leaf_hash_params.handle().h, two_to_one_params.handle().h, root.ctypes.data,
+            check(lib.akp_merkle_verify_multipath_te(_leaf_handle(cfg, leaf_hash_params).h, _two_handle(cfg, two_to_one_params).h, root.ctypes.data,
                                                      mm.ctypes.data if mm.size else None, m, L, idx.ctypes.data, sibs.ctypes.data,
                                                      pre.ctypes.data, suf.ctypes.data if len(flat) else None, len(flat), depth, C.byref(ok)))
         return bool(ok.value)
@@ -435,6 +445,9 @@ class GpuMerkleTree:
         n, fe, h = C.c_size_t(), C.c_uint32(), C.c_size_t()
         check(lib.akp_merkle_tree_info(self._h, C.byref(n), C.byref(fe), C.byref(h)))
         self.n_leaves, self._fe, self._height = n.value, fe.value, h.value
+        want = int(np.prod(config.digest_shape)) // 4
+        if self._fe != want:  # every host buffer below is sized from config.digest_shape
+            raise TypeError("tree handle holds %d Fr per digest, %s expects %d" % (self._fe, config.__name__, want))
 
     @staticmethod
     def _leaf_array(config, leaves):
@@ -450,7 +463,7 @@ class GpuMerkleTree:
         x, n, k = cls._leaf_array(config, leaves)
         h = C.c_void_p()
         fn = lib.akp_merkle_tree_build_poseidon if config is PoseidonFieldConfig else lib.akp_merkle_tree_build_te
-        check(fn(leaf_hash_param.handle().h, two_to_one_hash_param.handle().h, x.ctypes.data if x.size else None, n, k, C.byref(h)))
+        check(fn(_leaf_handle(config, leaf_hash_param).h, _two_handle(config, two_to_one_hash_param).h, x.ctypes.data if x.size else None, n, k, C.byref(h)))
         return cls(config, leaf_hash_param, two_to_one_hash_param, h)
 
     @classmethod
@@ -459,7 +472,7 @@ class GpuMerkleTree:
         d = np.ascontiguousarray(leaf_digests, dtype=np.uint64).reshape((-1,) + config.digest_shape)
         h = C.c_void_p()
         fn = lib.akp_merkle_tree_from_digests_poseidon if config is PoseidonFieldConfig else lib.akp_merkle_tree_from_digests_te
-        check(fn(leaf_hash_param.handle().h, two_to_one_hash_param.handle().h, d.ctypes.data, len(d), C.byref(h)))
+        check(fn(_leaf_handle(config, leaf_hash_param).h, _two_handle(config, two_to_one_hash_param).h, d.ctypes.data, len(d), C.byref(h)))
         return cls(config, leaf_hash_param, two_to_one_hash_param, h)
 
     @classmethod
@@ -573,8 +586,8 @@ class MultiGpu:
         (leaf_nodes, non_leaf_nodes, root) in the reference's global heap order (nodes None when want_nodes is False)."""
         import ctypes as C
         G = self.size
-        lh = [leaf_hash_param.handle(self.ctx(r)) for r in range(G)]
-        th = [two_to_one_hash_param.handle(self.ctx(r)) for r in range(G)]
+        lh = [_leaf_handle(config, leaf_hash_param, self.ctx(r)) for r in range(G)]
+        th = [_two_handle(config, two_to_one_hash_param, self.ctx(r)) for r in range(G)]
         for cfg in (leaf_hash_param, two_to_one_hash_param):  # destroyed with this object, before their contexts
             if not any(cfg is c for c in self._param_owners):
                 self._param_owners.append(cfg)
