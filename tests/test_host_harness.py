@@ -17,7 +17,7 @@ vp = C.c_void_p
 
 @pytest.fixture(scope="module")
 def H():
-    h = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "harness.so"))
+    h = C.CDLL(os.environ.get("AKP_HARNESS_SO") or os.path.join(ROOT, "tests", "host_harness", "harness.so"))
     h.hh_poseidon_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t, C.c_int]
     h.hh_poseidon_crh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int]
     h.hh_f29_raw_mul.argtypes = [vp, vp, C.c_int, vp]
