@@ -23,8 +23,12 @@ Extra objects on the same JSON line (rank 0):
                 shards + ONE all-gather of sub-roots over RCCL)
   pedersen      BASELINE config 4: Pedersen 4x256 CRH over 2^20 x 128 B per GPU, sampled oracle parity, roofline
   bh_merkle     BASELINE config 5: Bowe-Hopwood 63x9 tree, 2^23 x 32 B leaves per GPU (2^26 on 8 GPUs)
+  proofs        SURVEY.md 8(f) ranks 1-2 as the reference benches them (benches/merkle_tree.rs:60-191): batched generate_proof,
+                Path::verify, generate_multi_proof + MultiPath::verify and update_batch on an HBM-resident 2^20-leaf tree, Poseidon
+                and Bowe-Hopwood configurations (tools/bench_proofs.py), items/s + device ms + sampled oracle parity
   host_path     PCIe-inclusive rates of the host-pointer entry points (pageable and pinned buffers)
-  cpu_baseline  oracle C restatement ("port") on this host: 1 thread and the best thread count
+  cpu_baseline  oracle C restatement ("port") on this host: 1 thread and the best thread count; `cores` is the EFFECTIVE core
+                count (min of affinity, cgroup quota, hardware threads); Pedersen and Bowe-Hopwood-tree legs beside the permutation
 The oracle is used only as checker and as the `cpu_baseline` leg.
 """
 import argparse
@@ -184,6 +188,8 @@ def main():
     ap.add_argument("--pedersen-log2", type=int, default=20, help="Pedersen 4x256 messages per GPU (BASELINE config 4; 0 disables)")
     ap.add_argument("--bh-merkle-log2", type=int, default=23,
                     help="Bowe-Hopwood 63x9 tree: leaves PER GPU (BASELINE config 5 is 2^23 per GPU on 8 GPUs; 0 disables)")
+    ap.add_argument("--proofs-log2", type=int, default=20, help="leaves of the HBM-resident trees of the proof / verify / update legs (0 disables)")
+    ap.add_argument("--proofs-m-log2", type=int, default=16, help="paths per call of the proof / verify legs")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of each sustained loop (0 disables)")
     ap.add_argument("--sustain-log2-big", type=int, default=24, help="second sustained size (0 disables)")
     ap.add_argument("--settle-launches", type=int, default=120, help="untimed launches before the W warm-up steps (clock ramp)")
@@ -456,6 +462,18 @@ def main():
                 raise SystemExit("Bowe-Hopwood leg: sampled nodes differ from the oracle")
         del d_leaves, res, tb
 
+    # ---- proofs, verification, updates on a resident 2^20-leaf tree (one process only) ----------
+    proofs = None
+    if args.proofs_log2 and world == 1 and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_proofs
+        proofs = {}
+        for name in ("poseidon", "bh"):
+            proofs[name] = bench_proofs.run(name, args.proofs_log2, min(args.proofs_m_log2, args.proofs_log2), local_rank)
+            if not proofs[name]["all_parity_bit_exact"]:
+                raise SystemExit("proofs leg (%s): a parity / control check failed: %s" % (name, json.dumps(proofs[name])))
+        proofs["profiles"] = "profiles/r03_s*/proofs_* (rocprofv3 --kernel-trace --stats of `python tools/bench_proofs.py`)"
+
     # ================= the headline: W warm-up + K timed steps of the 2^20-state permutation ==========================
     parity = {"probe_kernel": lib.akp_poseidon_kernel_for(ph.h, n, 0).decode(), "timed_buffer_states_checked": 0, "bit_exact": None}
     step()  # one pass outside W: its output is checked against the oracle on a strided sample of the TIMED buffer
@@ -623,44 +641,71 @@ def main():
                               "valu_instructions_per_permutation": 74752, "valu_busy_percent": 97.4,
                               "valu_counters_static_from": "profiles/r02_s26/pmc_counters_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy; NOT measured in this run)"}},
     }
-    for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("host_path", host_path)):
+    for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("proofs", proofs), ("host_path", host_path)):
         if leg:
             out[key] = leg
     if not args.no_cpu_baseline and world == 1:
         from oracle import cref
         hw = cref.hardware_threads()
         info = cpu_info()
-        cal = host_states[:8192]
-        c0 = time.perf_counter()
-        ora.permute_batch(cal[:2048], threads=1)
-        rate1 = 2048 / (time.perf_counter() - c0)
-        best = (rate1, 1)
-        for cand in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), min(hw, 16), min(hw, 8)}, reverse=True):
+        # what this process can really use: affinity mask, cgroup CPU quota and hardware threads, whichever is smallest
+        bounds = {"hardware threads": hw, "affinity mask": info["affinity_cpus"], "cgroup quota": info["cgroup_cpu_quota"]}
+        basis, eff_cores = min(((k, v) for k, v in bounds.items() if v), key=lambda kv: kv[1])
+        cands = sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), min(hw, 16), min(hw, 8), max(1, int(round(eff_cores)))}, reverse=True)
+
+        def cpu_leg(run, total, seconds, cal, quant=lambda k: k):
+            """`run(k, threads)` processes the first k items; returns (rate at the best thread count, threads, 1-thread rate, items
+            timed).  Whole passes over min(total, rate * seconds) items until `seconds` have been spent."""
             c0 = time.perf_counter()
-            ora.permute_batch(cal, threads=cand)
-            r = len(cal) / (time.perf_counter() - c0)
-            if r > best[0]:
-                best = (r, cand)
-        rate, threads = best
-        sample = int(min(n, max(16384, rate * args.cpu_seconds)))
-        passes = 0
-        c0 = time.perf_counter()
-        while True:  # whole passes over the sample until ~cpu_seconds have been spent
-            ora.permute_batch(host_states[:sample], threads=threads)
-            passes += 1
-            cpu_s = time.perf_counter() - c0
-            if sample < n or cpu_s >= args.cpu_seconds:
-                break
-        sample *= passes
-        rate_n = sample / cpu_s
-        out["cpu_baseline"] = {"value": rate_n, "unit": "permutations/s", "cores": threads, "kind": "port",
+            run(quant(max(2, cal // 8)), 1)
+            rate1 = quant(max(2, cal // 8)) / (time.perf_counter() - c0)
+            best = (rate1, 1)
+            for cand in cands:
+                c0 = time.perf_counter()
+                run(cal, cand)
+                r = cal / (time.perf_counter() - c0)
+                if r > best[0]:
+                    best = (r, cand)
+            rate, threads = best
+            sample = quant(int(min(total, max(cal, rate * seconds))))
+            passes = 0
+            c0 = time.perf_counter()
+            while True:
+                run(sample, threads)
+                passes += 1
+                cpu_s = time.perf_counter() - c0
+                if sample < total or cpu_s >= seconds:
+                    break
+            return sample * passes / cpu_s, threads, rate1, sample * passes
+        rate_n, threads, rate1, sample = cpu_leg(lambda k, th: ora.permute_batch(host_states[:k], threads=th), n, args.cpu_seconds, 8192)
+        out["cpu_baseline"] = {"value": rate_n, "unit": "permutations/s", "cores": eff_cores, "cores_basis": basis, "kind": "port",
                                "threads_used": threads, "rate_1_thread": rate1, "effective_cores": rate_n / rate1,
                                "hardware_threads": hw, **info,
                                "sample": "%d permutations over the same 2^%d states, reference-shaped C restatement (oracle/c/akp_oracle.c: "
                                          "dense MDS, square-and-multiply, one permutation per call as the reference), %d pthreads (best of a "
-                                         "thread-count sweep); `effective_cores` = that rate / the 1-thread rate: what the container's CPU "
-                                         "share really delivered" % (sample, args.log2_states, threads)}
+                                         "thread-count sweep); `cores` = min(affinity, cgroup quota, hardware threads) = what this container "
+                                         "may use; `effective_cores` = that rate / the 1-thread rate: what it really delivered" % (sample, args.log2_states, threads)}
         out["gpu_over_cpu"] = value / rate_n
+        curve_seconds = max(2.0, args.cpu_seconds / 3.0)
+        if pedersen:  # BASELINE configs[3] on the CPU: bit-by-bit conditional additions as crh/pedersen/mod.rs:112-124
+            from crypto_primitives_amd import params as cparams3
+            cur = cref.CurveParams(4, 256, cparams3.pedersen_generators(0xA5A50004, 4, 256))
+            cm = np.random.default_rng(0xA5A50004).integers(0, 256, size=(1 << 16, 128), dtype=np.uint8)
+            r_n, th, r1, smp = cpu_leg(lambda k, t_: cur.pedersen_crh_batch(cm[:k], k, 128, threads=t_), len(cm), curve_seconds, 2048)
+            out["cpu_baseline"]["pedersen"] = {"value": r_n, "unit": "hashes/s", "threads_used": th, "rate_1_thread": r1, "effective_cores": r_n / r1,
+                                               "sample": "%d Pedersen 4x256 hashes of 128-byte messages (orc_pedersen_crh_batch)" % smp,
+                                               "gpu_over_cpu": pedersen["hashes_per_s"] / r_n}
+        if bh_merkle:  # BASELINE configs[4] on the CPU: the whole tree (leaf hashes + inner levels, barrier per level), 2^k leaves
+            from crypto_primitives_amd import params as cparams4
+            curb = cref.CurveParams(63, 9, cparams4.bowe_hopwood_generators(0xA5A50005, 63, 9))
+            cl = np.random.default_rng(0xA5A50005).integers(0, 256, size=(1 << 16, 32), dtype=np.uint8)
+
+            def pow2(k):
+                return 1 << max(1, int(k).bit_length() - 1)  # the largest power of two <= k (a tree needs one)
+            r_n, th, r1, smp = cpu_leg(lambda k, t_: curb.merkle_build(1, curb, cl[:k], k, 32, threads=t_), len(cl), curve_seconds, 2048, pow2)
+            out["cpu_baseline"]["bh_merkle"] = {"value": r_n, "unit": "leaves/s", "threads_used": th, "rate_1_thread": r1, "effective_cores": r_n / r1,
+                                                "sample": "Bowe-Hopwood 63x9 trees over %d leaves of 32 bytes in total (orc_curve_merkle_build, power-of-two trees)" % smp,
+                                                "gpu_over_cpu": bh_merkle["leaves_per_s"] / r_n}
     print(json.dumps(out))
     if dist:
         dist.barrier()

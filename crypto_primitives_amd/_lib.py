@@ -63,6 +63,7 @@ def _load():
         "akp_ctx_create": (i32, [i32, pp]),
         "akp_ctx_destroy": (None, [vp]),
         "akp_ctx_synchronize": (i32, [vp]),
+        "akp_ctx_stream": (vp, [vp]),
         "akp_fr_to_mont": (i32, [u64p, u64p, sz]),
         "akp_fr_from_mont": (i32, [u64p, u64p, sz]),
         "akp_poseidon_params_create": (i32, [vp, u32, u32, u64, u32, u32, u64p, u64p, pp]),
@@ -85,6 +86,7 @@ def _load():
         "akp_te_params_create": (i32, [vp, i32, u32, u32, u64p, pp]),
         "akp_te_params_destroy": (None, [vp]),
         "akp_te_params_info": (i32, [vp, vp, vp, vp, sz, vp]),
+        "akp_te_entry_bytes": (u32, []),
         "akp_te_crh_batch": (i32, [vp, u8p, sz, sz, u64p]),
         "akp_te_crh_batch_dev": (i32, [vp, u8p, sz, sz, u64p, vp]),
         "akp_te_two_to_one_batch": (i32, [vp, u8p, u8p, sz, sz, u64p]),

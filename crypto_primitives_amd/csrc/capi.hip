@@ -140,6 +140,7 @@ extern "C" int32_t akp_ctx_synchronize(akp_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return AKP_OK;
 }
+extern "C" void* akp_ctx_stream(akp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 // `_dev` entry points use the caller's stream verbatim (NULL = HIP's legacy default stream, which is what
 // torch's default stream is), so event timing and ordering follow the caller's stream semantics.
 static inline hipStream_t pick_stream(akp_ctx*, void* s) { return (hipStream_t)s; }
@@ -980,9 +981,9 @@ struct akp_te_params {
     u32 n_gen = 0;             // W * N flat generators
     u32 digit_bits = 0;        // Pedersen: table digit width D (1..8)
     u32 group = 1;             // Bowe-Hopwood: chunks per table step (1..4)
-    NielsPad* d_lut = nullptr;   // Pedersen: [ceil(n_gen/D)][2^D] (signed-subset table: [ceil(n_gen/D)][2^(D-1)]); BH: group table
-    NielsPad* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]; Pedersen signed-subset: cprefix [n_digits + 1]
-    NielsPad* d_tail = nullptr;  // BH: sum of G[c] over the zero-padded tail chunks [tail_from, tail_to) of the last compress shape
+    TeEntry* d_lut = nullptr;    // Pedersen: [ceil(n_gen/D)][2^D] (signed-subset table: [ceil(n_gen/D)][2^(D-1)]); BH: group table
+    TeEntry* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]; Pedersen signed-subset: cprefix [n_digits + 1]
+    TeEntry* d_tail = nullptr;  // BH: sum of G[c] over the zero-padded tail chunks [tail_from, tail_to) of the last compress shape
     u32 tail_from = 0, tail_to = 0;
     bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
 };
@@ -1030,19 +1031,19 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
         }
         if (e == hipSuccess && bad == 0) {
             u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 16, 2, 17);
-            while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(NielsPad) > te_table_cap()) --D;
+            while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(TeEntry) > te_table_cap()) --D;
             size_t n_digits = (n_gen + D - 1) / D, entries = n_digits << (D - 1);
-            e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
             while (e == hipErrorOutOfMemory && D > 8) {  // a crowded device: a narrower digit needs half the table
                 (void)hipGetLastError();
                 --D;
                 n_digits = (n_gen + D - 1) / D;
                 entries = n_digits << (D - 1);
-                e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+                e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
             }
             p->digit_bits = D;
             p->signed_subset = true;
-            if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(NielsPad));
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_pedersen_slut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_half, (u32)n_gen, D, (u32)entries, p->d_lut);
                 hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half, (u32)n_gen, D, (u32)n_digits, p->d_lut1);
@@ -1054,10 +1055,10 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             // would exceed 192 MB; AKP_PEDERSEN_DIGIT_BITS overrides (1..14).  Measured 2^20 x 128 B on MI355X:
             // D = 4: 73 M/s, 8: 151, 10: 177, 12: 199, 13: 209, 14: 220 (175 MB table; round 2: 13 beats 14, profiles/r02_s8).
             u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 13, 1, 14);
-            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(NielsPad) > te_table_cap()) --D;
+            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(TeEntry) > te_table_cap()) --D;
             p->digit_bits = D;
             const size_t entries = ((n_gen + D - 1) / D) << D;
-            e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, D, (u32)entries, p->d_lut);
                 e = hipGetLastError();
@@ -1067,22 +1068,22 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
         if (d_bad) (void)hipFree(d_bad);
     } else {
         u32 G = env_u32("AKP_BH_GROUP", 5, 1, 5);
-        while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(NielsPad) > te_table_cap(true))) --G;
+        while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(TeEntry) > te_table_cap(true))) --G;
         p->group = G;
-        if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(NielsPad));
+        if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(TeEntry));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen, p->d_lut1);
             e = hipGetLastError();
         }
         if (G > 1) {
             size_t entries = (n_gen / G) << (3 * G - 1);
-            if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
             while (e == hipErrorOutOfMemory && G > 2) {  // a crowded device: a smaller group needs an eighth of the table
                 (void)hipGetLastError();
                 --G;
                 p->group = G;
                 entries = (n_gen / G) << (3 * G - 1);
-                e = hipMalloc(&p->d_lut, entries * sizeof(NielsPad));
+                e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
             }
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_bh_lutg, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, G, (u32)entries, p->d_lut);
@@ -1101,6 +1102,7 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     *out = p;
     return AKP_OK;
 }
+extern "C" uint32_t akp_te_entry_bytes(void) { return (uint32_t)sizeof(TeEntry); }
 extern "C" void akp_te_params_destroy(akp_te_params* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
@@ -1145,7 +1147,7 @@ extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bi
         } else {
             entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)(p->n_gen / p->group) << (3 * p->group - 1)) : 0);
         }
-        *table_bytes = entries * sizeof(NielsPad);
+        *table_bytes = entries * sizeof(TeEntry);
     }
     if (steps) {
         u32 g = 0, st = 0;
@@ -1170,11 +1172,11 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (data_len > msg_len || !tail_on) data_len = msg_len;
     u32 groups = 0, steps = 0;
     te_steps(p, data_len, &groups, &steps);
-    const NielsPad* tail = nullptr;
+    const TeEntry* tail = nullptr;
     if (p->kind == AKP_TE_BOWE_HOPWOOD && data_len < msg_len) {
         const u32 from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, p->n_gen), to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3, p->n_gen);
         if (from < to) {
-            if (!p->d_tail) HIP_TRY(hipMalloc(&p->d_tail, sizeof(NielsPad)));
+            if (!p->d_tail) HIP_TRY(hipMalloc(&p->d_tail, sizeof(TeEntry)));
             if (p->tail_from != from || p->tail_to != to) {  // stream-ordered: later launches on other streams go through ctx_scratch-style events below
                 HIP_TRY(hipStreamSynchronize(s));           // an earlier shape's constant may still be in use (rare: one shape per parameter set)
                 hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, s, p->d_lut1, from, to, p->d_tail);

@@ -42,6 +42,19 @@ struct Niels {
 struct alignas(128) NielsPad {
     u32 w[32];
 };
+// Packed alternative (round 3 A/B, `make packed96`): the three values as CANONICAL 256-bit integers (8 dwords each, no
+// padding) = 96 bytes.  The 16-bit signed Pedersen table shrinks from 268 MB to 201 MB -- inside the 256 MB Infinity Cache --
+// and an entry is six 16-byte loads instead of seven, at the price of re-limbing 3 x 256 bits into 3 x 9 limbs of 29 bits in
+// registers (~50 VALU instructions per step) and of entries that straddle two 128-byte lines.  Canonical values are
+// non-negative with limbs < 2^29: they satisfy every operand bound the 128-byte form does.
+struct alignas(32) Niels96 {
+    u32 w[24];
+};
+#if defined(AKP_TE_PACKED96)
+typedef Niels96 TeEntry;
+#else
+typedef NielsPad TeEntry;
+#endif
 struct Ext {
     FS X, Y, Z, T;  // x = X/Z, y = Y/Z, T = XY/Z  -- normalised (product outputs)
 };
@@ -120,6 +133,30 @@ AKP_HD void store_niels(NielsPad* p, const Niels& n) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
+AKP_HD Niels niels_of_words24(const u32* w) {
+    Niels r;
+    r.ypx = f29_unpack<true>(Fr{{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]}});
+    r.ymx = f29_unpack<true>(Fr{{w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]}});
+    r.dxy = f29_unpack<true>(Fr{{w[16], w[17], w[18], w[19], w[20], w[21], w[22], w[23]}});
+    return r;
+}
+AKP_HD Niels load_niels(const Niels96* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5];
+    const u32 w[24] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w,
+                       v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w, v5.x, v5.y, v5.z, v5.w};
+    return niels_of_words24(w);
+}
+AKP_HD void store_niels(Niels96* p, const Niels& n) {
+    const Fr a = f29_canonical_pack(n.ypx), b = f29_canonical_pack(n.ymx), c = f29_canonical_pack(n.dxy);
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
+    q[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
+    q[2] = make_uint4(b.l[0], b.l[1], b.l[2], b.l[3]);
+    q[3] = make_uint4(b.l[4], b.l[5], b.l[6], b.l[7]);
+    q[4] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+    q[5] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+}
 AKP_HD Niels niels_of_ext(const Ext& acc) {  // affine point of acc, as a table entry
     const FS zi = f29_inv(acc.Z);
     return niels_from_affine(f29_mul(acc.X, zi), f29_mul(acc.Y, zi));
@@ -142,7 +179,7 @@ AKP_HD Niels te_pedersen_lut_entry(const Fr* __restrict__ gens_affine /*[N*W][2]
     return niels_of_ext(acc);
 }
 __global__ void te_build_pedersen_lut(const Fr* __restrict__ gens_affine, u32 n_gen, u32 D, u32 n_entries,
-                                      NielsPad* __restrict__ lut /*[n_digits][2^D]*/) {
+                                      TeEntry* __restrict__ lut /*[n_digits][2^D]*/) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_entries) return;
     store_niels(lut + idx, te_pedersen_lut_entry(gens_affine, n_gen, D, idx));
@@ -156,7 +193,7 @@ AKP_HD Niels te_bh_lut_entry(const Fr* __restrict__ gens_affine /*[N*W][2] wire*
     for (u32 j = 0; j <= k; ++j) acc = te_madd(acc, gn);
     return niels_of_ext(acc);
 }
-__global__ void te_build_bh_lut(const Fr* __restrict__ gens_affine, u32 n_gen, NielsPad* __restrict__ lut) {
+__global__ void te_build_bh_lut(const Fr* __restrict__ gens_affine, u32 n_gen, TeEntry* __restrict__ lut) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_gen * 4u) return;
     store_niels(lut + idx, te_bh_lut_entry(gens_affine, idx));
@@ -177,7 +214,7 @@ AKP_HD Niels te_bh_lutg_entry(const Fr* __restrict__ gens_affine, u32 G, u32 idx
     }
     return niels_of_ext(acc);
 }
-__global__ void te_build_bh_lutg(const Fr* __restrict__ gens_affine, u32 G, u32 n_entries, NielsPad* __restrict__ lut) {
+__global__ void te_build_bh_lutg(const Fr* __restrict__ gens_affine, u32 G, u32 n_entries, TeEntry* __restrict__ lut) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_entries) return;
     store_niels(lut + idx, te_bh_lutg_entry(gens_affine, G, idx));
@@ -233,7 +270,7 @@ AKP_HD Niels te_pedersen_slut_entry(const NielsPad* __restrict__ half, u32 n_gen
     }
     return niels_of_ext(acc);
 }
-__global__ void te_build_pedersen_slut(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_entries, NielsPad* __restrict__ lut) {
+__global__ void te_build_pedersen_slut(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_entries, TeEntry* __restrict__ lut) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_entries) return;
     store_niels(lut + idx, te_pedersen_slut_entry(half, n_gen, D, idx));
@@ -246,7 +283,7 @@ AKP_HD Niels te_pedersen_cprefix_entry(const NielsPad* __restrict__ half, u32 n_
     for (u32 g = 0; g < upto; ++g) acc = te_madd(acc, load_niels(half + g));
     return niels_of_ext(acc);
 }
-__global__ void te_build_pedersen_cprefix(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_digits, NielsPad* __restrict__ cprefix) {
+__global__ void te_build_pedersen_cprefix(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_digits, TeEntry* __restrict__ cprefix) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > n_digits) return;
     store_niels(cprefix + k, te_pedersen_cprefix_entry(half, n_gen, D, k));
@@ -366,17 +403,25 @@ AKP_HD Ext te_madd_signed(const Ext& p, const Niels& q, u32 neg) {
     return r;
 }
 // A table entry on its way in: address, sign of the step, and the seven 16-byte pieces of the 128-byte line.
+constexpr int AKP_TE_ENTRY_VEC = sizeof(TeEntry) == 128 ? 7 : 6;  // 16-byte pieces that carry data
 struct NielsFetch {
-    const NielsPad* base;  // lut or lut1 (kept as it is: a pointer that went through an asm statement would lose its
-    u32 idx;               // address space and turn the loads into flat loads), entry index
+    const TeEntry* base;  // lut or lut1 (kept as it is: a pointer that went through an asm statement would lose its
+    u32 idx;              // address space and turn the loads into flat loads), entry index
     u32 neg;
-    uint4 v[7];
+    uint4 v[AKP_TE_ENTRY_VEC];
 };
 AKP_HD void te_fetch_all(NielsFetch& f) {
     const uint4* q = reinterpret_cast<const uint4*>(f.base + f.idx);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) f.v[k] = q[k];
+    for (int k = 0; k < AKP_TE_ENTRY_VEC; ++k) f.v[k] = q[k];
 }
+#if defined(AKP_TE_PACKED96)
+AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
+    const u32 w[24] = {f.v[0].x, f.v[0].y, f.v[0].z, f.v[0].w, f.v[1].x, f.v[1].y, f.v[1].z, f.v[1].w, f.v[2].x, f.v[2].y, f.v[2].z, f.v[2].w,
+                       f.v[3].x, f.v[3].y, f.v[3].z, f.v[3].w, f.v[4].x, f.v[4].y, f.v[4].z, f.v[4].w, f.v[5].x, f.v[5].y, f.v[5].z, f.v[5].w};
+    return niels_of_words24(w);
+}
+#else
 AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
     const u32 w[28] = {f.v[0].x, f.v[0].y, f.v[0].z, f.v[0].w, f.v[1].x, f.v[1].y, f.v[1].z, f.v[1].w, f.v[2].x, f.v[2].y,
                        f.v[2].z, f.v[2].w, f.v[3].x, f.v[3].y, f.v[3].z, f.v[3].w, f.v[4].x, f.v[4].y, f.v[4].z, f.v[4].w,
@@ -390,13 +435,14 @@ AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
     }
     return r;
 }
+#endif
 template <int KIND>
 AKP_HD MsgRaw te_step_bits(const uint8_t* __restrict__ msg, size_t msg_len, u32 D, u32 n_groups, u32 u) {
     u32 w;
     return msg_load(msg, msg_len, te_step_offset<KIND>(D, n_groups, u, &w));
 }
 template <int KIND>
-AKP_HD NielsSel te_step_fetch(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const MsgRaw& raw, size_t msg_len, u32 D,
+AKP_HD NielsSel te_step_fetch(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const MsgRaw& raw, size_t msg_len, u32 D,
                               u32 n_groups, u32 u) {
     u32 width;
     const size_t off = te_step_offset<KIND>(D, n_groups, u, &width);
@@ -423,7 +469,7 @@ AKP_HD NielsSel te_step_fetch(const NielsPad* __restrict__ lut, const NielsPad* 
 }
 // the same index computation without the load: address of the entry and sign of the step
 template <int KIND>
-AKP_HD void te_step_address(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const MsgRaw& raw, size_t msg_len, u32 D,
+AKP_HD void te_step_address(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const MsgRaw& raw, size_t msg_len, u32 D,
                             u32 n_groups, u32 u, NielsFetch& f) {
     u32 width;
     const size_t off = te_step_offset<KIND>(D, n_groups, u, &width);
@@ -458,7 +504,7 @@ AKP_HD void te_step_address(const NielsPad* __restrict__ lut, const NielsPad* __
     }
 }
 template <int KIND>
-AKP_HD Niels te_step_entry(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
+AKP_HD Niels te_step_entry(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const uint8_t* __restrict__ msg,
                            size_t msg_len, u32 D, u32 n_groups, u32 u) {
     return niels_apply(te_step_fetch<KIND>(lut, lut1, te_step_bits<KIND>(msg, msg_len, D, n_groups, u), msg_len, D, n_groups, u));
 }
@@ -474,7 +520,7 @@ AKP_HD void te_consume_after(MsgRaw& r, const Ext& after) {
 #endif
 }
 template <int KIND>
-AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
+AKP_HD Ext te_accumulate_item(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const uint8_t* __restrict__ msg,
                               size_t msg_len, u32 D, u32 n_groups, u32 n_steps) {
     // Software pipeline, two steps per iteration (two entry buffers, no register copies to rotate them).  Before the
     // addition of step u starts, the seven pieces of step u + 1's table line and the message bytes of step u + 2 are
@@ -517,7 +563,7 @@ AKP_HD Ext te_accumulate_item(const NielsPad* __restrict__ lut, const NielsPad* 
 }
 // partial sum over steps first, first + stride, ... (the whole message for first = 0, stride = 1)
 template <int KIND>
-AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1, const uint8_t* __restrict__ msg,
+AKP_HD Ext te_accumulate_strided(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const uint8_t* __restrict__ msg,
                                  size_t msg_len, u32 D, u32 n_groups, u32 n_steps, u32 first, u32 stride) {
     Ext acc;
     u32 start;
@@ -548,9 +594,9 @@ AKP_HD Ext te_accumulate_strided(const NielsPad* __restrict__ lut, const NielsPa
 // one more table entry every sum ends with -- the constant contribution of a zero-padded Bowe-Hopwood tail (a zero chunk
 // selects +g, crh/bowe_hopwood/mod.rs:167), see te_crh_dev.
 template <int KIND>
-__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
+__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
                                                            const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
-                                                           u32 n_steps, const NielsPad* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n) {
+                                                           u32 n_steps, const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     Ext acc = te_accumulate_item<KIND>(lut, lut1, msgs + idx * stride, msg_len, D, n_groups, n_steps);
@@ -560,7 +606,7 @@ __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(co
     f29_store_pad(xyz + idx * 3 + 2, acc.Z);
 }
 // sum of the single-chunk entries 1 * G[c], c in [from, to): the constant of a zero tail (one thread; once per parameter set)
-__global__ void te_bh_tail_kernel(const NielsPad* __restrict__ lut1, u32 from, u32 to, NielsPad* __restrict__ out) {
+__global__ void te_bh_tail_kernel(const TeEntry* __restrict__ lut1, u32 from, u32 to, TeEntry* __restrict__ out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     Ext acc = ext_from_niels(load_niels(lut1 + (size_t)from * 4u));
 #pragma unroll 1
@@ -613,9 +659,9 @@ __global__ void __launch_bounds__(256) te_finalize_kernel(const F29Pad* __restri
 #define AKP_TE_SPLIT 8
 // KIND: table kind (as te_accumulate_kernel); XONLY: digest = x coordinate (Bowe-Hopwood, Pedersen with TECompressor)
 template <int KIND, bool XONLY>
-__global__ void __launch_bounds__(64 * AKP_TE_SPLIT) te_crh_small_kernel(const NielsPad* __restrict__ lut, const NielsPad* __restrict__ lut1,
+__global__ void __launch_bounds__(64 * AKP_TE_SPLIT) te_crh_small_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
                                                                         const uint8_t* __restrict__ msgs, size_t msg_len, size_t msg_stride, u32 D,
-                                                                        u32 n_groups, u32 n_steps, const NielsPad* __restrict__ tail,
+                                                                        u32 n_groups, u32 n_steps, const TeEntry* __restrict__ tail,
                                                                         Fr* __restrict__ out, size_t n) {
     __shared__ u32 part[AKP_TE_SPLIT - 1][36][64];
     const u32 j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -69,6 +69,10 @@ int32_t akp_device_count(void);
 int32_t akp_ctx_create(int32_t device_id, akp_ctx** out);
 void akp_ctx_destroy(akp_ctx* ctx);
 int32_t akp_ctx_synchronize(akp_ctx* ctx);
+/* the hipStream_t (as void*) the HOST-POINTER entry points of this context enqueue their kernels and copies on: lets a caller
+ * bracket such a call with its own events (bench.py times the device side of the proof / update entry points this way) or
+ * order its own work behind it.  NULL for a NULL context.  The stream belongs to the context. */
+void* akp_ctx_stream(akp_ctx* ctx);
 
 /* ---- pinned host memory (optional) ----------------------------------------------------------- */
 /* The host-pointer entry points accept any host memory.  Pageable memory: batches larger than one chunk
@@ -160,6 +164,9 @@ void akp_te_params_destroy(akp_te_params* p);
  * number of table steps (curve additions + 1) an input of msg_len bytes takes. */
 int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset,
                            size_t* table_bytes, size_t msg_len, uint32_t* steps);
+/* bytes one table entry occupies in HBM = what one lane gathers per table step (128: one cache line per entry, the default
+ * build; 96: the packed A/B build, `make packed96`) */
+uint32_t akp_te_entry_bytes(void);
 /* pedersen::CRH::evaluate (crh/pedersen/mod.rs:76-129) / bowe_hopwood::CRH::evaluate
  * (crh/bowe_hopwood/mod.rs:114-186): n messages of msg_len bytes each ->
  * n digests (2 Fr for Pedersen, 1 Fr for Bowe-Hopwood). */

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libakp_oracle.so")
+_SO = os.environ.get("AKP_ORACLE_SO") or os.path.join(_HERE, "_build", "libakp_oracle.so")  # AKP_ORACLE_SO: the sanitizer build (tests/test_sanitizers.py)
 _lib = None
 
 u64p = C.POINTER(C.c_uint64)

@@ -114,11 +114,15 @@ void hh_f29_inv(const Fr* a, const Fr* b, Fr* o) {
 }
 // worst-case limb patterns fed straight into the multipliers (internal limbs, not via the wire):
 // returns a*b/2^261 mod p canonical for FU (limbs given), and for FS.
-void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int is_signed, Fr* o) {
-    if (is_signed) { FS x, y; for (int i = 0; i < 9; ++i) { x.l[i] = (int32_t)al[i]; y.l[i] = (int32_t)bl[i]; }
-        o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
+void hh_f29_raw_mul(const uint32_t* al, const uint32_t* bl, int flags, Fr* o) {
+    // flags: bit 0 signed flavour, bit 1 skip the square, bit 2 skip the three-term dot product -- a routine is only run on
+    // operands inside ITS documented limb bounds, so that the sanitizer build (make ubsan: signed-integer-overflow) flags every
+    // accumulator overflow as the bug it would be
+    const bool sqr = !(flags & 2), dot = !(flags & 4);
+    if (flags & 1) { FS x, y; for (int i = 0; i < 9; ++i) { x.l[i] = (int32_t)al[i]; y.l[i] = (int32_t)bl[i]; }
+        o[0] = f29_canonical_pack(f29_mul(x, y)); if (sqr) o[1] = f29_canonical_pack(f29_sqr(x)); if (dot) o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
     else { FU x, y; for (int i = 0; i < 9; ++i) { x.l[i] = al[i]; y.l[i] = bl[i]; }
-        o[0] = f29_canonical_pack(f29_mul(x, y)); o[1] = f29_canonical_pack(f29_sqr(x)); o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
+        o[0] = f29_canonical_pack(f29_mul(x, y)); if (sqr) o[1] = f29_canonical_pack(f29_sqr(x)); if (dot) o[2] = f29_canonical_pack(f29_dot3(x, y, x, y, x, y)); }
 }
 
 // four / five-term dot products at their limb bounds (state limbs <= 2^29 + 2, balanced constant digits |d| <= 2^28), and the
@@ -210,7 +214,7 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
 // LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
 // kind 1 -> Bowe-Hopwood single table lut1 [n_gen][4] and, when group > 1, group table lut [n_gen/G][2^(3G-1)]
 // (hh_te_crh then takes D = group for kind 1).
-void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t D, uint32_t group, NielsPad* lut, NielsPad* lut1) {
+void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t D, uint32_t group, TeEntry* lut, TeEntry* lut1) {
     const u32 n_gen = W * N;
     if (kind == 2) {  // Pedersen, signed-subset table: lut [n_digits][2^(D-1)], lut1 = cprefix [n_digits + 1]
         std::vector<NielsPad> half(n_gen);
@@ -233,7 +237,7 @@ void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t 
     if (group > 1)
         for (u32 i = 0; i < ((n_gen / group) << (3 * group - 1)); ++i) store_niels(lut + i, te_bh_lutg_entry(gens, group, i));
 }
-void hh_te_crh(int kind, const NielsPad* lut, const NielsPad* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
+void hh_te_crh(int kind, const TeEntry* lut, const TeEntry* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
                uint32_t groups, uint32_t steps, size_t lanes, Fr* out) {
     std::vector<F29Pad> xyz(n * 3), prefix(n);
     for (size_t i = 0; i < n; ++i) {
@@ -249,7 +253,7 @@ void hh_te_crh(int kind, const NielsPad* lut, const NielsPad* lut1, const uint8_
 }
 // the small-batch kernel's arithmetic (te_crh_small_kernel) on the CPU: `split` strided partial sums, a binary tree of
 // full additions, one inversion per message
-void hh_te_crh_split(int kind, const NielsPad* lut, const NielsPad* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
+void hh_te_crh_split(int kind, const TeEntry* lut, const TeEntry* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
                      uint32_t groups, uint32_t steps, uint32_t split, Fr* out) {
     for (size_t i = 0; i < n; ++i) {
         std::vector<Ext> part(split);

@@ -268,7 +268,7 @@ def test_host_pointer_entry_points_stay_inside_their_buffers(cpa):
         gg.check("host tree %s" % nm)
     eln, enl = ora.merkle_build(ora, leaves, 1, threads=8)
     assert np.array_equal(gnl.host().reshape(n - 1, 4), enl) and np.array_equal(gr.host(), enl[0])
-    m, depth = 77, 10
+    m, depth = 77, 11  # log2(n) - 1 digests per path
     idx = rng.integers(0, n, size=m, dtype=np.uint64)
     gs, ga = HostGuard(m * 32), HostGuard(m * depth * 32)
     check(lib.akp_merkle_gather_paths(gln.ptr, gnl.ptr, n, 1, idx.ctypes.data, m, gs.ptr, ga.ptr))
@@ -303,7 +303,7 @@ def test_resident_tree_update_and_proofs_touch_nothing_else(cpa):
         fresh = cpa.MerkleTree.new(cpa.PoseidonFieldConfig, c, c, leaves)
         h = gt.to_host()
         assert np.array_equal(h.leaf_nodes, fresh.leaf_nodes) and np.array_equal(h.non_leaf_nodes, fresh.non_leaf_nodes), m
-        gs, ga = HostGuard(m * 32), HostGuard(m * 11 * 32)
+        gs, ga = HostGuard(m * 32), HostGuard(m * 12 * 32)  # log2(n) - 1 = 12 digests per path
         check(lib.akp_merkle_tree_gather_paths(gt._h, gidx.ptr, m, gs.ptr, ga.ptr))
         gs.check("tree gather siblings m=%d" % m)
         ga.check("tree gather auth m=%d" % m)

@@ -115,11 +115,12 @@ def test_f29_worst_case_limbs(H):
     for a, b in cases_u:
         A, B = np.array(a, np.uint32), np.array(b, np.uint32)
         O = np.zeros((3, 4), np.uint64)
-        H.hh_f29_raw_mul(P(A), P(B), 0, P(O))
+        dot = max(b) <= M29  # the three-term dot product takes its second operands normalised
+        H.hh_f29_raw_mul(P(A), P(B), 0 if dot else 4, P(O))
         va, vb = val(a, False), val(b, False)
         got = ofr.canon_array_to_ints(O)
         assert got[0] == va * vb * Rinv % p and got[1] == va * va * Rinv % p
-        if max(b) <= M29:
+        if dot:
             assert got[2] == 3 * va * vb * Rinv % p
     neg = lambda x: (1 << 32) - x
     cases_s = [([neg(M29)] * 8 + [neg(7)], [M30] * 8 + [9]), ([M30] * 8 + [neg(3)], [neg(M29)] * 8 + [neg(T)]), ([M29] * 8 + [T], [neg(M30)] * 8 + [0]),
@@ -127,11 +128,12 @@ def test_f29_worst_case_limbs(H):
     for a, b in cases_s:
         A, B = np.array(a, np.uint32), np.array(b, np.uint32)
         O = np.zeros((3, 4), np.uint64)
-        H.hh_f29_raw_mul(P(A), P(B), 1, P(O))
+        sqr = max(abs(val([x], True)) for x in a) <= M29 + 1  # squares of signed limbs need |limb| <= 2^29.7
+        H.hh_f29_raw_mul(P(A), P(B), 1 | (0 if sqr else 2) | 4, P(O))
         va, vb = val(a, True), val(b, True)
         got = ofr.canon_array_to_ints(O)
         assert got[0] == va * vb * Rinv % p
-        if max(abs(val([x], True)) for x in a) <= M29 + 1:  # squares of signed limbs need |limb| <= 2^29.7
+        if sqr:
             assert got[1] == va * va * Rinv % p
     # the Poseidon kernels run in the signed flavour (round 2): S-box inputs are non-negative with limbs 0..7 <= 2^30 - 1
     # and a small top limb (normalised value + normalised round key): column 7 of the square reaches 2^63 - 2^31;
@@ -142,7 +144,7 @@ def test_f29_worst_case_limbs(H):
                                    ([M30] * 8 + [T27], [0] * 9, True, False)]:
         A, B = np.array(a, np.uint32), np.array(b, np.uint32)
         O = np.zeros((3, 4), np.uint64)
-        H.hh_f29_raw_mul(P(A), P(B), 1, P(O))
+        H.hh_f29_raw_mul(P(A), P(B), 1 | (0 if chk_sqr else 2) | (0 if chk_dot else 4), P(O))
         va, vb = val(a, True), val(b, True)
         got = ofr.canon_array_to_ints(O)
         assert got[0] == va * vb * Rinv % p

@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Proof / verification / update legs of bench.py -- SURVEY.md section 8(f) ranks 1-2, measured the way the reference benches
+them (benches/merkle_tree.rs:60-191: generate_proof, Path::verify, generate_multi_proof, MultiPath::verify on a 2^20-leaf tree;
+functions merkle_tree/mod.rs:572-579, 172-212, 592-625, 262-331, 692-725).
+
+A 2^20-leaf tree is built once and stays RESIDENT IN HBM (`akp_merkle_tree_build_*`); every leg then runs against it through the
+C ABI with numpy / device buffers (no per-item Python):
+  generate_proof        akp_merkle_tree_gather_paths, m = 2^16 random indices (host outputs), and the all-leaves form of the
+                        reference's bench through akp_merkle_gather_paths_dev (paths stay in HBM)
+  verify_paths          akp_merkle_verify_paths_*: leaf hash + log2(n) two-to-one levels, all m paths advancing together
+  generate_multi_proof  gather + akp_merkle_multipath_encode (prefix_encode_path :795-805) over the sorted distinct indices
+  verify_multipath      akp_merkle_verify_multipath_* (the reference's memoisation: one hash per distinct node)
+  update_batch          akp_merkle_tree_update_batch, m = 2^10 and 2^16 new leaves
+Each leg reports items/s from the host wall clock (the entry points take host pointers: staging copies included), the device
+milliseconds between two events on the context's stream (`akp_ctx_stream`), and sampled oracle parity: the oracle recomputes
+the root from sampled (leaf, path) pairs and must land on the GPU tree's root.
+
+Stand-alone (for rocprofv3):  python tools/bench_proofs.py [--config poseidon|bh] [--log2-leaves 20] [--log2-m 16]
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class _Timer:
+    """host wall clock + device time between two events recorded on the context's own stream"""
+
+    def __init__(self, torch, ctx_stream, sync):
+        self.torch, self.s, self.sync = torch, ctx_stream, sync
+
+    def run(self, fn, reps=3):
+        fn()  # warm-up: scratch growth, pinned staging, first-use table work
+        self.sync()
+        wall, dev = [], []
+        for _ in range(reps):
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(self.s)
+            t0 = time.perf_counter()
+            fn()
+            wall.append(time.perf_counter() - t0)
+            e1.record(self.s)
+            self.sync()
+            dev.append(e0.elapsed_time(e1))
+        return min(wall), min(dev)
+
+
+def _oracle_root_from_paths(kind, ora, leaves, idx, sibs, auth):
+    """Path::verify (merkle_tree/mod.rs:172-212) with the ORACLE's hashes, vectorised over the sample: returns the roots the
+    paths lead to.  kind 'poseidon': leaves [k,1,4] Fr wire, digests [.,4]; kind 'bh': leaves [k,32] bytes, digests [.,4] Fr."""
+    from oracle import cref
+    k, depth = len(idx), auth.shape[1]
+    thr = max(1, min(16, os.cpu_count() or 1))
+
+    def two(l, r):
+        if kind == "poseidon":
+            return ora.two_to_one_batch(np.ascontiguousarray(l), np.ascontiguousarray(r), threads=thr)
+        buf = np.zeros((len(l), 70), np.uint8)  # (63 * 9) / 8 = 70-byte buffer: LE(left) || LE(right), zero tail
+        buf[:, :32] = cref.from_mont(np.ascontiguousarray(l)).view(np.uint8).reshape(len(l), 32)
+        buf[:, 32:64] = cref.from_mont(np.ascontiguousarray(r)).view(np.uint8).reshape(len(l), 32)
+        return np.asarray(ora.bh_crh_batch(buf, len(l), 70, threads=thr)).reshape(len(l), 4)
+    if kind == "poseidon":
+        cur = ora.crh_batch(np.ascontiguousarray(leaves), leaves.shape[1], threads=thr)
+    else:
+        cur = np.asarray(ora.bh_crh_batch(np.ascontiguousarray(leaves), k, leaves.shape[1], threads=thr)).reshape(k, 4)
+    bit = (idx & 1).astype(bool)
+    cur = two(np.where(bit[:, None], sibs, cur), np.where(bit[:, None], cur, sibs))
+    pos = idx >> 1
+    for lvl in range(depth - 1, -1, -1):
+        bit = (pos & 1).astype(bool)
+        a = auth[:, lvl]
+        cur = two(np.where(bit[:, None], a, cur), np.where(bit[:, None], cur, a))
+        pos >>= 1
+    return cur
+
+
+def run(config, log2_leaves=20, log2_m=16, device_index=0, seed=0xA5A50006):
+    import torch
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import field, params as cparams
+    from crypto_primitives_amd._lib import lib, check
+    from crypto_primitives_amd.crh import bowe_hopwood, pedersen
+    from oracle import cref
+
+    dev = torch.device("cuda", device_index)
+    ctx = cpa.default_context(device_index)
+    n, m = 1 << log2_leaves, 1 << log2_m
+    depth = log2_leaves - 1
+    rng = np.random.default_rng(seed)
+    if config == "poseidon":
+        cfg = cpa.get_default_poseidon_parameters(2, False)
+        lh = th = cfg.handle(ctx)
+        leaves = field.random_fr(n, seed=seed).reshape(n, 1, 4)
+        leaf_len, kind = 1, "poseidon"
+        ora = cref.Poseidon(cfg.full_rounds, cfg.partial_rounds, cfg.alpha, cfg.rate, cfg.capacity, cfg.ark, cfg.mds)
+        build, verify, verify_multi = lib.akp_merkle_tree_build_poseidon, lib.akp_merkle_verify_paths_poseidon, lib.akp_merkle_verify_multipath_poseidon
+        new_leaves = lambda k, s: field.random_fr(k, seed=s).reshape(k, 1, 4)  # noqa: E731
+        label = "Poseidon leaf + two-to-one (rate 2), 1-Fr leaves, IdentityDigestConverter"
+    else:
+        gens = cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+        B = bowe_hopwood.Parameters(gens)
+        lh = th = pedersen.te_handle(B, bowe_hopwood.CRH, ctx)
+        leaves = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        leaf_len, kind = 32, "bh"
+        ora = cref.CurveParams(63, 9, gens)
+        build, verify, verify_multi = lib.akp_merkle_tree_build_te, lib.akp_merkle_verify_paths_te, lib.akp_merkle_verify_multipath_te
+        new_leaves = lambda k, s: np.random.default_rng(s).integers(0, 256, size=(k, 32), dtype=np.uint8)  # noqa: E731
+        label = "Bowe-Hopwood 63x9 leaf + two-to-one over Jubjub, 32-byte leaves, ByteDigestConverter"
+    cs = torch.cuda.ExternalStream(lib.akp_ctx_stream(ctx.h), device=dev)
+
+    def sync():
+        check(lib.akp_ctx_synchronize(ctx.h))
+        torch.cuda.synchronize(dev)
+    T = _Timer(torch, cs, sync)
+    out = {"config": label, "leaves": n, "paths_per_call": m, "path_digests": depth,
+           "reference_bench": "benches/merkle_tree.rs:60-191 (2^20 leaves); reference functions merkle_tree/mod.rs:572-579, 172-212, 592-625, 262-331, 692-725",
+           "timing": "items/s from the host wall clock of the host-pointer entry point (staging copies included); device_ms between two "
+                     "events on the context's stream"}
+
+    tree = C.c_void_p()
+    t0 = time.perf_counter()
+    check(build(lh.h, th.h, leaves.ctypes.data, n, leaf_len, C.byref(tree)))
+    out["build_resident_tree_seconds_first_call"] = time.perf_counter() - t0  # includes table / scratch set-up and the leaf copy-in
+    root = np.empty(4, np.uint64)
+    check(lib.akp_merkle_tree_root(tree, root.ctypes.data))
+    samp = np.unique(np.concatenate([np.arange(16), np.linspace(0, m - 1, 49).astype(np.int64)]))
+
+    # ---- generate_proof (:572-579): m random indices, host outputs ------------------------------------------------------
+    idx = rng.integers(0, n, size=m, dtype=np.uint64)
+    sibs = np.empty((m, 4), np.uint64)
+    auth = np.empty((m, depth, 4), np.uint64)
+    wall, dms = T.run(lambda: check(lib.akp_merkle_tree_gather_paths(tree, idx.ctypes.data, m, sibs.ctypes.data, auth.ctypes.data)))
+    roots = _oracle_root_from_paths(kind, ora, leaves[idx[samp].astype(np.int64)], idx[samp].astype(np.int64), sibs[samp], auth[samp])
+    ok_gen = bool((roots == root[None, :]).all())
+    out["generate_proof"] = {"proofs_per_s": m / wall, "wall_ms": wall * 1e3, "device_ms": dms, "bytes_out_per_proof": 32 * (depth + 1),
+                             "sampled_parity_bit_exact": ok_gen, "parity_samples": int(len(samp)),
+                             "parity_note": "oracle Path::verify of the sampled (leaf, proof) pairs lands on the GPU tree's root"}
+    # the reference's bench shape: a proof for EVERY leaf; paths stay in HBM (akp_merkle_gather_paths_dev on the tree's own vectors)
+    d_ln, d_nl = C.c_void_p(), C.c_void_p()
+    check(lib.akp_merkle_tree_device_ptrs(tree, C.byref(d_ln), C.byref(d_nl)))
+    d_idx = torch.arange(n, dtype=torch.int64, device=dev)
+    d_sib = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    d_auth = torch.empty((n, depth, 4), dtype=torch.int64, device=dev)
+    ts = torch.cuda.current_stream(dev)
+    for _ in range(2):
+        check(lib.akp_merkle_gather_paths_dev(ctx.h, d_ln, d_nl, n, 1, d_idx.data_ptr(), n, d_sib.data_ptr(), d_auth.data_ptr(), ts.cuda_stream))
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.akp_merkle_gather_paths_dev(ctx.h, d_ln, d_nl, n, 1, d_idx.data_ptr(), n, d_sib.data_ptr(), d_auth.data_ptr(), ts.cuda_stream))
+    e1.record()
+    torch.cuda.synchronize(dev)
+    all_ms = e0.elapsed_time(e1)
+    probe = torch.from_numpy(idx[samp].astype(np.int64)).to(dev)
+    same = bool(np.array_equal(d_auth[probe].cpu().numpy().view(np.uint64), auth[samp])) and bool(np.array_equal(d_sib[probe].cpu().numpy().view(np.uint64), sibs[samp]))
+    out["generate_proof_all_leaves_dev"] = {"proofs": n, "device_ms": all_ms, "proofs_per_s": n / (all_ms / 1e3),
+                                            "GBps_written": n * 32.0 * (depth + 1) / (all_ms / 1e3) / 1e9, "matches_host_form": same}
+    del d_idx, d_sib, d_auth
+
+    # ---- Path::verify (:172-212), m paths in one call ----------------------------------------------------------------------
+    lv = np.ascontiguousarray(leaves[idx.astype(np.int64)])
+    okf = np.zeros(m, np.uint8)
+    wall, dms = T.run(lambda: check(verify(lh.h, th.h, root.ctypes.data, lv.ctypes.data, m, leaf_len, idx.ctypes.data, sibs.ctypes.data, auth.ctypes.data, depth, okf.ctypes.data)))
+    all_ok = bool((okf == 1).all())
+    bad = lv.copy()
+    bad[7] = lv[8] if not np.array_equal(lv[7], lv[8]) else lv[9]  # negative control: one wrong leaf must fail, and only that one
+    okb = np.zeros(m, np.uint8)
+    check(verify(lh.h, th.h, root.ctypes.data, bad.ctypes.data, m, leaf_len, idx.ctypes.data, sibs.ctypes.data, auth.ctypes.data, depth, okb.ctypes.data))
+    out["verify_paths"] = {"paths_per_s": m / wall, "wall_ms": wall * 1e3, "device_ms": dms, "hashes_per_path": depth + 2, "hashes_per_s_device": m * (depth + 2) / (dms / 1e3),
+                           "all_accepted": all_ok, "negative_control_rejected_only_the_wrong_leaf": bool(okb[7] == 0 and okb.sum() == m - 1),
+                           "sampled_parity_bit_exact": ok_gen and all_ok,
+                           "parity_note": "the same sampled paths verify under the oracle (generate_proof) and every GPU flag is 1"}
+
+    # ---- generate_multi_proof (:592-625) + MultiPath::verify (:262-331) over the sorted distinct indices ---------------------
+    uidx = np.unique(idx)
+    mu = len(uidx)
+    usib = np.empty((mu, 4), np.uint64)
+    uauth = np.empty((mu, depth, 4), np.uint64)
+    pre = np.zeros(mu, np.uint64)
+    suf = np.empty((mu * depth, 4), np.uint64)
+    cnt = C.c_size_t(0)
+
+    def gen_multi():
+        check(lib.akp_merkle_tree_gather_paths(tree, uidx.ctypes.data, mu, usib.ctypes.data, uauth.ctypes.data))
+        check(lib.akp_merkle_multipath_encode(uauth.ctypes.data, mu, depth, 1, pre.ctypes.data, suf.ctypes.data, C.byref(cnt)))
+    wall, dms = T.run(gen_multi)
+    # prefix lengths against a plain numpy restatement of prefix_encode_path (:795-805) on the gathered paths
+    eq = (uauth[1:] == uauth[:-1]).all(axis=2)
+    exp_pre = np.concatenate([[0], np.where(eq.all(axis=1), depth, np.argmin(eq, axis=1))]).astype(np.uint64)
+    out["generate_multi_proof"] = {"distinct_indices": int(mu), "proofs_per_s": mu / wall, "wall_ms": wall * 1e3, "device_ms": dms,
+                                   "suffix_digests": int(cnt.value), "dense_digests": int(mu * depth), "compression": cnt.value / float(mu * depth),
+                                   "prefix_lengths_match_restatement": bool(np.array_equal(pre, exp_pre))}
+    ulv = np.ascontiguousarray(leaves[uidx.astype(np.int64)])
+    okm = C.c_int32(0)
+    wall, dms = T.run(lambda: check(verify_multi(lh.h, th.h, root.ctypes.data, ulv.ctypes.data, mu, leaf_len, uidx.ctypes.data, usib.ctypes.data, pre.ctypes.data,
+                                                 suf.ctypes.data, cnt.value, depth, C.byref(okm))))
+    accepted = bool(okm.value == 1)
+    # negative control on the FIRST path: the reference memoises nodes by tree index (:272-317, `entry().or_insert_with`), so
+    # only the first path that reaches a node contributes to it -- a later path's wrong sibling is absorbed where its chain
+    # merges into an earlier one (reference semantics, reproduced bit for bit: tests/test_gpu_tree_handle.py); path 0 is the
+    # first to reach every node on its way to the root
+    bsib = usib.copy()
+    bsib[0, 0] ^= np.uint64(1)
+    okn = C.c_int32(1)
+    check(verify_multi(lh.h, th.h, root.ctypes.data, ulv.ctypes.data, mu, leaf_len, uidx.ctypes.data, bsib.ctypes.data, pre.ctypes.data, suf.ctypes.data, cnt.value, depth, C.byref(okn)))
+    out["verify_multipath"] = {"leaves_per_s": mu / wall, "wall_ms": wall * 1e3, "device_ms": dms, "accepted": accepted,
+                               "negative_control_rejected": bool(okn.value == 0),
+                               "sampled_parity_bit_exact": accepted and out["generate_multi_proof"]["prefix_lengths_match_restatement"] and ok_gen}
+
+    # ---- update (:692-702), batched: m_u new leaves, every level one hash launch over the distinct touched nodes --------------
+    out["update_batch"] = {}
+    for lg in sorted({10, log2_m}):
+        mu2 = 1 << lg
+        uix = rng.choice(n, size=mu2, replace=False).astype(np.uint64)
+        sets = [new_leaves(mu2, seed + 17 * lg + r) for r in range(5)]
+        state = {"r": 0}
+
+        def upd():
+            nl_ = sets[state["r"] % len(sets)]
+            state["r"] += 1
+            check(lib.akp_merkle_tree_update_batch(tree, uix.ctypes.data, nl_.ctypes.data, mu2, leaf_len))
+        wall, dms = T.run(upd)
+        last = sets[(state["r"] - 1) % len(sets)]
+        leaves[uix.astype(np.int64)] = last  # the tree now holds these
+        check(lib.akp_merkle_tree_root(tree, root.ctypes.data))
+        sp = np.unique(np.concatenate([np.arange(8), np.linspace(0, mu2 - 1, 25).astype(np.int64)]))
+        pidx = np.concatenate([uix[sp], rng.integers(0, n, size=8, dtype=np.uint64)])  # updated leaves and untouched ones
+        ps, pa = np.empty((len(pidx), 4), np.uint64), np.empty((len(pidx), depth, 4), np.uint64)
+        check(lib.akp_merkle_tree_gather_paths(tree, pidx.ctypes.data, len(pidx), ps.ctypes.data, pa.ctypes.data))
+        roots = _oracle_root_from_paths(kind, ora, leaves[pidx.astype(np.int64)], pidx.astype(np.int64), ps, pa)
+        out["update_batch"]["2^%d" % lg] = {"leaves_per_s": mu2 / wall, "wall_ms": wall * 1e3, "device_ms": dms,
+                                            "sampled_parity_bit_exact": bool((roots == root[None, :]).all()), "parity_samples": int(len(pidx)),
+                                            "parity_note": "after the update, oracle Path::verify of updated and untouched leaves lands on the new GPU root"}
+    lib.akp_merkle_tree_destroy(tree)
+    out["all_parity_bit_exact"] = bool(out["generate_proof"]["sampled_parity_bit_exact"] and out["verify_paths"]["sampled_parity_bit_exact"]
+                                       and out["verify_paths"]["negative_control_rejected_only_the_wrong_leaf"]
+                                       and out["verify_multipath"]["sampled_parity_bit_exact"] and out["verify_multipath"]["negative_control_rejected"]
+                                       and out["generate_proof_all_leaves_dev"]["matches_host_form"]
+                                       and all(v["sampled_parity_bit_exact"] for v in out["update_batch"].values()))
+    return out
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="both", choices=["poseidon", "bh", "both"])
+    ap.add_argument("--log2-leaves", type=int, default=20)
+    ap.add_argument("--log2-m", type=int, default=16)
+    a = ap.parse_args()
+    import torch  # noqa: F401  (before the product: one HIP runtime)
+    res = {c: run(c, a.log2_leaves, a.log2_m) for c in (["poseidon", "bh"] if a.config == "both" else [a.config])}
+    print(json.dumps(res))
