@@ -149,10 +149,13 @@ def measure_hbm_copy(torch, dev, nbytes=1 << 30, reps=10):
         return None
 
 
-def one_process_leg(log2_leaves):
-    """Child process of the Merkle leg: the same 2^k-leaf Poseidon tree through the C ABI's single-process multi-device
-    entry point (what a Rust host calls): all visible GPUs (a power of two, at most 8), leaves in pageable host memory,
-    one host thread per device, RCCL all-gather of the sub-roots inside libakp.so.  PCIe-inclusive.  Prints one JSON line."""
+def one_process_leg(log2_leaves, bh_log2_per_gpu=0):
+    """Child process of the Merkle leg: the same 2^k-leaf Poseidon tree -- and the Bowe-Hopwood tree of BASELINE configs[4] at
+    2^j leaves per device -- through the C ABI's single-process multi-device entry points (what a Rust host calls): all visible
+    GPUs (a power of two, at most 8), leaves in pageable host memory, one host thread per device, RCCL all-gather of the
+    sub-roots inside libakp.so.  PCIe-inclusive, with the per-phase breakdown the library records (akp_multi_last_phases), so
+    that the first run on a multi-GPU node yields copy-in + sub-tree / all-gather / top / copy-out, not one number.  Prints one
+    JSON line."""
     import numpy as np
     import torch
     import crypto_primitives_amd as cpa
@@ -164,17 +167,34 @@ def one_process_leg(log2_leaves):
     cfg = cpa.get_default_poseidon_parameters(2, False)
     leaves = field.random_fr(total, seed=0xA5A50003).reshape(total, 1, 4)
     mg = cpa.MultiGpu(list(range(g)))
-    mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves[: 1 << 16], want_nodes=False)  # handles, scratch, RCCL warm-up
-    mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
-    secs = []
-    for _ in range(3):
-        m0 = time.perf_counter()
-        _, _, mroot = mg.build_sharded(cpa.PoseidonFieldConfig, cfg, cfg, leaves, want_nodes=False)
-        secs.append(time.perf_counter() - m0)
+
+    def timed(config, lp, tp, lv):
+        mg.build_sharded(config, lp, tp, lv[: 1 << 12], want_nodes=False)  # handles, tables, scratch, RCCL warm-up
+        mg.build_sharded(config, lp, tp, lv, want_nodes=False)
+        best = None
+        for _ in range(3):
+            m0 = time.perf_counter()
+            _, _, mroot = mg.build_sharded(config, lp, tp, lv, want_nodes=False)
+            sec = time.perf_counter() - m0
+            if best is None or sec < best[0]:
+                best = (sec, mg.last_phases(), mroot)
+        return best
+    secs, phases, mroot = timed(cpa.PoseidonFieldConfig, cfg, cfg, leaves)
+    res = {"entry_point": "akp_merkle_build_sharded_poseidon", "devices": g, "seconds": secs, "phases_ms": phases,
+           "includes": "copy-in of the leaves from pageable memory over PCIe (one host thread per device)",
+           "collective": "ncclAllGather of %d sub-roots" % g, "root_limb0": int(np.asarray(mroot).reshape(-1)[0])}
+    if bh_log2_per_gpu:
+        from crypto_primitives_amd import params as cparams
+        from crypto_primitives_amd.crh import bowe_hopwood
+        B = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9))
+        nb = g << bh_log2_per_gpu
+        per = 1 << bh_log2_per_gpu
+        lv = np.concatenate([np.random.default_rng(0xA5A50005 + r).integers(0, 256, size=(per, 32), dtype=np.uint8) for r in range(g)])  # rank r's shard of the torchrun leg
+        bsecs, bphases, broot = timed(cpa.BoweHopwoodByteConfig, B, B, lv)
+        res["bowe_hopwood"] = {"entry_point": "akp_merkle_build_sharded_te", "leaves": nb, "leaves_per_device": per, "seconds": bsecs, "leaves_per_s": nb / bsecs,
+                               "phases_ms": bphases, "root_limb0": int(np.asarray(broot).reshape(-1)[0])}
     mg.close()
-    print(json.dumps({"entry_point": "akp_merkle_build_sharded_poseidon", "devices": g, "seconds": min(secs), "seconds_all": secs,
-                      "includes": "copy-in of the leaves from pageable memory over PCIe (one host thread per device)",
-                      "collective": "ncclAllGather of %d sub-roots" % g, "root_limb0": int(np.asarray(mroot).reshape(-1)[0])}))
+    print(json.dumps(res))
     return 0
 
 
@@ -197,9 +217,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-process-leg", type=int, default=0, help=argparse.SUPPRESS)  # internal: child process of the Merkle leg
+    ap.add_argument("--one-process-bh", type=int, default=0, help=argparse.SUPPRESS)   # internal: its Bowe-Hopwood share per device
     args = ap.parse_args()
     if args.one_process_leg:
-        return one_process_leg(args.one_process_leg)
+        return one_process_leg(args.one_process_leg, args.one_process_bh)
 
     # test hook (tests/test_gpu_bench_contract.py): AKP_BENCH_SHARED_GPU=1 puts every rank on GPU 0 and carries the
     # collectives over gloo, so the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
@@ -325,7 +346,7 @@ def main():
         if world == 1 and not shared_gpu and os.environ.get("AKP_BENCH_NO_MULTI") != "1":
             # in a child process with a time limit: a first-ever n_dev > 1 RCCL bring-up must not be able to take the headline
             # measurement down with it (a crash or a hang there is reported here, nothing else)
-            cmd = [sys.executable, os.path.abspath(__file__), "--one-process-leg", str(args.merkle_log2)]
+            cmd = [sys.executable, os.path.abspath(__file__), "--one-process-leg", str(args.merkle_log2), "--one-process-bh", str(args.bh_merkle_log2)]
             try:
                 cp = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
                 line = [l for l in cp.stdout.splitlines() if l.startswith("{")]

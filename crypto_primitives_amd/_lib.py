@@ -128,6 +128,7 @@ def _load():
         "akp_multi_destroy": (None, [vp]),
         "akp_multi_size": (i32, [vp]),
         "akp_multi_ctx": (vp, [vp, i32]),
+        "akp_multi_last_phases": (i32, [vp, C.POINTER(C.c_double)]),
         "akp_merkle_build_sharded_poseidon": (i32, [vp, pp, pp, u64p, sz, sz, u64p, u64p, u64p]),
         "akp_merkle_build_sharded_te": (i32, [vp, pp, pp, u8p, sz, sz, u64p, u64p, u64p]),
     }

@@ -77,7 +77,20 @@ struct akp_ctx {
     // more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
     hipStream_t pipe[7] = {};
     hipEvent_t chunk_event[8] = {};  // copy-stream -> compute-stream hand-over of leaf chunks (host_tree_build)
+    // where the last host-pointer tree build left its inner nodes (heap order, `last_tree_nodes` digests): what the
+    // multi-device build reads for the all-gather of the sub-roots and the per-device copy-outs -- an explicit hand-over
+    // instead of a convention about scratch slots
+    const void* last_tree_non_leaf = nullptr;
+    size_t last_tree_nodes = 0;
+    // parameter handles created on this context and still alive.  akp_ctx_destroy with live handles releases the device
+    // resources and marks the context dead; the struct itself goes with the last handle, whose compute calls fail cleanly
+    // until then (handles created on akp_multi_ctx may outlive akp_multi_destroy without touching freed memory)
+    int live_handles = 0;
+    bool dead = false;
 };
+static void ctx_handle_released(akp_ctx* c) {
+    if (c && --c->live_handles == 0 && c->dead) delete c;
+}
 // scratch slot `slot` with at least `bytes`, to be used on stream `s`: if the previous use was enqueued on a different
 // stream, `s` first waits for it (event record + stream wait; nothing blocks on the host)
 static int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out, hipStream_t s) {
@@ -132,6 +145,17 @@ extern "C" void akp_ctx_destroy(akp_ctx* c) {
     for (int i = 0; i < 7; ++i)
         if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = nullptr;
+    for (int i = 0; i < SCR_COUNT; ++i) { c->scratch[i] = nullptr; c->scratch_bytes[i] = 0; c->slot_event[i] = nullptr; c->slot_used[i] = false; }
+    for (int i = 0; i < 8; ++i) c->chunk_event[i] = nullptr;
+    for (int i = 0; i < 7; ++i) c->pipe[i] = nullptr;
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
+    c->last_tree_non_leaf = nullptr;
+    if (c->live_handles > 0) {
+        c->dead = true;  // freed by ctx_handle_released when the last handle goes
+        return;
+    }
     delete c;
 }
 extern "C" int32_t akp_ctx_synchronize(akp_ctx* c) {
@@ -361,6 +385,7 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
         if (!fr_words_reduced(mds + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "mds[%zu] not reduced", i);
     akp_poseidon* p = new akp_poseidon();
     p->ctx = ctx;
+    if (ctx) ++ctx->live_handles;
     p->dims = PoseidonDims{t, rate, capacity, full_rounds, partial_rounds, alpha};
     p->ark.resize(na);
     p->mds.resize(nm);
@@ -451,6 +476,7 @@ extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (p->d_fmats_f29) (void)hipFree(p->d_fmats_f29);
     if (p->d_sparse_f29) (void)hipFree(p->d_sparse_f29);
     if (p->d_sbox0_f29) (void)hipFree(p->d_sbox0_f29);
+    ctx_handle_released(p->ctx);
     delete p;
 }
 extern "C" int32_t akp_poseidon_params_dims(const akp_poseidon* p, uint32_t* full_rounds, uint32_t* partial_rounds,
@@ -739,6 +765,7 @@ extern "C" const char* akp_poseidon_kernel_for(const akp_poseidon* p, size_t n, 
     do {                                                                                                   \
         if (!(p)) return fail(AKP_ERR_BAD_PARAMS, what ": params is NULL");                                \
         if (!(p)->ctx) return fail(AKP_ERR_HIP, what ": parameter handle has no device context (no CPU fallback)"); \
+        if ((p)->ctx->dead) return fail(AKP_ERR_BAD_PARAMS, what ": the context of this handle was destroyed");  \
         HIP_TRY(hipSetDevice((p)->ctx->device));                                                           \
     } while (0)
 
@@ -1007,6 +1034,7 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     HIP_TRY(hipSetDevice(ctx->device));
     akp_te_params* p = new akp_te_params();
     p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
+    ++ctx->live_handles;
     Fr* d_g = nullptr;
     hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
@@ -1110,6 +1138,7 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
     if (p->d_lut) (void)hipFree(p->d_lut);
     if (p->d_lut1) (void)hipFree(p->d_lut1);
     if (p->d_tail) (void)hipFree(p->d_tail);
+    ctx_handle_released(p->ctx);
     delete p;
 }
 
@@ -1243,6 +1272,7 @@ static int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
 #define NEED_TE(p, what)                                                    \
     do {                                                                    \
         if (!(p)) return fail(AKP_ERR_BAD_PARAMS, what ": params is NULL"); \
+        if ((p)->ctx->dead) return fail(AKP_ERR_BAD_PARAMS, what ": the context of this handle was destroyed"); \
         HIP_TRY(hipSetDevice((p)->ctx->device));                            \
     } while (0)
 
@@ -1418,6 +1448,8 @@ static int32_t host_tree_build(akp_ctx* c, const void* leaves, size_t n, size_t 
     if (h_root) HIP_TRY(hipMemcpyAsync(h_root, d_nl, dig_bytes, hipMemcpyDeviceToHost, comp));
     HIP_TRY(hipStreamSynchronize(copy));
     HIP_TRY(hipStreamSynchronize(comp));
+    c->last_tree_non_leaf = d_nl;
+    c->last_tree_nodes = n - 1;
     return AKP_OK;
 }
 

@@ -480,6 +480,13 @@ class GpuMerkleTree:
         d = config.default_leaf_digest()
         return cls.new_with_leaf_digest(config, leaf_hash_param, two_to_one_hash_param, np.stack([d] * (1 << (height - 1))))
 
+    def last_phases(self):
+        """phase breakdown of the last build_sharded call (akp_multi_last_phases), milliseconds, maximum over the devices"""
+        import ctypes as C
+        ms = (C.c_double * 5)()
+        check(lib.akp_multi_last_phases(self._h, ms))
+        return {"copy_in_and_subtree_ms": ms[0], "allgather_ms": ms[1], "top_levels_ms": ms[2], "copy_out_ms": ms[3], "whole_call_ms": ms[4]}
+
     def close(self):
         if getattr(self, "_h", None):
             lib.akp_merkle_tree_destroy(self._h)
@@ -612,10 +619,9 @@ class MultiGpu:
     def close(self):
         if getattr(self, "_h", None):
             for cfg in self._param_owners:  # parameter handles created on our contexts go first
-                for c in self._ctxs.values():
-                    hobj = cfg._handles.pop(id(c), None)
-                    if hobj is not None:
-                        hobj.__del__()
+                ours = {id(c) for c in self._ctxs.values()}
+                for key in [k for k in cfg._handles if (k[0] if isinstance(k, tuple) else k) in ours]:  # te handles are keyed (ctx, kind)
+                    cfg._handles.pop(key).__del__()
             self._param_owners.clear()
             self._ctxs.clear()
             lib.akp_multi_destroy(self._h)

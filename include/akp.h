@@ -305,8 +305,15 @@ int32_t akp_merkle_verify_multipath_te(akp_te_params* leaf_params, akp_te_params
 int32_t akp_multi_create(const int32_t* device_ids, int32_t n_dev, akp_multi** out);
 void akp_multi_destroy(akp_multi* m);
 int32_t akp_multi_size(const akp_multi* m);
-/* context of device slot i (owned by m): create that device's parameter handles on it */
+/* context of device slot i (owned by m): create that device's parameter handles on it.  Handles may outlive akp_multi_destroy:
+ * their compute calls then fail with AKP_ERR_BAD_PARAMS and destroying them stays valid (the context struct goes with its
+ * last handle) */
 akp_ctx* akp_multi_ctx(akp_multi* m, int32_t i);
+/* phase breakdown of the last akp_merkle_build_sharded_* call on m, milliseconds, maximum over the devices (ms_out[5]):
+ * [0] leaf copy-in + sub-tree build (host wall clock of the slowest device thread), [1] the ncclAllGather of the sub-roots,
+ * [2] the top G - 1 nodes, [3] copy-out of inner nodes / root (device time between events on each device's stream),
+ * [4] the whole call (host wall clock) */
+int32_t akp_multi_last_phases(const akp_multi* m, double* ms_out);
 /* MerkleTree::new over all devices of m: device r hashes leaves [r n/G, (r+1) n/G) into its own sub-tree, ONE
  * ncclAllGather moves the G sub-roots (xGMI), every device computes the top G-1 nodes.  leaf_params[r] and
  * two_to_one_params[r] are handles created on akp_multi_ctx(m, r).  Host buffers and outputs exactly as

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline"}
 SMALL = ["--log2-states", "16", "--merkle-log2", "12", "--pedersen-log2", "10", "--bh-merkle-log2", "9", "--sustain-seconds", "0.2",
-         "--sustain-log2-big", "0"]
+         "--sustain-log2-big", "0", "--proofs-log2", "12", "--proofs-m-log2", "8"]
 
 
 def _check(out):
@@ -39,6 +39,16 @@ def test_bench_single_process():
     assert d["pedersen"]["sampled_parity_bit_exact"] and d["bh_merkle"]["sampled_parity_bit_exact"] and d["merkle"]["sampled_parity_bit_exact"]
     assert d["bh_merkle"]["leaves"] == 512 and d["pedersen"]["roofline"]["frac"] > 0
     assert d["host_path"]["pinned"]["permutations_per_s"] > 0 and d["sustained"]["2^16"]["launches"] >= 8
+    assert cb["cores_basis"] in ("cgroup quota", "affinity mask", "hardware threads") and cb["cores"] <= cb["hardware_threads"] and cb["threads_used"] >= 1
+    assert cb["pedersen"]["value"] > 0 and cb["bh_merkle"]["value"] > 0
+    for cfg in ("poseidon", "bh"):  # proofs, verification, updates on a resident tree
+        pr = d["proofs"][cfg]
+        assert pr["all_parity_bit_exact"] and pr["leaves"] == 1 << 12
+        for leg in ("generate_proof", "verify_paths", "generate_multi_proof", "verify_multipath"):
+            assert pr[leg]["wall_ms"] > 0 and pr[leg]["device_ms"] > 0
+        assert set(pr["update_batch"]) == {"2^8", "2^10"}
+    leg = d["merkle"]["one_process_c_abi"]  # the C ABI's multi-device entry points, with the phase breakdown
+    assert leg["root_matches"] and leg["phases_ms"]["whole_call_ms"] > 0 and leg["bowe_hopwood"]["phases_ms"]["copy_in_and_subtree_ms"] > 0
 
 
 def test_bench_under_torchrun_world1():
@@ -66,6 +76,28 @@ def test_bench_multi_rank_code_path_on_one_gpu(world):
     assert d["merkle"]["leaves"] == 1 << 12 and d["bh_merkle"]["leaves"] == world << 9 and d["bh_merkle"]["scaling"] == "weak"
     assert d["launch"]["ranks"] == world and len(d["launch"]["rank_devices"]) == world
     assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1  # rank 0 only
+
+
+def test_bench_on_all_real_devices_nccl():
+    """One rank per PHYSICAL GPU over RCCL: world = the largest power of two <= min(device_count, 8).  On a one-GPU box there is
+    nothing beyond test_bench_under_torchrun_world1 to run, so it skips; the moment a node has more devices this is a true
+    world > 1 run of the sharded legs (leaf-range shards, one all-gather of the sub-roots) with no test hook involved."""
+    import torch
+    ndev = torch.cuda.device_count()
+    world = 1
+    while world * 2 <= min(ndev, 8):
+        world *= 2
+    if world < 2:
+        pytest.skip("one visible GPU: world > 1 over RCCL needs a multi-GPU node (world 1 is test_bench_under_torchrun_world1)")
+    env = {k: v for k, v in os.environ.items() if k != "AKP_BENCH_SHARED_GPU"}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", "29561", "bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"]
+                       + SMALL, cwd=ROOT, capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    d = _check(p.stdout)
+    assert d["n_gpus"] == world and d["launch"]["backend"].startswith("nccl") and sorted(d["launch"]["rank_devices"]) == list(range(world))
+    assert d["merkle"]["sampled_parity_bit_exact"] and d["bh_merkle"]["sampled_parity_bit_exact"] and d["bh_merkle"]["leaves"] == world << 9
 
 
 def test_bench_self_launches_ranks_from_plain_python():
