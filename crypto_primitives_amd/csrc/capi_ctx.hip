@@ -1,0 +1,178 @@
+// capi_ctx.hip -- part of libakp.so (implementation of include/akp.h): errors, contexts, pinned host memory, host field helpers
+// Product code.  Never includes, links or calls anything under oracle/; there is no CPU fallback for any compute entry
+// point (a missing device is AKP_ERR_HIP).
+#include "capi_internal.hpp"
+
+// ------------------------------------------------------------------------------------------
+// errors
+static thread_local std::string g_last_error;
+int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+extern "C" const char* akp_last_error(void) { return g_last_error.c_str(); }
+extern "C" int32_t akp_abi_version(void) { return AKP_ABI_VERSION; }
+extern "C" int32_t akp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t env_size(const char* name, size_t dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? (size_t)strtoull(e, nullptr, 10) : dflt;
+}
+u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
+    const char* e = getenv(name);
+    if (!e) return dflt;
+    long v = strtol(e, nullptr, 10);
+    return (v < (long)lo || v > (long)hi) ? dflt : (u32)v;
+}
+
+// ------------------------------------------------------------------------------------------
+// context: device, stream, grow-only scratch slots
+void ctx_handle_released(akp_ctx* c) {
+    if (c && --c->live_handles == 0 && c->dead) delete c;
+}
+// scratch slot `slot` with at least `bytes`, to be used on stream `s`: if the previous use was enqueued on a different
+// stream, `s` first waits for it (event record + stream wait; nothing blocks on the host)
+int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out, hipStream_t s) {
+    if (bytes == 0) bytes = 16;
+    if (c->slot_used[slot] && c->slot_stream[slot] != s) {
+        if (!c->slot_event[slot]) HIP_TRY(hipEventCreateWithFlags(&c->slot_event[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->slot_event[slot], c->slot_stream[slot]));
+        HIP_TRY(hipStreamWaitEvent(s, c->slot_event[slot], 0));
+    }
+    c->slot_used[slot] = true;
+    c->slot_stream[slot] = s;
+    if (c->scratch_bytes[slot] < bytes) {
+        if (c->scratch[slot]) {
+            HIP_TRY(hipDeviceSynchronize());  // work enqueued on other streams may still read it
+            HIP_TRY(hipFree(c->scratch[slot]));
+            c->scratch[slot] = nullptr;
+            c->scratch_bytes[slot] = 0;
+        }
+        HIP_TRY(hipMalloc(&c->scratch[slot], bytes));
+        c->scratch_bytes[slot] = bytes;
+    }
+    *out = c->scratch[slot];
+    return AKP_OK;
+}
+extern "C" int32_t akp_ctx_create(int32_t device_id, akp_ctx** out) {
+    if (!out) return fail(AKP_ERR_BAD_PARAMS, "akp_ctx_create: out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(AKP_ERR_HIP, "akp_ctx_create: device %d not present (%d visible)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    akp_ctx* c = new akp_ctx();
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(AKP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return AKP_OK;
+}
+extern "C" void akp_ctx_destroy(akp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < SCR_COUNT; ++i) {
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+        if (c->slot_event[i]) (void)hipEventDestroy(c->slot_event[i]);
+    }
+    for (int i = 0; i < 8; ++i)
+        if (c->chunk_event[i]) (void)hipEventDestroy(c->chunk_event[i]);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int i = 0; i < 7; ++i)
+        if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = nullptr;
+    for (int i = 0; i < SCR_COUNT; ++i) {
+        c->scratch[i] = nullptr;
+        c->scratch_bytes[i] = 0;
+        c->slot_event[i] = nullptr;
+        c->slot_used[i] = false;
+    }
+    for (int i = 0; i < 8; ++i) c->chunk_event[i] = nullptr;
+    for (int i = 0; i < 7; ++i) c->pipe[i] = nullptr;
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
+    c->last_tree_non_leaf = nullptr;
+    if (c->live_handles > 0) {
+        c->dead = true;  // freed by ctx_handle_released when the last handle goes
+        return;
+    }
+    delete c;
+}
+extern "C" int32_t akp_ctx_synchronize(akp_ctx* c) {
+    if (!c) return fail(AKP_ERR_BAD_PARAMS, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return AKP_OK;
+}
+extern "C" void* akp_ctx_stream(akp_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------
+// pinned host memory for callers that want the host-pointer entry points to run at PCIe speed: copies from / to
+// pageable memory are staged by the runtime and block the calling thread, pinned (or registered) buffers stream
+// asynchronously in both directions at once.  The entry points accept either kind.
+extern "C" int32_t akp_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(AKP_ERR_BAD_PARAMS, "out is NULL");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return AKP_OK;
+}
+extern "C" int32_t akp_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return AKP_OK;
+}
+extern "C" int32_t akp_host_register(void* p, size_t bytes) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "pointer is NULL");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return AKP_OK;
+}
+extern "C" int32_t akp_host_unregister(void* p) {
+    if (p) HIP_TRY(hipHostUnregister(p));
+    return AKP_OK;
+}
+
+void* device_alias(const void* host, size_t bytes) {
+    if (!host || bytes == 0) return nullptr;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: not an error for the caller
+        return nullptr;
+    }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) == hipSuccess) {
+        if ((const char*)a.devicePointer + bytes > (const char*)base + size) return nullptr;  // only part of the buffer is pinned
+    } else {
+        (void)hipGetLastError();
+    }
+    return a.devicePointer;
+}
+
+// ------------------------------------------------------------------------------------------
+// host field helpers
+extern "C" int32_t akp_fr_to_mont(const uint64_t* canonical, uint64_t* mont, size_t n) {
+    if ((!canonical || !mont) && n) return fail(AKP_ERR_BAD_PARAMS, "akp_fr_to_mont: NULL buffer");
+    for (size_t i = 0; i < n; ++i) {
+        if (!fr_words_reduced(canonical + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "akp_fr_to_mont: element %zu is not < p", i);
+        fr_to_words(fr_to_mont(fr_from_words(canonical + 4 * i)), mont + 4 * i);
+    }
+    return AKP_OK;
+}
+extern "C" int32_t akp_fr_from_mont(const uint64_t* mont, uint64_t* canonical, size_t n) {
+    if ((!canonical || !mont) && n) return fail(AKP_ERR_BAD_PARAMS, "akp_fr_from_mont: NULL buffer");
+    for (size_t i = 0; i < n; ++i) fr_to_words(fr_from_mont(fr_from_words(mont + 4 * i)), canonical + 4 * i);
+    return AKP_OK;
+}
+

@@ -1,0 +1,421 @@
+// capi_te.hip -- part of libakp.so (implementation of include/akp.h): Pedersen / Bowe-Hopwood over Jubjub: tables, batch entry points
+// Product code.  Never includes, links or calls anything under oracle/; there is no CPU fallback for any compute entry
+// point (a missing device is AKP_ERR_HIP).
+#include "capi_internal.hpp"
+#include "te_kernels.hpp"
+
+// ------------------------------------------------------------------------------------------
+// Pedersen / Bowe-Hopwood
+// largest precomputed table, bytes: the digit width / chunk grouping is reduced until the table fits.  Pedersen: 320 MiB
+// admits 16-bit digits for the 4 x 256 window of BASELINE config 4 (64 steps x 2^15 entries x 128 B = 268 MB; measured on
+// MI355X, 2^20 x 128 B: 15 bits / 145 MB 3.37 ms, 16 bits 3.25 ms, 17 bits / 512 MB 3.28 ms -- past the 256 MiB Infinity
+// Cache the gather costs what the shorter sum saves).  Bowe-Hopwood: 256 MiB admits groups of five chunks for the 63 x 9
+// window of config 5 (113 groups x 2^14 entries x 128 B = 237 MB, of which the 64-byte inputs of a tree touch the first
+// 73 MB; 2.16 -> 1.78 ms per 2^20 two-to-one hashes against groups of four).  (Round 2 swept them through AKP_TE_TABLE_MB; the knob is gone.)
+static size_t te_table_cap(bool bowe_hopwood = false) {
+    return (size_t)(bowe_hopwood ? 256u : 320u) << 20;
+}
+extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
+    if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
+    if (!out || !gens) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
+    if (kind != AKP_TE_PEDERSEN && kind != AKP_TE_BOWE_HOPWOOD && kind != AKP_TE_PEDERSEN_X) return fail(AKP_ERR_BAD_PARAMS,
+            "unknown kind %d", kind);
+    if (W == 0 || N == 0) return fail(AKP_ERR_BAD_PARAMS, "empty window");
+    if (kind == AKP_TE_BOWE_HOPWOOD && W > 63) return fail(AKP_ERR_BAD_PARAMS,
+            "Bowe-Hopwood window size %u > 63 (bowe_hopwood/mod.rs:81-101)", W);
+    const size_t n_gen = (size_t)W * N;
+    if (n_gen > (1u << 22)) return fail(AKP_ERR_BAD_PARAMS, "window %ux%u too large", W, N);
+    for (size_t i = 0; i < 2 * n_gen; ++i)
+        if (!fr_words_reduced(gens + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "generator coordinate %zu not reduced", i);
+    HIP_TRY(hipSetDevice(ctx->device));
+    akp_te_params* p = new akp_te_params();
+    p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
+    ++ctx->live_handles;
+    Fr* d_g = nullptr;
+    hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
+    if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
+    if (kind == AKP_TE_PEDERSEN || kind == AKP_TE_PEDERSEN_X) {
+        // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
+        // stores 2^(D-1) entries per digit.  Default D = 15: 4x256 is 69 steps over a 163 MB table.  Measured on MI355X, 2^20 x 128 B
+        // (profiles/r02_s9): signed D = 13 / 14 / 15: 2.70 / 2.75 / 2.88e8 hashes/s; plain table D = 13: 2.56e8.
+        // AKP_PEDERSEN_PLAIN=1 keeps the plain table (the A/B arm, and the fallback for generators outside the subgroup).
+        NielsPad* d_half = nullptr;
+        u32* d_bad = nullptr;
+        u32 bad = 1;
+        if (!getenv("AKP_PEDERSEN_PLAIN")) {
+            if (e == hipSuccess) e = hipMalloc(&d_half, n_gen * sizeof(NielsPad));
+            if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(u32));
+            if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_halve_generators, dim3((unsigned)((n_gen + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
+                        d_half, d_bad);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess && bad == 0) {
+            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 16, 2, 17);
+            while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(TeEntry) > te_table_cap()) --D;
+            size_t n_digits = (n_gen + D - 1) / D, entries = n_digits << (D - 1);
+            e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+            while (e == hipErrorOutOfMemory && D > 8) {  // a crowded device: a narrower digit needs half the table
+                (void)hipGetLastError();
+                --D;
+                n_digits = (n_gen + D - 1) / D;
+                entries = n_digits << (D - 1);
+                e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+            }
+            p->digit_bits = D;
+            p->signed_subset = true;
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_build_pedersen_slut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
+                        (u32)n_gen, D, (u32)entries, p->d_lut);
+                hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
+                        (u32)n_gen, D, (u32)n_digits, p->d_lut1);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        } else if (e == hipSuccess) {
+            // plain table.  digit width: 13 bits (4x256: 79 steps, 93 MB table, served from the 256 MB Infinity Cache) unless the table
+            // would exceed 192 MB; AKP_PEDERSEN_DIGIT_BITS overrides (1..14).  Measured 2^20 x 128 B on MI355X:
+            // D = 4: 73 M/s, 8: 151, 10: 177, 12: 199, 13: 209, 14: 220 (175 MB table; round 2: 13 beats 14, profiles/r02_s8).
+            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 13, 1, 14);
+            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(TeEntry) > te_table_cap()) --D;
+            p->digit_bits = D;
+            const size_t entries = ((n_gen + D - 1) / D) << D;
+            e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
+                        D, (u32)entries, p->d_lut);
+                e = hipGetLastError();
+            }
+        }
+        if (d_half) (void)hipFree(d_half);
+        if (d_bad) (void)hipFree(d_bad);
+    } else {
+        u32 G = env_u32("AKP_BH_GROUP", 5, 1, 5);
+        while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(TeEntry) > te_table_cap(true))) --G;
+        p->group = G;
+        if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(TeEntry));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
+                    p->d_lut1);
+            e = hipGetLastError();
+        }
+        if (G > 1) {
+            size_t entries = (n_gen / G) << (3 * G - 1);
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+            while (e == hipErrorOutOfMemory && G > 2) {  // a crowded device: a smaller group needs an eighth of the table
+                (void)hipGetLastError();
+                --G;
+                p->group = G;
+                entries = (n_gen / G) << (3 * G - 1);
+                e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+            }
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(te_build_bh_lutg, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, G, (u32)entries,
+                        p->d_lut);
+                e = hipGetLastError();
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_g) (void)hipFree(d_g);
+    if (e != hipSuccess) {
+        if (p->d_lut) (void)hipFree(p->d_lut);
+        if (p->d_lut1) (void)hipFree(p->d_lut1);
+        delete p;
+        return fail(AKP_ERR_HIP, "akp_te_params_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return AKP_OK;
+}
+extern "C" uint32_t akp_te_entry_bytes(void) { return (uint32_t)sizeof(TeEntry); }
+extern "C" void akp_te_params_destroy(akp_te_params* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (p->d_lut) (void)hipFree(p->d_lut);
+    if (p->d_lut1) (void)hipFree(p->d_lut1);
+    if (p->d_tail) (void)hipFree(p->d_tail);
+    ctx_handle_released(p->ctx);
+    delete p;
+}
+
+// table steps a message of msg_len bytes touches (later digits are zero / absent): Pedersen pads with zero
+// bytes (those digits select the identity); Bowe-Hopwood stops at ceil(bits/3) chunks = `groups` triples +
+// left-over singles.
+static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32* n_steps) {
+    const size_t bits = msg_len * 8;
+    if (te_is_pedersen(p)) {
+        const size_t used = std::min<size_t>(bits, p->n_gen);
+        *n_groups = 0;
+        *n_steps = (u32)((used + p->digit_bits - 1) / p->digit_bits);
+        return;
+    }
+    const size_t chunks = std::min<size_t>((bits + 2) / 3, (size_t)p->n_gen);
+    if (p->group > 1) {
+        *n_groups = (u32)(chunks / p->group);
+        *n_steps = (u32)(chunks / p->group + chunks % p->group);
+    } else {
+        *n_groups = 0;
+        *n_steps = (u32)chunks;
+    }
+}
+extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset, size_t* table_bytes,
+        size_t msg_len,
+                                      uint32_t* steps) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_info: params is NULL");
+    const bool ped = te_is_pedersen(p);
+    if (digit_bits_or_group) *digit_bits_or_group = ped ? p->digit_bits : p->group;
+    if (signed_subset) *signed_subset = ped && p->signed_subset ? 1 : 0;
+    if (table_bytes) {
+        size_t entries;
+        if (ped) {
+            const size_t n_digits = (p->n_gen + p->digit_bits - 1) / p->digit_bits;
+            entries = p->signed_subset ? (n_digits << (p->digit_bits - 1)) + n_digits + 1 : n_digits << p->digit_bits;
+        } else {
+            entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)(p->n_gen / p->group) << (3 * p->group - 1)) : 0);
+        }
+        *table_bytes = entries * sizeof(TeEntry);
+    }
+    if (steps) {
+        u32 g = 0, st = 0;
+        te_steps(p, msg_len, &g, &st);
+        *steps = st;
+    }
+    return AKP_OK;
+}
+// accumulate + finalize on device buffers.  scratch: SCR_E (xyz), SCR_F (prefix)
+// `data_len` <= msg_len: the bytes [data_len, msg_len) of every message are known to be zero (the padding of a two-to-one
+// buffer, crh/bowe_hopwood/mod.rs:219-224) and are not read.  Pedersen: zero bits select nothing, the sum simply stops
+// earlier.  Bowe-Hopwood: a zero chunk still adds +g (:167), so the chunks that lie wholly in the padding contribute the
+// CONSTANT sum of their generators: one table entry (computed once per shape, te_bh_tail_kernel) added at the end instead
+// of one table step per five chunks -- a 63 x 9 inner node (64 bytes of digests in a 70-byte buffer) takes 35 + 1 steps
+// instead of 39.
+int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len) {
+    if (msg_len * 8 > te_input_bits(p))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
+    if (n == 0) return AKP_OK;
+    if (n > ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32", n);
+    const bool tail_on = env_u32("AKP_BH_ZERO_TAIL", 1, 0, 1) != 0;  // 0: walk the padding chunk by chunk (A/B arm; read per call)
+    if (data_len > msg_len || !tail_on) data_len = msg_len;
+    u32 groups = 0, steps = 0;
+    te_steps(p, data_len, &groups, &steps);
+    const TeEntry* tail = nullptr;
+    if (p->kind == AKP_TE_BOWE_HOPWOOD && data_len < msg_len) {
+        const u32 from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, p->n_gen), to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3,
+                p->n_gen);
+        if (from < to) {
+            if (!p->d_tail) HIP_TRY(hipMalloc(&p->d_tail, sizeof(TeEntry)));
+            // stream-ordered: later launches on other streams go through ctx_scratch-style events below
+            if (p->tail_from != from || p->tail_to != to) {
+                // an earlier shape's constant may still be in use (rare: one shape per parameter set)
+                HIP_TRY(hipStreamSynchronize(s));
+                hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, s, p->d_lut1, from, to, p->d_tail);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(s));
+                p->tail_from = from;
+                p->tail_to = to;
+            }
+            tail = p->d_tail;
+        }
+    }
+    size_t stride = msg_len;
+    if (data_len > 0 && data_len < 4) {  // the kernels fetch message bits with one 32-bit load: pad 1..3-byte messages to four bytes
+        void* pad = nullptr;
+        if (int32_t rc = ctx_scratch(p->ctx, SCR_L, n * 4, &pad, s)) return rc;
+        hipLaunchKernelGGL(te_pad4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_msgs, stride, (u32)data_len,
+                (uint8_t*)pad, n);
+        HIP_TRY(hipGetLastError());
+        d_msgs = (const uint8_t*)pad;
+        stride = 4;
+        data_len = 4;  // three zero bytes at most: they select nothing (Pedersen) / lie past the steps counted above (Bowe-Hopwood)
+    }
+    // small batches (tree tops) are bound by the latency of one message: split each one over AKP_TE_SPLIT waves
+    static const size_t split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
+    if (n <= split_max) {
+        const unsigned sgrid = (unsigned)((n + 63) / 64);
+        const bool xy = p->kind == AKP_TE_PEDERSEN;  // digest = (x, y); otherwise x only
+        if (te_is_pedersen(p) && p->signed_subset) {
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<2, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
+                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+            else hipLaunchKernelGGL((te_crh_small_kernel<2, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
+                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+        } else if (te_is_pedersen(p)) {
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<0, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
+                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+            else hipLaunchKernelGGL((te_crh_small_kernel<0, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
+                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+        } else {
+            hipLaunchKernelGGL((te_crh_small_kernel<1, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs,
+                    data_len, stride, p->group, groups, steps, tail, d_out, n);
+        }
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    }
+    void *xyz = nullptr, *prefix = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (te_is_pedersen(p) && p->signed_subset)
+        hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride,
+                p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
+    else if (te_is_pedersen(p))
+        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride,
+                p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
+    else
+        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->group,
+                groups, steps, tail, (F29Pad*)xyz, n);
+    HIP_TRY(hipGetLastError());
+    // share one inversion among up to 64 messages per lane, but keep `target` lanes busy when n allows.  Measured at 2^20
+    // Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K / 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 /
+    // 3.29 / 3.46 ms for accumulate + finalize (two boxes): one wave per SIMD it is (a compile-time choice since round 3).
+    constexpr size_t target = 65536;
+    size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / target));
+    size_t lanes = (n + chain - 1) / chain;
+    const unsigned fgrid = (unsigned)((lanes + 255) / 256);
+    if (p->kind == AKP_TE_PEDERSEN)
+        hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, s, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, lanes);
+    else
+        hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, s, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, lanes);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
+
+extern "C" int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out, void* stream) {
+    NEED_TE(p, "akp_te_crh_batch_dev");
+    return te_crh_dev(p, d_msgs, n, msg_len, (Fr*)d_out, pick_stream(p->ctx, stream));
+}
+extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_t n, size_t msg_len, uint64_t* out) {
+    NEED_TE(p, "akp_te_crh_batch");
+    if (msg_len * 8 > te_input_bits(p))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
+    if (n == 0) return AKP_OK;
+    if (!out || (!msgs && msg_len)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    const size_t fe = te_fe_per_digest(p);
+    akp_ctx* c = p->ctx;
+    void *dm = nullptr, *dout = nullptr;
+    hipStream_t s = c->stream;
+    // Large batches: chunks of 2^17 messages, double-buffered -- the copy-in of chunk
+    // i + 1 and the copy-out of chunk i - 1 run on their own streams under the kernels of chunk i (a 4x256 Pedersen hash
+    // moves 128 B in and 64 B out for 3 us of kernel time per 1000 hashes: serial copies would double the call).
+    constexpr size_t chunk = (size_t)1 << 17;
+    if (n <= chunk || msg_len == 0) {
+        if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
+        if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dout, s)) return rc;
+        if (msg_len) HIP_TRY(hipMemcpyAsync(dm, msgs, n * msg_len, hipMemcpyHostToDevice, s));
+        if (int32_t rc = te_crh_dev(p, (const uint8_t*)dm, n, msg_len, (Fr*)dout, s)) return rc;
+        HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return AKP_OK;
+    }
+    const size_t dig = fe * sizeof(Fr);
+    if (int32_t rc = ctx_scratch(c, SCR_A, 2 * chunk * msg_len, &dm, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, 2 * chunk * dig, &dout, s)) return rc;
+    for (int i = 0; i < 2; ++i)
+        if (!c->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i)
+        if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
+    hipStream_t cin = c->pipe[0], cout = c->pipe[1];
+    hipEvent_t *in_done = c->chunk_event, *comp_done = c->chunk_event + 2, *out_done = c->chunk_event + 4;
+    HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the copy streams start behind whatever used the scratch last
+    HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));
+    HIP_TRY(hipStreamWaitEvent(cout, c->chunk_event[7], 0));
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    for (size_t ci = 0; ci <= n_chunks; ++ci) {
+        if (ci < n_chunks) {
+            const size_t done = ci * chunk, cnt = std::min(chunk, n - done);
+            const int b = (int)(ci & 1);
+            uint8_t* d_in = (uint8_t*)dm + (size_t)b * chunk * msg_len;
+            Fr* d_o = (Fr*)((char*)dout + (size_t)b * chunk * dig);
+            if (ci >= 2) HIP_TRY(hipStreamWaitEvent(cin, comp_done[b], 0));  // the kernels of chunk ci - 2 have read this half
+            HIP_TRY(hipMemcpyAsync(d_in, msgs + done * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
+            HIP_TRY(hipEventRecord(in_done[b], cin));
+            HIP_TRY(hipStreamWaitEvent(s, in_done[b], 0));
+            if (ci >= 2) HIP_TRY(hipStreamWaitEvent(s, out_done[b], 0));  // the copy-out of chunk ci - 2 has drained this half
+            if (int32_t rc = te_crh_dev(p, d_in, cnt, msg_len, d_o, s)) return rc;
+            HIP_TRY(hipEventRecord(comp_done[b], s));
+        }
+        if (ci >= 1) {  // issued after the copy-in of the next chunk: the copy engines serve the queues in issue order
+            const size_t co = ci - 1, done = co * chunk, cnt = std::min(chunk, n - done);
+            const int b = (int)(co & 1);
+            HIP_TRY(hipStreamWaitEvent(cout, comp_done[b], 0));
+            HIP_TRY(hipMemcpyAsync((char*)out + done * dig, (char*)dout + (size_t)b * chunk * dig, cnt * dig, hipMemcpyDeviceToHost, cout));
+            HIP_TRY(hipEventRecord(out_done[b], cout));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(cin));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize(cout));
+    return AKP_OK;
+}
+extern "C" int32_t akp_te_two_to_one_batch(akp_te_params* p, const uint8_t* left, const uint8_t* right, size_t n, size_t half_len,
+        uint64_t* out) {
+    NEED_TE(p, "akp_te_two_to_one_batch");
+    if (n == 0) return AKP_OK;
+    if (!out || ((!left || !right) && half_len)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    const size_t buflen = ((size_t)p->W * p->N) / 8;  // both schemes size the buffer from pedersen's INPUT_SIZE_BITS
+    const size_t fe = te_fe_per_digest(p);
+    void *dl = nullptr, *dr = nullptr, *dbuf = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * half_len, &dl, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * half_len, &dr, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * buflen, &dbuf, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * fe * sizeof(Fr), &dout, p->ctx->stream)) return rc;
+    hipStream_t s = p->ctx->stream;
+    if (half_len) {
+        HIP_TRY(hipMemcpyAsync(dl, left, n * half_len, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dr, right, n * half_len, hipMemcpyHostToDevice, s));
+    }
+    if (buflen) {
+        const size_t work = n * buflen;
+        hipLaunchKernelGGL(te_concat_bytes_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, (const uint8_t*)dl,
+                (const uint8_t*)dr, half_len, buflen, (uint8_t*)dbuf, n);
+        HIP_TRY(hipGetLastError());
+    }
+    // the buffer past left || right is zero padding: te_crh_dev skips it (Pedersen) or adds its constant (Bowe-Hopwood)
+    if (int32_t rc = te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, (Fr*)dout, s, std::min(buflen, 2 * half_len))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+// one level of compress(): serialise digest pairs into per-node buffers (SCR_D), hash into d_out
+int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_right, size_t n, Fr* d_out, hipStream_t s) {
+    if (n == 0) return AKP_OK;
+    const size_t buflen = ((size_t)p->W * p->N) / 8;
+    const u32 fe = te_fe_per_digest(p);
+    const size_t used = std::min<size_t>(buflen, (size_t)2 * fe * 32);
+    void* dbuf = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * buflen, &dbuf, s)) return rc;
+    const size_t work = n * 2 * fe;
+    hipLaunchKernelGGL(te_serialize_pairs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, d_left, d_right, fe, buflen,
+            (uint8_t*)dbuf, n);
+    HIP_TRY(hipGetLastError());
+    const bool tail_on = env_u32("AKP_BH_ZERO_TAIL", 1, 0, 1) != 0;
+    if (used < buflen && !tail_on) {  // with the zero-tail shortcut the padding bytes are never read
+        const size_t tw = n * (buflen - used);
+        hipLaunchKernelGGL(te_zero_tail_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, s, (uint8_t*)dbuf, buflen, used, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return te_crh_dev(p, (const uint8_t*)dbuf, n, buflen, d_out, s, used);
+}
+extern "C" int32_t akp_te_compress_batch(akp_te_params* p, const uint64_t* left, const uint64_t* right, size_t n, uint64_t* out) {
+    NEED_TE(p, "akp_te_compress_batch");
+    if (n == 0) return AKP_OK;
+    if (!left || !right || !out) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    const size_t fe = te_fe_per_digest(p);
+    void *dl = nullptr, *dr = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_A, n * fe * sizeof(Fr), &dl, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_B, n * fe * sizeof(Fr), &dr, p->ctx->stream)) return rc;
+    if (int32_t rc = ctx_scratch(p->ctx, SCR_C, n * fe * sizeof(Fr), &dout, p->ctx->stream)) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dl, left, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dr, right, n * fe * sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (int32_t rc = te_compress_dev(p, (const Fr*)dl, (const Fr*)dr, n, (Fr*)dout, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * fe * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return AKP_OK;
+}
+

@@ -27,24 +27,10 @@
 // on load / store, except in the full form, which computes on the wire values directly.
 #pragma once
 #include "f29.hpp"
+#include "akp_types.hpp"
 
 namespace akp {
 
-struct PoseidonDims {
-    u32 t, rate, capacity, full_rounds, partial_rounds;
-    u64 alpha;
-};
-
-AKP_HD Fr load_fr_global(const Fr* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    const uint4 lo = q[0], hi = q[1];
-    return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
-}
-AKP_HD void store_fr_global(Fr* p, const Fr& v) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-}
 AKP_HD FP ldc(const F29Pad* p) { return f29_load_pad<AKP_PS>(p); }  // wave-uniform address -> scalar loads
 
 // wire-format parameter array -> internal form (run once per parameter set)

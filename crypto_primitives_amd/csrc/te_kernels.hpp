@@ -28,6 +28,7 @@
 // With fixed bases the table method needs no buckets and no cross-lane reduction (DESIGN.md "Pedersen").
 #pragma once
 #include "f29.hpp"
+#include "akp_types.hpp"
 
 namespace akp {
 
@@ -36,25 +37,6 @@ AKP_F29_CONST(f29_inv2, 0x1fffffddu, 0x00000117u, 0x0e5b08c0u, 0x05272e00u, 0x17
 struct Niels {
     FS ypx, ymx, dxy;  // (y + x)/2, (y - x)/2, d*x*y   -- normalised
 };
-// Table entry: the 27 limbs back to back in ONE 128-byte cache line (w[0..8] = (y+x)/2, w[9..17] = (y-x)/2, w[18..26] = dxy,
-// 5 dwords of padding): a lane's entry is two 64-byte L2 sectors and seven 16-byte loads.  (Round 1-2 layout: three
-// 48-byte padded elements = 144 B, 3.3 sectors and twelve loads per entry; the gather was 19 % of the Pedersen kernel.)
-struct alignas(128) NielsPad {
-    u32 w[32];
-};
-// Packed alternative (round 3 A/B, `make packed96`): the three values as CANONICAL 256-bit integers (8 dwords each, no
-// padding) = 96 bytes.  The 16-bit signed Pedersen table shrinks from 268 MB to 201 MB -- inside the 256 MB Infinity Cache --
-// and an entry is six 16-byte loads instead of seven, at the price of re-limbing 3 x 256 bits into 3 x 9 limbs of 29 bits in
-// registers (~50 VALU instructions per step) and of entries that straddle two 128-byte lines.  Canonical values are
-// non-negative with limbs < 2^29: they satisfy every operand bound the 128-byte form does.
-struct alignas(32) Niels96 {
-    u32 w[24];
-};
-#if defined(AKP_TE_PACKED96)
-typedef Niels96 TeEntry;
-#else
-typedef NielsPad TeEntry;
-#endif
 struct Ext {
     FS X, Y, Z, T;  // x = X/Z, y = Y/Z, T = XY/Z  -- normalised (product outputs)
 };

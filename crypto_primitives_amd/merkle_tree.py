@@ -480,13 +480,6 @@ class GpuMerkleTree:
         d = config.default_leaf_digest()
         return cls.new_with_leaf_digest(config, leaf_hash_param, two_to_one_hash_param, np.stack([d] * (1 << (height - 1))))
 
-    def last_phases(self):
-        """phase breakdown of the last build_sharded call (akp_multi_last_phases), milliseconds, maximum over the devices"""
-        import ctypes as C
-        ms = (C.c_double * 5)()
-        check(lib.akp_multi_last_phases(self._h, ms))
-        return {"copy_in_and_subtree_ms": ms[0], "allgather_ms": ms[1], "top_levels_ms": ms[2], "copy_out_ms": ms[3], "whole_call_ms": ms[4]}
-
     def close(self):
         if getattr(self, "_h", None):
             lib.akp_merkle_tree_destroy(self._h)
@@ -615,6 +608,13 @@ class MultiGpu:
         check(fn(self._h, la, ta, x.ctypes.data if x.size else None, n, k, ln.ctypes.data if want_nodes else None,
                  nl.ctypes.data if want_nodes else None, root.ctypes.data))
         return ln, nl, root
+
+    def last_phases(self):
+        """phase breakdown of the last build_sharded call (akp_multi_last_phases), milliseconds, maximum over the devices"""
+        import ctypes as C
+        ms = (C.c_double * 5)()
+        check(lib.akp_multi_last_phases(self._h, ms))
+        return {"copy_in_and_subtree_ms": ms[0], "allgather_ms": ms[1], "top_levels_ms": ms[2], "copy_out_ms": ms[3], "whole_call_ms": ms[4]}
 
     def close(self):
         if getattr(self, "_h", None):

@@ -33,7 +33,7 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
     std::vector<F29Pad> ark, mds, mpre, sparse, sbox0, mpre_w, sparse_w, ark_f, fmats_f, sparse_f, sbox0_f;
     bool has_lane1 = false, has_full = false;
     PoseidonConsts c;     // what the wave-per-lane kernels get (lane-0 form)
-    PoseidonConsts cfile; // what the one-lane-per-item kernels get: full form, else lane-1 form, else c (as capi.hip does)
+    PoseidonConsts cfile; // what the one-lane-per-item kernels get: full form, else lane-1 form, else c (as capi_poseidon.hip does)
     PoseidonConsts creg;  // == cfile (kept for the t = 3 register-path call sites)
     T3Host(uint32_t t, uint32_t rf, uint32_t rp, uint64_t alpha, const Fr* a, const Fr* m, bool sparse_form) {
         std::vector<Fr> av(a, a + (size_t)(rf + rp) * t), mv(m, m + (size_t)t * t);
@@ -52,7 +52,7 @@ struct T3Host {  // constants in internal form for any t (name kept from the t =
         if (o.ok) { ark = to29(o.ark_mod.data(), o.ark_mod.size()); mpre = to29(o.mpre.data(), o.mpre.size()); sparse = to29(o.sparse.data(), o.sparse.size());
                     c = PoseidonConsts{ark.data(), mds.data(), mpre.data(), sparse.data(), nullptr, o.scaled ? 1u : 0u}; }
         else { ark = to29(av.data(), av.size()); c = PoseidonConsts{ark.data(), mds.data(), nullptr, nullptr, nullptr, 0u}; }
-        if (rf >= 2) {  // as capi.hip does: from the round keys the kernels use
+        if (rf >= 2) {  // as capi_poseidon.hip does: from the round keys the kernels use
             const std::vector<Fr> s0 = poseidon_sbox0(o.ok ? o.ark_mod : av, t, alpha);
             sbox0 = to29(s0.data(), s0.size());
             c.sbox0 = sbox0.data();
@@ -159,7 +159,7 @@ void hh_poseidon_permute(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate
             states[i * 3] = f29_to_wire(s0); states[i * 3 + 1] = f29_to_wire(s1); states[i * 3 + 2] = f29_to_wire(s2);
             continue;
         }
-        // t = 4, 5 with the full / lane-1 form: the register-resident path (as capi.hip routes large batches)
+        // t = 4, 5 with the full / lane-1 form: the register-resident path (as capi_poseidon.hip routes large batches)
         if ((D.t >= 4 && D.t <= 9) && force_generic == 0 && (th->cfile.scaled == 3u || th->cfile.scaled == 2u) && th->cfile.sparse) {
             auto run = [&](auto tag, auto ff) {
                 constexpr u32 T = decltype(tag)::value;
@@ -211,7 +211,7 @@ void hh_poseidon_crh(uint32_t rf, uint32_t rp, uint64_t alpha, uint32_t rate, ui
     }
     delete th;
 }
-// LUT construction exactly as capi.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
+// LUT construction exactly as capi_te.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
 // kind 1 -> Bowe-Hopwood single table lut1 [n_gen][4] and, when group > 1, group table lut [n_gen/G][2^(3G-1)]
 // (hh_te_crh then takes D = group for kind 1).
 void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t D, uint32_t group, TeEntry* lut, TeEntry* lut1) {

@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
     assert cpa.lib.akp_abi_version() == cpa._lib.AKP_ABI_VERSION == 2
 
 
+def test_library_exports_nothing_but_the_header():
+    """the library is four translation units since round 3; what crosses between them (fail, ctx_scratch, launch_crh,
+    te_crh_dev ...) has hidden visibility: the dynamic symbol table holds the header's entry points and nothing else"""
+    import subprocess
+    import crypto_primitives_amd as cpa
+    out = subprocess.run(["nm", "-D", "--defined-only", cpa.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in ("T", "W"))
+    assert exported == _header_symbols(), sorted(set(exported) ^ set(_header_symbols()))
+
+
 def test_product_never_imports_oracle():
     """the product package must not reference oracle/ (a CPU fallback would void parity claims)"""
     pkg = os.path.join(ROOT, "crypto_primitives_amd")
