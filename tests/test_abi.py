@@ -35,7 +35,7 @@ def test_library_exports_nothing_but_the_header():
     import subprocess
     import crypto_primitives_amd as cpa
     out = subprocess.run(["nm", "-D", "--defined-only", cpa.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in ("T", "W"))
+    exported = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T")  # strong functions (weak = inline C++ library code)
     assert exported == _header_symbols(), sorted(set(exported) ^ set(_header_symbols()))
 
 
