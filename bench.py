@@ -51,6 +51,24 @@ MODMUL_PER_PERM_REF = 626        # reference-shaped count
 PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49579.75 + 98304.0) * 1024 / (1 << 20)
 PMC_TRAFFIC_SOURCE = "profiles/r02_s26/pmc_counters_poseidon.txt"
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
+# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r03_s4/pmc_te_line128.txt: rocprofv3 --pmc, one counter per pass;
+# NOT measured in this run).  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B): with it the
+# accumulate kernels fetch ~1.07 x the table bytes they gather -- every table line comes from the Infinity Cache / HBM, the L2 only
+# serves the second half of a line (TCC_HIT = TCC_MISS: two 64-byte requests per 128-byte entry, the first misses, the second hits).
+PMC_TE = {"source": "profiles/r03_s4/pmc_te_line128.txt",
+          "pedersen_128B": {"fetch_kb": 4520651 + 164359, "write_kb": 147466 + 114688, "valu_instr": 1531920384 + 47370240},  # accumulate<2> + finalize<0>
+          "bh_32B": {"fetch_kb": 957788 + 163841, "write_kb": 147473 + 81920, "valu_instr": 421838848 + 38817792},          # accumulate<1> + finalize<1>
+          "bh_70B": {"fetch_kb": 2267504 + 163841, "write_kb": 147473 + 81920, "valu_instr": 936509440 + 38817792, "steps": 39}}
+MADS_PER_PRODUCT = 153           # multiply-adds of one field product (81 limb products + 72 reduction products)
+
+
+def te_counters(key, hashes, steps_scale=1.0):
+    """bytes / instructions for `hashes` hashes from the per-2^20 PMC figures (gather-proportional parts scaled by steps_scale)"""
+    c = PMC_TE[key]
+    per = hashes / float(1 << 20)
+    return {"traffic": (2.0 * c["fetch_kb"] * steps_scale + c["write_kb"]) * 1024.0 * per, "valu_instr": c["valu_instr"] * steps_scale * per}
+
+
 MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
 # (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:
 # 55 S-boxes; full-round rows: 20 with unit diagonal (dot2), 4 dot3; partial rounds: dot3 + one product (lane-1 form), the
@@ -398,9 +416,18 @@ def main():
                     "roofline": {"bound": "hbm", "kernels": "te_accumulate_kernel<2> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
                                  "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": 192.0 * npd / kavg / 1e9 / HBM_PEAK_GBS,
-                                 "table_bytes_gathered_per_hash": psteps * 128, "gather_over_algorithmic": psteps * 128 / 192.0,
+                                 "traffic": te_counters("pedersen_128B", npd)["traffic"],
+                                 "traffic_over_algorithmic": te_counters("pedersen_128B", npd)["traffic"] / (192.0 * npd),
+                                 "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_kernel<2> + te_finalize_kernel<0>; "
+                                                        "NOT measured in this run)",
+                                 "table_bytes_gathered_per_hash": psteps * int(lib.akp_te_entry_bytes()),
+                                 "gather_over_algorithmic": psteps * int(lib.akp_te_entry_bytes()) / 192.0,
                                  "table": pinfo,
                                  "valu": {"table_steps_per_hash": psteps, "field_products_per_step": 7,
+                                          "valu_instructions_per_hash": te_counters("pedersen_128B", 1)["valu_instr"],
+                                          "v_mad_per_s": (psteps * 7 + 6) * MADS_PER_PRODUCT * npd / kavg,
+                                          "frac_of_mad_issue_peak": (psteps * 7 + 6) * MADS_PER_PRODUCT * npd / kavg / (VALU_PEAK_WAVE_INSTR * 64),
+                                          "v_mad_note": "7 products per table step + ~6 per hash in the shared-inversion pass, 153 multiply-adds each",
                                           "note": "VALU-issue bound like the permutation: one mixed addition of 7 products per table step "
                                                   "(signed-subset table); one 128-byte line per entry, gathered through L2 / Infinity Cache / HBM "
                                                   "(counters: profiles/r02_s26/pmc_counters_te.txt; gather share: profiles/r02_s19/te_gather_probe.txt, r02_s24)"}}}
@@ -457,11 +484,20 @@ def main():
                                   "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                   "table": B.handle(ctx).info(32),
+                                  "traffic": te_counters("bh_32B", per)["traffic"] + te_counters("bh_70B", per - 1, (B.handle(ctx).info(64)["steps"] + 1) / 39.0)["traffic"],
+                                  "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
+                                                         "for the leaf level and 2^20 x 70 B scaled to the inner nodes' table steps; levels of <= 2^14 nodes run the split kernel; "
+                                                         "NOT measured in this run)",
                                   "valu": {"table_steps_per_leaf_hash": B.handle(ctx).info(32)["steps"],
                                            "table_steps_per_inner_node": B.handle(ctx).info(64)["steps"] + 1,
                                            "inner_node_note": "64 bytes of digests in a 70-byte buffer: the table steps of the 64 data bytes + one constant "
                                                               "entry for the zero-padded tail (a zero chunk adds +g); %d steps if the padding is walked" % B.handle(ctx).info(70)["steps"],
                                            "field_products_per_step": 7}}}
+        rfb = bh_merkle["roofline"]
+        rfb["traffic_over_algorithmic"] = rfb["traffic"] / (160.0 * per)
+        bh_mads = (per * (rfb["valu"]["table_steps_per_leaf_hash"] * 7 + 6) + (per - 1) * (rfb["valu"]["table_steps_per_inner_node"] * 7 + 6)) * MADS_PER_PRODUCT
+        rfb["valu"]["v_mad_per_s"] = bh_mads / (dev_ms / 1e3)
+        rfb["valu"]["frac_of_mad_issue_peak"] = bh_mads / (dev_ms / 1e3) / (VALU_PEAK_WAVE_INSTR * 64)
         if rank == 0:
             from oracle import cref
             cur = cref.CurveParams(63, 9, gens)
