@@ -50,6 +50,14 @@ def _padd(p, q):  # projective (X:Y:Z) unified addition, a = -1 (add-2008-bbjlp)
     return (X3, Y3, F * G % Q)
 
 
+SUBGROUP_ORDER = 6554484396890773809930967563523245729705921265872317281365359162392183254199  # r: prime order of the Jubjub subgroup
+
+
+def _te_mul(pt, k):
+    """k * pt for an affine point (x, y) -> affine (x, y); the identity is (0, 1)"""
+    return _affine(_smul(pt, k))
+
+
 def _affine(p):
     zi = pow(p[2], -1, Q)
     return (p[0] * zi % Q, p[1] * zi % Q)

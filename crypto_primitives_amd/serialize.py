@@ -31,23 +31,38 @@ def fr_bytes(wire) -> bytes:
 
 
 def fr_from_bytes(b: bytes, n: int) -> np.ndarray:
+    if len(b) < 32 * n:
+        raise ValueError("truncated input: %d field elements need %d bytes, got %d" % (n, 32 * n, len(b)))
     c = np.frombuffer(b[: 32 * n], dtype="<u8").reshape(n, 4).astype(np.uint64)
-    return field.to_mont(c)
+    return field.to_mont(c)  # raises on a non-canonical element (>= p), as ark-serialize's Fp deserialisation does
 
 
 class _Reader:
+    """bounds-checked cursor: a truncated or over-long length prefix raises ValueError (ark-serialize returns
+    SerializationError::InvalidData / an io error there), never an IndexError or a silent short read"""
+
     def __init__(self, b):
         self.b, self.o = memoryview(b), 0
 
+    def take(self, nbytes):
+        if nbytes < 0 or self.o + nbytes > len(self.b):
+            raise ValueError("truncated input: %d bytes wanted at offset %d, %d left" % (nbytes, self.o, len(self.b) - self.o))
+        out = bytes(self.b[self.o: self.o + nbytes])
+        self.o += nbytes
+        return out
+
     def u64(self):
-        v = struct.unpack_from("<Q", self.b, self.o)[0]
-        self.o += 8
-        return v
+        return struct.unpack("<Q", self.take(8))[0]
+
+    def count(self, item_bytes):
+        """a Vec length prefix, checked against what is left so that a corrupt length cannot ask for gigabytes"""
+        n = self.u64()
+        if n * item_bytes > len(self.b) - self.o:
+            raise ValueError("length prefix %d does not fit the %d bytes left" % (n, len(self.b) - self.o))
+        return n
 
     def fr(self, n):
-        out = fr_from_bytes(bytes(self.b[self.o: self.o + 32 * n]), n)
-        self.o += 32 * n
-        return out
+        return fr_from_bytes(self.take(32 * n), n)
 
 
 def serialize_poseidon_config(cfg) -> bytes:
@@ -66,8 +81,8 @@ def deserialize_poseidon_config(b: bytes):
     from .sponge.poseidon import PoseidonConfig
     r = _Reader(b)
     rf, rp, alpha = r.u64(), r.u64(), r.u64()
-    ark = [r.fr(r.u64()) for _ in range(r.u64())]
-    mds = [r.fr(r.u64()) for _ in range(r.u64())]
+    ark = [r.fr(r.count(32)) for _ in range(r.count(8))]
+    mds = [r.fr(r.count(32)) for _ in range(r.count(8))]
     rate, cap = r.u64(), r.u64()
     return PoseidonConfig(rf, rp, alpha, np.stack(ark), np.stack(mds), rate, cap)
 
@@ -86,10 +101,33 @@ def te_points_bytes(points_wire, compress=False) -> bytes:
     return bytes(out)
 
 
-def te_points_from_bytes(b: bytes, n: int, compress=False) -> np.ndarray:
-    """inverse of te_points_bytes -> [n, 2, 4] wire format; raises ValueError on a y with no point on the curve"""
+def _validate_points(flat_xy):
+    """ark-serialize's default `Validate::Yes` for twisted-Edwards affine points (flat [x0, y0, x1, y1, ...] canonical ints): on
+    the curve -x^2 + y^2 = 1 + d x^2 y^2 and in the prime-order subgroup (r * P = O).  Off-curve or small-order generators would
+    otherwise go straight into the GPU tables."""
+    from .params import _D, SUBGROUP_ORDER, _te_mul
+    q = field.MODULUS
+    for i in range(0, len(flat_xy), 2):
+        x, y = int(flat_xy[i]), int(flat_xy[i + 1])
+        x2, y2 = x * x % q, y * y % q
+        if (y2 - x2 - 1 - _D * x2 % q * y2) % q:
+            raise ValueError("point %d is not on the curve" % (i // 2))
+        if _te_mul((x, y), SUBGROUP_ORDER) != (0, 1):
+            raise ValueError("point %d is not in the prime-order subgroup" % (i // 2))
+
+
+def te_points_from_bytes(b: bytes, n: int, compress=False, validate=True) -> np.ndarray:
+    """inverse of te_points_bytes -> [n, 2, 4] wire format.  Raises ValueError on truncated input, on a compressed y with no
+    point on the curve and -- with validate (the default, ark-serialize's `Validate::Yes`) -- on a point that is not on the
+    curve or not in the prime-order subgroup.  validate=False is `deserialize_*_unchecked`."""
+    per = 32 if compress else 64
+    if len(b) < per * n:
+        raise ValueError("truncated input: %d points need %d bytes, got %d" % (n, per * n, len(b)))
     if not compress:
-        return fr_from_bytes(b, 2 * n).reshape(n, 2, 4)
+        pts = fr_from_bytes(b, 2 * n).reshape(n, 2, 4)
+        if validate:
+            _validate_points(field.to_ints(pts.reshape(-1, 4)))
+        return pts
     from .params import _sqrt, _D
     q = field.MODULUS
     vals = []
@@ -107,6 +145,8 @@ def te_points_from_bytes(b: bytes, n: int, compress=False) -> np.ndarray:
         if (x > q - x) != neg:
             x = (q - x) % q
         vals += [x, y]
+    if validate:
+        _validate_points(vals)
     return field.fr(vals).reshape(n, 2, 4)
 
 
@@ -118,14 +158,15 @@ def serialize_te_parameters(params, compress=False) -> bytes:
     return b"".join(out)
 
 
-def deserialize_te_parameters(b: bytes, cls, compress=False):
+def deserialize_te_parameters(b: bytes, cls, compress=False, validate=True):
     r = _Reader(b)
     rows = []
     per = 32 if compress else 64
-    for _ in range(r.u64()):
-        w = r.u64()
-        rows.append(te_points_from_bytes(bytes(r.b[r.o: r.o + per * w]), w, compress))
-        r.o += per * w
+    for _ in range(r.count(8)):
+        w = r.count(per)
+        rows.append(te_points_from_bytes(r.take(per * w), w, compress, validate))
+    if not rows or any(len(x) != len(rows[0]) for x in rows):
+        raise ValueError("generators must be a non-empty rectangular Vec<Vec<_>>")
     return cls(np.stack(rows))
 
 
@@ -138,10 +179,7 @@ def _digest_bytes(d, compress=False) -> bytes:
 
 def _read_digest(r, config, compress):
     if config.digest_shape == (2, 4):
-        per = 32 if compress else 64
-        d = te_points_from_bytes(bytes(r.b[r.o: r.o + per]), 1, compress)[0]
-        r.o += per
-        return d
+        return te_points_from_bytes(r.take(32 if compress else 64), 1, compress)[0]
     return r.fr(1).reshape(config.digest_shape)
 
 
@@ -157,7 +195,7 @@ def deserialize_path(b: bytes, config, compress=False):
     from .merkle_tree import Path
     r = _Reader(b)
     sib = _read_digest(r, config, compress)
-    auth = [_read_digest(r, config, compress) for _ in range(r.u64())]
+    auth = [_read_digest(r, config, compress) for _ in range(r.count(32))]
     return Path(config, sib, auth, r.u64())
 
 
@@ -175,8 +213,8 @@ def serialize_multi_path(mp, compress=False) -> bytes:
 def deserialize_multi_path(b: bytes, config, compress=False):
     from .merkle_tree import MultiPath
     r = _Reader(b)
-    sibs = [_read_digest(r, config, compress) for _ in range(r.u64())]
-    pre = [r.u64() for _ in range(r.u64())]
-    suf = [[_read_digest(r, config, compress) for _ in range(r.u64())] for _ in range(r.u64())]
-    idx = [r.u64() for _ in range(r.u64())]
+    sibs = [_read_digest(r, config, compress) for _ in range(r.count(32))]
+    pre = [r.u64() for _ in range(r.count(8))]
+    suf = [[_read_digest(r, config, compress) for _ in range(r.count(32))] for _ in range(r.count(8))]
+    idx = [r.u64() for _ in range(r.count(8))]
     return MultiPath(config, sibs, pre, suf, idx)

@@ -1,6 +1,6 @@
 //! Poseidon over BLS12-381 Fr on the GPU: `CRHScheme`, `TwoToOneCRHScheme` (`crh/poseidon/mod.rs:14-79`) and the
 //! duplex sponge (`sponge/poseidon/mod.rs:47-370`).
-use crate::runtime::{check, fingerprint, flatten, fr_from_limbs, with_runtime, words, words_mut};
+use crate::runtime::{check, flatten, fr_from_limbs, with_runtime, words, words_mut};
 use crate::{ffi, Error, Fr};
 use ark_crypto_primitives::crh::{CRHScheme, TwoToOneCRHScheme};
 use ark_crypto_primitives::sponge::poseidon::PoseidonConfig;
@@ -10,24 +10,27 @@ use ark_std::{borrow::Borrow, rand::Rng, vec::Vec};
 
 /// device handle for `cfg` on the calling thread's context (created once per distinct parameter set)
 pub(crate) fn handle(cfg: &PoseidonConfig<Fr>) -> Result<*mut ffi::AkpPoseidon, Error> {
-    let seed = (cfg.full_rounds as u64) << 48 | (cfg.partial_rounds as u64) << 32 | (cfg.rate as u64) << 16 | cfg.capacity as u64 ^ cfg.alpha << 8;
-    let key = fingerprint(seed, cfg.ark.iter().flatten().chain(cfg.mds.iter().flatten()));
+    // scalar parameters in the tag, every round key and matrix entry in the key: a cache hit compares all of them
+    let tag = (cfg.full_rounds as u64) << 48 ^ (cfg.partial_rounds as u64) << 32 ^ (cfg.rate as u64) << 16 ^ (cfg.capacity as u64) ^ cfg.alpha.rotate_left(24);
+    // PoseidonConfig::new's shape asserts (sponge/poseidon/mod.rs:191-217) are repeated by the library
+    let (ark, mds) = (flatten(&cfg.ark), flatten(&cfg.mds));
+    let mut key = Vec::with_capacity(ark.len() + mds.len() + 1);
+    key.push(Fr::from(cfg.alpha)); // the full alpha (the tag only carries a mix of it)
+    key.extend_from_slice(&ark);
+    key.extend_from_slice(&mds);
     with_runtime(|rt| {
-        if let Some(h) = rt.poseidon.get(&key) {
-            return Ok(*h);
-        }
-        // PoseidonConfig::new's shape asserts (sponge/poseidon/mod.rs:191-217) are repeated by the library
-        let (ark, mds) = (flatten(&cfg.ark), flatten(&cfg.mds));
-        let mut h = core::ptr::null_mut();
-        check(
-            unsafe {
-                ffi::akp_poseidon_params_create(rt.ctx, cfg.full_rounds as u32, cfg.partial_rounds as u32, cfg.alpha, cfg.rate as u32,
-                                                cfg.capacity as u32, words(&ark), words(&mds), &mut h)
-            },
-            0,
-        )?;
-        rt.poseidon.insert(key, h);
-        Ok(h)
+        let ctx = rt.ctx.0;
+        rt.poseidon.get_or_create(tag, &key, || {
+            let mut h = core::ptr::null_mut();
+            check(
+                unsafe {
+                    ffi::akp_poseidon_params_create(ctx, cfg.full_rounds as u32, cfg.partial_rounds as u32, cfg.alpha, cfg.rate as u32,
+                                                    cfg.capacity as u32, words(&ark), words(&mds), &mut h)
+                },
+                0,
+            )?;
+            Ok(h)
+        })
     })
 }
 

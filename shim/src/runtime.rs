@@ -2,7 +2,7 @@
 use crate::ffi;
 use crate::{Error, Fr};
 use ark_ff::{BigInt, PrimeField};
-use ark_std::{cell::RefCell, collections::BTreeMap, string::String, vec::Vec};
+use ark_std::{cell::RefCell, string::String, vec::Vec};
 use core::ffi::CStr;
 
 /// `Fr` must be 4 x u64 Montgomery limbs (`Fp(BigInt([u64; 4]), PhantomData)`), byte-identical to the ABI's wire
@@ -59,12 +59,69 @@ pub fn check(rc: i32, len: usize) -> Result<(), Error> {
     }
 }
 
-/// One context per OS thread + the parameter handles created on it, keyed by a fingerprint of the parameter contents
-/// (the traits hand us `&Parameters` on every call and a handle owns device tables worth tens of MB).
+/// Handle cache of one thread: the traits hand us `&Parameters` on every call and a handle owns device tables worth up to
+/// hundreds of MB, so handles are kept per distinct parameter set.  An entry stores the FULL key material next to the
+/// handle: the 64-bit fingerprint only narrows the search, a hit needs `tag` and every field element to be equal -- a
+/// fingerprint collision (trivial to construct for attacker-supplied or deserialised parameters) can therefore never hand out
+/// another set's tables.  Bounded: beyond `cap` entries the least recently used handle is destroyed (its device tables with
+/// it), so a thread that walks through many parameter sets does not pin their tables until it exits.
+pub struct HandleCache<H: Copy> {
+    entries: Vec<CacheEntry<H>>,
+    tick: u64,
+    cap: usize,
+    destroy: unsafe extern "C" fn(H),
+}
+struct CacheEntry<H> {
+    fp: u64,
+    tag: u64,
+    key: Vec<Fr>,
+    handle: H,
+    last_use: u64,
+}
+impl<H: Copy> HandleCache<H> {
+    pub fn new(cap: usize, destroy: unsafe extern "C" fn(H)) -> Self {
+        Self { entries: Vec::new(), tick: 0, cap, destroy }
+    }
+    /// the handle of (`tag`, `key`), created with `create` on a miss; `tag` carries the scalar parameters (dimensions, kind)
+    pub fn get_or_create(&mut self, tag: u64, key: &[Fr], create: impl FnOnce() -> Result<H, Error>) -> Result<H, Error> {
+        self.tick += 1;
+        let fp = fingerprint(tag, key.iter());
+        if let Some(e) = self.entries.iter_mut().find(|e| e.fp == fp && e.tag == tag && e.key.as_slice() == key) {
+            e.last_use = self.tick;
+            return Ok(e.handle);
+        }
+        let handle = create()?;
+        if self.entries.len() >= self.cap {
+            let (i, _) = self.entries.iter().enumerate().min_by_key(|(_, e)| e.last_use).expect("cap > 0");
+            let old = self.entries.swap_remove(i);
+            unsafe { (self.destroy)(old.handle) };
+        }
+        self.entries.push(CacheEntry { fp, tag, key: key.to_vec(), handle, last_use: self.tick });
+        Ok(handle)
+    }
+}
+impl<H: Copy> Drop for HandleCache<H> {
+    fn drop(&mut self) {
+        for e in self.entries.drain(..) {
+            unsafe { (self.destroy)(e.handle) };
+        }
+    }
+}
+
+/// One context per OS thread + the parameter handles created on it.  A handle returned by a cache stays valid until `cap`
+/// OTHER parameter sets have been used on this thread; the trait implementations use it within the call that asked for it.
 pub struct ThreadRuntime {
-    pub ctx: *mut ffi::AkpCtx,
-    pub poseidon: BTreeMap<u64, *mut ffi::AkpPoseidon>,
-    pub te: BTreeMap<(i32, u64), *mut ffi::AkpTeParams>,
+    // field order = drop order: the handle caches go before the context they were created on
+    pub poseidon: HandleCache<*mut ffi::AkpPoseidon>,
+    pub te: HandleCache<*mut ffi::AkpTeParams>,
+    pub ctx: CtxGuard,
+}
+/// owns the thread's `akp_ctx`
+pub struct CtxGuard(pub *mut ffi::AkpCtx);
+impl Drop for CtxGuard {
+    fn drop(&mut self) {
+        unsafe { ffi::akp_ctx_destroy(self.0) };
+    }
 }
 impl ThreadRuntime {
     fn new() -> Self {
@@ -73,20 +130,8 @@ impl ThreadRuntime {
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { ffi::akp_ctx_create(dev, &mut ctx) };
         assert_eq!(rc, ffi::AKP_OK, "akp_ctx_create({dev}) failed: there is no CPU fallback");
-        Self { ctx, poseidon: BTreeMap::new(), te: BTreeMap::new() }
-    }
-}
-impl Drop for ThreadRuntime {
-    fn drop(&mut self) {
-        unsafe {
-            for (_, h) in self.poseidon.iter() {
-                ffi::akp_poseidon_params_destroy(*h);
-            }
-            for (_, h) in self.te.iter() {
-                ffi::akp_te_params_destroy(*h);
-            }
-            ffi::akp_ctx_destroy(self.ctx);
-        }
+        // Poseidon constants are a few KB per set; a curve-hash set owns up to ~270 MB of tables
+        Self { poseidon: HandleCache::new(64, ffi::akp_poseidon_params_destroy), te: HandleCache::new(4, ffi::akp_te_params_destroy), ctx: CtxGuard(ctx) }
     }
 }
 thread_local! {

@@ -1,7 +1,7 @@
 //! Pedersen and Bowe-Hopwood CRH over Jubjub (`ark_ed_on_bls12_381`) on the GPU
 //! (`crh/pedersen/mod.rs:23-209`, `crh/bowe_hopwood/mod.rs:31-240`) and the Pedersen hashes composed with `TECompressor`
 //! (`crh/injective_map/mod.rs:16-108`).
-use crate::runtime::{check, fingerprint, fr_from_limbs, with_runtime, words};
+use crate::runtime::{check, fr_from_limbs, with_runtime, words};
 use crate::{ffi, Error, Fr};
 use ark_crypto_primitives::crh::{bowe_hopwood, pedersen, CRHScheme, TwoToOneCRHScheme};
 use ark_ec::CurveGroup;
@@ -19,15 +19,15 @@ fn te_handle(kind: i32, gens: &[Vec<EdwardsProjective>]) -> Result<*mut ffi::Akp
     let window_size = gens.first().map_or(0, |r| r.len());
     assert!(gens.iter().all(|r| r.len() == window_size), "ragged generator table");
     let xy = affine_words(gens);
-    let key = (kind, fingerprint(((window_size as u64) << 32) | num_windows as u64, xy.iter()));
+    // kind and window shape in the tag, every generator coordinate in the key (compared in full on a hit)
+    let tag = (kind as u64) << 56 ^ (window_size as u64) << 32 ^ num_windows as u64;
     with_runtime(|rt| {
-        if let Some(h) = rt.te.get(&key) {
-            return Ok(*h);
-        }
-        let mut h = core::ptr::null_mut();
-        check(unsafe { ffi::akp_te_params_create(rt.ctx, kind, window_size as u32, num_windows as u32, words(&xy), &mut h) }, 0)?;
-        rt.te.insert(key, h);
-        Ok(h)
+        let ctx = rt.ctx.0;
+        rt.te.get_or_create(tag, &xy, || {
+            let mut h = core::ptr::null_mut();
+            check(unsafe { ffi::akp_te_params_create(ctx, kind, window_size as u32, num_windows as u32, words(&xy), &mut h) }, 0)?;
+            Ok(h)
+        })
     })
 }
 /// n equal-length messages -> digests as wire words (2 Fr per Pedersen digest, 1 per Bowe-Hopwood digest)

@@ -55,3 +55,34 @@ def test_parameters_paths_round_trip_both_modes():
     # field digests are identical in the two modes
     fpath = cpa.Path(cpa.PoseidonFieldConfig, g[0, 0, 0], [g[0, 1, 0]], 1)
     assert ser.serialize_path(fpath, True) == ser.serialize_path(fpath, False)
+
+
+def test_deserialisation_rejects_truncated_and_invalid_input():
+    """length prefixes and payloads are bounds-checked (ValueError, never IndexError / a silent short read), and
+    twisted-Edwards points are validated like ark-serialize's default `Validate::Yes`: on the curve and in the prime-order
+    subgroup -- off-curve generators must not reach the GPU tables.  validate=False is the `_unchecked` form."""
+    import pytest
+    from crypto_primitives_amd import serialize as S, params, field
+    from crypto_primitives_amd.crh import pedersen
+    P = pedersen.Parameters(params.pedersen_generators(7, 3, 2))
+    for compress in (False, True):
+        b = S.serialize_te_parameters(P, compress)
+        assert np.array_equal(S.deserialize_te_parameters(b, pedersen.Parameters, compress).generators, P.generators)
+        for cut in (0, 1, 7, 9, 20, len(b) - 1):
+            with pytest.raises(ValueError):
+                S.deserialize_te_parameters(b[:cut], pedersen.Parameters, compress)
+        huge = (1 << 40).to_bytes(8, "little") + b[8:]  # a length prefix far beyond the payload
+        with pytest.raises(ValueError):
+            S.deserialize_te_parameters(huge, pedersen.Parameters, compress)
+    bad = bytearray(S.serialize_te_parameters(P, False))
+    bad[16] ^= 1  # x of the first generator: no longer on the curve
+    with pytest.raises(ValueError, match="not on the curve"):
+        S.deserialize_te_parameters(bytes(bad), pedersen.Parameters, False)
+    assert S.deserialize_te_parameters(bytes(bad), pedersen.Parameters, False, validate=False).generators.shape == P.generators.shape
+    order2 = S.te_points_bytes(field.fr([0, field.MODULUS - 1]).reshape(1, 2, 4))  # (0, -1): on the curve, order 2
+    with pytest.raises(ValueError, match="prime-order subgroup"):
+        S.te_points_from_bytes(order2, 1)
+    cfg_b = S.serialize_poseidon_config(__import__("crypto_primitives_amd").get_default_poseidon_parameters(2, False))
+    for cut in (5, 30, len(cfg_b) - 3):
+        with pytest.raises(ValueError):
+            S.deserialize_poseidon_config(cfg_b[:cut])
