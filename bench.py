@@ -529,6 +529,9 @@ def main():
             proofs[name] = bench_proofs.run(name, args.proofs_log2, min(args.proofs_m_log2, args.proofs_log2), local_rank)
             if not proofs[name]["all_parity_bit_exact"]:
                 raise SystemExit("proofs leg (%s): a parity / control check failed: %s" % (name, json.dumps(proofs[name])))
+        proofs["sponge"] = bench_proofs.run_sponge(args.proofs_log2, local_rank)  # 8(f) rank 4: device-resident duplex sponges
+        if not proofs["sponge"]["sampled_parity_bit_exact"]:
+            raise SystemExit("sponge leg: sampled squeezes differ from the oracle")
         proofs["profiles"] = "profiles/r03_s*/proofs_* (rocprofv3 --kernel-trace --stats of `python tools/bench_proofs.py`)"
 
     # ================= the headline: W warm-up + K timed steps of the 2^20-state permutation ==========================

@@ -81,6 +81,8 @@ def _load():
         "akp_sponge_destroy": (None, [vp]),
         "akp_sponge_absorb": (i32, [vp, u64p, sz]),
         "akp_sponge_squeeze": (i32, [vp, u64p, sz]),
+        "akp_sponge_absorb_dev": (i32, [vp, u64p, sz, vp]),
+        "akp_sponge_squeeze_dev": (i32, [vp, u64p, sz, vp]),
         "akp_sponge_get_state": (i32, [vp, u64p, C.POINTER(i32), C.POINTER(u32)]),
         "akp_sponge_set_state": (i32, [vp, u64p, i32, u32]),
         "akp_te_params_create": (i32, [vp, i32, u32, u32, u64p, pp]),

@@ -534,11 +534,10 @@ static int32_t sponge_io(akp_sponge* s, size_t elems) {
     }
     return AKP_OK;
 }
-static int32_t sponge_permute(akp_sponge* s) { return launch_permute(s->p, s->d_state, s->batch, s->p->ctx->stream); }
+static int32_t sponge_permute(akp_sponge* s, hipStream_t st) { return launch_permute(s->p, s->d_state, s->batch, st); }
 // absorb_internal (sponge/poseidon/mod.rs:124-153)
-static int32_t sponge_absorb_internal(akp_sponge* s, u32 idx, size_t k) {
+static int32_t sponge_absorb_internal(akp_sponge* s, u32 idx, size_t k, const Fr* d_elems, hipStream_t st) {
     const PoseidonDims& D = s->p->dims;
-    hipStream_t st = s->p->ctx->stream;
     size_t e0 = 0, remaining = k;
     for (;;) {
         const bool last = idx + remaining <= D.rate;
@@ -546,7 +545,7 @@ static int32_t sponge_absorb_internal(akp_sponge* s, u32 idx, size_t k) {
         if (count) {
             const size_t work = s->batch * count;
             hipLaunchKernelGGL(sponge_add_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, s->d_state, D.t,
-                               D.capacity + idx, s->d_io, k, e0, count, s->batch);
+                               D.capacity + idx, d_elems, k, e0, count, s->batch);
             HIP_TRY(hipGetLastError());
         }
         if (last) {
@@ -554,39 +553,46 @@ static int32_t sponge_absorb_internal(akp_sponge* s, u32 idx, size_t k) {
             s->index = idx + (u32)remaining;
             return AKP_OK;
         }
-        if (int32_t rc = sponge_permute(s)) return rc;
+        if (int32_t rc = sponge_permute(s, st)) return rc;
         e0 += count;
         remaining -= count;
         idx = 0;
     }
 }
+// CryptographicSponge::absorb (sponge/poseidon/mod.rs:236-257) on elements that are already on the device, enqueued on `st`
+static int32_t sponge_absorb_core(akp_sponge* s, const Fr* d_elems, size_t k, hipStream_t st) {
+    if (s->mode == 0) {  // :243-250
+        u32 idx = s->index;
+        if (idx == s->p->dims.rate) {
+            if (int32_t rc = sponge_permute(s, st)) return rc;
+            idx = 0;
+        }
+        return sponge_absorb_internal(s, idx, k, d_elems, st);
+    }
+    return sponge_absorb_internal(s, 0, k, d_elems, st);  // :251-255 no permutation between squeeze and absorb
+}
 extern "C" int32_t akp_sponge_absorb(akp_sponge* s, const uint64_t* elems, size_t k) {
     if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");
     if (k == 0) return AKP_OK;  // :238-240
     if (!elems) return fail(AKP_ERR_BAD_PARAMS, "elems is NULL");
-    HIP_TRY(hipSetDevice(s->p->ctx->device));
+    NEED_DEV(s->p, "akp_sponge_absorb");
     if (int32_t rc = sponge_io(s, s->batch * k)) return rc;
     hipStream_t st = s->p->ctx->stream;
     HIP_TRY(hipMemcpyAsync(s->d_io, elems, s->batch * k * sizeof(Fr), hipMemcpyHostToDevice, st));
-    int32_t rc;
-    if (s->mode == 0) {  // :243-250
-        u32 idx = s->index;
-        if (idx == s->p->dims.rate) {
-            if ((rc = sponge_permute(s))) return rc;
-            idx = 0;
-        }
-        rc = sponge_absorb_internal(s, idx, k);
-    } else {  // :251-255 no permutation between squeeze and absorb
-        rc = sponge_absorb_internal(s, 0, k);
-    }
-    if (rc) return rc;
+    if (int32_t rc = sponge_absorb_core(s, s->d_io, k, st)) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return AKP_OK;
 }
+extern "C" int32_t akp_sponge_absorb_dev(akp_sponge* s, const uint64_t* d_elems, size_t k, void* stream) {
+    if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");
+    if (k == 0) return AKP_OK;
+    if (!d_elems) return fail(AKP_ERR_BAD_PARAMS, "d_elems is NULL");
+    NEED_DEV(s->p, "akp_sponge_absorb_dev");
+    return sponge_absorb_core(s, (const Fr*)d_elems, k, pick_stream(s->p->ctx, stream));
+}
 // squeeze_internal (sponge/poseidon/mod.rs:156-186)
-static int32_t sponge_squeeze_internal(akp_sponge* s, u32 idx, size_t n_out) {
+static int32_t sponge_squeeze_internal(akp_sponge* s, u32 idx, size_t n_out, Fr* d_out, hipStream_t st) {
     const PoseidonDims& D = s->p->dims;
-    hipStream_t st = s->p->ctx->stream;
     size_t o0 = 0, remaining = n_out;
     for (;;) {
         const bool last = idx + remaining <= D.rate;
@@ -594,7 +600,7 @@ static int32_t sponge_squeeze_internal(akp_sponge* s, u32 idx, size_t n_out) {
         if (count) {
             const size_t work = s->batch * count;
             hipLaunchKernelGGL(sponge_copy_out_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, s->d_state, D.t,
-                               D.capacity + idx, s->d_io, n_out, o0, count, s->batch);
+                               D.capacity + idx, d_out, n_out, o0, count, s->batch);
             HIP_TRY(hipGetLastError());
         }
         if (last) {
@@ -605,32 +611,39 @@ static int32_t sponge_squeeze_internal(akp_sponge* s, u32 idx, size_t n_out) {
         o0 += count;
         remaining -= count;
         if (remaining != 0)
-            if (int32_t rc = sponge_permute(s)) return rc;
+            if (int32_t rc = sponge_permute(s, st)) return rc;
         idx = 0;
     }
+}
+// squeeze_native_field_elements (sponge/poseidon/mod.rs:324-344) into a device buffer, enqueued on `st`
+static int32_t sponge_squeeze_core(akp_sponge* s, Fr* d_out, size_t n_out, hipStream_t st) {
+    if (s->mode == 0) {  // :331-334 (permutes even when n_out == 0)
+        if (int32_t rc = sponge_permute(s, st)) return rc;
+        return sponge_squeeze_internal(s, 0, n_out, d_out, st);
+    }
+    u32 idx = s->index;  // :335-341
+    if (idx == s->p->dims.rate) {
+        if (int32_t rc = sponge_permute(s, st)) return rc;
+        idx = 0;
+    }
+    return sponge_squeeze_internal(s, idx, n_out, d_out, st);
 }
 extern "C" int32_t akp_sponge_squeeze(akp_sponge* s, uint64_t* out, size_t n_out) {
     if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");
     if (!out && n_out) return fail(AKP_ERR_BAD_PARAMS, "out is NULL");
-    HIP_TRY(hipSetDevice(s->p->ctx->device));
+    NEED_DEV(s->p, "akp_sponge_squeeze");
     if (int32_t rc = sponge_io(s, s->batch * std::max<size_t>(n_out, 1))) return rc;
     hipStream_t st = s->p->ctx->stream;
-    int32_t rc;
-    if (s->mode == 0) {  // :331-334 (permutes even when n_out == 0)
-        if ((rc = sponge_permute(s))) return rc;
-        rc = sponge_squeeze_internal(s, 0, n_out);
-    } else {  // :335-341
-        u32 idx = s->index;
-        if (idx == s->p->dims.rate) {
-            if ((rc = sponge_permute(s))) return rc;
-            idx = 0;
-        }
-        rc = sponge_squeeze_internal(s, idx, n_out);
-    }
-    if (rc) return rc;
+    if (int32_t rc = sponge_squeeze_core(s, s->d_io, n_out, st)) return rc;
     if (n_out) HIP_TRY(hipMemcpyAsync(out, s->d_io, s->batch * n_out * sizeof(Fr), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return AKP_OK;
+}
+extern "C" int32_t akp_sponge_squeeze_dev(akp_sponge* s, uint64_t* d_out, size_t n_out, void* stream) {
+    if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");
+    if (!d_out && n_out) return fail(AKP_ERR_BAD_PARAMS, "d_out is NULL");
+    NEED_DEV(s->p, "akp_sponge_squeeze_dev");
+    return sponge_squeeze_core(s, (Fr*)d_out, n_out, pick_stream(s->p->ctx, stream));
 }
 extern "C" int32_t akp_sponge_get_state(akp_sponge* s, uint64_t* state, int32_t* mode, uint32_t* index) {
     if (!s) return fail(AKP_ERR_BAD_PARAMS, "sponge is NULL");

@@ -140,6 +140,11 @@ void akp_sponge_destroy(akp_sponge* s);
 int32_t akp_sponge_absorb(akp_sponge* s, const uint64_t* elems, size_t elems_per_instance);
 /* squeeze_native_field_elements(n): out is [batch][n] Fr (host) */
 int32_t akp_sponge_squeeze(akp_sponge* s, uint64_t* out, size_t n_per_instance);
+/* the same on DEVICE buffers ([batch][k] Fr in, [batch][n] Fr out), enqueued on `stream` without synchronising: a batch of
+ * sponges driven entirely from HBM (the state never leaves the device either way).  Calls on one sponge must be issued in
+ * program order on one stream (the duplex bookkeeping is host-side). */
+int32_t akp_sponge_absorb_dev(akp_sponge* s, const uint64_t* d_elems, size_t elems_per_instance, void* stream);
+int32_t akp_sponge_squeeze_dev(akp_sponge* s, uint64_t* d_out, size_t n_per_instance, void* stream);
 /* SpongeExt::{into_state,from_state} (sponge/mod.rs:184-191): state is [batch][t] Fr;
  * mode 0 = Absorbing{index}, 1 = Squeezing{index}. */
 int32_t akp_sponge_get_state(akp_sponge* s, uint64_t* state, int32_t* mode, uint32_t* index);

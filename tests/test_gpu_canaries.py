@@ -334,3 +334,42 @@ def test_crh_class_decides_the_digest_width(cpa):
         pedersen.CRH.evaluate_batch(B, msgs[:2])
     with pytest.raises(TypeError):
         bowe_hopwood.CRH.evaluate_batch(P, msgs[:2])
+
+
+def test_sponge_dev_entry_points(cpa, torch_dev):
+    """akp_sponge_absorb_dev / akp_sponge_squeeze_dev (sponge/poseidon/mod.rs:236-257, 324-344 on device buffers): a ragged batch
+    of sponges, absorb 3 / squeeze 2 / absorb 2 / squeeze 5 (crosses rate blocks in both modes), guard bands around every
+    buffer, digests equal to the host-pointer form and to the oracle's sponge"""
+    lib, check = cpa.lib, cpa._lib.check
+    s = _stream(torch_dev)
+    for rate in (2, 3):
+        c = cpa.get_default_poseidon_parameters(rate, False)
+        ora = cref_poseidon(po.get_default_poseidon_parameters(rate, False))
+        ph = c.handle(cpa.default_context(0)).h
+        for n in (1, 65, 1000):
+            a1, a2 = rand_fr_array(n * 3, 8100 + n).reshape(n, 3, 4), rand_fr_array(n * 2, 8200 + n).reshape(n, 2, 4)
+            g1, g2 = DevGuard(torch_dev, a1.nbytes, a1), DevGuard(torch_dev, a2.nbytes, a2)
+            o1, o2 = DevGuard(torch_dev, n * 2 * 32), DevGuard(torch_dev, n * 5 * 32)
+            sp = C.c_void_p()
+            check(lib.akp_sponge_create(ph, n, C.byref(sp)))
+            check(lib.akp_sponge_absorb_dev(sp, g1.ptr, 3, s))
+            check(lib.akp_sponge_squeeze_dev(sp, o1.ptr, 2, s))
+            check(lib.akp_sponge_absorb_dev(sp, g2.ptr, 2, s))
+            check(lib.akp_sponge_squeeze_dev(sp, o2.ptr, 5, s))
+            for gg, nm in ((g1, "absorb 1"), (g2, "absorb 2"), (o1, "squeeze 1"), (o2, "squeeze 2")):
+                gg.check("sponge %s n=%d rate=%d" % (nm, n, rate))
+            lib.akp_sponge_destroy(sp)
+            got1, got2 = o1.host().reshape(n, 2, 4), o2.host().reshape(n, 5, 4)
+            # the host-pointer form on a second sponge batch
+            sp2 = C.c_void_p()
+            check(lib.akp_sponge_create(ph, n, C.byref(sp2)))
+            h1, h2 = np.empty((n, 2, 4), np.uint64), np.empty((n, 5, 4), np.uint64)
+            check(lib.akp_sponge_absorb(sp2, a1.ctypes.data, 3))
+            check(lib.akp_sponge_squeeze(sp2, h1.ctypes.data, 2))
+            check(lib.akp_sponge_absorb(sp2, a2.ctypes.data, 2))
+            check(lib.akp_sponge_squeeze(sp2, h2.ctypes.data, 5))
+            lib.akp_sponge_destroy(sp2)
+            assert np.array_equal(got1, h1) and np.array_equal(got2, h2), (rate, n)
+            for i in sorted({0, n // 2, n - 1}):
+                exp = ora.sponge_script([3, -2, 2, -5], np.concatenate([a1[i], a2[i]]), 7)
+                assert np.array_equal(np.concatenate([got1[i], got2[i]]), exp), (rate, n, i)

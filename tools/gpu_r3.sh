@@ -38,6 +38,9 @@ proofsprof) echo "== rocprofv3 kernel stats of tools/bench_proofs.py =="
      rm -rf $OUT/pp_$CFG
    done
    python tools/bench_proofs.py > $OUT/proofs.json 2> $OUT/proofs.err; tail -3 $OUT/proofs.err;;
+gaps) echo "== launch gaps of the narrow tree levels =="
+   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/gaps -o t -- python $GRAFT_REPO_ROOT/tools/gpu_level_gaps.py run > $OUT/gaps_run.log 2>&1)
+   python tools/gpu_level_gaps.py analyse $OUT/gaps > $OUT/level_gaps.txt 2>&1; grep "==\|total" $OUT/level_gaps.txt; rm -rf $OUT/gaps;;
 teab) for V in line128 packed96; do
      if [ $V = packed96 ]; then export AKP_LIB=$GRAFT_REPO_ROOT/crypto_primitives_amd/lib/libakp_packed96.so; else unset AKP_LIB; fi
      echo "== te entry layout: $V (AKP_LIB=${AKP_LIB:-default}) =="
