@@ -57,7 +57,7 @@ def analyse(d):
         # the last build = the trailing run of launches after the last gap of > 1 ms (the synchronize between builds)
         cut = 0
         for i in range(1, len(ks)):
-            if int(ks[i]["Start_Timestamp"]) - int(ks[i - 1]["End_Timestamp"]) > 1_000_000:
+            if int(ks[i]["Start_Timestamp"]) - int(ks[i - 1]["End_Timestamp"]) > 15_000:  # the synchronize between two builds
                 cut = i
         ks = ks[cut:]
         print("== %s: last build, %d launches ==" % (label, len(ks)))
@@ -69,7 +69,7 @@ def analyse(d):
             dur = (e - s) / 1e3
             grid = int(r.get("Grid_Size", 0) or 0)
             wg = int(r.get("Workgroup_Size", 256) or 256)
-            narrow = grid <= (1 << 15) * 4  # <= 2^15 items (the latency kernels use several lanes per item)
+            narrow = "coop" in r["Kernel_Name"] or "small" in r["Kernel_Name"]  # the latency kernels: levels of <= 2^15 / 2^14 nodes
             print("  %-34s grid %9d wg %4d  %9.1f us  gap %7.1f us" % (r["Kernel_Name"].split("(")[0][-34:], grid, wg, dur, gap))
             tot_k += dur
             tot_g += gap
@@ -77,7 +77,7 @@ def analyse(d):
                 nar_k += dur
                 nar_g += gap
             prev_end = e
-        print("  total: kernels %.1f us, gaps %.1f us; launches with <= 2^17 lanes: kernels %.1f us, gaps %.1f us" % (tot_k, tot_g, nar_k, nar_g))
+        print("  total: kernels %.1f us, gaps %.1f us; narrow levels (latency kernels): kernels %.1f us, gaps before them %.1f us" % (tot_k, tot_g, nar_k, nar_g))
 
 
 if __name__ == "__main__":
