@@ -55,6 +55,7 @@ struct akp_ctx {
     // more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
     hipStream_t pipe[7] = {};
     hipEvent_t chunk_event[8] = {};  // copy-stream -> compute-stream hand-over of leaf chunks (host_tree_build)
+    hipEvent_t te_event[2] = {};     // AKP_TE_SPLIT_FINALIZE build arm: hand-over to / from the side stream of the finalize pass
     // where the last host-pointer tree build left its inner nodes (heap order, `last_tree_nodes` digests): what the
     // multi-device build reads for the all-gather of the sub-roots and the per-device copy-outs -- an explicit hand-over
     // instead of a convention about scratch slots

@@ -259,30 +259,64 @@ int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg
     void *xyz = nullptr, *prefix = nullptr;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    if (te_is_pedersen(p) && p->signed_subset)
-        hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride,
-                p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
-    else if (te_is_pedersen(p))
-        hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride,
-                p->digit_bits, groups, steps, tail, (F29Pad*)xyz, n);
-    else
-        hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, s, p->d_lut, p->d_lut1, d_msgs, data_len, stride, p->group,
-                groups, steps, tail, (F29Pad*)xyz, n);
-    HIP_TRY(hipGetLastError());
-    // share one inversion among up to 64 messages per lane, but keep `target` lanes busy when n allows.  Measured at 2^20
-    // Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K / 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 /
-    // 3.29 / 3.46 ms for accumulate + finalize (two boxes): one wave per SIMD it is (a compile-time choice since round 3).
-    constexpr size_t target = 65536;
-    size_t chain = std::min<size_t>(64, std::max<size_t>(1, n / target));
-    size_t lanes = (n + chain - 1) / chain;
-    const unsigned fgrid = (unsigned)((lanes + 255) / 256);
-    if (p->kind == AKP_TE_PEDERSEN)
-        hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, s, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, lanes);
-    else
-        hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, s, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, lanes);
-    HIP_TRY(hipGetLastError());
-    return AKP_OK;
+    const u32 fe = te_fe_per_digest(p);
+    // messages [first, first + cnt): extended-coordinate sums into xyz
+    auto accumulate = [&](size_t first, size_t cnt, hipStream_t st) -> int32_t {
+        const unsigned grid = (unsigned)((cnt + 255) / 256);
+        const uint8_t* m = d_msgs + first * stride;
+        F29Pad* x = (F29Pad*)xyz + first * 3;
+        if (te_is_pedersen(p) && p->signed_subset)
+            hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, st, p->d_lut, p->d_lut1, m, data_len, stride, p->digit_bits,
+                    groups, steps, tail, x, cnt);
+        else if (te_is_pedersen(p))
+            hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, st, p->d_lut, p->d_lut1, m, data_len, stride, p->digit_bits,
+                    groups, steps, tail, x, cnt);
+        else
+            hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, st, p->d_lut, p->d_lut1, m, data_len, stride, p->group,
+                    groups, steps, tail, x, cnt);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    };
+    // projective -> affine for the same range.  One inversion is shared among up to 64 messages per lane, but `target` lanes
+    // stay busy when the range allows.  Measured at 2^20 Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K /
+    // 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 / 3.29 / 3.46 ms for accumulate + finalize (two boxes): one wave
+    // per SIMD it is (a compile-time choice since round 3).
+    auto finalize = [&](size_t first, size_t cnt, hipStream_t st) -> int32_t {
+        constexpr size_t target = 65536;
+        const size_t chain = std::min<size_t>(64, std::max<size_t>(1, cnt / target));
+        const size_t lanes = (cnt + chain - 1) / chain;
+        const unsigned fgrid = (unsigned)((lanes + 255) / 256);
+        const F29Pad* x = (const F29Pad*)xyz + first * 3;
+        F29Pad* pre = (F29Pad*)prefix + first;
+        if (p->kind == AKP_TE_PEDERSEN)
+            hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, st, x, pre, d_out + first * fe, cnt, lanes);
+        else
+            hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, st, x, pre, d_out + first * fe, cnt, lanes);
+        HIP_TRY(hipGetLastError());
+        return AKP_OK;
+    };
+#if defined(AKP_TE_SPLIT_FINALIZE)
+    // A/B arm (`make splitfin`, round 3): the latency-bound finalize pass of the first half runs on a side stream under the
+    // accumulate kernel of the second half.  Measured: see profiles/r03_s8 -- not the default.
+    if (n >= ((size_t)1 << 19)) {
+        akp_ctx* c = p->ctx;
+        if (!c->pipe[3]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[3], hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i)
+            if (!c->te_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->te_event[i], hipEventDisableTiming));
+        const size_t half = (n / 2 + 255) & ~(size_t)255;
+        if (int32_t rc = accumulate(0, half, s)) return rc;
+        HIP_TRY(hipEventRecord(c->te_event[0], s));
+        HIP_TRY(hipStreamWaitEvent(c->pipe[3], c->te_event[0], 0));
+        if (int32_t rc = finalize(0, half, c->pipe[3])) return rc;
+        HIP_TRY(hipEventRecord(c->te_event[1], c->pipe[3]));
+        if (int32_t rc = accumulate(half, n - half, s)) return rc;
+        if (int32_t rc = finalize(half, n - half, s)) return rc;
+        HIP_TRY(hipStreamWaitEvent(s, c->te_event[1], 0));
+        return AKP_OK;
+    }
+#endif
+    if (int32_t rc = accumulate(0, n, s)) return rc;
+    return finalize(0, n, s);
 }
 
 extern "C" int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out, void* stream) {

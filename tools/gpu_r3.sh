@@ -41,6 +41,13 @@ proofsprof) echo "== rocprofv3 kernel stats of tools/bench_proofs.py =="
 gaps) echo "== launch gaps of the narrow tree levels =="
    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/gaps -o t -- python $GRAFT_REPO_ROOT/tools/gpu_level_gaps.py run > $OUT/gaps_run.log 2>&1)
    python tools/gpu_level_gaps.py analyse $OUT/gaps > $OUT/level_gaps.txt 2>&1; grep "==\|total" $OUT/level_gaps.txt; rm -rf $OUT/gaps;;
+finab) for V in default splitfin; do
+     if [ $V = splitfin ]; then export AKP_LIB=$GRAFT_REPO_ROOT/crypto_primitives_amd/lib/libakp_splitfin.so; else unset AKP_LIB; fi
+     echo "== finalize overlap: $V (AKP_LIB=${AKP_LIB:-default}) =="
+     for R in 1 2; do python tools/gpu_te_gather_probe.py 2>&1 | grep "random" ; done | tee $OUT/te_probe_$V.txt
+     python bench.py --steps 3 --warmup 1 --merkle-log2 0 --proofs-log2 0 --no-cpu-baseline --no-host-path --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench legs: pedersen %.4g hashes/s (%.3f ms), bh tree 2^23 %.2f ms' % (d['pedersen']['hashes_per_s'], d['pedersen']['ms_per_batch'], d['bh_merkle']['seconds']*1e3))" | tee -a $OUT/te_probe_$V.txt
+     if [ $V = splitfin ]; then timeout 900 python -m pytest tests/test_gpu_curves.py tests/test_gpu_canaries.py -m gpu -q 2>&1 | tail -2 | tee -a $OUT/te_probe_$V.txt; fi
+   done; unset AKP_LIB;;
 teab) for V in line128 packed96; do
      if [ $V = packed96 ]; then export AKP_LIB=$GRAFT_REPO_ROOT/crypto_primitives_amd/lib/libakp_packed96.so; else unset AKP_LIB; fi
      echo "== te entry layout: $V (AKP_LIB=${AKP_LIB:-default}) =="
