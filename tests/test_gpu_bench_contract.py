@@ -47,6 +47,11 @@ def test_bench_single_process():
         for leg in ("generate_proof", "verify_paths", "generate_multi_proof", "verify_multipath"):
             assert pr[leg]["wall_ms"] > 0 and pr[leg]["device_ms"] > 0
         assert set(pr["update_batch"]) == {"2^8", "2^10"}
+    assert d["proofs"]["sponge"]["sampled_parity_bit_exact"] and d["proofs"]["sponge"]["permutations_per_sponge"] == 4
+    for leg in ("pedersen", "bh_merkle"):  # the curve-hash roofline blocks carry counter traffic and the v_mad view
+        rf = d[leg]["roofline"]
+        assert rf["traffic"] > 0 and rf["traffic_over_algorithmic"] > 1 and "NOT measured in this run" in rf["traffic_static_from"]
+        assert 0 < rf["valu"]["frac_of_mad_issue_peak"] < 1
     leg = d["merkle"]["one_process_c_abi"]  # the C ABI's multi-device entry points, with the phase breakdown
     assert leg["root_matches"] and leg["phases_ms"]["whole_call_ms"] > 0 and leg["bowe_hopwood"]["phases_ms"]["copy_in_and_subtree_ms"] > 0
 
