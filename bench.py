@@ -47,9 +47,10 @@ ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODMUL_PER_PERM_REF = 626        # reference-shaped count
 # HBM bytes per permutation from PMC passes of an earlier session (NOT measured in this run; see `static_from`):
-# (2 * 49 579.75 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B)
-PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49579.75 + 98304.0) * 1024 / (1 << 20)
-PMC_TRAFFIC_SOURCE = "profiles/r02_s26/pmc_counters_poseidon.txt"
+# (2 * 49 583.19 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B); re-collected in round 3 on the
+# four-unit library: FETCH_SIZE 49 583 KB, WRITE_SIZE 98 304 KB, SQ_INSTS_VALU 1 224 736 768, VALUBusy 95.6-96.1 %
+PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49583.1875 + 98304.0) * 1024 / (1 << 20)
+PMC_TRAFFIC_SOURCE = "profiles/r03_s11/pmc_counters_poseidon.txt"
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0   # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
 # curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r03_s4/pmc_te_line128.txt: rocprofv3 --pmc, one counter per pass;
 # NOT measured in this run).  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B): with it the
@@ -698,8 +699,8 @@ def main():
                               "v_mad_per_s": MADS_PER_PERM * n / kern_avg_s,
                               "v_mad_peak_per_s": VALU_PEAK_WAVE_INSTR * 64,
                               "frac_of_mad_issue_peak": MADS_PER_PERM * n / kern_avg_s / (VALU_PEAK_WAVE_INSTR * 64),
-                              "valu_instructions_per_permutation": 74752, "valu_busy_percent": 97.4,
-                              "valu_counters_static_from": "profiles/r02_s26/pmc_counters_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy; NOT measured in this run)"}},
+                              "valu_instructions_per_permutation": 1224736768 // 16384, "valu_busy_percent": 96.1,
+                              "valu_counters_static_from": "profiles/r03_s11/pmc_counters_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy; NOT measured in this run)"}},
     }
     for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("proofs", proofs), ("host_path", host_path)):
         if leg:

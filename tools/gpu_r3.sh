@@ -38,6 +38,8 @@ proofsprof) echo "== rocprofv3 kernel stats of tools/bench_proofs.py =="
      rm -rf $OUT/pp_$CFG
    done
    python tools/bench_proofs.py > $OUT/proofs.json 2> $OUT/proofs.err; tail -3 $OUT/proofs.err;;
+pmc) for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU VALUBusy GRBM_GUI_ACTIVE; do pmc_pass $C poseidon python $GRAFT_REPO_ROOT/tools/prof_driver.py poseidon; done
+   grep "permute_t3\|crh_t3" $OUT/pmc_poseidon.txt | cut -c1-200;;
 gaps) echo "== launch gaps of the narrow tree levels =="
    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/gaps -o t -- python $GRAFT_REPO_ROOT/tools/gpu_level_gaps.py run > $OUT/gaps_run.log 2>&1)
    python tools/gpu_level_gaps.py analyse $OUT/gaps > $OUT/level_gaps.txt 2>&1; grep "==\|total" $OUT/level_gaps.txt; rm -rf $OUT/gaps;;
