@@ -431,7 +431,7 @@ def main():
                                           "v_mad_note": "7 products per table step + ~6 per hash in the shared-inversion pass, 153 multiply-adds each",
                                           "note": "VALU-issue bound like the permutation: one mixed addition of 7 products per table step "
                                                   "(signed-subset table); one 128-byte line per entry, gathered through L2 / Infinity Cache / HBM "
-                                                  "(counters: profiles/r02_s26/pmc_counters_te.txt; gather share: profiles/r02_s19/te_gather_probe.txt, r02_s24)"}}}
+                                                  "(counters and entry-layout A/B: profiles/r03_s4; gather share: profiles/r03_s4/te_gather_probe_line128.txt, profiles/r03_s10)"}}}
         if args.sustain_seconds > 0:  # clock / power under the gather-heavy kernel (the permutation's figures are in `sustained`)
             count = int(min(2000, max(8, 0.5 * args.sustain_seconds / max(kavg, 1e-4))))
             torch.cuda.synchronize(dev)
