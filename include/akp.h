@@ -79,8 +79,9 @@ void* akp_ctx_stream(akp_ctx* ctx);
  * (2^18 items) are cut into chunks whose copy-in / kernel / copy-out overlap on three streams (the copies are
  * staged by the runtime).  Memory from akp_host_alloc, or registered with akp_host_register, is addressed by the
  * Poseidon batch kernels DIRECTLY (zero copy: every item is read once and written once over PCIe, both directions
- * at the same time) when all buffers of a call are of that kind.  Register a buffer as a whole: the runtime rejects
- * copies that straddle registered and unregistered memory. */
+ * at the same time) when all buffers of a call are of that kind; akp_te_crh_batch writes its digests directly into a
+ * pinned / registered `out` (the messages still go through a device copy: they are read bit-window by bit-window).
+ * Register a buffer as a whole: the runtime rejects copies that straddle registered and unregistered memory. */
 int32_t akp_host_alloc(size_t bytes, void** out);
 int32_t akp_host_free(void* p);
 int32_t akp_host_register(void* p, size_t bytes);
