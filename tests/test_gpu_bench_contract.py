@@ -46,6 +46,7 @@ def test_bench_single_process():
         assert pr["all_parity_bit_exact"] and pr["leaves"] == 1 << 12
         for leg in ("generate_proof", "verify_paths", "generate_multi_proof", "verify_multipath"):
             assert pr[leg]["wall_ms"] > 0 and pr[leg]["device_ms"] > 0
+        assert pr["create"]["wall_ms"] > 0 and pr["create"]["hashes"] == 2 * pr["leaves"] - 1
         assert set(pr["update_batch"]) == {"2^8", "2^10"}
     assert d["proofs"]["sponge"]["sampled_parity_bit_exact"] and d["proofs"]["sponge"]["permutations_per_sponge"] == 4
     for leg in ("pedersen", "bh_merkle"):  # the curve-hash roofline blocks carry counter traffic and the v_mad view
