@@ -1,0 +1,77 @@
+// Test-only harness, curve-hash half (see harness.hip): the product's table construction, digit accumulation, shared-inversion
+// finalisation and digest serialisation (crypto_primitives_amd/csrc/te_kernels.hpp) on the CPU.  A unit of its own so that the
+// two halves compile in parallel; both are linked into harness.so.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "../../crypto_primitives_amd/csrc/fr.hpp"
+#include "../../crypto_primitives_amd/csrc/f29.hpp"
+#include "../../crypto_primitives_amd/csrc/te_kernels.hpp"
+using namespace akp;
+
+extern "C" {
+// LUT construction exactly as capi_te.hip does it: kind 0 -> Pedersen with digit width D (lut: [ceil(n_gen/D)][2^D]);
+// kind 1 -> Bowe-Hopwood single table lut1 [n_gen][4] and, when group > 1, group table lut [n_gen/G][2^(3G-1)]
+// (hh_te_crh then takes D = group for kind 1).
+void hh_te_build_lut(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t D, uint32_t group, TeEntry* lut, TeEntry* lut1) {
+    const u32 n_gen = W * N;
+    if (kind == 2) {  // Pedersen, signed-subset table: lut [n_digits][2^(D-1)], lut1 = cprefix [n_digits + 1]
+        std::vector<NielsPad> half(n_gen);
+        for (u32 g = 0; g < n_gen; ++g) {
+            Niels h;
+            (void)te_half_generator(gens, g, h);
+            store_niels(&half[g], h);
+        }
+        const u32 n_digits = (n_gen + D - 1) / D;
+        for (u32 i = 0; i < (n_digits << (D - 1)); ++i) store_niels(lut + i, te_pedersen_slut_entry(half.data(), n_gen, D, i));
+        for (u32 k = 0; k <= n_digits; ++k) store_niels(lut1 + k, te_pedersen_cprefix_entry(half.data(), n_gen, D, k));
+        return;
+    }
+    if (kind == 0) {
+        const u32 entries = ((n_gen + D - 1) / D) << D;
+        for (u32 i = 0; i < entries; ++i) store_niels(lut + i, te_pedersen_lut_entry(gens, n_gen, D, i));
+        return;
+    }
+    for (u32 i = 0; i < n_gen * 4; ++i) store_niels(lut1 + i, te_bh_lut_entry(gens, i));
+    if (group > 1)
+        for (u32 i = 0; i < ((n_gen / group) << (3 * group - 1)); ++i) store_niels(lut + i, te_bh_lutg_entry(gens, group, i));
+}
+void hh_te_crh(int kind, const TeEntry* lut, const TeEntry* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
+               uint32_t groups, uint32_t steps, size_t lanes, Fr* out) {
+    std::vector<F29Pad> xyz(n * 3), prefix(n);
+    for (size_t i = 0; i < n; ++i) {
+        Ext a = kind == 0 ? te_accumulate_item<0>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps)
+                          : (kind == 2 ? te_accumulate_item<2>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps)
+                                       : te_accumulate_item<1>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps));
+        f29_store_pad(&xyz[3 * i], a.X); f29_store_pad(&xyz[3 * i + 1], a.Y); f29_store_pad(&xyz[3 * i + 2], a.Z);
+    }
+    for (size_t l = 0; l < lanes && l < n; ++l) {
+        if (kind != 1) te_finalize_lane<0>(xyz.data(), prefix.data(), out, n, lanes, l);
+        else te_finalize_lane<1>(xyz.data(), prefix.data(), out, n, lanes, l);
+    }
+}
+// the small-batch kernel's arithmetic (te_crh_small_kernel) on the CPU: `split` strided partial sums, a binary tree of
+// full additions, one inversion per message
+void hh_te_crh_split(int kind, const TeEntry* lut, const TeEntry* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,
+                     uint32_t groups, uint32_t steps, uint32_t split, Fr* out) {
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<Ext> part(split);
+        for (u32 j = 0; j < split; ++j)
+            part[j] = kind == 0 ? te_accumulate_strided<0>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps, j, split)
+                                : (kind == 2 ? te_accumulate_strided<2>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps, j, split)
+                                             : te_accumulate_strided<1>(lut, lut1, msgs + i * msg_len, msg_len, D, groups, steps, j, split));
+        for (u32 stride = 1; stride < split; stride <<= 1)
+            for (u32 j = 0; j + stride < split; j += 2 * stride) part[j] = te_add_ext(part[j], part[j + stride]);
+        const FS zi = f29_inv(part[0].Z);
+        if (kind != 1) { out[2 * i] = f29_to_wire(f29_mul(part[0].X, zi)); out[2 * i + 1] = f29_to_wire(f29_mul(part[0].Y, zi)); }
+        else out[i] = f29_to_wire(f29_mul(part[0].X, zi));
+    }
+}
+// 1 when the generator is in the prime-order subgroup (2 * (G / 2) == G)
+int hh_te_in_subgroup(const Fr* gen_affine) {
+    Niels h;
+    return te_half_generator(gen_affine, 0, h) ? 1 : 0;
+}
+void hh_te_serialize_pairs(const Fr* left, const Fr* right, uint32_t fe, size_t buflen, uint8_t* buf, size_t n) {
+    for (size_t t = 0; t < n * 2 * fe; ++t) te_serialize_pair_fe(left, right, fe, buflen, buf, t);
+}
+}
