@@ -107,6 +107,9 @@ class PoseidonSponge {
         check(akp_sponge_squeeze(h_, out.empty() ? nullptr : out[0].data(), n));
         return out;
     }
+    // the same on device buffers ([batch][k] Fr in, [batch][n] Fr out), enqueued on `stream` (akp_sponge_{absorb,squeeze}_dev)
+    void absorb_dev(const uint64_t* d_elems, size_t elems_per_instance, void* stream) { check(akp_sponge_absorb_dev(h_, d_elems, elems_per_instance, stream)); }
+    void squeeze_native_field_elements_dev(uint64_t* d_out, size_t n, void* stream) { check(akp_sponge_squeeze_dev(h_, d_out, n, stream)); }
 
   private:
     akp_sponge* h_ = nullptr;
