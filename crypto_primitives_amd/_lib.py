@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AKP_LIB", os.path.join(_HERE, "lib", "libakp.so"))
 
 AKP_OK, AKP_ERR_BAD_LENGTH, AKP_ERR_BAD_PARAMS, AKP_ERR_HIP, AKP_ERR_RCCL, AKP_ERR_NOT_POW2 = 0, 1, 2, 3, 4, 5
-AKP_ABI_VERSION = 2
+AKP_ABI_VERSION = 3
 TE_PEDERSEN, TE_BOWE_HOPWOOD, TE_PEDERSEN_X = 0, 1, 2
 
 
@@ -126,6 +126,16 @@ def _load():
         "akp_merkle_multipath_decode": (i32, [u64p, u64p, sz, sz, sz, u32, u64p]),
         "akp_merkle_verify_multipath_poseidon": (i32, [vp, vp, u64p, u64p, sz, sz, u64p, u64p, u64p, u64p, sz, sz, C.POINTER(i32)]),
         "akp_merkle_verify_multipath_te": (i32, [vp, vp, u64p, u8p, sz, sz, u64p, u64p, u64p, u64p, sz, sz, C.POINTER(i32)]),
+        "akp_serialize_digests": (i32, [u64p, sz, u32, i32, u8p, sz, C.POINTER(sz)]),
+        "akp_deserialize_digests": (i32, [u8p, sz, sz, u32, i32, i32, u64p]),
+        "akp_serialize_poseidon_config": (i32, [vp, u8p, sz, C.POINTER(sz)]),
+        "akp_deserialize_poseidon_config": (i32, [vp, u8p, sz, pp]),
+        "akp_serialize_te_parameters": (i32, [u64p, u32, u32, i32, u8p, sz, C.POINTER(sz)]),
+        "akp_deserialize_te_parameters": (i32, [u8p, sz, i32, i32, u64p, sz, C.POINTER(u32), C.POINTER(u32)]),
+        "akp_serialize_path": (i32, [u64p, u64p, sz, u64, u32, i32, u8p, sz, C.POINTER(sz)]),
+        "akp_deserialize_path": (i32, [u8p, sz, u32, i32, i32, u64p, u64p, sz, C.POINTER(sz), C.POINTER(u64)]),
+        "akp_serialize_multipath": (i32, [u64p, u64p, u64p, u64p, u64p, sz, sz, u32, i32, u8p, sz, C.POINTER(sz)]),
+        "akp_deserialize_multipath": (i32, [u8p, sz, u32, i32, i32, C.POINTER(sz), C.POINTER(sz), u64p, u64p, u64p, u64p, u64p, sz, sz]),
         "akp_multi_create": (i32, [C.POINTER(i32), i32, pp]),
         "akp_multi_destroy": (None, [vp]),
         "akp_multi_size": (i32, [vp]),

@@ -61,9 +61,9 @@ struct akp_ctx {
     // instead of a convention about scratch slots
     const void* last_tree_non_leaf = nullptr;
     size_t last_tree_nodes = 0;
-    // parameter handles created on this context and still alive.  akp_ctx_destroy with live handles releases the device
-    // resources and marks the context dead; the struct itself goes with the last handle, whose compute calls fail cleanly
-    // until then (handles created on akp_multi_ctx may outlive akp_multi_destroy without touching freed memory)
+    // handles created on this context and still alive: parameter sets, trees, sponges.  akp_ctx_destroy with live handles
+    // releases the device resources and marks the context dead; the struct itself goes with the last handle, whose compute
+    // calls fail cleanly until then (handles created on akp_multi_ctx may outlive akp_multi_destroy without touching freed memory)
     int live_handles = 0;
     bool dead = false;
 };
@@ -205,7 +205,14 @@ struct akp_poseidon {
     F29Pad* d_fmats_f29 = nullptr;
     F29Pad* d_sparse_f29 = nullptr;
     F29Pad* d_sbox0_f29 = nullptr;
+    // trees and sponges built on this handle keep using it (akp_merkle_tree::pleaf / ptwo, akp_sponge::p): they pin it, and
+    // akp_poseidon_params_destroy on a pinned handle only marks it -- the memory goes with the last pin (a host that drops its
+    // parameter objects before its trees, e.g. an LRU handle cache, cannot leave them with a dangling pointer)
+    int pins = 0;
+    bool destroy_pending = false;
 };
+static inline void poseidon_pin(akp_poseidon* p) { if (p) ++p->pins; }
+void poseidon_unpin(akp_poseidon* p);
 #define NEED_DEV(p, what)                                                                                  \
     do {                                                                                                   \
         if (!(p)) return fail(AKP_ERR_BAD_PARAMS, what ": params is NULL");                                \
@@ -230,7 +237,11 @@ struct akp_te_params {
     TeEntry* d_tail = nullptr;  // BH: sum of G[c] over the zero-padded tail chunks [tail_from, tail_to) of the last compress shape
     u32 tail_from = 0, tail_to = 0;
     bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
+    int pins = 0;                // as akp_poseidon::pins
+    bool destroy_pending = false;
 };
+static inline void te_pin(akp_te_params* p) { if (p) ++p->pins; }
+void te_unpin(akp_te_params* p);
 // Pedersen arithmetic (subset-sum tables over W * N generators): the plain hash and the one composed with TECompressor
 static inline bool te_is_pedersen(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN || p->kind == AKP_TE_PEDERSEN_X; }
 static inline u32 te_fe_per_digest(const akp_te_params* p) { return p->kind == AKP_TE_PEDERSEN ? 2u : 1u; }

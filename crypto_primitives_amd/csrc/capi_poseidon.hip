@@ -117,8 +117,15 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
     *out = p;
     return AKP_OK;
 }
+void poseidon_unpin(akp_poseidon* p) {
+    if (p && --p->pins == 0 && p->destroy_pending) akp_poseidon_params_destroy(p);
+}
 extern "C" void akp_poseidon_params_destroy(akp_poseidon* p) {
     if (!p) return;
+    if (p->pins > 0) {  // a tree or a sponge still computes with it: freed by its last unpin
+        p->destroy_pending = true;
+        return;
+    }
     if (p->ctx) (void)hipSetDevice(p->ctx->device);
     if (p->d_ark) (void)hipFree(p->d_ark);
     if (p->d_mds) (void)hipFree(p->d_mds);
@@ -511,15 +518,20 @@ extern "C" int32_t akp_sponge_create(akp_poseidon* p, size_t batch, akp_sponge**
         delete s;
         return fail(AKP_ERR_HIP, "akp_sponge_create: %s", hipGetErrorString(e));
     }
+    poseidon_pin(p);            // the sponge keeps computing with these parameters ...
+    ++p->ctx->live_handles;     // ... on this context: both outlive it
     *out = s;
     return AKP_OK;
 }
 extern "C" void akp_sponge_destroy(akp_sponge* s) {
     if (!s) return;
-    (void)hipSetDevice(s->p->ctx->device);
+    akp_ctx* c = s->p->ctx;
+    (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->d_io) (void)hipFree(s->d_io);
+    poseidon_unpin(s->p);
+    ctx_handle_released(c);
     delete s;
 }
 static int32_t sponge_io(akp_sponge* s, size_t elems) {

@@ -15,6 +15,7 @@
 static size_t te_table_cap(bool bowe_hopwood = false) {
     return (size_t)(bowe_hopwood ? 256u : 320u) << 20;
 }
+extern "C" void akp_te_params_destroy(akp_te_params* p);
 extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
     if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
     if (!out || !gens) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
@@ -124,17 +125,24 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_g) (void)hipFree(d_g);
     if (e != hipSuccess) {
-        if (p->d_lut) (void)hipFree(p->d_lut);
-        if (p->d_lut1) (void)hipFree(p->d_lut1);
-        delete p;
-        return fail(AKP_ERR_HIP, "akp_te_params_create: %s", hipGetErrorString(e));
+        const std::string why = hipGetErrorString(e);
+        (void)hipGetLastError();
+        akp_te_params_destroy(p);  // frees whatever was allocated and gives the context its handle count back
+        return fail(AKP_ERR_HIP, "akp_te_params_create: %s", why.c_str());
     }
     *out = p;
     return AKP_OK;
 }
 extern "C" uint32_t akp_te_entry_bytes(void) { return (uint32_t)sizeof(TeEntry); }
+void te_unpin(akp_te_params* p) {
+    if (p && --p->pins == 0 && p->destroy_pending) akp_te_params_destroy(p);
+}
 extern "C" void akp_te_params_destroy(akp_te_params* p) {
     if (!p) return;
+    if (p->pins > 0) {  // a tree still computes with it: freed by its last unpin
+        p->destroy_pending = true;
+        return;
+    }
     (void)hipSetDevice(p->ctx->device);
     (void)hipDeviceSynchronize();
     if (p->d_lut) (void)hipFree(p->d_lut);
@@ -195,7 +203,35 @@ extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bi
 // CONSTANT sum of their generators: one table entry (computed once per shape, te_bh_tail_kernel) added at the end instead
 // of one table step per five chunks -- a 63 x 9 inner node (64 bytes of digests in a 70-byte buffer) takes 35 + 1 steps
 // instead of 39.
+// workgroup size of te_accumulate_lds_kernel for messages of data_len bytes at a pitch of `stride`: the largest whose LDS image
+// fits 40 KB (128-byte pitch: 256 messages = 33.8 KB, four workgroups per CU); 0 = pitch above 640 bytes or an empty / padded
+// message: the per-lane global loads of te_accumulate_kernel.  A/B of the two kernels on resident messages
+// (profiles/r04_s1): Pedersen 4x256 3.294 -> 3.189 ms, Bowe-Hopwood 64 B 1.824 -> 1.762 ms per 2^20 hashes.
+static unsigned te_lds_block(size_t data_len, size_t stride) {
+    if (data_len < 4) return 0;
+    unsigned block = 256;
+    while (block >= 64 && te_lds_image_bytes(block, data_len, stride) > 40960) block /= 2;
+    return block >= 64 ? block : 0;
+}
+static const size_t te_split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
+// `pipe` (host-pointer entry point with pinned buffers): the batch runs chunk by chunk -- kernels on `s`, the DMA copy-in of later
+// chunks on pipe->cin, the DMA copy-out of chunk i on pipe->side under the kernels of chunk i + 1.  Every buffer (messages,
+// xyz, prefix, digests) is sized for the whole batch, so no chunk waits for a buffer and all copies are issued up front.
+// Nothing synchronises here; the caller waits for the three streams.
+struct TePipe {
+    size_t chunk;
+    const uint8_t* h_msgs;  // pinned host source, copied to d_msgs chunk-wise by DMA
+    void* h_out;            // pinned host destination, filled from d_out chunk-wise by DMA
+    hipStream_t cin, side;
+    hipEvent_t ev_in, ev_acc;
+};
+static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len,
+        const TePipe* pipe);
 int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len) {
+    return te_crh_run(p, d_msgs, n, msg_len, d_out, s, data_len, nullptr);
+}
+static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len,
+        const TePipe* pipe) {
     if (msg_len * 8 > te_input_bits(p))
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
     if (n == 0) return AKP_OK;
@@ -235,8 +271,7 @@ int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg
         data_len = 4;  // three zero bytes at most: they select nothing (Pedersen) / lie past the steps counted above (Bowe-Hopwood)
     }
     // small batches (tree tops) are bound by the latency of one message: split each one over AKP_TE_SPLIT waves
-    static const size_t split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
-    if (n <= split_max) {
+    if (n <= te_split_max) {
         const unsigned sgrid = (unsigned)((n + 63) / 64);
         const bool xy = p->kind == AKP_TE_PEDERSEN;  // digest = (x, y); otherwise x only
         if (te_is_pedersen(p) && p->signed_subset) {
@@ -262,9 +297,27 @@ int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg
     const u32 fe = te_fe_per_digest(p);
     // messages [first, first + cnt): extended-coordinate sums into xyz
     auto accumulate = [&](size_t first, size_t cnt, hipStream_t st) -> int32_t {
-        const unsigned grid = (unsigned)((cnt + 255) / 256);
         const uint8_t* m = d_msgs + first * stride;
         F29Pad* x = (F29Pad*)xyz + first * 3;
+        // messages staged through LDS (te_accumulate_lds_kernel): the largest workgroup whose image fits 40 KB (a 128-byte
+        // pitch: 256 messages = 33.8 KB, four workgroups per CU); pitches above 640 bytes keep the per-lane global loads
+        const unsigned block = te_lds_block(data_len, stride);
+        if (block) {
+            const unsigned lgrid = (unsigned)((cnt + block - 1) / block);
+            const size_t shm = te_lds_image_bytes(block, data_len, stride);
+            if (te_is_pedersen(p) && p->signed_subset)
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<2>, dim3(lgrid), dim3(block), shm, st, p->d_lut, p->d_lut1, m, data_len, stride,
+                        p->digit_bits, groups, steps, tail, x, cnt);
+            else if (te_is_pedersen(p))
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<0>, dim3(lgrid), dim3(block), shm, st, p->d_lut, p->d_lut1, m, data_len, stride,
+                        p->digit_bits, groups, steps, tail, x, cnt);
+            else
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<1>, dim3(lgrid), dim3(block), shm, st, p->d_lut, p->d_lut1, m, data_len, stride,
+                        p->group, groups, steps, tail, x, cnt);
+            HIP_TRY(hipGetLastError());
+            return AKP_OK;
+        }
+        const unsigned grid = (unsigned)((cnt + 255) / 256);
         if (te_is_pedersen(p) && p->signed_subset)
             hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, st, p->d_lut, p->d_lut1, m, data_len, stride, p->digit_bits,
                     groups, steps, tail, x, cnt);
@@ -315,6 +368,27 @@ int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg
         return AKP_OK;
     }
 #endif
+    if (pipe) {
+        const size_t dig = fe * sizeof(Fr);
+        for (size_t first = 0; first < n; first += pipe->chunk) {
+            const size_t cnt = std::min(pipe->chunk, n - first);
+            if (pipe->h_msgs) {
+                HIP_TRY(hipMemcpyAsync((uint8_t*)d_msgs + first * stride, pipe->h_msgs + first * stride, cnt * stride, hipMemcpyHostToDevice,
+                        pipe->cin));
+                HIP_TRY(hipEventRecord(pipe->ev_in, pipe->cin));
+                HIP_TRY(hipStreamWaitEvent(s, pipe->ev_in, 0));
+            }
+            if (int32_t rc = accumulate(first, cnt, s)) return rc;
+            // the finalize pass stays on `s`: beside an accumulate kernel it takes 0.43 ms instead of 0.055 ms and slows that kernel
+            // from 0.40 to 0.58 ms per 2^17 messages (both want the vector ALUs; profiles/r04_s3)
+            if (int32_t rc = finalize(first, cnt, s)) return rc;
+            HIP_TRY(hipEventRecord(pipe->ev_acc, s));
+            HIP_TRY(hipStreamWaitEvent(pipe->side, pipe->ev_acc, 0));
+            HIP_TRY(hipMemcpyAsync((char*)pipe->h_out + first * dig, (const char*)d_out + first * dig, cnt * dig, hipMemcpyDeviceToHost,
+                    pipe->side));
+        }
+        return AKP_OK;
+    }
     if (int32_t rc = accumulate(0, n, s)) return rc;
     return finalize(0, n, s);
 }
@@ -338,27 +412,49 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     // moves 128 B in and 64 B out for 3 us of kernel time per 1000 hashes: serial copies would double the call).
     constexpr size_t chunk = (size_t)1 << 17;
     const size_t dig = fe * sizeof(Fr);
-    // Zero-copy OUTPUT (round 3): when `out` is pinned / registered host memory (akp_host_alloc, akp_host_register) the
-    // finalize pass writes the digests straight into it over PCIe (coalesced 32- / 64-byte stores per message) and the
-    // copy-out stream disappears; the copy-in of pinned messages is then a true asynchronous DMA in the other direction.
-    // The messages themselves always go through a device copy: the accumulate kernel reads a message's bits with ~64
-    // scattered 32-bit loads, tolerable from HBM, not over PCIe.
-    // Measured (profiles/r03_s12, 2^20 Pedersen hashes): pinned buffers 1.59e8/s with copies -> 1.96e8/s with this; pageable
-    // buffers (runtime-staged copies) 2.33e8/s remain the faster way to feed this entry point.
-    char* out_alias = (char*)device_alias(out, n * dig);
+    const bool out_pinned = device_alias(out, n * dig) != nullptr;
+    // Pinned / registered buffers on both sides (round 4): everything is asynchronous -- the messages come in by DMA chunk after
+    // chunk (all copies issued up front: the device buffers hold the whole batch), the kernels of the chunks run back to back
+    // on the context stream, and the digests of chunk i leave by DMA on a side stream under the kernels of chunk i + 1.
+    // Measured and dropped on the way (profiles/r04_s2, r04_s3): (1) round 3's finalize pass storing straight into the pinned
+    // buffer -- 16-byte stores at a 64-byte pitch cross PCIe at 17 GB/s, 0.47 ms per 2^17 digests against 0.05 ms into HBM
+    // + 0.15 ms of DMA; (2) the accumulate kernel reading pinned messages in place (it reads every byte once, through LDS):
+    // every resident workgroup waits for PCIe at the same moments, 5.1 ms per 2^20 hashes in one launch and 6.0 ms
+    // chunked, against 0.30 ms of DMA per chunk that hides completely; (3) the finalize pass on the side stream.
+    // A pageable buffer on either side keeps the double-buffered loop below (its staged copies block this thread, which
+    // that loop's issue order is built around).
+    if (n > te_split_max && msg_len >= 4 && out_pinned && device_alias(msgs, n * msg_len)) {
+        if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
+        if (!c->pipe[4]) {  // the copy-out stream: its copy kernels should not queue behind the hash kernels' workgroups
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&c->pipe[4], hipStreamNonBlocking, hi));  // median 4.41 -> 4.24 ms per 2^20 hashes (profiles/r04_s3)
+        }
+        for (int i = 0; i < 8; ++i)
+            if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
+        const TePipe pipe{chunk /* 2^16 / 2^18 / 2^19 measured slower, profiles/r04_s3 */, msgs, out, c->pipe[0], c->pipe[4], c->chunk_event[0], c->chunk_event[1]};
+        if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
+        if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
+        HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
+        HIP_TRY(hipStreamWaitEvent(pipe.cin, c->chunk_event[7], 0));
+        HIP_TRY(hipStreamWaitEvent(pipe.side, c->chunk_event[7], 0));
+        const int32_t rc = te_crh_run(p, (const uint8_t*)dm, n, msg_len, (Fr*)dout, s, msg_len, &pipe);
+        HIP_TRY(hipStreamSynchronize(pipe.cin));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipStreamSynchronize(pipe.side));
+        return rc;
+    }
     if (n <= chunk || msg_len == 0) {
         if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
-        if (!out_alias)
-            if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
+        if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
         if (msg_len) HIP_TRY(hipMemcpyAsync(dm, msgs, n * msg_len, hipMemcpyHostToDevice, s));
-        if (int32_t rc = te_crh_dev(p, (const uint8_t*)dm, n, msg_len, out_alias ? (Fr*)out_alias : (Fr*)dout, s)) return rc;
-        if (!out_alias) HIP_TRY(hipMemcpyAsync(out, dout, n * dig, hipMemcpyDeviceToHost, s));
+        if (int32_t rc = te_crh_dev(p, (const uint8_t*)dm, n, msg_len, (Fr*)dout, s)) return rc;
+        HIP_TRY(hipMemcpyAsync(out, dout, n * dig, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         return AKP_OK;
     }
     if (int32_t rc = ctx_scratch(c, SCR_A, 2 * chunk * msg_len, &dm, s)) return rc;
-    if (!out_alias)
-        if (int32_t rc = ctx_scratch(c, SCR_B, 2 * chunk * dig, &dout, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, 2 * chunk * dig, &dout, s)) return rc;
     for (int i = 0; i < 2; ++i)
         if (!c->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i)
@@ -374,16 +470,16 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
             const size_t done = ci * chunk, cnt = std::min(chunk, n - done);
             const int b = (int)(ci & 1);
             uint8_t* d_in = (uint8_t*)dm + (size_t)b * chunk * msg_len;
-            Fr* d_o = out_alias ? (Fr*)(out_alias + done * dig) : (Fr*)((char*)dout + (size_t)b * chunk * dig);
+            Fr* d_o = (Fr*)((char*)dout + (size_t)b * chunk * dig);
             if (ci >= 2) HIP_TRY(hipStreamWaitEvent(cin, comp_done[b], 0));  // the kernels of chunk ci - 2 have read this half
             HIP_TRY(hipMemcpyAsync(d_in, msgs + done * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
             HIP_TRY(hipEventRecord(in_done[b], cin));
             HIP_TRY(hipStreamWaitEvent(s, in_done[b], 0));
-            if (ci >= 2 && !out_alias) HIP_TRY(hipStreamWaitEvent(s, out_done[b], 0));  // the copy-out of chunk ci - 2 has drained this half
+            if (ci >= 2) HIP_TRY(hipStreamWaitEvent(s, out_done[b], 0));  // the copy-out of chunk ci - 2 has drained this half
             if (int32_t rc = te_crh_dev(p, d_in, cnt, msg_len, d_o, s)) return rc;
             HIP_TRY(hipEventRecord(comp_done[b], s));
         }
-        if (ci >= 1 && !out_alias) {  // issued after the copy-in of the next chunk: the copy engines serve the queues in issue order
+        if (ci >= 1) {  // issued after the copy-in of the next chunk: the copy engines serve the queues in issue order
             const size_t co = ci - 1, done = co * chunk, cnt = std::min(chunk, n - done);
             const int b = (int)(co & 1);
             HIP_TRY(hipStreamWaitEvent(cout, comp_done[b], 0));

@@ -306,6 +306,24 @@ AKP_HD u32 msg_combine(const MsgRaw& r, size_t len, size_t o, u32 w) {
     const u32 shift = (u32)(o - 8 * msg_word_addr(len, o));  // 0..7, or up to 31 next to the end of the message
     return (r.word >> shift) & ((1u << w) - 1u);
 }
+#if defined(__HIPCC__)
+// The same message read from the workgroup's LDS image of its messages (te_accumulate_lds_kernel): `img` is a byte-for-byte
+// copy of the 16-byte-aligned global range that covers the workgroup's messages, with one pad dword after every 32 dwords
+// (dword d of the range lives at img[d + (d >> 5)]) so that lanes whose messages lie 128 bytes apart read different
+// banks; `at` is the byte offset of this lane's message inside the range.  The unaligned 32-bit window is two dword
+// reads and a funnel shift.
+struct MsgLds {
+    const u32* img;
+    u32 at;
+};
+__device__ __forceinline__ MsgRaw msg_load(const MsgLds& m, size_t len, size_t o) {
+    if (len == 0) return MsgRaw{0u};
+    const u32 a = m.at + (u32)msg_word_addr(len, o);
+    const u32 d = a >> 2, sh = (a & 3u) * 8u;
+    const u32 lo = m.img[d + (d >> 5)], hi = m.img[(d + 1u) + ((d + 1u) >> 5)];
+    return MsgRaw{__builtin_amdgcn_alignbit(hi, lo, sh)};
+}
+#endif
 
 // ---- accumulate: one message per lane ------------------------------------------------------------
 // A step is split into three stages so that no load is consumed in the stage that issues it (the compiler places the
@@ -418,8 +436,8 @@ AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
     return r;
 }
 #endif
-template <int KIND>
-AKP_HD MsgRaw te_step_bits(const uint8_t* __restrict__ msg, size_t msg_len, u32 D, u32 n_groups, u32 u) {
+template <int KIND, class M = const uint8_t*>
+AKP_HD MsgRaw te_step_bits(const M& msg, size_t msg_len, u32 D, u32 n_groups, u32 u) {
     u32 w;
     return msg_load(msg, msg_len, te_step_offset<KIND>(D, n_groups, u, &w));
 }
@@ -485,8 +503,8 @@ AKP_HD void te_step_address(const TeEntry* __restrict__ lut, const TeEntry* __re
         }
     }
 }
-template <int KIND>
-AKP_HD Niels te_step_entry(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const uint8_t* __restrict__ msg,
+template <int KIND, class M = const uint8_t*>
+AKP_HD Niels te_step_entry(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const M& msg,
                            size_t msg_len, u32 D, u32 n_groups, u32 u) {
     return niels_apply(te_step_fetch<KIND>(lut, lut1, te_step_bits<KIND>(msg, msg_len, D, n_groups, u), msg_len, D, n_groups, u));
 }
@@ -501,8 +519,8 @@ AKP_HD void te_consume_after(MsgRaw& r, const Ext& after) {
     (void)after;
 #endif
 }
-template <int KIND>
-AKP_HD Ext te_accumulate_item(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const uint8_t* __restrict__ msg,
+template <int KIND, class M = const uint8_t*>
+AKP_HD Ext te_accumulate_item(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1, const M& msg,
                               size_t msg_len, u32 D, u32 n_groups, u32 n_steps) {
     // Software pipeline, two steps per iteration (two entry buffers, no register copies to rotate them).  Before the
     // addition of step u starts, the seven pieces of step u + 1's table line and the message bytes of step u + 2 are
@@ -587,6 +605,50 @@ __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(co
     f29_store_pad(xyz + idx * 3 + 1, acc.Y);
     f29_store_pad(xyz + idx * 3 + 2, acc.Z);
 }
+#if defined(__HIPCC__)
+// The same with the workgroup's messages staged through LDS (round 4).  The kernel above reads the message bits of a step with
+// one 32-bit load per lane at a `stride`-byte pitch: 64 distinct cache lines per load instruction, 64 times per message,
+// competing with the table lines for the vector L1 -- and impossible over PCIe.  Here the workgroup copies the byte range
+// that holds its blockDim.x messages ONCE, with coalesced 16-byte loads (the range is widened to 16-byte boundaries: never
+// across a page), into an LDS image (layout: MsgLds) and every later bit window is two ds_read_b32.  Because each message
+// byte is now read exactly once, `msgs` may be the device alias of pinned / registered HOST memory: the host-pointer
+// entry point launches this kernel directly on the caller's buffer (zero copy, no staging copy, no second stream).
+// Dynamic LDS: te_lds_image_bytes(blockDim.x, msg_len, stride).
+AKP_HD size_t te_lds_image_bytes(size_t block, size_t msg_len, size_t stride) {
+    const size_t chunks = (15 + (block - 1) * stride + msg_len + 15) / 16;  // worst misalignment of the range's first byte
+    const size_t dwords = chunks * 4;
+    return (dwords + (dwords >> 5) + 4) * 4;
+}
+template <int KIND>
+__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
+                                                           const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
+                                                           u32 n_steps, const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n) {
+    extern __shared__ u32 te_msg_image[];
+    const size_t first = (size_t)blockIdx.x * blockDim.x;
+    const size_t cnt = n - first < blockDim.x ? n - first : blockDim.x;  // the grid covers n: cnt >= 1
+    const uint8_t* g0 = msgs + first * stride;
+    const u32 mis = (u32)((uintptr_t)g0 & 15u);
+    const uint4* a0 = reinterpret_cast<const uint4*>(g0 - mis);
+    const u32 chunks = (u32)((mis + (cnt - 1) * stride + msg_len + 15) >> 4);
+    for (u32 k = threadIdx.x; k < chunks; k += blockDim.x) {
+        const uint4 v = a0[k];
+        u32* w = te_msg_image + 4u * k + (k >> 3);  // dwords 4k .. 4k+3 share one 32-dword group: one pad offset
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+    }
+    __syncthreads();
+    const size_t idx = first + threadIdx.x;
+    if (idx >= n) return;
+    const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
+    Ext acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
+    if (tail) acc = te_madd(acc, load_niels(tail));
+    f29_store_pad(xyz + idx * 3, acc.X);
+    f29_store_pad(xyz + idx * 3 + 1, acc.Y);
+    f29_store_pad(xyz + idx * 3 + 2, acc.Z);
+}
+#endif
 // sum of the single-chunk entries 1 * G[c], c in [from, to): the constant of a zero tail (one thread; once per parameter set)
 __global__ void te_bh_tail_kernel(const TeEntry* __restrict__ lut1, u32 from, u32 to, TeEntry* __restrict__ out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;

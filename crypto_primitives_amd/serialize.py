@@ -1,220 +1,204 @@
 """ark-serialize-compatible byte encodings of the objects that cross the boundary.
 
-`#[derive(CanonicalSerialize)]` writes the fields in declaration order; `usize` as u64 LE; `Vec<T>` as a u64 LE
-length followed by the elements; `Fp` as 32 bytes little-endian canonical (non-Montgomery); a twisted-Edwards
-affine point uncompressed as x || y.  Structs covered: PoseidonConfig (sponge/poseidon/mod.rs:26-45),
-pedersen / bowe_hopwood Parameters (crh/pedersen/mod.rs:28-31, crh/bowe_hopwood/mod.rs:33-37), Path
-(merkle_tree/mod.rs:139-156), MultiPath (:239-257).  The byte layouts are inferred from ark-serialize's published
-conventions -- the reference holds no byte-level vectors for them (unpinned, like the digest encoding).
-Host-side glue; field conversions go through the C ABI (field.py).
+Python mirror of the C ABI's `akp_serialize_*` / `akp_deserialize_*` (include/akp.h, csrc/capi_serialize.hip): every byte is
+written and parsed by the library, so a Rust / C++ host and this module cannot disagree.  Structs covered: PoseidonConfig
+(sponge/poseidon/mod.rs:26-45), pedersen / bowe_hopwood Parameters (crh/pedersen/mod.rs:28-31,
+crh/bowe_hopwood/mod.rs:33-37), Path (merkle_tree/mod.rs:139-152), MultiPath (:239-254), both `Compress` modes.
 
-Both modes of `CanonicalSerialize` are provided (`compress=False / True`): field elements and lengths are identical in
-the two; a twisted-Edwards affine point compresses to y (32 bytes LE) with the sign of x in the top bit of the last
-byte -- set iff x is the lexicographically larger of (x, -x), i.e. x > (p - 1) / 2 (ark-ec's `TEFlags`), possible
-because y < 2^255.  Decompression solves x^2 = (y^2 - 1) / (1 + d y^2) for Jubjub (a = -1) and picks the root the flag
-names.  This, too, is restated from ark-ec's published behaviour and pinned by nothing the reference holds.
+`#[derive(CanonicalSerialize)]` writes the fields in declaration order; `usize` as u64 LE; `Vec<T>` as a u64 LE length
+followed by the elements; `Fp` as 32 bytes little-endian canonical (non-Montgomery); a twisted-Edwards affine point as
+x || y (uncompressed) or as y with the sign of x in the top bit of the last byte (compressed: set iff x > (p - 1) / 2, ark-ec's
+`TEFlags`).  The formats are restated from ark-serialize's published conventions; the independent restatement they are
+checked against is `oracle/serialize.py` (tests/test_serialize_cpu.py, tests/test_abi.py); byte-level reference vectors
+exist only once `shim/examples/emit_vectors.rs` has been run (unpinned until then).
+
+Readers validate like `Validate::Yes` by default (canonical field elements always; points on the curve and in the prime-order
+subgroup, in C++: about 0.2 ms per point); `validate=False` is `deserialize_*_unchecked`.  Errors are ValueError.
 """
-import struct
+import ctypes as C
 
 import numpy as np
 
-from . import field
+from ._lib import lib, check, AkpError
 
 
-def _u64(v):
-    return struct.pack("<Q", int(v))
+def _ser(call):
+    """size query, then the real call"""
+    n = C.c_size_t()
+    check(call(None, 0, C.byref(n)))
+    buf = (C.c_uint8 * max(n.value, 1))()
+    check(call(buf, n.value, C.byref(n)))
+    return bytes(buf[: n.value])
+
+
+def _de(rc):
+    try:
+        check(rc)
+    except AkpError as e:  # IncorrectInputLength (truncated / trailing bytes) is an AkpError too
+        raise ValueError(str(e)) from None
+
+
+def _in(b):
+    b = bytes(b)
+    return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0"), len(b)
+
+
+def _wire(a, fe):
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, fe, 4)
+
+
+def _fe_of(config):
+    return 2 if tuple(config.digest_shape) == (2, 4) else 1
+
+
+def digests_bytes(digests, fe, compress=False) -> bytes:
+    """digests [n, fe, 4] wire format -> their encodings back to back (no length prefix)"""
+    d = _wire(digests, fe)
+    return _ser(lambda out, cap, n: lib.akp_serialize_digests(d.ctypes.data, d.shape[0], fe, int(compress), out, cap, n))
+
+
+def digests_from_bytes(b, n, fe, compress=False, validate=True) -> np.ndarray:
+    buf, ln = _in(b)
+    out = np.empty((n, fe, 4), dtype=np.uint64)
+    _de(lib.akp_deserialize_digests(buf, ln, n, fe, int(compress), int(validate), out.ctypes.data))
+    return out
 
 
 def fr_bytes(wire) -> bytes:
     """wire-format element(s) -> canonical 32-byte LE each"""
-    return field.from_mont(np.ascontiguousarray(wire, dtype=np.uint64)).astype("<u8").tobytes()
+    return digests_bytes(wire, 1)
 
 
 def fr_from_bytes(b: bytes, n: int) -> np.ndarray:
     if len(b) < 32 * n:
         raise ValueError("truncated input: %d field elements need %d bytes, got %d" % (n, 32 * n, len(b)))
-    c = np.frombuffer(b[: 32 * n], dtype="<u8").reshape(n, 4).astype(np.uint64)
-    return field.to_mont(c)  # raises on a non-canonical element (>= p), as ark-serialize's Fp deserialisation does
-
-
-class _Reader:
-    """bounds-checked cursor: a truncated or over-long length prefix raises ValueError (ark-serialize returns
-    SerializationError::InvalidData / an io error there), never an IndexError or a silent short read"""
-
-    def __init__(self, b):
-        self.b, self.o = memoryview(b), 0
-
-    def take(self, nbytes):
-        if nbytes < 0 or self.o + nbytes > len(self.b):
-            raise ValueError("truncated input: %d bytes wanted at offset %d, %d left" % (nbytes, self.o, len(self.b) - self.o))
-        out = bytes(self.b[self.o: self.o + nbytes])
-        self.o += nbytes
-        return out
-
-    def u64(self):
-        return struct.unpack("<Q", self.take(8))[0]
-
-    def count(self, item_bytes):
-        """a Vec length prefix, checked against what is left so that a corrupt length cannot ask for gigabytes"""
-        n = self.u64()
-        if n * item_bytes > len(self.b) - self.o:
-            raise ValueError("length prefix %d does not fit the %d bytes left" % (n, len(self.b) - self.o))
-        return n
-
-    def fr(self, n):
-        return fr_from_bytes(self.take(32 * n), n)
-
-
-def serialize_poseidon_config(cfg) -> bytes:
-    t = cfg.rate + cfg.capacity
-    out = [_u64(cfg.full_rounds), _u64(cfg.partial_rounds), _u64(cfg.alpha), _u64(cfg.ark.shape[0])]
-    for row in cfg.ark:
-        out += [_u64(t), fr_bytes(row)]
-    out.append(_u64(t))
-    for row in cfg.mds:
-        out += [_u64(t), fr_bytes(row)]
-    out += [_u64(cfg.rate), _u64(cfg.capacity)]
-    return b"".join(out)
-
-
-def deserialize_poseidon_config(b: bytes):
-    from .sponge.poseidon import PoseidonConfig
-    r = _Reader(b)
-    rf, rp, alpha = r.u64(), r.u64(), r.u64()
-    ark = [r.fr(r.count(32)) for _ in range(r.count(8))]
-    mds = [r.fr(r.count(32)) for _ in range(r.count(8))]
-    rate, cap = r.u64(), r.u64()
-    return PoseidonConfig(rf, rp, alpha, np.stack(ark), np.stack(mds), rate, cap)
+    return digests_from_bytes(b[: 32 * n], n, 1).reshape(n, 4)
 
 
 def te_points_bytes(points_wire, compress=False) -> bytes:
     """affine points [n, 2, 4] (wire format) -> x || y each (uncompressed) or y with the x-sign flag (compressed)"""
-    pts = np.ascontiguousarray(points_wire, dtype=np.uint64).reshape(-1, 2, 4)
-    if not compress:
-        return fr_bytes(pts.reshape(-1, 4))
-    out = bytearray()
-    for x, y in zip(field.to_ints(pts[:, 0]), field.to_ints(pts[:, 1])):
-        b = bytearray(int(y).to_bytes(32, "little"))
-        if x > field.MODULUS - x:  # TEFlags::XIsNegative
-            b[31] |= 0x80
-        out += b
-    return bytes(out)
-
-
-def _validate_points(flat_xy):
-    """ark-serialize's default `Validate::Yes` for twisted-Edwards affine points (flat [x0, y0, x1, y1, ...] canonical ints): on
-    the curve -x^2 + y^2 = 1 + d x^2 y^2 and in the prime-order subgroup (r * P = O).  Off-curve or small-order generators would
-    otherwise go straight into the GPU tables."""
-    from .params import _D, SUBGROUP_ORDER, _te_mul
-    q = field.MODULUS
-    for i in range(0, len(flat_xy), 2):
-        x, y = int(flat_xy[i]), int(flat_xy[i + 1])
-        x2, y2 = x * x % q, y * y % q
-        if (y2 - x2 - 1 - _D * x2 % q * y2) % q:
-            raise ValueError("point %d is not on the curve" % (i // 2))
-        if _te_mul((x, y), SUBGROUP_ORDER) != (0, 1):
-            raise ValueError("point %d is not in the prime-order subgroup" % (i // 2))
+    return digests_bytes(points_wire, 2, compress)
 
 
 def te_points_from_bytes(b: bytes, n: int, compress=False, validate=True) -> np.ndarray:
-    """inverse of te_points_bytes -> [n, 2, 4] wire format.  Raises ValueError on truncated input, on a compressed y with no
-    point on the curve and -- with validate (the default, ark-serialize's `Validate::Yes`) -- on a point that is not on the
-    curve or not in the prime-order subgroup.  validate=False is `deserialize_*_unchecked`."""
+    """inverse of te_points_bytes -> [n, 2, 4] wire format"""
     per = 32 if compress else 64
     if len(b) < per * n:
         raise ValueError("truncated input: %d points need %d bytes, got %d" % (n, per * n, len(b)))
-    if not compress:
-        pts = fr_from_bytes(b, 2 * n).reshape(n, 2, 4)
-        if validate:
-            _validate_points(field.to_ints(pts.reshape(-1, 4)))
-        return pts
-    from .params import _sqrt, _D
-    q = field.MODULUS
-    vals = []
-    for i in range(n):
-        raw = bytearray(b[32 * i: 32 * i + 32])
-        neg = bool(raw[31] & 0x80)
-        raw[31] &= 0x7F
-        y = int.from_bytes(raw, "little")
-        if y >= q:
-            raise ValueError("non-canonical y coordinate")
-        y2 = y * y % q
-        x = _sqrt((y2 - 1) * pow(1 + _D * y2, -1, q))
-        if x is None:
-            raise ValueError("y is not the coordinate of a point of the curve")
-        if (x > q - x) != neg:
-            x = (q - x) % q
-        vals += [x, y]
-    if validate:
-        _validate_points(vals)
-    return field.fr(vals).reshape(n, 2, 4)
+    return digests_from_bytes(b[: per * n], n, 2, compress, validate)
+
+
+def serialize_poseidon_config(cfg) -> bytes:
+    h = _host_handle(cfg)  # host-only handle (no device): the library owns the byte format
+    try:
+        return _ser(lambda out, cap, n: lib.akp_serialize_poseidon_config(h, out, cap, n))
+    finally:
+        lib.akp_poseidon_params_destroy(h)
+
+
+def _host_handle(cfg):
+    h = C.c_void_p()
+    check(lib.akp_poseidon_params_create(None, cfg.full_rounds, cfg.partial_rounds, cfg.alpha, cfg.rate, cfg.capacity, cfg.ark.ctypes.data,
+                                         cfg.mds.ctypes.data, C.byref(h)))
+    return h
+
+
+def deserialize_poseidon_config(b: bytes):
+    from .sponge.poseidon import PoseidonConfig
+    buf, ln = _in(b)
+    h = C.c_void_p()
+    _de(lib.akp_deserialize_poseidon_config(None, buf, ln, C.byref(h)))
+    try:
+        rf, rp, r, c = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        alpha = C.c_uint64()
+        check(lib.akp_poseidon_params_dims(h, C.byref(rf), C.byref(rp), C.byref(alpha), C.byref(r), C.byref(c)))
+        t = r.value + c.value
+        ark = np.empty((rf.value + rp.value, t, 4), dtype=np.uint64)
+        mds = np.empty((t, t, 4), dtype=np.uint64)
+        check(lib.akp_poseidon_params_export(h, ark.ctypes.data, mds.ctypes.data))
+        return PoseidonConfig(rf.value, rp.value, alpha.value, ark, mds, r.value, c.value)
+    finally:
+        lib.akp_poseidon_params_destroy(h)
 
 
 def serialize_te_parameters(params, compress=False) -> bytes:
     """Parameters { generators: Vec<Vec<C>> }: projective points serialise as their affine form"""
-    out = [_u64(params.num_windows)]
-    for row in params.generators:
-        out += [_u64(params.window_size), te_points_bytes(row, compress)]
-    return b"".join(out)
+    g = np.ascontiguousarray(params.generators, dtype=np.uint64)
+    nw, ws = (g.shape[0], g.shape[1]) if g.size else (0, 0)
+    return _ser(lambda out, cap, n: lib.akp_serialize_te_parameters(g.ctypes.data if g.size else None, ws, nw, int(compress), out, cap, n))
 
 
 def deserialize_te_parameters(b: bytes, cls, compress=False, validate=True):
-    r = _Reader(b)
-    rows = []
-    per = 32 if compress else 64
-    for _ in range(r.count(8)):
-        w = r.count(per)
-        rows.append(te_points_from_bytes(r.take(per * w), w, compress, validate))
-    if not rows or any(len(x) != len(rows[0]) for x in rows):
-        raise ValueError("generators must be a non-empty rectangular Vec<Vec<_>>")
-    return cls(np.stack(rows))
+    buf, ln = _in(b)
+    ws, nw = C.c_uint32(), C.c_uint32()
+    _de(lib.akp_deserialize_te_parameters(buf, ln, int(compress), 0, None, 0, C.byref(ws), C.byref(nw)))
+    g = np.empty((nw.value, ws.value, 2, 4), dtype=np.uint64)
+    if g.size:
+        _de(lib.akp_deserialize_te_parameters(buf, ln, int(compress), int(validate), g.ctypes.data, nw.value * ws.value, C.byref(ws), C.byref(nw)))
+    return cls(g)
 
 
 def _digest_bytes(d, compress=False) -> bytes:
     d = np.asarray(d, dtype=np.uint64)
-    if compress and d.shape[-2:] == (2, 4):  # an affine point (Pedersen digest)
-        return te_points_bytes(d, True)
-    return fr_bytes(d.reshape(-1, 4))
-
-
-def _read_digest(r, config, compress):
-    if config.digest_shape == (2, 4):
-        return te_points_from_bytes(r.take(32 if compress else 64), 1, compress)[0]
-    return r.fr(1).reshape(config.digest_shape)
+    return digests_bytes(d, 2 if d.shape[-2:] == (2, 4) else 1, compress)
 
 
 def serialize_path(path, compress=False) -> bytes:
     """Path { leaf_sibling_hash, auth_path: Vec<InnerDigest>, leaf_index: usize }"""
-    out = [_digest_bytes(path.leaf_sibling_hash, compress), _u64(len(path.auth_path))]
-    out += [_digest_bytes(a, compress) for a in path.auth_path]
-    out.append(_u64(path.leaf_index))
-    return b"".join(out)
+    fe = _fe_of(path.config)
+    sib = _wire(path.leaf_sibling_hash, fe)
+    depth = len(path.auth_path)
+    auth = _wire(np.stack([np.asarray(a) for a in path.auth_path]), fe) if depth else np.zeros((0, fe, 4), np.uint64)
+    return _ser(lambda out, cap, n: lib.akp_serialize_path(sib.ctypes.data, auth.ctypes.data if depth else None, depth, int(path.leaf_index), fe,
+                                                           int(compress), out, cap, n))
 
 
-def deserialize_path(b: bytes, config, compress=False):
+def deserialize_path(b: bytes, config, compress=False, validate=True):
     from .merkle_tree import Path
-    r = _Reader(b)
-    sib = _read_digest(r, config, compress)
-    auth = [_read_digest(r, config, compress) for _ in range(r.count(32))]
-    return Path(config, sib, auth, r.u64())
+    fe = _fe_of(config)
+    buf, ln = _in(b)
+    depth, idx = C.c_size_t(), C.c_uint64()
+    _de(lib.akp_deserialize_path(buf, ln, fe, int(compress), 0, None, None, 0, C.byref(depth), C.byref(idx)))
+    sib = np.empty((fe, 4), dtype=np.uint64)
+    auth = np.empty((max(depth.value, 1), fe, 4), dtype=np.uint64)
+    _de(lib.akp_deserialize_path(buf, ln, fe, int(compress), int(validate), sib.ctypes.data, auth.ctypes.data, depth.value, C.byref(depth), C.byref(idx)))
+    shape = tuple(config.digest_shape)
+    return Path(config, sib.reshape(shape), [auth[j].reshape(shape) for j in range(depth.value)], idx.value)
 
 
 def serialize_multi_path(mp, compress=False) -> bytes:
     """MultiPath { leaf_siblings_hashes, auth_paths_prefix_lenghts, auth_paths_suffixes, leaf_indexes }"""
-    out = [_u64(len(mp.leaf_siblings_hashes))] + [_digest_bytes(d, compress) for d in mp.leaf_siblings_hashes]
-    out += [_u64(len(mp.auth_paths_prefix_lenghts))] + [_u64(v) for v in mp.auth_paths_prefix_lenghts]
-    out.append(_u64(len(mp.auth_paths_suffixes)))
-    for suf in mp.auth_paths_suffixes:
-        out += [_u64(len(suf))] + [_digest_bytes(d, compress) for d in suf]
-    out += [_u64(len(mp.leaf_indexes))] + [_u64(v) for v in mp.leaf_indexes]
-    return b"".join(out)
+    fe = _fe_of(mp.config)
+    m = len(mp.leaf_indexes)
+    if not (len(mp.leaf_siblings_hashes) == len(mp.auth_paths_prefix_lenghts) == len(mp.auth_paths_suffixes) == m):
+        raise ValueError("the four vectors of a MultiPath must have the same length")
+    sibs = _wire(np.stack([np.asarray(d) for d in mp.leaf_siblings_hashes]), fe) if m else np.zeros((0, fe, 4), np.uint64)
+    pre = np.asarray(list(mp.auth_paths_prefix_lenghts), dtype=np.uint64)
+    sl = np.asarray([len(s) for s in mp.auth_paths_suffixes], dtype=np.uint64)
+    flat = [np.asarray(d) for s in mp.auth_paths_suffixes for d in s]
+    suf = _wire(np.stack(flat), fe) if flat else np.zeros((0, fe, 4), np.uint64)
+    idx = np.asarray(list(mp.leaf_indexes), dtype=np.uint64)
+    return _ser(lambda out, cap, n: lib.akp_serialize_multipath(sibs.ctypes.data if m else None, pre.ctypes.data if m else None, sl.ctypes.data if m else None,
+                                                                suf.ctypes.data if flat else None, idx.ctypes.data if m else None, m, 0, fe, int(compress),
+                                                                out, cap, n))
 
 
-def deserialize_multi_path(b: bytes, config, compress=False):
+def deserialize_multi_path(b: bytes, config, compress=False, validate=True):
     from .merkle_tree import MultiPath
-    r = _Reader(b)
-    sibs = [_read_digest(r, config, compress) for _ in range(r.count(32))]
-    pre = [r.u64() for _ in range(r.count(8))]
-    suf = [[_read_digest(r, config, compress) for _ in range(r.count(32))] for _ in range(r.count(8))]
-    idx = [r.u64() for _ in range(r.count(8))]
-    return MultiPath(config, sibs, pre, suf, idx)
+    fe = _fe_of(config)
+    buf, ln = _in(b)
+    m, ns = C.c_size_t(), C.c_size_t()
+    _de(lib.akp_deserialize_multipath(buf, ln, fe, int(compress), 0, C.byref(m), C.byref(ns), None, None, None, None, None, 0, 0))
+    M, NS = m.value, ns.value
+    sibs = np.empty((max(M, 1), fe, 4), dtype=np.uint64)
+    pre, sl, idx = (np.empty(max(M, 1), dtype=np.uint64) for _ in range(3))
+    suf = np.empty((max(NS, 1), fe, 4), dtype=np.uint64)
+    _de(lib.akp_deserialize_multipath(buf, ln, fe, int(compress), int(validate), C.byref(m), C.byref(ns), sibs.ctypes.data, pre.ctypes.data, sl.ctypes.data,
+                                      suf.ctypes.data, idx.ctypes.data, M, NS))
+    shape = tuple(config.digest_shape)
+    suffixes, at = [], 0
+    for i in range(M):
+        k = int(sl[i])
+        suffixes.append([suf[at + j].reshape(shape) for j in range(k)])
+        at += k
+    return MultiPath(config, [sibs[i].reshape(shape) for i in range(M)], [int(v) for v in pre[:M]], suffixes, [int(v) for v in idx[:M]])

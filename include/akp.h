@@ -51,7 +51,7 @@ extern "C" {
 #define AKP_ERR_RCCL 4 /* RCCL could not be loaded / a collective of the multi-device entry points failed */
 #define AKP_ERR_NOT_POW2 5
 
-#define AKP_ABI_VERSION 2
+#define AKP_ABI_VERSION 3
 
 typedef struct akp_ctx akp_ctx;
 typedef struct akp_poseidon akp_poseidon; /* PoseidonConfig<Fr>, sponge/poseidon/mod.rs:27-45 */
@@ -75,13 +75,18 @@ int32_t akp_ctx_synchronize(akp_ctx* ctx);
 void* akp_ctx_stream(akp_ctx* ctx);
 
 /* ---- pinned host memory (optional) ----------------------------------------------------------- */
-/* The host-pointer entry points accept any host memory.  Pageable memory: batches larger than one chunk
- * (2^18 items) are cut into chunks whose copy-in / kernel / copy-out overlap on three streams (the copies are
- * staged by the runtime).  Memory from akp_host_alloc, or registered with akp_host_register, is addressed by the
- * Poseidon batch kernels DIRECTLY (zero copy: every item is read once and written once over PCIe, both directions
- * at the same time) when all buffers of a call are of that kind; akp_te_crh_batch writes its digests directly into a
- * pinned / registered `out` (the messages still go through a device copy: they are read bit-window by bit-window).
- * Register a buffer as a whole: the runtime rejects copies that straddle registered and unregistered memory. */
+/* The host-pointer entry points accept any host memory.  Pageable memory: batches larger than one chunk are cut into chunks
+ * whose copy-in / kernel / copy-out overlap on three streams (the copies are staged by the runtime and block the calling
+ * thread).  Memory from akp_host_alloc, or registered with akp_host_register:
+ *   - the Poseidon batch kernels address it DIRECTLY (zero copy: every item is read once and written once over PCIe, both
+ *     directions at the same time) when all buffers of a call are of that kind;
+ *   - akp_te_crh_batch, when BOTH `msgs` and `out` are of that kind, moves them by asynchronous DMA (all copy-ins issued up
+ *     front, copy-outs on a side stream under the next chunk's kernels) -- never by zero copy: in-place reads make every
+ *     workgroup wait for PCIe at the same moments and in-place 16-byte digest stores cross PCIe at 17 GB/s (measured,
+ *     profiles/r04_s2 .. r04_s3).  Pinned on one side only behaves like pageable memory.
+ * Either way is at least as fast as pageable buffers; the gain is small for the curve hashes (their kernel time exceeds the
+ * copy time) and 20 % for the Poseidon batches.  Register a buffer as a whole: the runtime rejects copies that straddle
+ * registered and unregistered memory. */
 int32_t akp_host_alloc(size_t bytes, void** out);
 int32_t akp_host_free(void* p);
 int32_t akp_host_register(void* p, size_t bytes);
@@ -248,8 +253,8 @@ int32_t akp_merkle_verify_paths_te(akp_te_params* leaf_params, akp_te_params* tw
 
 /* ---- Merkle tree resident in HBM (MerkleTree<P>, merkle_tree/mod.rs:383-725) ------------------------------------ */
 /* MerkleTree::new (:411-422): the two node vectors stay in device memory (leaf_nodes[n], non_leaf_nodes[n-1] in
- * heap order); the host asks for what it needs (root, proofs, the vectors).  The parameter handles must outlive
- * the tree.  leaves: n x leaf_len Fr (Poseidon) / n x leaf_len bytes (Pedersen, Bowe-Hopwood). */
+ * heap order); the host asks for what it needs (root, proofs, the vectors).  The tree pins its parameter handles:
+ * destroying one while the tree lives only defers its release to akp_merkle_tree_destroy (likewise akp_sponge).  leaves: n x leaf_len Fr (Poseidon) / n x leaf_len bytes (Pedersen, Bowe-Hopwood). */
 int32_t akp_merkle_tree_build_poseidon(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* leaves,
                                        size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
 int32_t akp_merkle_tree_build_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* leaves,
@@ -304,6 +309,50 @@ int32_t akp_merkle_verify_multipath_te(akp_te_params* leaf_params, akp_te_params
                                        const uint8_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indexes,
                                        const uint64_t* leaf_siblings_hashes, const uint64_t* prefix_lengths,
                                        const uint64_t* suffixes, size_t n_suffix_digests, size_t depth, int32_t* ok);
+
+/* ---- ark-serialize byte formats (host only: no device, no context) ---------------------------------------------------------- */
+/* Derived CanonicalSerialize / CanonicalDeserialize of the structs that cross the boundary, fields in declaration order:
+ * PoseidonConfig (sponge/poseidon/mod.rs:26-45), pedersen / bowe_hopwood Parameters (crh/pedersen/mod.rs:28-31,
+ * crh/bowe_hopwood/mod.rs:33-37), Path (merkle_tree/mod.rs:139-152), MultiPath (:239-254).  usize / u64: 8 bytes LE; Vec<T>: u64
+ * length + elements; Fq: 32 bytes LE of the canonical integer; affine point: x || y (compress = 0) or y with the sign of x in
+ * the top bit of the last byte (compress = 1); projective points serialise as their affine form.
+ * Writers: `out` may be NULL (size query); *out_len always receives the size; a buffer that is too small is
+ * AKP_ERR_BAD_LENGTH.  Readers: truncated input / trailing bytes are AKP_ERR_BAD_LENGTH, non-canonical field elements and
+ * (validate != 0, ark-serialize's Validate::Yes) points off the curve or outside the prime-order subgroup AKP_ERR_BAD_PARAMS;
+ * validate = 0 is deserialize_*_unchecked. */
+/* n digests back to back, no length prefix (fe_per_digest 1: Fq -- Poseidon / Bowe-Hopwood; 2: affine point -- Pedersen) */
+int32_t akp_serialize_digests(const uint64_t* digests, size_t n, uint32_t fe_per_digest, int32_t compress, uint8_t* out,
+                              size_t out_cap, size_t* out_len);
+int32_t akp_deserialize_digests(const uint8_t* in, size_t in_len, size_t n, uint32_t fe_per_digest, int32_t compress,
+                                int32_t validate, uint64_t* digests);
+/* PoseidonConfig: both modes write the same bytes.  The reader builds a handle (ctx may be NULL: host-only handle). */
+int32_t akp_serialize_poseidon_config(const akp_poseidon* p, uint8_t* out, size_t out_cap, size_t* out_len);
+int32_t akp_deserialize_poseidon_config(akp_ctx* ctx, const uint8_t* in, size_t in_len, akp_poseidon** out);
+/* Parameters { generators: Vec<Vec<C>> }: generators_affine is [num_windows][window_size] points as in akp_te_params_create.
+ * Reader: generators_affine == NULL only reports the shape; otherwise up to cap_points points are written. */
+int32_t akp_serialize_te_parameters(const uint64_t* generators_affine, uint32_t window_size, uint32_t num_windows,
+                                    int32_t compress, uint8_t* out, size_t out_cap, size_t* out_len);
+int32_t akp_deserialize_te_parameters(const uint8_t* in, size_t in_len, int32_t compress, int32_t validate,
+                                      uint64_t* generators_affine, size_t cap_points, uint32_t* window_size,
+                                      uint32_t* num_windows);
+/* Path { leaf_sibling_hash, auth_path (root side first), leaf_index }.  Reader: leaf_sibling_hash == NULL only reports
+ * *depth and *leaf_index. */
+int32_t akp_serialize_path(const uint64_t* leaf_sibling_hash, const uint64_t* auth_path, size_t depth, uint64_t leaf_index,
+                           uint32_t fe_per_digest, int32_t compress, uint8_t* out, size_t out_cap, size_t* out_len);
+int32_t akp_deserialize_path(const uint8_t* in, size_t in_len, uint32_t fe_per_digest, int32_t compress, int32_t validate,
+                             uint64_t* leaf_sibling_hash, uint64_t* auth_path, size_t auth_cap, size_t* depth,
+                             uint64_t* leaf_index);
+/* MultiPath in the flat form of akp_merkle_multipath_encode: m paths, suffixes concatenated; suffix i holds suffix_lengths[i]
+ * digests, or depth - prefix_lengths[i] when suffix_lengths is NULL.  Reader: leaf_siblings_hashes == NULL only reports *m
+ * and *n_suffix_digests; the four vectors of the struct must have the same length (the flat form cannot hold anything else). */
+int32_t akp_serialize_multipath(const uint64_t* leaf_siblings_hashes, const uint64_t* prefix_lengths,
+                                const uint64_t* suffix_lengths, const uint64_t* suffixes, const uint64_t* leaf_indexes, size_t m,
+                                size_t depth, uint32_t fe_per_digest, int32_t compress, uint8_t* out, size_t out_cap,
+                                size_t* out_len);
+int32_t akp_deserialize_multipath(const uint8_t* in, size_t in_len, uint32_t fe_per_digest, int32_t compress, int32_t validate,
+                                  size_t* m, size_t* n_suffix_digests, uint64_t* leaf_siblings_hashes, uint64_t* prefix_lengths,
+                                  uint64_t* suffix_lengths, uint64_t* suffixes, uint64_t* leaf_indexes, size_t m_cap,
+                                  size_t suffix_cap);
 
 /* ---- several GPUs from one process (merkle_tree/mod.rs:411-523 sharded by leaf range) -------- */
 /* akp_ctx_create for n_dev devices (a power of two, distinct ids) + ncclCommInitAll over them.  RCCL is loaded with

@@ -72,6 +72,13 @@ class PoseidonConfig {
         check(akp_poseidon_default_params(ctx.get(), rate, optimized_for_weights ? 1 : 0, &h));
         return PoseidonConfig(h);
     }
+    // CanonicalDeserialize (ark-serialize bytes of sponge/poseidon/mod.rs:26-45); ctx == nullptr: a host-only handle (inspection,
+    // re-serialisation; compute calls on it fail with AKP_ERR_HIP)
+    static PoseidonConfig deserialize(const Context* ctx, const std::vector<uint8_t>& bytes) {
+        akp_poseidon* h = nullptr;
+        check(akp_deserialize_poseidon_config(ctx ? ctx->get() : nullptr, bytes.data(), bytes.size(), &h));
+        return PoseidonConfig(h);
+    }
     ~PoseidonConfig() { akp_poseidon_params_destroy(h_); }
     PoseidonConfig(PoseidonConfig&& o) noexcept { *this = std::move(o); }
     PoseidonConfig& operator=(PoseidonConfig&& o) noexcept {
@@ -384,5 +391,94 @@ class GpuMerkleTree {
     size_t leaf_len_ = 0, n_ = 0, height_ = 0;
     akp_merkle_tree* h_ = nullptr;
 };
+
+
+// ---- CanonicalSerialize / CanonicalDeserialize (ark-serialize byte formats; akp_serialize_* / akp_deserialize_*) ---------------
+// `compress` is ark-serialize's Compress mode, `validate` its Validate mode (false = deserialize_*_unchecked).  Host only.
+namespace serialize {
+template <class Call>
+inline std::vector<uint8_t> write(Call call) {  // size query, then the real call
+    size_t n = 0;
+    check(call(nullptr, 0, &n));
+    std::vector<uint8_t> out(n);
+    check(call(out.data(), out.size(), &n));
+    return out;
+}
+// digests back to back, no length prefix: fe = 1 (Fq: Poseidon / Bowe-Hopwood / the x-only Pedersen hashes), 2 (affine point)
+inline std::vector<uint8_t> digests(const uint64_t* wire, size_t n, uint32_t fe, bool compress) {
+    return write([&](uint8_t* o, size_t cap, size_t* len) { return akp_serialize_digests(wire, n, fe, compress ? 1 : 0, o, cap, len); });
+}
+inline std::vector<uint8_t> poseidon_config(const PoseidonConfig& cfg) {
+    return write([&](uint8_t* o, size_t cap, size_t* len) { return akp_serialize_poseidon_config(cfg.get(), o, cap, len); });
+}
+// Parameters { generators }: [num_windows][window_size] affine points (x || y wire format), as akp_te_params_create takes them
+inline std::vector<uint8_t> te_parameters(const std::vector<FrWire>& generators_affine, uint32_t window_size, uint32_t num_windows, bool compress) {
+    return write([&](uint8_t* o, size_t cap, size_t* len) {
+        return akp_serialize_te_parameters(generators_affine.empty() ? nullptr : generators_affine[0].data(), window_size, num_windows, compress ? 1 : 0, o, cap,
+                                           len);
+    });
+}
+struct TeGenerators {
+    std::vector<FrWire> generators_affine;
+    uint32_t window_size = 0, num_windows = 0;
+};
+inline TeGenerators read_te_parameters(const std::vector<uint8_t>& in, bool compress, bool validate = true) {
+    TeGenerators g;
+    check(akp_deserialize_te_parameters(in.data(), in.size(), compress ? 1 : 0, 0, nullptr, 0, &g.window_size, &g.num_windows));
+    g.generators_affine.resize((size_t)g.window_size * g.num_windows * 2);
+    if (!g.generators_affine.empty())
+        check(akp_deserialize_te_parameters(in.data(), in.size(), compress ? 1 : 0, validate ? 1 : 0, g.generators_affine[0].data(),
+                                            (size_t)g.window_size * g.num_windows, &g.window_size, &g.num_windows));
+    return g;
+}
+// Path<PoseidonFieldConfig> (field digests: both modes write the same bytes)
+inline std::vector<uint8_t> path(const Path<PoseidonFieldConfig>& p, bool compress = false) {
+    return write([&](uint8_t* o, size_t cap, size_t* len) {
+        return akp_serialize_path(p.leaf_sibling_hash.data(), p.auth_path.empty() ? nullptr : p.auth_path[0].data(), p.auth_path.size(), p.leaf_index, 1,
+                                  compress ? 1 : 0, o, cap, len);
+    });
+}
+inline Path<PoseidonFieldConfig> read_path(const std::vector<uint8_t>& in, bool compress = false, bool validate = true) {
+    Path<PoseidonFieldConfig> p;
+    size_t depth = 0;
+    uint64_t idx = 0;
+    check(akp_deserialize_path(in.data(), in.size(), 1, compress ? 1 : 0, 0, nullptr, nullptr, 0, &depth, &idx));
+    p.auth_path.resize(depth);
+    check(akp_deserialize_path(in.data(), in.size(), 1, compress ? 1 : 0, validate ? 1 : 0, p.leaf_sibling_hash.data(),
+                               depth ? p.auth_path[0].data() : nullptr, depth, &depth, &idx));
+    p.leaf_index = (size_t)idx;
+    return p;
+}
+// MultiPath in the flat form of akp_merkle_multipath_encode (field digests)
+struct FlatMultiPath {
+    std::vector<FrWire> leaf_siblings_hashes, suffixes;
+    std::vector<uint64_t> prefix_lengths, suffix_lengths, leaf_indexes;
+};
+inline std::vector<uint8_t> multi_path(const FlatMultiPath& m, bool compress = false) {
+    return write([&](uint8_t* o, size_t cap, size_t* len) {
+        return akp_serialize_multipath(m.leaf_siblings_hashes.empty() ? nullptr : m.leaf_siblings_hashes[0].data(), m.prefix_lengths.data(),
+                                       m.suffix_lengths.data(), m.suffixes.empty() ? nullptr : m.suffixes[0].data(), m.leaf_indexes.data(),
+                                       m.leaf_indexes.size(), 0, 1, compress ? 1 : 0, o, cap, len);
+    });
+}
+inline FlatMultiPath read_multi_path(const std::vector<uint8_t>& in, bool compress = false, bool validate = true) {
+    FlatMultiPath m;
+    size_t n = 0, ns = 0;
+    check(akp_deserialize_multipath(in.data(), in.size(), 1, compress ? 1 : 0, 0, &n, &ns, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0));
+    m.leaf_siblings_hashes.resize(n ? n : 1);
+    m.prefix_lengths.resize(n ? n : 1);
+    m.suffix_lengths.resize(n ? n : 1);
+    m.leaf_indexes.resize(n ? n : 1);
+    m.suffixes.resize(ns ? ns : 1);
+    check(akp_deserialize_multipath(in.data(), in.size(), 1, compress ? 1 : 0, validate ? 1 : 0, &n, &ns, m.leaf_siblings_hashes[0].data(),
+                                    m.prefix_lengths.data(), m.suffix_lengths.data(), m.suffixes[0].data(), m.leaf_indexes.data(), n, ns));
+    m.leaf_siblings_hashes.resize(n);
+    m.prefix_lengths.resize(n);
+    m.suffix_lengths.resize(n);
+    m.leaf_indexes.resize(n);
+    m.suffixes.resize(ns);
+    return m;
+}
+}  // namespace serialize
 
 }  // namespace akp

@@ -63,8 +63,18 @@ pub fn check(rc: i32, len: usize) -> Result<(), Error> {
 /// hundreds of MB, so handles are kept per distinct parameter set.  An entry stores the FULL key material next to the
 /// handle: the 64-bit fingerprint only narrows the search, a hit needs `tag` and every field element to be equal -- a
 /// fingerprint collision (trivial to construct for attacker-supplied or deserialised parameters) can therefore never hand out
-/// another set's tables.  Bounded: beyond `cap` entries the least recently used handle is destroyed (its device tables with
-/// it), so a thread that walks through many parameter sets does not pin their tables until it exits.
+/// another set's tables.  Bounded: beyond `cap` entries the least recently used handle is handed to `akp_*_params_destroy`,
+/// so a thread that walks through many parameter sets does not keep their tables until it exits.
+///
+/// Eviction and objects that outlive the call: `GpuMerkleTree` and `GpuPoseidonSponge` keep the raw handle inside libakp
+/// (`akp_merkle_tree` stores its leaf / two-to-one handles, `akp_sponge` its parameters) for their whole lifetime.  The
+/// library PINS a parameter handle for every tree and sponge built on it (ABI version 3, `capi_internal.hpp` `pins`):
+/// `akp_*_params_destroy` on a pinned handle only marks it and the tables are released by the last
+/// `akp_merkle_tree_destroy` / `akp_sponge_destroy`.  An evicted handle that a live tree still uses therefore stays valid for
+/// that tree (no use-after-free from safe Rust, whatever the eviction order), and a later `get_or_create` of the same
+/// parameter set simply builds a fresh handle.  The same accounting covers the context: trees and sponges count as handles
+/// of their `akp_ctx`, so a tree moved to another thread survives the exit of the thread that built it (its calls then
+/// fail with a clean error instead of touching a freed context).
 pub struct HandleCache<H: Copy> {
     entries: Vec<CacheEntry<H>>,
     tick: u64,
@@ -108,8 +118,8 @@ impl<H: Copy> Drop for HandleCache<H> {
     }
 }
 
-/// One context per OS thread + the parameter handles created on it.  A handle returned by a cache stays valid until `cap`
-/// OTHER parameter sets have been used on this thread; the trait implementations use it within the call that asked for it.
+/// One context per OS thread + the parameter handles created on it.  A handle returned by a cache is used by the trait
+/// implementations within the call that asked for it, or handed to a tree / sponge constructor, which pins it (above).
 pub struct ThreadRuntime {
     // field order = drop order: the handle caches go before the context they were created on
     pub poseidon: HandleCache<*mut ffi::AkpPoseidon>,

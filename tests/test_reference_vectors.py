@@ -22,7 +22,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, GOLD)
 import reference_schema as rs  # noqa: E402
 
-from oracle import poseidon as po, jubjub as jj, pedersen as opd, bowe_hopwood as obh, merkle as omk  # noqa: E402
+from oracle import poseidon as po, jubjub as jj, pedersen as opd, bowe_hopwood as obh, merkle as omk, serialize as oser  # noqa: E402
 
 UNPINNED = ("parity unpinned (emitter not run): tests/golden/reference_vectors.json is absent -- run "
             "`cargo run --release --example emit_vectors` in shim/ on a machine with a Rust toolchain")
@@ -81,6 +81,25 @@ class Ser:
         return self.s.serialize_poseidon_config(PoseidonConfig(sec["full_rounds"], sec["partial_rounds"], sec["alpha"], ark, mds, sec["rate"], sec["capacity"]))
 
 
+# ---- serialisation through the ORACLE's independent restatement (oracle/serialize.py: python ints, nothing of the product) ----
+class OracleSer:
+    def digest(self, kind, d, compress):
+        return oser.digest(d, compress)
+
+    def path(self, kind, sib, auth, idx, compress):
+        return oser.path(sib, auth, idx, compress)
+
+    def multi_path(self, kind, mp, compress):
+        return oser.multi_path(mp["leaf_siblings_hashes"], mp["auth_paths_prefix_lenghts"], mp["auth_paths_suffixes"], mp["leaf_indexes"], compress)
+
+    def te_parameters(self, gens, compress):
+        return oser.te_parameters([[(int(p[0]), int(p[1])) for p in row] for row in gens], compress)
+
+    def poseidon_config(self, sec, compress):
+        return oser.poseidon_config(sec["full_rounds"], sec["partial_rounds"], sec["alpha"], [[int(x) for x in r] for r in sec["ark"]],
+                                    [[int(x) for x in r] for r in sec["mds"]], sec["rate"], sec["capacity"], compress)
+
+
 # ---- implementation 1: the python oracle --------------------------------------------------------------------------------
 class _OracleTree:
     def __init__(self, t, wrap):
@@ -108,7 +127,7 @@ class _OracleTree:
 
 class OracleImpl:
     def __init__(self):
-        self.ser = Ser()
+        self.ser = OracleSer()  # round 4: NOT the product's serializer -- every "uncompressed" / "compressed" field below is oracle bytes
 
     def curve(self, kind, sec):
         W, N = sec["window_size"], sec["num_windows"]
@@ -275,8 +294,83 @@ def test_consumer_detects_differences(oracle_vectors):
     assert all(len(e["uncompressed"]) == 128 and len(e["compressed"]) == 64 for e in oracle_vectors["pedersen"]["crh"])
 
 
+class _ProductSerOnOracleValues(OracleImpl):
+    """the ORACLE's hashes and trees, serialised by the PRODUCT (serialize.py -> C ABI): differs from `oracle_vectors` only in who
+    wrote the bytes, so the diff below is a byte-for-byte comparison of the two serialisers on every emitted struct.  No GPU."""
+
+    def __init__(self):
+        self.ser = Ser()
+
+
+def test_product_serializer_equals_the_oracle_serializer(inputs, oracle_vectors):
+    ours = rs.build_vectors(inputs, _ProductSerOnOracleValues())
+    bad, only_ref, only_ours = rs.diff(oracle_vectors, ours)
+    assert (bad, only_ref, only_ours) == ([], [], [])
+    n_hex = sum(1 for k, v in _walk(oracle_vectors) if k.endswith(("uncompressed", "compressed")) and isinstance(v, str))
+    assert n_hex >= 100  # digests, paths, multi-paths, parameters and configs, both modes
+
+
+def _walk(o, at=""):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            yield from _walk(v, at + "/" + k)
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            yield from _walk(v, "%s[%d]" % (at, i))
+    else:
+        yield at, o
+
+
+@pytest.mark.parametrize("mutation", ["swap_path_fields", "drop_vec_prefix", "flag_polarity", "config_field_order"])
+def test_a_wrong_product_serializer_is_caught(inputs, oracle_vectors, monkeypatch, mutation):
+    """the comparison above has teeth: a field-order or length-prefix mistake in the product serialiser (simulated by
+    monkey-patching serialize.py) is reported at the struct it breaks"""
+    from crypto_primitives_amd import serialize as S
+    if mutation == "swap_path_fields":  # leaf_index written before auth_path
+        good = S.serialize_path
+
+        def bad_path(path, compress=False):
+            b = good(path, compress)
+            per = 32 if (compress or S._fe_of(path.config) == 1) else 64
+            return b[:per] + b[-8:] + b[per:-8]
+        monkeypatch.setattr(S, "serialize_path", bad_path)
+        where = "/tree/proofs[0]/uncompressed"
+    elif mutation == "drop_vec_prefix":  # the Vec<usize> of leaf indexes without its length
+        good = S.serialize_multi_path
+
+        def bad_mp(mp, compress=False):
+            b = good(mp, compress)
+            m = len(mp.leaf_indexes)
+            return b[:len(b) - 8 * m - 8] + b[len(b) - 8 * m:]
+        monkeypatch.setattr(S, "serialize_multi_path", bad_mp)
+        where = "/tree/multi_proof/uncompressed"
+    elif mutation == "flag_polarity":  # sign flag set for the SMALLER of (x, -x)
+        good = S.digests_bytes
+
+        def bad_dig(d, fe, compress=False):
+            b = bytearray(good(d, fe, compress))
+            if fe == 2 and compress:
+                for i in range(31, len(b), 32):
+                    b[i] ^= 0x80
+            return bytes(b)
+        monkeypatch.setattr(S, "digests_bytes", bad_dig)
+        where = "/pedersen/crh[1]/compressed"
+    else:  # rate / capacity ahead of the matrices
+        good = S.serialize_poseidon_config
+
+        def bad_cfg(cfg):
+            b = good(cfg)
+            return b[:24] + b[-16:] + b[24:-16]
+        monkeypatch.setattr(S, "serialize_poseidon_config", bad_cfg)
+        where = "/poseidon/config_uncompressed"
+    section = ("poseidon",) if mutation == "config_field_order" else ("pedersen",)
+    ours = rs.build_vectors(inputs, _ProductSerOnOracleValues(), sections=section)
+    bad, _, _ = rs.diff({k: oracle_vectors[k] for k in section}, ours)
+    assert any(b.endswith(where) or where in b for b in bad), (mutation, bad[:5])
+
+
 def test_reference_vectors_pin_the_oracle(reference, inputs, oracle_vectors):
-    """WITH the emitter's file: every value the reference produced is reproduced by the python oracle and by serialize.py"""
+    """WITH the emitter's file: every value the reference produced is reproduced by the python oracle and by oracle/serialize.py"""
     assert reference["poseidon"]["reference_generator_matches_inputs"] is True
     bad, only_ref, _ = rs.diff({k: reference[k] for k in ("pedersen", "bowe_hopwood", "poseidon")}, oracle_vectors)
     assert not bad, "the oracle / serialize.py differ from the REFERENCE at: %s" % bad[:20]

@@ -86,3 +86,123 @@ def test_deserialisation_rejects_truncated_and_invalid_input():
     for cut in (5, 30, len(cfg_b) - 3):
         with pytest.raises(ValueError):
             S.deserialize_poseidon_config(cfg_b[:cut])
+
+
+# ---- round 4: the product's bytes (C ABI: akp_serialize_* / akp_deserialize_*) against the oracle's independent restatement ----
+def _ints(a):
+    from crypto_primitives_amd import field
+    return [int(v) for v in field.to_ints(np.asarray(a, dtype=np.uint64).reshape(-1, 4))]
+
+
+def _wire(vals, shape):
+    from crypto_primitives_amd import field
+    return field.fr([int(v) for v in vals]).reshape(shape)
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_every_struct_byte_for_byte_against_oracle_serialize(compress):
+    """writers: product bytes == oracle bytes; readers: each side parses the other's bytes to the same values"""
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import serialize as S
+    from crypto_primitives_amd.crh import pedersen
+    from oracle import serialize as O
+    pts = [jj.mul(jj.GENERATOR, k) for k in (1, 2, 3, 5, 7, 11, 13, 17, 19, jj.SUBGROUP_ORDER - 2)]
+    assert any(x > (jj.Q - 1) // 2 for x, _ in pts) and any(x <= (jj.Q - 1) // 2 for x, _ in pts)
+    fes = [(3 ** (40 + i) % jj.Q,) for i in range(10)] + [(0,), (jj.Q - 1,)]
+    # Parameters
+    g = [pts[0:3], pts[3:6]]
+    P = pedersen.Parameters(gens_array(g))
+    assert S.serialize_te_parameters(P, compress) == O.te_parameters(g, compress)
+    assert O.read_te_parameters(S.serialize_te_parameters(P, compress), compress) == [[tuple(p) for p in row] for row in g]
+    back = S.deserialize_te_parameters(O.te_parameters(g, compress), pedersen.Parameters, compress)
+    assert np.array_equal(back.generators, P.generators)
+    empty = S.deserialize_te_parameters(O.te_parameters([], compress), pedersen.Parameters, compress)  # ark-serialize accepts an empty Vec
+    assert empty.generators.size == 0
+    # Path and MultiPath, point digests (Pedersen) and field digests (Poseidon / Bowe-Hopwood)
+    for cfg, ds, shape in ((cpa.PedersenByteConfig, pts, (2, 4)), (cpa.PoseidonFieldConfig, fes, cpa.PoseidonFieldConfig.digest_shape)):
+        fe = len(ds[0])
+        w = [_wire(d, shape) for d in ds]
+        pb = S.serialize_path(cpa.Path(cfg, w[0], w[1:6], 29), compress)
+        assert pb == O.path(ds[0], ds[1:6], 29, compress)
+        sib, auth, idx = O.read_path(pb, fe, compress)
+        assert (tuple(sib), [tuple(a) for a in auth], idx) == (tuple(ds[0]), [tuple(d) for d in ds[1:6]], 29)
+        p2 = S.deserialize_path(O.path(ds[0], ds[1:6], 29, compress), cfg, compress)
+        assert p2.leaf_index == 29 and _ints(p2.leaf_sibling_hash) == list(ds[0]) and [_ints(a) for a in p2.auth_path] == [list(d) for d in ds[1:6]]
+        assert S.serialize_path(cpa.Path(cfg, w[0], [], 0), compress) == O.path(ds[0], [], 0, compress)  # a two-leaf tree: empty auth path
+        suf = [ds[3:6], [], ds[6:8]]
+        mb = S.serialize_multi_path(cpa.MultiPath(cfg, w[0:3], [0, 3, 1], [[_wire(d, shape) for d in s] for s in suf], [4, 5, 9]), compress)
+        assert mb == O.multi_path(ds[0:3], [0, 3, 1], suf, [4, 5, 9], compress)
+        got = O.read_multi_path(mb, fe, compress)
+        assert got["auth_paths_prefix_lenghts"] == [0, 3, 1] and got["leaf_indexes"] == [4, 5, 9] and [len(s) for s in got["auth_paths_suffixes"]] == [3, 0, 2]
+        m2 = S.deserialize_multi_path(O.multi_path(ds[0:3], [0, 3, 1], suf, [4, 5, 9], compress), cfg, compress)
+        assert m2.leaf_indexes == [4, 5, 9] and m2.auth_paths_prefix_lenghts == [0, 3, 1]
+        assert [[_ints(d) for d in s] for s in m2.auth_paths_suffixes] == [[list(d) for d in s] for s in suf]
+        assert [_ints(d) for d in m2.leaf_siblings_hashes] == [list(d) for d in ds[0:3]]
+    # PoseidonConfig (mode-independent)
+    cfgp = cpa.get_default_poseidon_parameters(2, False)
+    ob = O.poseidon_config(cfgp.full_rounds, cfgp.partial_rounds, cfgp.alpha, [_ints(r) for r in cfgp.ark], [_ints(r) for r in cfgp.mds], cfgp.rate,
+                           cfgp.capacity, compress)
+    assert S.serialize_poseidon_config(cfgp) == ob
+    rd = O.read_poseidon_config(ob)
+    assert (rd["full_rounds"], rd["partial_rounds"], rd["alpha"], rd["rate"], rd["capacity"]) == (8, 31, 17, 2, 1) and len(rd["ark"]) == 39
+    c2 = S.deserialize_poseidon_config(ob)
+    assert np.array_equal(c2.ark, cfgp.ark) and np.array_equal(c2.mds, cfgp.mds) and (c2.rate, c2.capacity, c2.alpha) == (2, 1, 17)
+
+
+def test_readers_agree_on_what_is_invalid():
+    """the oracle's reader and the product's reader reject the same malformed inputs (and the unchecked forms accept the same)"""
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import serialize as S
+    from oracle import serialize as O
+    pts = [jj.mul(jj.GENERATOR, k) for k in (2, 9, 33)]
+    good = O.path(pts[0], pts[1:], 3, False)
+
+    def both_reject(b, compress=False, fe=2, cfg=None):
+        cfg = cfg or cpa.PedersenByteConfig
+        with pytest.raises(O.FormatError):
+            O.read_path(b, fe, compress)
+        with pytest.raises(ValueError):
+            S.deserialize_path(b, cfg, compress)
+    both_reject(good[:-1])                       # truncated
+    both_reject(good + b"\0")                    # trailing byte
+    both_reject(good[:64] + (1 << 50).to_bytes(8, "little") + good[72:])  # absurd Vec length
+    off = bytearray(good); off[3] ^= 4
+    both_reject(bytes(off))                      # x changed: not on the curve
+    assert O.read_path(bytes(off), 2, False, validate=False)[2] == 3
+    assert S.deserialize_path(bytes(off), cpa.PedersenByteConfig, False, validate=False).leaf_index == 3
+    small = O.path((0, jj.Q - 1), [], 1, False)  # (0, -1): order 2
+    both_reject(small)
+    noncanon = jj.Q.to_bytes(32, "little") + good[32:]
+    both_reject(noncanon)
+    # compressed: a y with no point on the curve; a set flag on the point with x = 0 decodes to x = 0 again (the flag cannot be honoured)
+    ys = next(y for y in range(2, 50) if jj.fq_sqrt((y * y - 1) * pow(1 + jj.D * y * y, -1, jj.Q)) is None)
+    both_reject(ys.to_bytes(32, "little") + (0).to_bytes(8, "little") + (0).to_bytes(8, "little"), compress=True)
+    fgood = O.path((5,), [(6,), (7,)], 2, False)
+    both_reject(fgood[:32] + (3).to_bytes(8, "little") + fgood[40:], fe=1, cfg=cpa.PoseidonFieldConfig)  # a length one larger than the payload
+
+
+def test_c_abi_serializer_size_queries_and_small_buffers():
+    import ctypes as C
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd._lib import lib, AKP_ERR_BAD_LENGTH, AKP_ERR_BAD_PARAMS
+    from crypto_primitives_amd import field
+    d = field.fr([1, 2, 3, 4]).reshape(4, 1, 4)
+    n = C.c_size_t()
+    assert lib.akp_serialize_digests(d.ctypes.data, 4, 1, 0, None, 0, C.byref(n)) == 0 and n.value == 128
+    buf = (C.c_uint8 * 127)()
+    assert lib.akp_serialize_digests(d.ctypes.data, 4, 1, 0, buf, 127, C.byref(n)) == AKP_ERR_BAD_LENGTH and n.value == 128
+    assert b"128 bytes needed" in lib.akp_last_error()
+    assert lib.akp_serialize_digests(d.ctypes.data, 4, 3, 0, None, 0, C.byref(n)) == AKP_ERR_BAD_PARAMS
+    ok = (C.c_uint8 * 128)()
+    assert lib.akp_serialize_digests(d.ctypes.data, 4, 1, 0, ok, 128, C.byref(n)) == 0
+    assert bytes(ok) == b"".join(int(v).to_bytes(32, "little") for v in (1, 2, 3, 4))
+    back = np.zeros((4, 1, 4), np.uint64)
+    assert lib.akp_deserialize_digests(ok, 128, 4, 1, 0, 1, back.ctypes.data) == 0 and np.array_equal(back, d)
+    assert lib.akp_deserialize_digests(ok, 127, 4, 1, 0, 1, back.ctypes.data) == AKP_ERR_BAD_LENGTH
+    # a MultiPath whose four vectors differ in length is valid ark-serialize input the flat form cannot hold
+    from oracle import serialize as O
+    ragged = O.multi_path([(1,), (2,)], [0], [[(3,)]], [0, 1], False)
+    m, ns = C.c_size_t(), C.c_size_t()
+    raw = (C.c_uint8 * len(ragged)).from_buffer_copy(ragged)
+    assert lib.akp_deserialize_multipath(raw, len(ragged), 1, 0, 1, C.byref(m), C.byref(ns), None, None, None, None, None, 0, 0) == AKP_ERR_BAD_PARAMS
+    assert cpa.lib.akp_abi_version() == 3
