@@ -8,7 +8,7 @@ built library (lib/libakp.so); nothing here falls back to the CPU.
 from ._lib import lib, AkpError, IncorrectInputLength, NotPowerOfTwo, Context, default_context, LIB_PATH  # noqa: F401
 from . import field, params, sponge, crh, merkle_tree, commitment, serialize  # noqa: F401
 from .sponge import PoseidonConfig, PoseidonSponge, get_default_poseidon_parameters  # noqa: F401
-from .merkle_tree import MerkleTree, GpuMerkleTree, MultiGpu, Path, MultiPath, PoseidonFieldConfig, PedersenByteConfig, BoweHopwoodByteConfig, PedersenXByteConfig  # noqa: F401
+from .merkle_tree import MerkleTree, GpuMerkleTree, MultiGpu, ShardedMerkleTree, Path, MultiPath, PoseidonFieldConfig, PedersenByteConfig, BoweHopwoodByteConfig, PedersenXByteConfig  # noqa: F401
 
 __all__ = ["field", "params", "sponge", "crh", "merkle_tree", "PoseidonConfig", "PoseidonSponge",
            "get_default_poseidon_parameters", "MerkleTree", "Path", "MultiPath", "Context", "default_context"]

@@ -64,6 +64,7 @@ def _load():
         "akp_ctx_destroy": (None, [vp]),
         "akp_ctx_synchronize": (i32, [vp]),
         "akp_ctx_stream": (vp, [vp]),
+        "akp_clock_probe_dev": (i32, [vp, u32, u64p, vp]),
         "akp_fr_to_mont": (i32, [u64p, u64p, sz]),
         "akp_fr_from_mont": (i32, [u64p, u64p, sz]),
         "akp_poseidon_params_create": (i32, [vp, u32, u32, u64, u32, u32, u64p, u64p, pp]),
@@ -126,6 +127,19 @@ def _load():
         "akp_merkle_multipath_decode": (i32, [u64p, u64p, sz, sz, sz, u32, u64p]),
         "akp_merkle_verify_multipath_poseidon": (i32, [vp, vp, u64p, u64p, sz, sz, u64p, u64p, u64p, u64p, sz, sz, C.POINTER(i32)]),
         "akp_merkle_verify_multipath_te": (i32, [vp, vp, u64p, u8p, sz, sz, u64p, u64p, u64p, u64p, sz, sz, C.POINTER(i32)]),
+        "akp_merkle_tree_build_poseidon_dev": (i32, [vp, vp, u64p, sz, sz, pp]),
+        "akp_merkle_tree_build_te_dev": (i32, [vp, vp, u8p, sz, sz, pp]),
+        "akp_multi_tree_build_poseidon": (i32, [vp, pp, pp, u64p, sz, sz, pp]),
+        "akp_multi_tree_build_te": (i32, [vp, pp, pp, u8p, sz, sz, pp]),
+        "akp_multi_tree_build_poseidon_dev": (i32, [vp, pp, pp, pp, sz, sz, pp]),
+        "akp_multi_tree_build_te_dev": (i32, [vp, pp, pp, pp, sz, sz, pp]),
+        "akp_multi_tree_destroy": (None, [vp]),
+        "akp_multi_tree_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(i32)]),
+        "akp_multi_tree_root": (i32, [vp, u64p]),
+        "akp_multi_tree_shard": (vp, [vp, i32]),
+        "akp_multi_tree_gather_paths": (i32, [vp, u64p, sz, u64p, u64p]),
+        "akp_multi_tree_update_batch": (i32, [vp, u64p, vp, sz, sz]),
+        "akp_multi_tree_export": (i32, [vp, u64p, u64p]),
         "akp_serialize_digests": (i32, [u64p, sz, u32, i32, u8p, sz, C.POINTER(sz)]),
         "akp_deserialize_digests": (i32, [u8p, sz, sz, u32, i32, i32, u64p]),
         "akp_serialize_poseidon_config": (i32, [vp, u8p, sz, C.POINTER(sz)]),

@@ -124,6 +124,37 @@ extern "C" int32_t akp_ctx_synchronize(akp_ctx* c) {
 extern "C" void* akp_ctx_stream(akp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 // ------------------------------------------------------------------------------------------
+// effective shader clock (measurement plumbing for bench.py).  One wave runs a chain of dependent
+// v_mad_u64_u32 and reads s_memtime (shader-clock cycles on gfx950: 8.25 per dependent multiply-add at any clock,
+// profiles/r04_s4/clock_probe.txt) and s_memrealtime (constant 100 MHz) before and after: MHz = 100 * d(s_memtime) / d(s_memrealtime).
+// The DPM level sysfs reports ("sclk") is the ceiling of the current power state, not what the ALUs ran at.
+__global__ void clock_probe_kernel(uint64_t* __restrict__ out, u32 n, u32 seed) {
+    unsigned long long acc = seed + threadIdx.x;
+    const u32 a = seed | 1u;
+    const unsigned long long t0 = clock64(), w0 = wall_clock64();
+#pragma unroll 1
+    for (u32 i = 0; i < n; i += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = (unsigned long long)(u32)acc * a + acc;
+    }
+    const unsigned long long t1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = w1 - w0;
+        out[2] = acc;
+    }
+}
+extern "C" int32_t akp_clock_probe_dev(akp_ctx* c, uint32_t chain_len, uint64_t* d_out3, void* stream) {
+    if (!c) return fail(AKP_ERR_HIP, "akp_clock_probe_dev: a device context is required");
+    if (c->dead) return fail(AKP_ERR_BAD_PARAMS, "akp_clock_probe_dev: the context was destroyed");
+    if (!d_out3 || chain_len == 0) return fail(AKP_ERR_BAD_PARAMS, "akp_clock_probe_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out3, (chain_len + 15u) & ~15u, 0x9e3779b9u);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // pinned host memory for callers that want the host-pointer entry points to run at PCIe speed: copies from / to
 // pageable memory are staged by the runtime and block the calling thread, pinned (or registered) buffers stream
 // asynchronously in both directions at once.  The entry points accept either kind.

@@ -1,5 +1,5 @@
 // capi_merkle.hip -- part of libakp.so (implementation of include/akp.h): Merkle trees -- builds, proofs, verification; capi_tree.inc
-// (HBM-resident trees), capi_multi.inc (several GPUs)
+// (HBM-resident trees), capi_multi.inc (several GPUs), capi_multi_tree.inc (the tree sharded over several GPUs, resident)
 // Product code.  Never includes, links or calls anything under oracle/; there is no CPU fallback for any compute entry
 // point (a missing device is AKP_ERR_HIP).
 #include "capi_internal.hpp"
@@ -247,9 +247,10 @@ __global__ void merkle_compare_kernel(const Fr* __restrict__ cur, const Fr* __re
     ok[i] = eq ? 1 : 0;
 }
 // shared driver: `hash_leaves` fills d_cur; `two_to_one(left, right, out)` hashes one level
-template <class HashLeaves, class TwoToOne>
+// `walk(d_idx, d_sib, d_auth, d_root, d_ok, stream, &done)`: a one-launch form that may decline (done = false)
+template <class HashLeaves, class TwoToOne, class Walk>
 static int32_t verify_paths_common(akp_ctx* c, u32 fe, const uint64_t* root, size_t m, const uint64_t* idx, const uint64_t* sibs,
-                                   const uint64_t* auth, size_t depth, uint8_t* ok_out, HashLeaves hash_leaves, TwoToOne two_to_one) {
+                                   const uint64_t* auth, size_t depth, uint8_t* ok_out, HashLeaves hash_leaves, TwoToOne two_to_one, Walk walk) {
     if (m == 0) return AKP_OK;
     if (!root || !idx || !sibs || !ok_out || (depth && !auth)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
     const size_t dig = (size_t)fe * sizeof(Fr);
@@ -269,6 +270,13 @@ static int32_t verify_paths_common(akp_ctx* c, u32 fe, const uint64_t* root, siz
     HIP_TRY(hipMemcpyAsync(d_sib, sibs, m * dig, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_root, root, dig, hipMemcpyHostToDevice, s));
     if (depth) HIP_TRY(hipMemcpyAsync(d_auth, auth, m * depth * dig, hipMemcpyHostToDevice, s));
+    bool walked = false;
+    if (int32_t rc = walk((const uint64_t*)d_idx, (const Fr*)d_sib, (const Fr*)d_auth, (const Fr*)d_root, d_ok, s, &walked)) return rc;
+    if (walked) {
+        HIP_TRY(hipMemcpyAsync(ok_out, d_ok, m, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return AKP_OK;
+    }
     if (int32_t rc = hash_leaves((Fr*)d_cur, s)) return rc;
     const unsigned grid = (unsigned)((m * fe + 255) / 256);
     for (size_t step = 0; step <= depth; ++step) {
@@ -305,7 +313,15 @@ extern "C" int32_t akp_merkle_verify_paths_poseidon(akp_poseidon* leafp, akp_pos
             if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
             return launch_crh(leafp, (const Fr*)dl, nullptr, leaf_len, d_cur, m, s);
         },
-        [&](const Fr* l, const Fr* r, Fr* out, hipStream_t s) -> int32_t { return launch_crh(two, l, r, 2, out, m, s); });
+        [&](const Fr* l, const Fr* r, Fr* out, hipStream_t s) -> int32_t { return launch_crh(two, l, r, 2, out, m, s); },
+        [&](const uint64_t* d_idx, const Fr* d_sib, const Fr* d_auth, const Fr* d_root, uint8_t* d_ok, hipStream_t s, bool* done) -> int32_t {
+            *done = false;
+            if (leaf_len < 1 || leaf_len > 2) return AKP_OK;
+            void* dl = nullptr;
+            if (int32_t rc = ctx_scratch(c, SCR_A, m * leaf_len * sizeof(Fr), &dl, s)) return rc;
+            HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
+            return launch_verify_paths_t3(leafp, two, (const Fr*)dl, leaf_len, d_idx, d_sib, d_auth, depth, d_root, d_ok, m, s, done);
+        });
 }
 extern "C" int32_t akp_merkle_verify_paths_te(akp_te_params* leafp, akp_te_params* two, const uint64_t* root, const uint8_t* leaves,
         size_t m,
@@ -327,9 +343,14 @@ extern "C" int32_t akp_merkle_verify_paths_te(akp_te_params* leafp, akp_te_param
             if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len, hipMemcpyHostToDevice, s));
             return te_crh_dev(leafp, (const uint8_t*)dl, m, leaf_len, d_cur, s);
         },
-        [&](const Fr* l, const Fr* r, Fr* out, hipStream_t s) -> int32_t { return te_compress_dev(two, l, r, m, out, s); });
+        [&](const Fr* l, const Fr* r, Fr* out, hipStream_t s) -> int32_t { return te_compress_dev(two, l, r, m, out, s); },
+        [](const uint64_t*, const Fr*, const Fr*, const Fr*, uint8_t*, hipStream_t, bool* done) -> int32_t {
+            *done = false;  // curve hashes: level by level (a lane-walked path would gather table lines for 21 dependent hashes)
+            return AKP_OK;
+        });
 }
 
 #include "capi_tree.inc"
 #include "capi_multi.inc"
+#include "capi_multi_tree.inc"
 

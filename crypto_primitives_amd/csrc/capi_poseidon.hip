@@ -24,6 +24,17 @@ static int32_t upload_f29(akp_ctx* ctx, const std::vector<Fr>& v, F29Pad** out) 
     return AKP_OK;
 }
 
+// A/B arms whose comparison is settled (dense partial rounds, plain sparse form, lane-1 instead of the full form, LDS-file instead of
+// the register kernels for t = 4 .. 9): selectable by environment only in the test build (-DAKP_TEST_HOOKS, libakp_testhooks.so);
+// the simpler forms stay in libakp.so as the fallbacks of parameter sets that do not admit the faster ones
+static inline bool arm_env(const char* name) {
+#if defined(AKP_TEST_HOOKS)
+    return getenv(name) != nullptr;
+#else
+    (void)name;
+    return false;
+#endif
+}
 extern "C" void akp_poseidon_params_destroy(akp_poseidon* p);
 extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds, uint32_t partial_rounds, uint64_t alpha,
                                               uint32_t rate, uint32_t capacity, const uint64_t* ark, const uint64_t* mds,
@@ -70,12 +81,12 @@ extern "C" int32_t akp_poseidon_params_create(akp_ctx* ctx, uint32_t full_rounds
             delete p;
             return fail(AKP_ERR_HIP, "uploading Poseidon parameters: %s", hipGetErrorString(e));
         }
-        if (!getenv("AKP_POSEIDON_DENSE")) {
+        if (!arm_env("AKP_POSEIDON_DENSE")) {
             PoseidonOpt opt = poseidon_optimize(t, full_rounds, partial_rounds, p->ark, p->mds);
             PoseidonOpt optw = opt;
-            const bool rescale = opt.ok && !getenv("AKP_POSEIDON_NO_RESCALE");
+            const bool rescale = opt.ok && !arm_env("AKP_POSEIDON_NO_RESCALE");
             PoseidonFullForm ff;
-            if (rescale && !getenv("AKP_POSEIDON_NO_FULL_FORM") && poseidon_full_form(opt, t, full_rounds, partial_rounds, alpha, p->mds,
+            if (rescale && !arm_env("AKP_POSEIDON_NO_FULL_FORM") && poseidon_full_form(opt, t, full_rounds, partial_rounds, alpha, p->mds,
                     ff)) {
                 int32_t rc = upload_f29(ctx, ff.ark, &p->d_ark_f29);
                 if (!rc) rc = upload_f29(ctx, ff.fmats, &p->d_fmats_f29);
@@ -308,7 +319,7 @@ static bool generic_coop(size_t n) {
 // t = 4 .. 9 (the default rate-3 .. rate-8 instances): register-resident kernels for large batches when the parameter set has
 // the full form or the lane-1 form (AKP_POSEIDON_NO_REG_T=1 keeps the LDS-file kernels: the A/B arm)
 static bool reg_t_kernel(const akp_poseidon* p, size_t n, const PoseidonConsts& c) {
-    static const bool enabled = !getenv("AKP_POSEIDON_NO_REG_T");
+    static const bool enabled = !arm_env("AKP_POSEIDON_NO_REG_T");
     return enabled && (p->dims.t >= 4 && p->dims.t <= 9) && !generic_coop(n) && (c.scaled == 3u || c.scaled == 2u) && c.sparse != nullptr;
 }
 template <u32 T>
@@ -421,6 +432,31 @@ int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* 
             d_out, n);
     else hipLaunchKernelGGL(poseidon_crh_kernel<64>, dim3(grid), dim3(B), lds, s, p->dims, file_consts(p), in0, in1, k, d_out, n);
     HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
+// Path::verify for m paths in ONE launch (poseidon_verify_paths_t3_kernel); *done = false when the shape is outside that kernel
+// (t != 3, rate != 2, more than two leaf elements, parameter sets of different constant forms, or a batch small enough for the
+// latency kernels to win level by level): the caller then runs the level-by-level form.
+int32_t launch_verify_paths_t3(akp_poseidon* leafp, akp_poseidon* two, const Fr* d_leaves, size_t leaf_len, const uint64_t* d_idx, const Fr* d_sibs,
+        const Fr* d_auth, size_t depth, const Fr* d_root, uint8_t* d_ok, size_t m, hipStream_t s, bool* done) {
+    *done = false;
+    // A/B against the level-by-level form, 2^16 paths of a 2^20-leaf tree (profiles/r04_s4): 3.96 ms in this one kernel against
+    // 21 x (0.19 ms hash + 0.005 ms select) = 4.2 ms; 4.78 against 5.04 ms device time with the staging copies.  At 2^16 paths the
+    // machine holds ONE wave per SIMD either way, and a lone wave issues a dependent multiply-add every 8.25 cycles (4.4 with two
+    // waves): the chain of 21 permutations per lane is the floor, not the launches.
+    auto fits = [](const akp_poseidon* p) { return p->dims.t == 3 && p->dims.rate == 2 && p->dims.capacity == 1 && p->dims.full_rounds >= 2; };
+    if (!fits(leafp) || !fits(two) || leaf_len < 1 || leaf_len > 2 || m <= coop_max_items() || depth > 62) return AKP_OK;
+    const PoseidonConsts cl = t3_reg_consts(leafp), ct = t3_reg_consts(two);
+    if ((cl.scaled == 3u) != (ct.scaled == 3u)) return AKP_OK;
+    const dim3 grid((unsigned)((m + 255) / 256));
+    if (cl.scaled == 3u)
+        hipLaunchKernelGGL(poseidon_verify_paths_t3_kernel<true>, grid, dim3(256), t3_lds_cap(), s, leafp->dims, cl, two->dims, ct, d_leaves,
+                (u32)leaf_len, d_idx, d_sibs, d_auth, (u32)depth, d_root, d_ok, m);
+    else
+        hipLaunchKernelGGL(poseidon_verify_paths_t3_kernel<false>, grid, dim3(256), t3_lds_cap(), s, leafp->dims, cl, two->dims, ct, d_leaves,
+                (u32)leaf_len, d_idx, d_sibs, d_auth, (u32)depth, d_root, d_ok, m);
+    HIP_TRY(hipGetLastError());
+    *done = true;
     return AKP_OK;
 }
 // which kernel a batch of n items is routed to (the rule of launch_permute / launch_crh), so that a parity probe can

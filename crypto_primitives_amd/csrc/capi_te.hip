@@ -39,11 +39,17 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
         // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
         // stores 2^(D-1) entries per digit.  Default D = 15: 4x256 is 69 steps over a 163 MB table.  Measured on MI355X, 2^20 x 128 B
         // (profiles/r02_s9): signed D = 13 / 14 / 15: 2.70 / 2.75 / 2.88e8 hashes/s; plain table D = 13: 2.56e8.
-        // AKP_PEDERSEN_PLAIN=1 keeps the plain table (the A/B arm, and the fallback for generators outside the subgroup).
+        // The plain table stays as the fallback for generators outside the subgroup; as an A/B arm (AKP_PEDERSEN_PLAIN=1) it is
+        // selectable only in the test build (-DAKP_TEST_HOOKS).
         NielsPad* d_half = nullptr;
         u32* d_bad = nullptr;
         u32 bad = 1;
-        if (!getenv("AKP_PEDERSEN_PLAIN")) {
+#if defined(AKP_TEST_HOOKS)
+        const bool force_plain = getenv("AKP_PEDERSEN_PLAIN") != nullptr;
+#else
+        const bool force_plain = false;
+#endif
+        if (!force_plain) {
             if (e == hipSuccess) e = hipMalloc(&d_half, n_gen * sizeof(NielsPad));
             if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(u32));
             if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), ctx->stream);
@@ -213,6 +219,15 @@ static unsigned te_lds_block(size_t data_len, size_t stride) {
     while (block >= 64 && te_lds_image_bytes(block, data_len, stride) > 40960) block /= 2;
     return block >= 64 ? block : 0;
 }
+// the constant of a zero-padded Bowe-Hopwood tail instead of walking the padding chunk by chunk (-1.0 ms on a 2^23-leaf tree,
+// profiles/r02_s31); the other arm (AKP_BH_ZERO_TAIL=0, read per call) exists only in the test build
+static inline bool te_zero_tail_on() {
+#if defined(AKP_TEST_HOOKS)
+    return env_u32("AKP_BH_ZERO_TAIL", 1, 0, 1) != 0;
+#else
+    return true;
+#endif
+}
 static const size_t te_split_max = env_size("AKP_TE_SPLIT_MAX", (size_t)1 << 14);  // one workgroup per CU
 // `pipe` (host-pointer entry point with pinned buffers): the batch runs chunk by chunk -- kernels on `s`, the DMA copy-in of later
 // chunks on pipe->cin, the DMA copy-out of chunk i on pipe->side under the kernels of chunk i + 1.  Every buffer (messages,
@@ -236,7 +251,7 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
     if (n == 0) return AKP_OK;
     if (n > ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32", n);
-    const bool tail_on = env_u32("AKP_BH_ZERO_TAIL", 1, 0, 1) != 0;  // 0: walk the padding chunk by chunk (A/B arm; read per call)
+    const bool tail_on = te_zero_tail_on();
     if (data_len > msg_len || !tail_on) data_len = msg_len;
     u32 groups = 0, steps = 0;
     te_steps(p, data_len, &groups, &steps);
@@ -533,7 +548,7 @@ int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_right, s
     hipLaunchKernelGGL(te_serialize_pairs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, d_left, d_right, fe, buflen,
             (uint8_t*)dbuf, n);
     HIP_TRY(hipGetLastError());
-    const bool tail_on = env_u32("AKP_BH_ZERO_TAIL", 1, 0, 1) != 0;
+    const bool tail_on = te_zero_tail_on();
     if (used < buflen && !tail_on) {  // with the zero-tail shortcut the padding bytes are never read
         const size_t tw = n * (buflen - used);
         hipLaunchKernelGGL(te_zero_tail_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, s, (uint8_t*)dbuf, buflen, used, n);

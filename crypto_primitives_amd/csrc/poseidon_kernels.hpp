@@ -219,6 +219,43 @@ __global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, Po
     store_fr_global(out + idx, poseidon_crh_item_t3<FULLFORM>(D, C, in0, in1, k, idx));
 }
 
+// Path::verify (merkle_tree/mod.rs:172-212) with each lane walking its OWN path: leaf hash, then depth + 1 two-to-one hashes
+// of (current, sibling) ordered by the index bit of the level (select_left_right_child :367-381), compared with the root.
+// One launch for a whole batch of paths instead of one hash launch + one select launch per level: the chain of a lane
+// is the same depth + 2 permutations, but no level waits for the slowest wave of the previous one and nothing but the final
+// flag goes back to memory.  t = 3, rate 2, capacity 1, 1 or 2 leaf elements (each hash is ONE permutation of a fresh sponge:
+// sponge/poseidon/mod.rs:124-153,324-344); the host keeps the level-by-level form for everything else.  The leaf stage and the
+// two-to-one stages share one copy of the permutation (the constants are selected per stage; wave-uniform).
+template <bool FULLFORM>
+__global__ void __launch_bounds__(256) poseidon_verify_paths_t3_kernel(PoseidonDims DL, PoseidonT3Consts CL, PoseidonDims DT, PoseidonT3Consts CT,
+                                                                       const Fr* __restrict__ leaves, u32 leaf_len, const uint64_t* __restrict__ idx,
+                                                                       const Fr* __restrict__ sibs, const Fr* __restrict__ auth, u32 depth,
+                                                                       const Fr* __restrict__ root, uint8_t* __restrict__ ok, size_t m) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t li = idx[i];
+    Fr cur = load_fr_global(leaves + i * leaf_len);
+    Fr other = leaf_len > 1 ? load_fr_global(leaves + i * leaf_len + 1) : Fr{{0, 0, 0, 0, 0, 0, 0, 0}};
+    u32 other_first = 0;  // 1: `other` is the left input
+#pragma unroll 1
+    for (u32 stage = 0; stage < depth + 2; ++stage) {
+        const bool leaf = stage == 0;
+        const PoseidonDims D = leaf ? DL : DT;
+        const PoseidonT3Consts C = leaf ? CL : CT;
+        const Fr a = other_first ? other : cur, b = other_first ? cur : other;
+        FP s0 = f29_zero<AKP_PS>();
+        FP s1 = f29_weak_norm(FULLFORM ? f29_unpack<AKP_PS>(a) : f29_from_wire<AKP_PS>(a));
+        FP s2 = (leaf && leaf_len == 1) ? f29_zero<AKP_PS>() : f29_weak_norm(FULLFORM ? f29_unpack<AKP_PS>(b) : f29_from_wire<AKP_PS>(b));
+        poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2, (leaf && leaf_len == 1) ? 5u : 1u, 2u);
+        cur = FULLFORM ? f29_canonical_pack(s1) : f29_to_wire(s1);
+        if (stage <= depth) {  // the sibling of the level the NEXT stage hashes: step = stage (0 = leaf level)
+            other = load_fr_global(stage == 0 ? sibs + i : auth + i * depth + (depth - stage));
+            other_first = (u32)((li >> stage) & 1u);
+        }
+    }
+    ok[i] = fr_eq(cur, load_fr_global(root)) ? 1 : 0;
+}
+
 // =============================== any t: LDS "register file" ========================================
 // slot s, limb i, lane l -> dword (s*9 + i)*BLOCK + l : consecutive lanes hit consecutive banks.
 template <int BLOCK>

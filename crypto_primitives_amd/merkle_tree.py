@@ -568,6 +568,7 @@ class MultiGpu:
         self._h = h
         self._ctxs = {}
         self._param_owners = []
+        self._trees = []
         self.size = lib.akp_multi_size(h)
 
     def ctx(self, i):
@@ -584,15 +585,7 @@ class MultiGpu:
     def build_sharded(self, config, leaf_hash_param, two_to_one_hash_param, leaves, want_nodes=True):
         """MerkleTree::new (:411-523) over all devices: akp_merkle_build_sharded_{poseidon,te}.  Returns
         (leaf_nodes, non_leaf_nodes, root) in the reference's global heap order (nodes None when want_nodes is False)."""
-        import ctypes as C
-        G = self.size
-        lh = [_leaf_handle(config, leaf_hash_param, self.ctx(r)) for r in range(G)]
-        th = [_two_handle(config, two_to_one_hash_param, self.ctx(r)) for r in range(G)]
-        for cfg in (leaf_hash_param, two_to_one_hash_param):  # destroyed with this object, before their contexts
-            if not any(cfg is c for c in self._param_owners):
-                self._param_owners.append(cfg)
-        la = (C.c_void_p * G)(*[h.h for h in lh])
-        ta = (C.c_void_p * G)(*[h.h for h in th])
+        la, ta = self._handles(config, leaf_hash_param, two_to_one_hash_param)
         shp = config.digest_shape
         if config is PoseidonFieldConfig:
             x = np.ascontiguousarray(leaves, dtype=np.uint64)
@@ -609,8 +602,38 @@ class MultiGpu:
                  nl.ctypes.data if want_nodes else None, root.ctypes.data))
         return ln, nl, root
 
+    def _handles(self, config, leaf_hash_param, two_to_one_hash_param):
+        import ctypes as C
+        G = self.size
+        lh = [_leaf_handle(config, leaf_hash_param, self.ctx(r)) for r in range(G)]
+        th = [_two_handle(config, two_to_one_hash_param, self.ctx(r)) for r in range(G)]
+        for cfg in (leaf_hash_param, two_to_one_hash_param):  # destroyed with this object, before their contexts
+            if not any(cfg is c for c in self._param_owners):
+                self._param_owners.append(cfg)
+        return (C.c_void_p * G)(*[h.h for h in lh]), (C.c_void_p * G)(*[h.h for h in th])
+
+    def build_tree(self, config, leaf_hash_param, two_to_one_hash_param, leaves=None, device_leaf_ptrs=None, n_leaves=None, leaf_len=None):
+        """MerkleTree::new (:411-422) sharded over all devices and RESIDENT there (akp_multi_tree_build_*): a ShardedMerkleTree.
+        `leaves`: host leaves in global order; or `device_leaf_ptrs` = one device address per slot (that slot's n / G leaves,
+        already in its memory) with `n_leaves` and `leaf_len`."""
+        import ctypes as C
+        la, ta = self._handles(config, leaf_hash_param, two_to_one_hash_param)
+        h = C.c_void_p()
+        pos = config is PoseidonFieldConfig
+        if device_leaf_ptrs is None:
+            x, n, k = GpuMerkleTree._leaf_array(config, leaves)
+            fn = lib.akp_multi_tree_build_poseidon if pos else lib.akp_multi_tree_build_te
+            check(fn(self._h, la, ta, x.ctypes.data if x.size else None, n, k, C.byref(h)))
+        else:
+            ptrs = (C.c_void_p * self.size)(*[int(p) for p in device_leaf_ptrs])
+            fn = lib.akp_multi_tree_build_poseidon_dev if pos else lib.akp_multi_tree_build_te_dev
+            check(fn(self._h, la, ta, ptrs, n_leaves, leaf_len, C.byref(h)))
+        t = ShardedMerkleTree(self, config, h)
+        self._trees.append(t)
+        return t
+
     def last_phases(self):
-        """phase breakdown of the last build_sharded call (akp_multi_last_phases), milliseconds, maximum over the devices"""
+        """phase breakdown of the last build_sharded / build_tree call (akp_multi_last_phases), milliseconds, maximum over the devices"""
         import ctypes as C
         ms = (C.c_double * 5)()
         check(lib.akp_multi_last_phases(self._h, ms))
@@ -618,6 +641,9 @@ class MultiGpu:
 
     def close(self):
         if getattr(self, "_h", None):
+            for t in self._trees:  # resident trees first (they pin their parameter handles)
+                t.close()
+            self._trees.clear()
             for cfg in self._param_owners:  # parameter handles created on our contexts go first
                 ours = {id(c) for c in self._ctxs.values()}
                 for key in [k for k in cfg._handles if (k[0] if isinstance(k, tuple) else k) in ours]:  # te handles are keyed (ctx, kind)
@@ -632,3 +658,59 @@ class MultiGpu:
             self.close()
         except Exception:
             pass
+
+
+class ShardedMerkleTree:
+    """MerkleTree<P> sharded over the devices of a MultiGpu and resident there (akp_multi_tree, include/akp.h): every device keeps
+    the sub-tree of its leaf range in its HBM, the top log2(G) levels are replicated.  root / generate_proofs / update_batch
+    follow GpuMerkleTree; `to_host()` gathers the reference's two vectors in global heap order."""
+
+    def __init__(self, multi, config, handle):
+        import ctypes as C
+        self._multi, self.config, self._h = multi, config, handle
+        n, fe, h, g = C.c_size_t(), C.c_uint32(), C.c_size_t(), C.c_int32()
+        check(lib.akp_multi_tree_info(self._h, C.byref(n), C.byref(fe), C.byref(h), C.byref(g)))
+        self.n_leaves, self._fe, self._height, self.n_dev = n.value, fe.value, h.value, g.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.akp_multi_tree_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def root(self):
+        r = np.empty(self.config.digest_shape, dtype=np.uint64)
+        check(lib.akp_multi_tree_root(self._h, r.ctypes.data))
+        return r
+
+    def height(self):
+        return self._height
+
+    def generate_proofs(self, indexes):
+        idx = np.ascontiguousarray(list(indexes), dtype=np.uint64)
+        m, shp, depth = len(idx), self.config.digest_shape, self._height - 2
+        sibs = np.empty((m,) + shp, dtype=np.uint64)
+        auth = np.empty((m, max(depth, 0)) + shp, dtype=np.uint64)
+        check(lib.akp_multi_tree_gather_paths(self._h, idx.ctypes.data, m, sibs.ctypes.data, auth.ctypes.data if depth > 0 else None))
+        return [Path(self.config, sibs[i], [auth[i, j] for j in range(max(depth, 0))], int(idx[i])) for i in range(m)]
+
+    def generate_proof(self, index) -> Path:
+        return self.generate_proofs([index])[0]
+
+    def update_batch(self, indices, new_leaves):
+        idx = np.ascontiguousarray(list(indices), dtype=np.uint64)
+        x, n, k = GpuMerkleTree._leaf_array(self.config, new_leaves)
+        assert n == len(idx), "one leaf per index"
+        check(lib.akp_multi_tree_update_batch(self._h, idx.ctypes.data, x.ctypes.data if x.size else None, n, k))
+
+    def to_host(self, leaf_hash_param=None, two_to_one_hash_param=None) -> MerkleTree:
+        shp = self.config.digest_shape
+        ln = np.empty((self.n_leaves,) + shp, dtype=np.uint64)
+        nl = np.empty((self.n_leaves - 1,) + shp, dtype=np.uint64)
+        check(lib.akp_multi_tree_export(self._h, ln.ctypes.data, nl.ctypes.data))
+        return MerkleTree(self.config, leaf_hash_param, two_to_one_hash_param, ln, nl)

@@ -59,6 +59,7 @@ typedef struct akp_te_params akp_te_params; /* pedersen::Parameters / bowe_hopwo
 typedef struct akp_sponge akp_sponge;     /* batch of PoseidonSponge<Fr>, sponge/poseidon/mod.rs:54-63 */
 typedef struct akp_merkle_tree akp_merkle_tree; /* MerkleTree<P> resident in HBM, merkle_tree/mod.rs:383-396 */
 typedef struct akp_multi akp_multi;       /* the GPUs of one node driven from one process + their RCCL communicator */
+typedef struct akp_multi_tree akp_multi_tree; /* MerkleTree<P> sharded over the devices of an akp_multi, resident in their HBM */
 
 int32_t akp_abi_version(void);
 const char* akp_last_error(void);
@@ -73,6 +74,11 @@ int32_t akp_ctx_synchronize(akp_ctx* ctx);
  * bracket such a call with its own events (bench.py times the device side of the proof / update entry points this way) or
  * order its own work behind it.  NULL for a NULL context.  The stream belongs to the context. */
 void* akp_ctx_stream(akp_ctx* ctx);
+/* Effective shader clock (measurement plumbing, no hashing): enqueues ONE wave that runs `chain_len` dependent v_mad_u64_u32 on
+ * `stream` and writes three u64 to the device buffer d_out3: [0] shader-clock cycles (s_memtime), [1] ticks of the constant
+ * 100 MHz clock (s_memrealtime) over the same interval, [2] the chain's value.  MHz = 100 * [0] / [1]; cycles per dependent
+ * multiply-add = [0] / chain_len.  The DPM level sysfs calls "sclk" is a ceiling, not what the ALUs ran at. */
+int32_t akp_clock_probe_dev(akp_ctx* ctx, uint32_t chain_len, uint64_t* d_out3, void* stream);
 
 /* ---- pinned host memory (optional) ----------------------------------------------------------- */
 /* The host-pointer entry points accept any host memory.  Pageable memory: batches larger than one chunk are cut into chunks
@@ -84,9 +90,11 @@ void* akp_ctx_stream(akp_ctx* ctx);
  *     front, copy-outs on a side stream under the next chunk's kernels) -- never by zero copy: in-place reads make every
  *     workgroup wait for PCIe at the same moments and in-place 16-byte digest stores cross PCIe at 17 GB/s (measured,
  *     profiles/r04_s2 .. r04_s3).  Pinned on one side only behaves like pageable memory.
- * Either way is at least as fast as pageable buffers; the gain is small for the curve hashes (their kernel time exceeds the
- * copy time) and 20 % for the Poseidon batches.  Register a buffer as a whole: the runtime rejects copies that straddle
- * registered and unregistered memory. */
+ * Pinned buffers gain 20 % for the Poseidon batches (3.5e8 against 2.9e8 permutations/s).  For the curve hashes they are a wash:
+ * both kinds sit at the floor of eight chunked launches (median 4.2 - 5.1 ms pinned against 4.3 - 4.5 ms pageable per 2^20 Pedersen
+ * hashes, depending on the power state of the box; one pinned call in ~14 waits +6 ms in the runtime) -- feed them from whatever
+ * memory the host already has.  Register a buffer as a whole: the runtime rejects copies that straddle registered and
+ * unregistered memory. */
 int32_t akp_host_alloc(size_t bytes, void** out);
 int32_t akp_host_free(void* p);
 int32_t akp_host_register(void* p, size_t bytes);
@@ -259,6 +267,11 @@ int32_t akp_merkle_tree_build_poseidon(akp_poseidon* leaf_params, akp_poseidon* 
                                        size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
 int32_t akp_merkle_tree_build_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* leaves,
                                  size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
+/* the same from leaves that are already in device memory (synchronises the context stream before returning) */
+int32_t akp_merkle_tree_build_poseidon_dev(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* d_leaves,
+                                           size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
+int32_t akp_merkle_tree_build_te_dev(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* d_leaves,
+                                     size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
 /* MerkleTree::new_with_leaf_digest (:424-523); with all-default digests this is MerkleTree::blank (:400-408).
  * leaf_digests: n_leaves digests (1 Fr; 2 Fr for Pedersen). */
 int32_t akp_merkle_tree_from_digests_poseidon(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params,
@@ -379,6 +392,39 @@ int32_t akp_merkle_build_sharded_poseidon(akp_multi* m, akp_poseidon* const* lea
 int32_t akp_merkle_build_sharded_te(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
                                     const uint8_t* leaves, size_t n_leaves, size_t leaf_len, uint64_t* leaf_nodes,
                                     uint64_t* non_leaf_nodes, uint64_t* root_out);
+
+
+/* ---- the tree sharded over several GPUs, RESIDENT (MerkleTree<P> as an object: merkle_tree/mod.rs:383-396, 526-579, 629-702) --- */
+/* Device r of G keeps the sub-tree over leaves [r n/G, (r+1) n/G) in its own HBM (an ordinary akp_merkle_tree on akp_multi_ctx(m, r));
+ * the top of the tree -- heap nodes 0 .. 2G-2: the G-1 nodes above the sub-roots and the sub-roots -- is replicated on every device
+ * and on the host, refreshed after the build and after every update by ONE all-gather of the sub-roots + the top levels.  No node
+ * array ever crosses a link or PCIe unless akp_multi_tree_export asks for it.  Parameter handle arrays as for
+ * akp_merkle_build_sharded_*; the tree pins them.  akp_multi_last_phases reports the phases of the last build. */
+/* MerkleTree::new (:411-422) from host leaves (global order; device r's range is copied in by its own host thread) */
+int32_t akp_multi_tree_build_poseidon(akp_multi* m, akp_poseidon* const* leaf_params, akp_poseidon* const* two_to_one_params,
+                                      const uint64_t* leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
+int32_t akp_multi_tree_build_te(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
+                                const uint8_t* leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
+/* the same from leaves that are already resident: d_leaves[r] = device r's n_leaves / G leaves, in ITS memory */
+int32_t akp_multi_tree_build_poseidon_dev(akp_multi* m, akp_poseidon* const* leaf_params, akp_poseidon* const* two_to_one_params,
+                                          const uint64_t* const* d_leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
+int32_t akp_multi_tree_build_te_dev(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
+                                    const uint8_t* const* d_leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
+void akp_multi_tree_destroy(akp_multi_tree* t); /* before akp_multi_destroy(m) */
+int32_t akp_multi_tree_info(const akp_multi_tree* t, size_t* n_leaves, uint32_t* fe_per_digest, size_t* height, int32_t* n_dev);
+/* MerkleTree::root (:526-528), from the replicated top (no device access) */
+int32_t akp_multi_tree_root(akp_multi_tree* t, uint64_t* root_out);
+/* the sub-tree handle of device slot r (owned by t): its device pointers (akp_merkle_tree_device_ptrs) for local `_dev` work */
+akp_merkle_tree* akp_multi_tree_shard(akp_multi_tree* t, int32_t r);
+/* MerkleTree::generate_proof (:572-579) for m GLOBAL leaf indices: each index is served by the device that owns it; outputs as
+ * akp_merkle_tree_gather_paths (auth_paths [m][log2(n) - 1], root side first: log2 G top siblings, then the local path) */
+int32_t akp_multi_tree_gather_paths(akp_multi_tree* t, const uint64_t* leaf_indices, size_t m, uint64_t* leaf_sibling_hashes,
+                                    uint64_t* auth_paths);
+/* MerkleTree::update (:692-702), batched as akp_merkle_tree_update_batch: per-shard updates, then the exchange */
+int32_t akp_multi_tree_update_batch(akp_multi_tree* t, const uint64_t* leaf_indices, const void* new_leaves, size_t m,
+                                    size_t leaf_len);
+/* the reference's two vectors in GLOBAL heap order (checkpoints, tests); either pointer may be NULL */
+int32_t akp_multi_tree_export(akp_multi_tree* t, uint64_t* leaf_nodes, uint64_t* non_leaf_nodes);
 
 #ifdef __cplusplus
 }

@@ -314,11 +314,28 @@ fn emit_poseidon(sec: &Value) -> String {
     )
 }
 
+fn fnv1a64_hex(bytes: &[u8]) -> String {
+    let mut h = 0xcbf2_9ce4_8422_2325u64;
+    for b in bytes {
+        h = (h ^ *b as u64).wrapping_mul(0x0000_0100_0000_01b3);
+    }
+    format!("{:016x}", h)
+}
+
 fn main() {
     let dir = std::path::Path::new(env!("CARGO_MANIFEST_DIR")).join("..").join("tests").join("golden");
     let inputs: Value = serde_json::from_reader(std::fs::File::open(dir.join("emitter_inputs.json")).expect("tests/golden/emitter_inputs.json")).expect("JSON");
+    // provenance: which sources produced the file -- the emitter's git commit and a digest of Cargo.lock (the reference's arkworks
+    // dependencies are git patches with no pinned revision: Cargo.lock is what names the `algebra` HEAD that was compiled)
+    let manifest = std::path::Path::new(env!("CARGO_MANIFEST_DIR"));
+    let git_sha = std::process::Command::new("git").arg("-C").arg(manifest).args(["rev-parse", "HEAD"]).output().ok()
+        .and_then(|o| String::from_utf8(o.stdout).ok()).map(|s| s.trim().to_string()).filter(|s| !s.is_empty()).unwrap_or_else(|| "unknown".into());
+    let lock_digest = std::fs::read(manifest.join("Cargo.lock")).map(|b| fnv1a64_hex(&b)).unwrap_or_else(|_| "no Cargo.lock".into());
+    let lock_sha256 = std::process::Command::new("sha256sum").arg(manifest.join("Cargo.lock")).output().ok()
+        .and_then(|o| String::from_utf8(o.stdout).ok()).and_then(|s| s.split_whitespace().next().map(|x| x.to_string())).unwrap_or_else(|| "sha256sum unavailable".into());
     let out = format!(
-        "{{\"source\":\"outputs of the reference crates (ark-crypto-primitives + arkworks algebra) on tests/golden/emitter_inputs.json, written by shim/examples/emit_vectors.rs\",\n\"pedersen\":{},\n\"bowe_hopwood\":{},\n\"poseidon\":{}}}\n",
+        "{{\"source\":\"outputs of the reference crates (ark-crypto-primitives + arkworks algebra) on tests/golden/emitter_inputs.json, written by shim/examples/emit_vectors.rs\",\n\"emitter\":{{\"git_sha\":\"{}\",\"cargo_lock_sha256\":\"{}\",\"cargo_lock_fnv1a64\":\"{}\"}},\n\"pedersen\":{},\n\"bowe_hopwood\":{},\n\"poseidon\":{}}}\n",
+        git_sha, lock_sha256, lock_digest,
         emit_pedersen(&inputs["pedersen"]),
         emit_bowe_hopwood(&inputs["bowe_hopwood"]),
         emit_poseidon(&inputs["poseidon"])

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline"}
 SMALL = ["--log2-states", "16", "--merkle-log2", "12", "--pedersen-log2", "10", "--bh-merkle-log2", "9", "--sustain-seconds", "0.2",
-         "--sustain-log2-big", "0", "--proofs-log2", "12", "--proofs-m-log2", "8"]
+         "--sustain-log2-big", "0", "--proofs-log2", "12", "--proofs-m-log2", "8", "--sweep-max-log2", "20"]
 
 
 def _check(out):
@@ -55,6 +55,20 @@ def test_bench_single_process():
         assert 0 < rf["valu"]["frac_of_mad_issue_peak"] < 1
     leg = d["merkle"]["one_process_c_abi"]  # the C ABI's multi-device entry points, with the phase breakdown
     assert leg["root_matches"] and leg["phases_ms"]["whole_call_ms"] > 0 and leg["bowe_hopwood"]["phases_ms"]["copy_in_and_subtree_ms"] > 0
+    rt = leg["resident_tree"]  # the sharded RESIDENT tree (akp_multi_tree_*): built, queried and updated without moving its nodes
+    assert rt["root_before_updates_matches_the_sharded_build"] and rt["sampled_proofs_verify"] and rt["proofs_ms"] > 0 and rt["update_ms"] > 0
+    # round 4: the line explains itself across boxes
+    rf = d["roofline"]
+    assert 500 < rf["effective_sclk_mhz"] < 3500 and 7.5 < rf["effective_sclk"]["cycles_per_dependent_mad"] < 20  # 8.25 on an idle SIMD of gfx950
+    assert len(rf["effective_sclk"]["before_timed_steps_mhz"]) >= 1 and len(rf["effective_sclk"]["after_timed_steps_mhz"]) >= 1
+    assert 0 < rf["valu"]["frac_of_mad_issue_peak"] < 1 and (rf["power_w_under_load"] is None or rf["power_w_under_load"] > 20)
+    pt = d["sweep"]["points"]["2^20"]
+    assert pt["permutations_per_s"] > 1e6 and pt["tree_leaves_per_s"] > 1e5 and 0 < pt["permute_hbm_frac"] < 1
+    ps = d["predicted_scaling"]
+    assert 0 < ps["merkle_strong"]["8_gpus"]["efficiency"] <= 1.0 and 0 < ps["bh_merkle_weak"]["8_gpus"]["efficiency"] <= 1.0
+    assert d["curve_parity"].startswith(("unpinned (emitter not run)", "pinned by"))
+    hp = d["host_path"]
+    assert hp["pedersen_pinned"]["digests_equal_the_pageable_call"] and hp["pedersen_pinned"]["ms_min"] <= hp["pedersen_pinned"]["ms_per_batch"] <= hp["pedersen_pinned"]["ms_max"]
 
 
 def test_bench_under_torchrun_world1():

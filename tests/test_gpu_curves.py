@@ -187,22 +187,18 @@ def test_table_variants_agree(cpa):
                     assert tuple(ints(dp[i])) == opd.evaluate(g, 5, 13, bytes(m[i]))
                     assert ints(db[i])[0] == obh.evaluate(gb, 7, 5, bytes(mb[i]))
             assert np.array_equal(dp, ref_p) and np.array_equal(db, ref_b), (D, grp)
-        # the plain table (round 1) as A/B arm of the signed-subset table, at several digit widths
-        os.environ["AKP_PEDERSEN_PLAIN"] = "1"
-        for D in (13, 5, 1):
-            os.environ["AKP_PEDERSEN_DIGIT_BITS"] = str(D)
-            assert np.array_equal(pedersen.CRH.evaluate_batch(pedersen.Parameters(gens_array(g)), m), ref_p), ("plain", D)
+        # (the plain table of round 1 as an arm of its own: tests/test_gpu_multi_slots.py, test build only; here it runs as the
+        # fallback for generators outside the prime subgroup, test_pedersen_generators_outside_the_prime_subgroup)
     finally:
         os.environ.pop("AKP_PEDERSEN_DIGIT_BITS", None)
         os.environ.pop("AKP_BH_GROUP", None)
-        os.environ.pop("AKP_PEDERSEN_PLAIN", None)
 
 
 def test_upstream_jubjub_kat_on_the_gpu(cpa, jubjub_kat):
     """the Pedersen kernels (table build from the caller's generators, mixed additions, shared inversion, wire encoding of the
     coordinates) reproduce ark-ed-on-bls12-381's scalar-multiplication vector: one window of 256 generators 2^j * g -- computed
-    by the PRODUCT's host code, not by the oracle -- evaluates (f1 * f2) * g of the upstream test.  Both table kinds, both
-    device paths."""
+    by the PRODUCT's host code, not by the oracle -- evaluates (f1 * f2) * g of the upstream test.  Both device paths; the plain
+    table repeats it in the test build (tests/test_gpu_multi_slots.py)."""
     import os
     from crypto_primitives_amd import params as cparams, field
     from crypto_primitives_amd.crh import pedersen
@@ -214,19 +210,13 @@ def test_upstream_jubjub_kat_on_the_gpu(cpa, jubjub_kat):
         cur = cparams._padd(cur, cur)
     gens = field.fr([c for pt in pts for c in pt]).reshape(1, 256, 2, 4)
     msg = np.frombuffer(scalar.to_bytes(32, "little"), dtype=np.uint8)
-    try:
-        for plain in ("", "1"):
-            if plain:
-                os.environ["AKP_PEDERSEN_PLAIN"] = plain
-            P = pedersen.Parameters(gens)
-            assert tuple(ints(pedersen.CRH.evaluate(P, bytes(msg)))) == k["f1f2g"], plain
-            batch = np.tile(msg, (20000, 1))  # accumulate + finalize kernels
-            batch[1:, 0] ^= np.arange(1, 20000, dtype=np.uint64).astype(np.uint8)  # other scalars around it; row 0 stays the KAT
-            got = pedersen.CRH.evaluate_batch(P, batch)
-            assert tuple(ints(got[0])) == k["f1f2g"], plain
-            assert tuple(ints(got[256])) == k["f1f2g"]  # 256 & 0xff == 0: the same scalar again
-    finally:
-        os.environ.pop("AKP_PEDERSEN_PLAIN", None)
+    P = pedersen.Parameters(gens)
+    assert tuple(ints(pedersen.CRH.evaluate(P, bytes(msg)))) == k["f1f2g"]
+    batch = np.tile(msg, (20000, 1))  # accumulate + finalize kernels
+    batch[1:, 0] ^= np.arange(1, 20000, dtype=np.uint64).astype(np.uint8)  # other scalars around it; row 0 stays the KAT
+    got = pedersen.CRH.evaluate_batch(P, batch)
+    assert tuple(ints(got[0])) == k["f1f2g"]
+    assert tuple(ints(got[256])) == k["f1f2g"]  # 256 & 0xff == 0: the same scalar again
 
 
 def test_pedersen_generators_outside_the_prime_subgroup(cpa):
@@ -323,11 +313,6 @@ def test_bowe_hopwood_compress_zero_tail_constant(cpa, W, N):
         for i in pick:
             li, ri = field.to_ints(l[i])[0], field.to_ints(r[i])[0]
             assert ints(got[i])[0] == obh.two_to_one_compress(g, W, N, li, ri), (W, N, n, int(i))
-        try:
-            os.environ["AKP_BH_ZERO_TAIL"] = "0"
-            assert np.array_equal(bowe_hopwood.TwoToOneCRH.compress_batch(B, l, r), got)
-        finally:
-            os.environ.pop("AKP_BH_ZERO_TAIL", None)
 
 
 def test_host_batches_larger_than_one_chunk(cpa, ped, bhp):

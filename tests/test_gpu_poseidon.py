@@ -272,8 +272,10 @@ def test_generic_kernels_both_ways(cpa, coop_max, no_reg):
     import os, subprocess, sys
     here = os.path.abspath(__file__)
     env = dict(os.environ, AKP_POSEIDON_GENERIC_COOP_MAX=coop_max)
-    if no_reg:
+    if no_reg:  # an A/B arm: readable only by the test build of the library (make testhooks)
         env["AKP_POSEIDON_NO_REG_T"] = no_reg
+        env["AKP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(here)), "crypto_primitives_amd", "lib", "libakp_testhooks.so")
+        assert os.path.exists(env["AKP_LIB"]), "make -C crypto_primitives_amd/csrc testhooks"
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                         "test_generic_kernel_on_custom_t or test_crh_other_rates or test_permute_all_default_configs"],
                        env=env, capture_output=True, text=True, timeout=900,

@@ -1,0 +1,73 @@
+"""`bh_merkle`: BASELINE configs[4] -- MerkleTree::new, Bowe-Hopwood 63 x 9 over Jubjub, 2^23 leaves of 32 bytes PER GPU (weak
+scaling: 2^26 on 8 GPUs), ByteDigestConverter"""
+import time
+
+from .common import HBM_PEAK_GBS, MADS_PER_PRODUCT, PMC_TE, VALU_PEAK_WAVE_INSTR, te_counters
+
+
+def run(env):
+    args, np, torch = env.args, env.np, env.torch
+    if not args.bh_merkle_log2:
+        return None
+    from crypto_primitives_amd import params as cparams
+    from crypto_primitives_amd.crh import bowe_hopwood
+    per = 1 << args.bh_merkle_log2
+    total = per * env.world
+    gens = cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    B = bowe_hopwood.Parameters(gens)
+    leaves = np.random.default_rng(0xA5A50005 + env.rank).integers(0, 256, size=(per, 32), dtype=np.uint8)
+    d_leaves = torch.from_numpy(leaves).to(env.dev)
+    tb = env.GpuTeBackend(B, B, device=env.dev)
+    env.build_sharded(tb, d_leaves, total, env.dist)  # untimed full-size warm-up (tables, scratch, RCCL)
+    env.barrier()
+    reps = 3
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    m0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        res = env.build_sharded(tb, d_leaves, total, env.dist)
+        b.record()
+    env.barrier()
+    bsec = env.max_over_ranks(time.perf_counter() - m0) / reps
+    dev_ms = sum(a.elapsed_time(b) for a, b in evs) / reps
+    h = B.handle(env.ctx)
+    bh_merkle = {"config": "BASELINE configs[4]: MerkleTree::new, Bowe-Hopwood 63x9 over Jubjub, 32-byte leaves, ByteDigestConverter",
+                 "leaves": total, "leaves_per_gpu": per, "seconds": bsec, "leaves_per_s": total / bsec, "scaling": "weak",
+                 "roofline": {"bound": "hbm", "kernels": "te_accumulate_lds_kernel<1> + te_finalize_kernel<1> + te_serialize_pairs_kernel per level",
+                              "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                              "table": h.info(32),
+                              "traffic": te_counters("bh_32B", per)["traffic"] + te_counters("bh_70B", per - 1, (h.info(64)["steps"] + 1) / 39.0)["traffic"],
+                              "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
+                                                     "for the leaf level and 2^20 x 70 B scaled to the inner nodes' table steps; levels of <= 2^14 nodes run the split kernel; "
+                                                     "NOT measured in this run)",
+                              "valu": {"table_steps_per_leaf_hash": h.info(32)["steps"],
+                                       "table_steps_per_inner_node": h.info(64)["steps"] + 1,
+                                       "inner_node_note": "64 bytes of digests in a 70-byte buffer: the table steps of the 64 data bytes + one constant "
+                                                          "entry for the zero-padded tail (a zero chunk adds +g); %d steps if the padding is walked" % h.info(70)["steps"],
+                                       "field_products_per_step": 7}}}
+    rfb = bh_merkle["roofline"]
+    rfb["traffic_over_algorithmic"] = rfb["traffic"] / (160.0 * per)
+    bh_mads = (per * (rfb["valu"]["table_steps_per_leaf_hash"] * 7 + 6) + (per - 1) * (rfb["valu"]["table_steps_per_inner_node"] * 7 + 6)) * MADS_PER_PRODUCT
+    rfb["valu"]["v_mad_per_s"] = bh_mads / (dev_ms / 1e3)
+    rfb["valu"]["frac_of_mad_issue_peak"] = bh_mads / (dev_ms / 1e3) / (VALU_PEAK_WAVE_INSTR * 64)
+    if env.rank == 0:
+        from oracle import cref
+        cur = cref.CurveParams(63, 9, gens)
+        ln = res["leaf_nodes"].cpu().numpy().view(np.uint64).reshape(per, 4)
+        nl = res["non_leaf_nodes"].cpu().numpy().view(np.uint64).reshape(per - 1, 4)
+        si = np.unique(np.linspace(0, per - 1, 129).astype(np.int64))
+        ok = np.array_equal(ln[si], cur.bh_crh_batch(np.ascontiguousarray(leaves[si]), len(si), 32, threads=env.ora_threads))
+        # inner nodes from their children: buffer = LE(left) || LE(right) zero-padded to (63 * 9) / 8 = 70 bytes
+        ni = np.unique(np.concatenate([np.arange(0, min(32, per - 1)), np.linspace(0, per - 2, 97).astype(np.int64)]))
+
+        def child(ix):
+            return np.where((ix < per - 1)[:, None], nl[np.clip(ix, 0, per - 2)], ln[np.clip(ix - (per - 1), 0, per - 1)])
+        buf = np.zeros((len(ni), 70), np.uint8)
+        buf[:, :32] = cref.from_mont(np.ascontiguousarray(child(2 * ni + 1))).view(np.uint8).reshape(len(ni), 32)
+        buf[:, 32:64] = cref.from_mont(np.ascontiguousarray(child(2 * ni + 2))).view(np.uint8).reshape(len(ni), 32)
+        ok = ok and np.array_equal(nl[ni], cur.bh_crh_batch(buf, len(ni), 70, threads=env.ora_threads))
+        bh_merkle["sampled_parity_bit_exact"] = bool(ok)
+        if not ok:
+            raise SystemExit("Bowe-Hopwood leg: sampled nodes differ from the oracle")
+    return bh_merkle

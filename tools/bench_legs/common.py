@@ -1,0 +1,193 @@
+"""constants, sensors and plumbing shared by bench.py and its legs"""
+import glob
+import json
+import os
+import subprocess
+
+ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+MODMUL_PER_PERM_REF = 626        # reference-shaped count
+# HBM bytes per permutation from PMC passes of an earlier session (NOT measured in this run; see `static_from`):
+# (2 * 49 583.19 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B); re-collected in round 3 on the
+# four-unit library: FETCH_SIZE 49 583 KB, WRITE_SIZE 98 304 KB, SQ_INSTS_VALU 1 224 736 768, VALUBusy 95.6-96.1 %
+PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49583.1875 + 98304.0) * 1024 / (1 << 20)
+PMC_TRAFFIC_SOURCE = "profiles/r03_s11/pmc_counters_poseidon.txt"
+NOMINAL_SCLK_MHZ = 2400.0
+CYCLES_PER_WAVE_MAD = 4.0        # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
+SIMDS = 256 * 4
+
+
+def valu_peak_wave_instr(sclk_mhz=NOMINAL_SCLK_MHZ):
+    """wave-level v_mad instructions per second the chip can issue at `sclk_mhz`"""
+    return SIMDS * sclk_mhz * 1e6 / CYCLES_PER_WAVE_MAD
+
+
+VALU_PEAK_WAVE_INSTR = valu_peak_wave_instr()
+# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r03_s4/pmc_te_line128.txt: rocprofv3 --pmc, one counter per pass;
+# NOT measured in this run).  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B): with it the
+# accumulate kernels fetch ~1.07 x the table bytes they gather -- every table line comes from the Infinity Cache / HBM, the L2 only
+# serves the second half of a line (TCC_HIT = TCC_MISS: two 64-byte requests per 128-byte entry, the first misses, the second hits).
+PMC_TE = {"source": "profiles/r03_s4/pmc_te_line128.txt",
+          "pedersen_128B": {"fetch_kb": 4520651 + 164359, "write_kb": 147466 + 114688, "valu_instr": 1531920384 + 47370240},  # accumulate<2> + finalize<0>
+          "bh_32B": {"fetch_kb": 957788 + 163841, "write_kb": 147473 + 81920, "valu_instr": 421838848 + 38817792},          # accumulate<1> + finalize<1>
+          "bh_70B": {"fetch_kb": 2267504 + 163841, "write_kb": 147473 + 81920, "valu_instr": 936509440 + 38817792, "steps": 39}}
+MADS_PER_PRODUCT = 153           # multiply-adds of one field product (81 limb products + 72 reduction products)
+MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
+# (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:
+# 55 S-boxes; full-round rows: 20 with unit diagonal (dot2), 4 dot3; partial rounds: dot3 + one product (lane-1 form), the
+# last one dot2 + one product; no conversion products.
+
+
+def te_counters(key, hashes, steps_scale=1.0):
+    """bytes / instructions for `hashes` hashes from the per-2^20 PMC figures (gather-proportional parts scaled by steps_scale)"""
+    c = PMC_TE[key]
+    per = hashes / float(1 << 20)
+    return {"traffic": (2.0 * c["fetch_kb"] * steps_scale + c["write_kb"]) * 1024.0 * per, "valu_instr": c["valu_instr"] * steps_scale * per}
+
+
+class Env:
+    """what a leg needs: modules (torch, np, cpa, field, lib, check), the device / context / stream, the default Poseidon config and
+    its handle, rank plumbing (rank, world, local_rank, dist, shared_gpu, barrier(), max_over_ranks()), the oracle handle of rank 0
+    (`ora`, checker only) and the parsed arguments"""
+
+
+def _card_dirs():
+    return sorted(glob.glob("/sys/class/drm/card*/device"))
+
+
+def gpu_clock_mhz(index=0):
+    """shader clock LEVEL of the current power state: the entry pp_dpm_sclk marks with '*' (highest over the cards that expose one
+    -- a box may list an idle integrated device first), else `rocm-smi --showclocks --json`; None when unreadable.  A ceiling, not
+    the effective clock: that is `roofline.effective_sclk_mhz` (akp_clock_probe_dev)."""
+    best = None
+    try:
+        for d in _card_dirs():
+            path = os.path.join(d, "pp_dpm_sclk")
+            if not os.path.exists(path):
+                continue
+            for line in open(path).read().splitlines():
+                if line.strip().endswith("*"):
+                    v = float(line.split(":")[1].strip().split("M")[0])
+                    best = v if best is None else max(best, v)
+    except Exception:
+        pass
+    if best is not None and best > 200.0:
+        return best
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+        vals = []
+        for card in json.loads(out).values():
+            for k, v in card.items():
+                if "sclk" in k.lower() and "(" in str(v):
+                    vals.append(float(str(v).split("(")[1].split("M")[0]))
+        if vals:
+            return max(vals + ([best] if best else []))
+    except Exception:
+        pass
+    return best
+
+
+def gpu_sensors():
+    """socket power (W), its cap (W) and the hottest temperature (C) of the BUSIEST card, from hwmon: power1_input (what the MI355X
+    boxes expose, label PPT; round 3 only looked for power1_average and reported None everywhere) or power1_average, power1_cap,
+    temp*_input.  A box shows every GPU of its node; the one this process loads is the one that draws the most.  Values None when
+    unreadable."""
+    best = None
+    for d in _card_dirs():
+        for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+            def rd(name, scale):
+                try:
+                    return float(open(os.path.join(hw, name)).read().strip()) / scale
+                except Exception:
+                    return None
+            w = rd("power1_input", 1e6)
+            if w is None:
+                w = rd("power1_average", 1e6)
+            if w is None:
+                continue
+            temps = [t for t in (rd(os.path.basename(p), 1e3) for p in glob.glob(os.path.join(hw, "temp*_input"))) if t is not None]
+            rec = {"power_w": w, "power_cap_w": rd("power1_cap", 1e6), "temp_c_max": max(temps) if temps else None, "source": "hwmon " + os.path.basename(hw)}
+            if best is None or w > best["power_w"]:
+                best = rec
+    return best or {"power_w": None, "power_cap_w": None, "temp_c_max": None, "source": None}
+
+
+def gpu_power_w():
+    return gpu_sensors()["power_w"]
+
+
+def cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = None
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "affinity_cpus": aff, "cgroup_cpu_quota": quota}
+
+
+def measure_hbm_copy(torch, dev, nbytes=1 << 30, reps=10):
+    """Read+write GB/s of a plain 1 GiB device-to-device copy on this box (the measured HBM rate beside the
+    vendor 8 TB/s).  Measurement plumbing only -- not part of the hashed path."""
+    try:
+        a = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        b = torch.empty_like(a)
+        a.zero_()
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        secs = e0.elapsed_time(e1) / 1e3 / reps
+        del a, b
+        return 2 * nbytes / secs / 1e9
+    except Exception:  # pragma: no cover - measurement is best effort
+        return None
+
+
+class ClockProbe:
+    """effective shader clock through akp_clock_probe_dev: one wave, a chain of dependent multiply-adds, shader-clock cycles
+    against the constant 100 MHz clock.  `launch()` enqueues a probe on its own stream (non-blocking: it may run BESIDE the
+    timed kernels, one wave among ~16 000); `read()` returns the list of MHz values of the probes that have finished."""
+
+    def __init__(self, env, chain_len=1 << 20, slots=32):
+        self.env, self.chain_len = env, chain_len
+        self.stream = env.torch.cuda.Stream(device=env.dev)
+        self.pool = env.torch.zeros((slots, 3), dtype=env.torch.int64, device=env.dev)  # allocated and cleared BEFORE any timed region
+        env.torch.cuda.synchronize(env.dev)
+        self.used = 0
+        self.first = 0
+
+    def launch(self):
+        if self.used >= self.pool.shape[0]:
+            return
+        t = self.pool[self.used]
+        self.env.check(self.env.lib.akp_clock_probe_dev(self.env.ctx.h, self.chain_len, t.data_ptr(), self.stream.cuda_stream))
+        self.used += 1
+
+    def read(self):
+        """the probes launched since the last read"""
+        self.stream.synchronize()
+        rows = self.pool[self.first:self.used].cpu().numpy().view("uint64")
+        self.first = self.used
+        out = []
+        for c, w, _ in rows:
+            c, w = int(c), int(w)
+            if w:
+                out.append({"mhz": 100.0 * c / w, "cycles_per_dependent_mad": c / float(self.chain_len), "ms": w / 1e5})
+        return out

@@ -1,0 +1,81 @@
+"""`pedersen`: BASELINE configs[3] -- pedersen::CRH over Jubjub, window 4 x 256, 2^20 messages of 128 bytes per GPU, resident"""
+import time
+
+from .common import HBM_PEAK_GBS, MADS_PER_PRODUCT, PMC_TE, VALU_PEAK_WAVE_INSTR, gpu_clock_mhz, gpu_sensors, te_counters
+
+
+def run(env):
+    args, np, torch, lib, check = env.args, env.np, env.torch, env.lib, env.check
+    if not args.pedersen_log2:
+        return None
+    from crypto_primitives_amd import params as cparams
+    from crypto_primitives_amd.crh import pedersen as cped
+    npd = 1 << args.pedersen_log2
+    gens = cparams.pedersen_generators(0xA5A50004, 4, 256)
+    hP = cped.Parameters(gens).handle(env.ctx)
+    msgs = np.random.default_rng(0xA5A50004 + env.rank).integers(0, 256, size=(npd, 128), dtype=np.uint8)
+    d_msgs = torch.from_numpy(msgs).to(env.dev)
+    d_out = torch.empty((npd, 8), dtype=torch.int64, device=env.dev)
+
+    def ped_step():
+        check(lib.akp_te_crh_batch_dev(hP.h, d_msgs.data_ptr(), npd, 128, d_out.data_ptr(), env.stream))
+    for _ in range(3):
+        ped_step()
+    env.barrier()
+    reps = 10
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    p0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        ped_step()
+        b.record()
+    env.barrier()
+    psec = env.max_over_ranks(time.perf_counter() - p0)
+    kms = sorted(a.elapsed_time(b) for a, b in evs)
+    kavg = sum(kms) / len(kms) / 1e3
+    pinfo = hP.info(128)
+    psteps = pinfo["steps"]
+    tc = te_counters("pedersen_128B", npd)
+    pedersen = {"config": "BASELINE configs[3]: pedersen::CRH, Jubjub, window 4x256, 128-byte messages", "messages_per_gpu": npd,
+                "hashes_per_s": npd * env.world * reps / psec, "ms_per_batch": psec / reps * 1e3,
+                "roofline": {"bound": "hbm", "kernels": "te_accumulate_lds_kernel<2> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
+                             "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 192.0 * npd / kavg / 1e9 / HBM_PEAK_GBS,
+                             "traffic": tc["traffic"], "traffic_over_algorithmic": tc["traffic"] / (192.0 * npd),
+                             "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_kernel<2> + te_finalize_kernel<0>, the round-3 "
+                                                    "kernel with per-lane message loads; NOT measured in this run)",
+                             "table_bytes_gathered_per_hash": psteps * int(lib.akp_te_entry_bytes()),
+                             "gather_over_algorithmic": psteps * int(lib.akp_te_entry_bytes()) / 192.0,
+                             "table": pinfo,
+                             "valu": {"table_steps_per_hash": psteps, "field_products_per_step": 7,
+                                      "valu_instructions_per_hash": te_counters("pedersen_128B", 1)["valu_instr"],
+                                      "v_mad_per_s": (psteps * 7 + 6) * MADS_PER_PRODUCT * npd / kavg,
+                                      "frac_of_mad_issue_peak": (psteps * 7 + 6) * MADS_PER_PRODUCT * npd / kavg / (VALU_PEAK_WAVE_INSTR * 64),
+                                      "v_mad_note": "7 products per table step + ~6 per hash in the shared-inversion pass, 153 multiply-adds each; peak at the nominal 2.4 GHz",
+                                      "note": "VALU-issue bound like the permutation: one mixed addition of 7 products per table step (signed-subset table); "
+                                              "message bits come from an LDS image of the workgroup's messages (round 4, -3 %: profiles/r04_s1); one 128-byte line "
+                                              "per table entry, gathered through L2 / Infinity Cache / HBM: 0.18 ms of a 3.19 ms launch for presenting 64 distinct "
+                                              "lines per load, 0.32 ms for the lines that miss L2 (profiles/r04_s1/README.md; counters profiles/r03_s4)"}}}
+    if args.sustain_seconds > 0:  # clock / power under the gather-heavy kernel (the permutation's figures are in `sustained`)
+        count = int(min(2000, max(8, 0.5 * args.sustain_seconds / max(kavg, 1e-4))))
+        torch.cuda.synchronize(env.dev)
+        s0 = time.perf_counter()
+        for _ in range(count):
+            ped_step()
+        time.sleep(min(0.25, 0.25 * count * kavg))  # sample while the queue is still draining
+        cmid, sens = gpu_clock_mhz(env.local_rank), gpu_sensors()
+        torch.cuda.synchronize(env.dev)
+        ssec = time.perf_counter() - s0
+        pedersen["sustained"] = {"launches": count, "seconds": ssec, "hashes_per_s": npd * count / ssec, "sclk_level_mhz_during": cmid, "power_w_during": sens["power_w"],
+                                 "power_cap_w": sens["power_cap_w"], "temp_c_max_during": sens["temp_c_max"]}
+    if env.rank == 0:
+        from oracle import cref
+        cur = cref.CurveParams(4, 256, gens)
+        si = np.unique(np.concatenate([np.arange(64), np.linspace(0, npd - 1, 193).astype(np.int64)]))
+        got = d_out.cpu().numpy().view(np.uint64).reshape(npd, 2, 4)[si]
+        ok = bool(np.array_equal(got, cur.pedersen_crh_batch(np.ascontiguousarray(msgs[si]), len(si), 128, threads=env.ora_threads)))
+        pedersen["sampled_parity_bit_exact"] = ok
+        pedersen["parity_samples"] = int(len(si))
+        if not ok:
+            raise SystemExit("Pedersen leg: sampled digests differ from the oracle")
+    return pedersen
