@@ -105,6 +105,7 @@ def _load():
         "akp_merkle_gather_paths": (i32, [u64p, u64p, sz, u32, u64p, sz, u64p, u64p]),
         "akp_merkle_gather_paths_dev": (i32, [vp, u64p, u64p, sz, u32, u64p, sz, u64p, u64p, vp]),
         "akp_merkle_verify_paths_poseidon": (i32, [vp, vp, u64p, u64p, sz, sz, u64p, u64p, u64p, sz, u8p]),
+        "akp_merkle_verify_paths_poseidon_dev": (i32, [vp, vp, u64p, u64p, sz, sz, u64p, u64p, u64p, sz, u8p, vp]),
         "akp_merkle_verify_paths_te": (i32, [vp, vp, u64p, u8p, sz, sz, u64p, u64p, u64p, sz, u8p]),
         "akp_poseidon_kernel_for": (C.c_char_p, [vp, sz, i32]),
         "akp_host_alloc": (i32, [sz, pp]),
@@ -140,6 +141,9 @@ def _load():
         "akp_multi_tree_gather_paths": (i32, [vp, u64p, sz, u64p, u64p]),
         "akp_multi_tree_update_batch": (i32, [vp, u64p, vp, sz, sz]),
         "akp_multi_tree_export": (i32, [vp, u64p, u64p]),
+        "akp_multi_tree_check_update": (i32, [vp, u64, vp, sz, u64p, C.POINTER(i32)]),
+        "akp_multi_tree_from_digests_poseidon": (i32, [vp, pp, pp, u64p, sz, pp]),
+        "akp_multi_tree_from_digests_te": (i32, [vp, pp, pp, u64p, sz, pp]),
         "akp_serialize_digests": (i32, [u64p, sz, u32, i32, u8p, sz, C.POINTER(sz)]),
         "akp_deserialize_digests": (i32, [u8p, sz, sz, u32, i32, i32, u64p]),
         "akp_serialize_poseidon_config": (i32, [vp, u8p, sz, C.POINTER(sz)]),

@@ -323,6 +323,41 @@ extern "C" int32_t akp_merkle_verify_paths_poseidon(akp_poseidon* leafp, akp_pos
             return launch_verify_paths_t3(leafp, two, (const Fr*)dl, leaf_len, d_idx, d_sib, d_auth, depth, d_root, d_ok, m, s, done);
         });
 }
+// the same with every buffer already in device memory (proofs produced by akp_merkle_gather_paths_dev can be checked where they
+// lie): enqueues on `stream`, no synchronisation.  d_ok_out: m bytes.  Shapes outside the one-launch kernel (launch_verify_paths_t3)
+// run level by level on context scratch.
+extern "C" int32_t akp_merkle_verify_paths_poseidon_dev(akp_poseidon* leafp, akp_poseidon* two, const uint64_t* d_root, const uint64_t* d_leaves,
+        size_t m, size_t leaf_len, const uint64_t* d_idx, const uint64_t* d_sibs, const uint64_t* d_auth, size_t depth, uint8_t* d_ok_out,
+        void* stream) {
+    NEED_DEV(leafp, "akp_merkle_verify_paths_poseidon_dev");
+    NEED_DEV(two, "akp_merkle_verify_paths_poseidon_dev");
+    if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "parameters belong to different contexts");
+    if (m == 0) return AKP_OK;
+    if (!d_root || !d_idx || !d_sibs || !d_ok_out || (depth && !d_auth) || (leaf_len && !d_leaves)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    akp_ctx* c = leafp->ctx;
+    hipStream_t s = pick_stream(c, stream);
+    bool walked = false;
+    if (int32_t rc = launch_verify_paths_t3(leafp, two, (const Fr*)d_leaves, leaf_len, d_idx, (const Fr*)d_sibs, (const Fr*)d_auth, depth, (const Fr*)d_root,
+            d_ok_out, m, s, &walked))
+        return rc;
+    if (walked) return AKP_OK;
+    void *d_cur = nullptr, *d_l = nullptr, *d_r = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_G, m * sizeof(Fr), &d_cur, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_H, m * sizeof(Fr), &d_l, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_I, m * sizeof(Fr), &d_r, s)) return rc;
+    if (int32_t rc = launch_crh(leafp, (const Fr*)d_leaves, nullptr, leaf_len, (Fr*)d_cur, m, s)) return rc;
+    const unsigned grid = (unsigned)((m + 255) / 256);
+    for (size_t step = 0; step <= depth; ++step) {
+        const Fr* sib = step == 0 ? (const Fr*)d_sibs : (const Fr*)d_auth + (depth - step);
+        hipLaunchKernelGGL(merkle_select_kernel, dim3(grid), dim3(256), 0, s, (const Fr*)d_cur, sib, step == 0 ? (size_t)1 : depth, 1u, d_idx, (u32)step,
+                (Fr*)d_l, (Fr*)d_r, m);
+        HIP_TRY(hipGetLastError());
+        if (int32_t rc = launch_crh(two, (const Fr*)d_l, (const Fr*)d_r, 2, (Fr*)d_cur, m, s)) return rc;
+    }
+    hipLaunchKernelGGL(merkle_compare_kernel, dim3(grid), dim3(256), 0, s, (const Fr*)d_cur, (const Fr*)d_root, 1u, d_ok_out, m);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
 extern "C" int32_t akp_merkle_verify_paths_te(akp_te_params* leafp, akp_te_params* two, const uint64_t* root, const uint8_t* leaves,
         size_t m,
         size_t leaf_len, const uint64_t* idx, const uint64_t* sibs, const uint64_t* auth, size_t depth,

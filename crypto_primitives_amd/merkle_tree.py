@@ -632,6 +632,18 @@ class MultiGpu:
         self._trees.append(t)
         return t
 
+    def build_tree_with_leaf_digest(self, config, leaf_hash_param, two_to_one_hash_param, leaf_digests):
+        """MerkleTree::new_with_leaf_digest (:424-523) sharded and resident; with all-default digests: MerkleTree::blank (:400-408)"""
+        import ctypes as C
+        la, ta = self._handles(config, leaf_hash_param, two_to_one_hash_param)
+        d = np.ascontiguousarray(leaf_digests, dtype=np.uint64).reshape((-1,) + config.digest_shape)
+        h = C.c_void_p()
+        fn = lib.akp_multi_tree_from_digests_poseidon if config is PoseidonFieldConfig else lib.akp_multi_tree_from_digests_te
+        check(fn(self._h, la, ta, d.ctypes.data, len(d), C.byref(h)))
+        t = ShardedMerkleTree(self, config, h)
+        self._trees.append(t)
+        return t
+
     def last_phases(self):
         """phase breakdown of the last build_sharded / build_tree call (akp_multi_last_phases), milliseconds, maximum over the devices"""
         import ctypes as C
@@ -707,6 +719,37 @@ class ShardedMerkleTree:
         x, n, k = GpuMerkleTree._leaf_array(self.config, new_leaves)
         assert n == len(idx), "one leaf per index"
         check(lib.akp_multi_tree_update_batch(self._h, idx.ctypes.data, x.ctypes.data if x.size else None, n, k))
+
+    def update(self, index, new_leaf):  # :692-702
+        self.update_batch([index], [new_leaf] if self.config is not PoseidonFieldConfig else np.asarray(new_leaf, dtype=np.uint64)[None])
+
+    def check_update(self, index, new_leaf, asserted_new_root) -> bool:  # :707-725
+        import ctypes as C
+        x, _, k = GpuMerkleTree._leaf_array(self.config, [new_leaf] if self.config is not PoseidonFieldConfig else np.asarray(new_leaf, dtype=np.uint64)[None])
+        root = np.ascontiguousarray(asserted_new_root, dtype=np.uint64)
+        ok = C.c_int32(0)
+        check(lib.akp_multi_tree_check_update(self._h, int(index), x.ctypes.data if x.size else None, k, root.ctypes.data, C.byref(ok)))
+        return ok.value == 1
+
+    def generate_multi_proof(self, indexes) -> MultiPath:
+        """:592-625: sorted, de-duplicated indexes; paths gathered from the owning shards, prefix_encode_path through the ABI"""
+        import ctypes as C
+        idxs = sorted(set(int(i) for i in indexes))
+        idx = np.array(idxs, dtype=np.uint64)
+        m, shp, depth = len(idx), self.config.digest_shape, max(self._height - 2, 0)
+        sibs = np.empty((m,) + shp, dtype=np.uint64)
+        auth = np.empty((m, depth) + shp, dtype=np.uint64)
+        check(lib.akp_multi_tree_gather_paths(self._h, idx.ctypes.data, m, sibs.ctypes.data, auth.ctypes.data if depth else None))
+        pre = np.zeros(m, dtype=np.uint64)
+        suf = np.empty((m * depth,) + shp, dtype=np.uint64)
+        cnt = C.c_size_t(0)
+        check(lib.akp_merkle_multipath_encode(auth.ctypes.data if depth else None, m, depth, self._fe, pre.ctypes.data, suf.ctypes.data if depth else None, C.byref(cnt)))
+        suffixes, o = [], 0
+        for i in range(m):
+            k = depth - int(pre[i])
+            suffixes.append([suf[o + j].copy() for j in range(k)])
+            o += k
+        return MultiPath(self.config, [sibs[i] for i in range(m)], [int(x) for x in pre], suffixes, idxs)
 
     def to_host(self, leaf_hash_param=None, two_to_one_hash_param=None) -> MerkleTree:
         shp = self.config.digest_shape

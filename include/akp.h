@@ -253,6 +253,12 @@ int32_t akp_merkle_verify_paths_poseidon(akp_poseidon* leaf_params, akp_poseidon
                                          const uint64_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indices,
                                          const uint64_t* leaf_sibling_hashes, const uint64_t* auth_paths, size_t depth,
                                          uint8_t* ok_out);
+/* the same with every buffer in device memory (paths from akp_merkle_gather_paths_dev are verified where they lie); d_ok_out: m
+ * bytes; enqueues on `stream`, no synchronisation */
+int32_t akp_merkle_verify_paths_poseidon_dev(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* d_root,
+                                             const uint64_t* d_leaves, size_t m, size_t leaf_len, const uint64_t* d_leaf_indices,
+                                             const uint64_t* d_leaf_sibling_hashes, const uint64_t* d_auth_paths, size_t depth,
+                                             uint8_t* d_ok_out, void* stream);
 int32_t akp_merkle_verify_paths_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint64_t* root,
                                    const uint8_t* leaves, size_t m, size_t leaf_len, const uint64_t* leaf_indices,
                                    const uint64_t* leaf_sibling_hashes, const uint64_t* auth_paths, size_t depth,
@@ -423,6 +429,14 @@ int32_t akp_multi_tree_gather_paths(akp_multi_tree* t, const uint64_t* leaf_indi
 /* MerkleTree::update (:692-702), batched as akp_merkle_tree_update_batch: per-shard updates, then the exchange */
 int32_t akp_multi_tree_update_batch(akp_multi_tree* t, const uint64_t* leaf_indices, const void* new_leaves, size_t m,
                                     size_t leaf_len);
+/* MerkleTree::check_update (:707-725) on the sharded tree: *ok = 1 and the update is kept iff the new root equals asserted_new_root */
+int32_t akp_multi_tree_check_update(akp_multi_tree* t, uint64_t leaf_index, const void* new_leaf, size_t leaf_len,
+                                    const uint64_t* asserted_new_root, int32_t* ok);
+/* MerkleTree::new_with_leaf_digest (:424-523) / blank (:400-408) over the devices: n_leaves digests in global order (host) */
+int32_t akp_multi_tree_from_digests_poseidon(akp_multi* m, akp_poseidon* const* leaf_params, akp_poseidon* const* two_to_one_params,
+                                             const uint64_t* leaf_digests, size_t n_leaves, akp_multi_tree** out);
+int32_t akp_multi_tree_from_digests_te(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
+                                       const uint64_t* leaf_digests, size_t n_leaves, akp_multi_tree** out);
 /* the reference's two vectors in GLOBAL heap order (checkpoints, tests); either pointer may be NULL */
 int32_t akp_multi_tree_export(akp_multi_tree* t, uint64_t* leaf_nodes, uint64_t* non_leaf_nodes);
 

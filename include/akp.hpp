@@ -393,6 +393,85 @@ class GpuMerkleTree {
 };
 
 
+// ---- several GPUs from one process (akp_multi_*): MerkleTree<P> sharded by leaf range, resident in every device's HBM ------------
+// Poseidon field config.  One context + one parameter handle set per device; the RCCL communicator lives inside the library.
+class MultiGpu {
+  public:
+    explicit MultiGpu(const std::vector<int32_t>& device_ids) { check(akp_multi_create(device_ids.data(), (int32_t)device_ids.size(), &h_)); }
+    ~MultiGpu() {
+        params_.clear();  // parameter handles first: they were created on this object's contexts
+        akp_multi_destroy(h_);
+    }
+    MultiGpu(const MultiGpu&) = delete;
+    MultiGpu& operator=(const MultiGpu&) = delete;
+    int size() const { return akp_multi_size(h_); }
+    akp_multi* get() const { return h_; }
+    // Fr::get_default_poseidon_parameters on every device (kept until this object goes)
+    std::vector<akp_poseidon*> default_poseidon_parameters(uint32_t rate, bool optimized_for_weights) {
+        std::vector<akp_poseidon*> out;
+        for (int r = 0; r < size(); ++r) {
+            akp_poseidon* p = nullptr;
+            check(akp_poseidon_default_params(akp_multi_ctx(h_, r), rate, optimized_for_weights ? 1 : 0, &p));
+            params_.emplace_back(p, &akp_poseidon_params_destroy);
+            out.push_back(p);
+        }
+        return out;
+    }
+    // phases of the last sharded build, milliseconds: sub-trees / all-gather / top levels / copy-out / whole call
+    std::array<double, 5> last_phases() const {
+        std::array<double, 5> ms{};
+        check(akp_multi_last_phases(h_, ms.data()));
+        return ms;
+    }
+
+  private:
+    akp_multi* h_ = nullptr;
+    std::vector<std::unique_ptr<akp_poseidon, void (*)(akp_poseidon*)>> params_;
+};
+// MerkleTree<P> over the devices of a MultiGpu: akp_multi_tree_* (root :526-528, generate_proof :572-579, update :692-702)
+class ShardedMerkleTree {
+  public:
+    using Digest = FrWire;
+    // MerkleTree::new (:411-422): host leaves in global order; leaf_params[r] / two_params[r] live on device slot r
+    ShardedMerkleTree(MultiGpu& m, const std::vector<akp_poseidon*>& leaf_params, const std::vector<akp_poseidon*>& two_params,
+                      const std::vector<FrWire>& leaves, size_t leaf_len)
+        : leaf_len_(leaf_len) {
+        check(akp_multi_tree_build_poseidon(m.get(), leaf_params.data(), two_params.data(), leaves.empty() ? nullptr : leaves[0].data(),
+                                            leaf_len ? leaves.size() / leaf_len : 0, leaf_len, &h_));
+        uint32_t fe = 0;
+        int32_t g = 0;
+        check(akp_multi_tree_info(h_, &n_, &fe, &height_, &g));
+    }
+    ~ShardedMerkleTree() { akp_multi_tree_destroy(h_); }  // before its MultiGpu
+    ShardedMerkleTree(const ShardedMerkleTree&) = delete;
+    ShardedMerkleTree& operator=(const ShardedMerkleTree&) = delete;
+    Digest root() const {
+        Digest r;
+        check(akp_multi_tree_root(h_, r.data()));
+        return r;
+    }
+    size_t height() const { return height_; }
+    std::vector<Path<PoseidonFieldConfig>> generate_proofs(const std::vector<uint64_t>& indexes) const {
+        const size_t m = indexes.size(), depth = height_ - 2;
+        std::vector<FrWire> sib(m), auth(m * depth);
+        check(akp_multi_tree_gather_paths(h_, indexes.data(), m, m ? sib[0].data() : nullptr, (m && depth) ? auth[0].data() : nullptr));
+        std::vector<Path<PoseidonFieldConfig>> out(m);
+        for (size_t i = 0; i < m; ++i) {
+            out[i].leaf_index = (size_t)indexes[i];
+            out[i].leaf_sibling_hash = sib[i];
+            out[i].auth_path.assign(auth.begin() + i * depth, auth.begin() + (i + 1) * depth);
+        }
+        return out;
+    }
+    void update_batch(const std::vector<uint64_t>& indexes, const std::vector<FrWire>& new_leaves) {
+        check(akp_multi_tree_update_batch(h_, indexes.data(), new_leaves.empty() ? nullptr : new_leaves[0].data(), indexes.size(), leaf_len_));
+    }
+
+  private:
+    size_t leaf_len_ = 0, n_ = 0, height_ = 0;
+    akp_multi_tree* h_ = nullptr;
+};
+
 // ---- CanonicalSerialize / CanonicalDeserialize (ark-serialize byte formats; akp_serialize_* / akp_deserialize_*) ---------------
 // `compress` is ark-serialize's Compress mode, `validate` its Validate mode (false = deserialize_*_unchecked).  Host only.
 namespace serialize {

@@ -14,6 +14,9 @@
 //! * [`merkle::GpuMerkleTree`] -- `MerkleTree<P>` resident on the device (new / blank / root / generate_proof /
 //!   generate_multi_proof / update / check_update), plus `into_reference_vectors` for code that reads the
 //!   reference's `leaf_nodes` / `non_leaf_nodes`.
+//! * [`sharded::MultiGpu`], [`sharded::GpuShardedMerkleTree`] -- the same tree over all GPUs of a node from this one process
+//!   (leaf-range shards resident per device, ONE all-gather of the sub-roots over RCCL inside the library): new / root /
+//!   generate_proof(s) / update_batch.
 //!
 //! Threading: an `akp_ctx` is not thread-safe, distinct contexts are.  The reference calls `evaluate` /
 //! `compress` concurrently from rayon workers (`merkle_tree/mod.rs:417,458,494`); here every OS thread lazily gets
@@ -25,6 +28,7 @@ pub mod ffi;
 pub mod merkle;
 pub mod poseidon;
 pub mod runtime;
+pub mod sharded;
 pub mod te;
 
 pub use ark_crypto_primitives::Error;

@@ -196,6 +196,13 @@ impl<W: pedersen::Window> TwoToOneCRHScheme for PedersenTwoToOneCRHCompressor<W>
     }
 }
 
+/// (window_size, num_windows, affine x || y words) of a generator table: what `akp_te_params_create` takes (the sharded tree
+/// creates its handles on other contexts than this thread's: [`crate::sharded`])
+pub(crate) fn window_words(gens: &[Vec<EdwardsProjective>]) -> (usize, usize, Vec<Fr>) {
+    let window_size = gens.first().map_or(0, |r| r.len());
+    assert!(gens.iter().all(|r| r.len() == window_size), "ragged generator table");
+    (window_size, gens.len(), affine_words(gens))
+}
 pub(crate) fn pedersen_handle(p: &pedersen::Parameters<EdwardsProjective>) -> Result<*mut ffi::AkpTeParams, Error> {
     te_handle(ffi::AKP_TE_PEDERSEN, &p.generators)
 }

@@ -129,6 +129,39 @@ int main(int argc, char** argv) {
         REQUIRE(gt.check_update(0, {fr_from_u64(7)}, tree3.root()) && gt.root() == tree3.root());
         try { gt.update_batch({8}, {fr_from_u64(1)}); REQUIRE(false); } catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_PARAMS); }
     }
+    // one process, all devices of this box (a power of two): the sharded resident tree answers like the single-device one
+    {
+        int ndev = akp_device_count(), g = 1;
+        while (g * 2 <= (ndev < 8 ? ndev : 8)) g *= 2;
+        std::vector<int32_t> ids;
+        for (int i = 0; i < g; ++i) ids.push_back(i);
+        MultiGpu mg(ids);
+        auto mp = mg.default_poseidon_parameters(2, false);
+        std::vector<FrWire> lv;
+        for (uint64_t i = 1; i <= 64; ++i) lv.push_back(fr_from_u64(i * 7 + 1));
+        ShardedMerkleTree st(mg, mp, mp, lv, 1);
+        GpuMerkleTree ref(cfg, cfg, lv, 1);
+        REQUIRE(st.height() == 7 && st.root() == ref.root());
+        auto ps = st.generate_proofs({0, 31, 32, 63});
+        auto pr = ref.generate_proofs({0, 31, 32, 63});
+        for (size_t i = 0; i < ps.size(); ++i) REQUIRE(ps[i].auth_path == pr[i].auth_path && ps[i].leaf_sibling_hash == pr[i].leaf_sibling_hash);
+        REQUIRE(ps[2].verify(cfg, cfg, st.root(), {lv[32]}));
+        st.update_batch({5, 63}, {fr_from_u64(1000), fr_from_u64(1001)});
+        ref.update_batch({5, 63}, {fr_from_u64(1000), fr_from_u64(1001)});
+        REQUIRE(st.root() == ref.root() && mg.last_phases()[4] > 0);
+        std::printf("sharded tree over %d device(s) OK\n", g);
+    }
+    // a serialised proof survives the round trip through the ark-serialize byte format (akp.hpp serialize namespace)
+    {
+        auto proof = tree.generate_proof(5);
+        auto bytes = serialize::path(proof);
+        REQUIRE(bytes.size() == 32 + 8 + 2 * 32 + 8);
+        auto back = serialize::read_path(bytes);
+        REQUIRE(back.leaf_index == 5 && back.auth_path == proof.auth_path && back.verify(cfg, cfg, root, {leaves[5]}));
+        auto cb = serialize::poseidon_config(cfg);
+        PoseidonConfig cfg2 = PoseidonConfig::deserialize(&ctx, cb);
+        REQUIRE(poseidon::CRH::evaluate(cfg2, {a, b}) == poseidon::CRH::evaluate(cfg, {a, b}));
+    }
     // reference returns None for rate 9
     try { PoseidonConfig::get_default_poseidon_parameters(ctx, 9, false); REQUIRE(false); } catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_PARAMS); }
     if (argc > 1 && te_cases(ctx, argv[1]) != 0) return 1;

@@ -151,6 +151,22 @@ def test_sharded_resident_tree_poseidon(cpa, G, monkeypatch):
         with pytest.raises(cpa.AkpError):
             st.update_batch([n], new[:1])
         assert np.array_equal(st.root(), ref.root())  # untouched by the rejected call
+        # check_update (:707-725): a wrong asserted root leaves the sharded tree as it was, the right one commits the update
+        before = st.to_host().non_leaf_nodes.copy()
+        cand = rand_fr_array(k, 5 + n).reshape(k, 4)
+        assert not st.check_update(per - 1, cand, st.root())
+        assert np.array_equal(st.to_host().non_leaf_nodes, before) and np.array_equal(st.root(), ref.root())
+        ref.update_batch([per - 1], cand[None])
+        assert st.check_update(per - 1, cand, ref.root()) and np.array_equal(st.root(), ref.root())
+        assert np.array_equal(st.to_host().non_leaf_nodes, ref.to_host().non_leaf_nodes)
+        # generate_multi_proof over the shards == the single-device handle's, and it verifies
+        want_mp, got_mp = ref.generate_multi_proof(idx), st.generate_multi_proof(idx)
+        assert got_mp.leaf_indexes == want_mp.leaf_indexes and got_mp.auth_paths_prefix_lenghts == want_mp.auth_paths_prefix_lenghts
+        assert all(np.array_equal(a, b) for sa, sb in zip(got_mp.auth_paths_suffixes, want_mp.auth_paths_suffixes) for a, b in zip(sa, sb))
+        # new_with_leaf_digest over the shards: the same inner nodes from the leaf digests alone
+        st3 = mg.build_tree_with_leaf_digest(cpa.PoseidonFieldConfig, c, c, ref.to_host().leaf_nodes)
+        assert np.array_equal(st3.root(), ref.root()) and np.array_equal(st3.to_host().non_leaf_nodes, ref.to_host().non_leaf_nodes)
+        st3.close()
         st.close()
         ref.close()
     ph = mg.last_phases()

@@ -28,7 +28,7 @@ def test_ffi_prototypes_equal_header_symbols_and_library_exports():
     assert "akp_poseidon_crh_batch(p: *mut AkpPoseidon, inputs: *const u64, n: usize, elems_per_input: usize, out: *mut u64) -> i32" in rs
     assert "leaf_params: *const *mut AkpPoseidon" in rs and "akp_multi_ctx(m: *mut AkpMulti, i: i32) -> *mut AkpCtx" in rs
     # every extern the hand-written sources call exists in ffi.rs
-    for f in ("runtime.rs", "poseidon.rs", "te.rs", "merkle.rs"):
+    for f in ("runtime.rs", "poseidon.rs", "te.rs", "merkle.rs", "sharded.rs"):
         src = open(os.path.join(ROOT, "shim", "src", f)).read()
         for name in set(re.findall(r"ffi::(akp_[a-z0-9_]+)", src)):
             assert name in protos, (f, name)

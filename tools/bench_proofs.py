@@ -173,6 +173,33 @@ def run(config, log2_leaves=20, log2_m=16, device_index=0, seed=0xA5A50006):
     same = bool(np.array_equal(d_auth[probe].cpu().numpy().view(np.uint64), auth[samp])) and bool(np.array_equal(d_sib[probe].cpu().numpy().view(np.uint64), sibs[samp]))
     out["generate_proof_all_leaves_dev"] = {"proofs": n, "device_ms": all_ms, "proofs_per_s": n / (all_ms / 1e3),
                                             "GBps_written": n * 32.0 * (depth + 1) / (all_ms / 1e3) / 1e9, "matches_host_form": same}
+    if kind == "poseidon":
+        # ... and Path::verify for every one of those proofs where they lie (akp_merkle_verify_paths_poseidon_dev: one launch, each
+        # lane walks its path; nothing crosses PCIe): the throughput shape of the row -- 2^k paths fill the machine
+        d_leaves = torch.from_numpy(np.ascontiguousarray(leaves).view(np.int64)).to(dev)
+        d_root = torch.from_numpy(root.view(np.int64).copy()).to(dev)
+        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+        def vall():
+            check(lib.akp_merkle_verify_paths_poseidon_dev(lh.h, th.h, d_root.data_ptr(), d_leaves.data_ptr(), n, leaf_len, d_idx.data_ptr(), d_sib.data_ptr(),
+                                                           d_auth.data_ptr(), depth, d_ok.data_ptr(), ts.cuda_stream))
+        vall()
+        torch.cuda.synchronize(dev)
+        e0.record()
+        vall()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        vms = e0.elapsed_time(e1)
+        accepted = int(d_ok.sum().item())
+        d_sib[12345 % n, 1] ^= 1  # negative control: one wrong sibling fails exactly its own flag
+        vall()
+        torch.cuda.synchronize(dev)
+        okc = d_ok.cpu().numpy()
+        out["verify_all_leaves_dev"] = {"paths": n, "device_ms": vms, "paths_per_s": n / (vms / 1e3), "hashes_per_path": depth + 2,
+                                        "hashes_per_s_device": n * (depth + 2) / (vms / 1e3), "all_accepted": accepted == n,
+                                        "negative_control_rejected_only_the_wrong_sibling": bool(okc[12345 % n] == 0 and int(okc.sum()) == n - 1),
+                                        "kernel": "poseidon_verify_paths_t3_kernel (each lane walks its own path)"}
+        del d_leaves, d_ok
     del d_idx, d_sib, d_auth
 
     # ---- Path::verify (:172-212), m paths in one call ----------------------------------------------------------------------
@@ -254,6 +281,8 @@ def run(config, log2_leaves=20, log2_m=16, device_index=0, seed=0xA5A50006):
                                        and out["verify_paths"]["negative_control_rejected_only_the_wrong_leaf"]
                                        and out["verify_multipath"]["sampled_parity_bit_exact"] and out["verify_multipath"]["negative_control_rejected"]
                                        and out["generate_proof_all_leaves_dev"]["matches_host_form"]
+                                       and (kind != "poseidon" or (out["verify_all_leaves_dev"]["all_accepted"]
+                                                                   and out["verify_all_leaves_dev"]["negative_control_rejected_only_the_wrong_sibling"]))
                                        and all(v["sampled_parity_bit_exact"] for v in out["update_batch"].values()))
     return out
 
