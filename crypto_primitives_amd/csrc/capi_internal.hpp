@@ -221,7 +221,7 @@ void poseidon_unpin(akp_poseidon* p);
         HIP_TRY(hipSetDevice((p)->ctx->device));                                                           \
     } while (0)
 // the batch launchers the tree code shares with the batch entry points: route n items to the register / latency / LDS-file kernels
-int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s);
+int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s, bool host_memory = false);
 int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s);
 int32_t launch_verify_paths_t3(akp_poseidon* leafp, akp_poseidon* two, const Fr* d_leaves, size_t leaf_len, const uint64_t* d_idx, const Fr* d_sibs,
         const Fr* d_auth, size_t depth, const Fr* d_root, uint8_t* d_ok, size_t m, hipStream_t s, bool* done);

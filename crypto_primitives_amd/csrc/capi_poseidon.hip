@@ -354,11 +354,22 @@ static unsigned t3_lds_cap() {
     constexpr unsigned w = 4;
     return (160u * 1024u / w) & ~1023u;
 }
-int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s) {
+int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s, bool host_memory) {
     if (n == 0) return AKP_OK;
     if (n > AKP_MAX_BATCH) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^36", n);
     if (p->dims.t == 3 && n > coop_max_items()) {
         const PoseidonConsts c = t3_reg_consts(p);
+        // states in pinned HOST memory (the zero-copy path of akp_poseidon_permute_batch): whole-line transfers through an LDS tile.
+        // A/B against six 16-byte accesses per lane (profiles/r04_s6/poseidon_hostpath_staged_ab.txt): 2^20 states 3.10 -> 3.01 ms,
+        // 2^22 states 10.85 -> 10.11 ms (37 -> 40 GB/s in each direction at once: the duplex limit of the link).
+        if (host_memory && ((uintptr_t)d_states & 15u) == 0) {
+            if (c.scaled == 3u) hipLaunchKernelGGL((poseidon_permute_t3_kernel<true, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s,
+                    p->dims, c, d_states, n);
+            else hipLaunchKernelGGL((poseidon_permute_t3_kernel<false, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims, c,
+                    d_states, n);
+            HIP_TRY(hipGetLastError());
+            return AKP_OK;
+        }
         if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_permute_t3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256),
                 t3_lds_cap(), s, p->dims, c, d_states, n);
         else hipLaunchKernelGGL(poseidon_permute_t3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims,
@@ -483,8 +494,9 @@ extern "C" int32_t akp_poseidon_permute_batch(akp_poseidon* p, uint64_t* states,
     if (!states) return fail(AKP_ERR_BAD_PARAMS, "states is NULL");
     const HostIn in[1] = {{states, p->dims.t * sizeof(Fr), SCR_A}};
     return pipelined_batch(p->ctx, n, in, 1, states, p->dims.t * sizeof(Fr), -1,
-                           [&](void* const* di, void*, size_t cnt, hipStream_t s) -> int32_t { return launch_permute(p, (Fr*)di[0], cnt,
-                                   s); });
+                           [&](void* const* di, void*, size_t cnt, hipStream_t s) -> int32_t {
+                               return launch_permute(p, (Fr*)di[0], cnt, s, device_alias(states, 16) == di[0]);  // true on the zero-copy path
+                           });
 }
 extern "C" int32_t akp_poseidon_crh_batch_dev(akp_poseidon* p, const uint64_t* d_inputs, size_t n, size_t k, uint64_t* d_out,
         void* stream) {

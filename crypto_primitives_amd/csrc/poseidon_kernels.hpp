@@ -185,31 +185,81 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
     return f29_to_wire(out);
 }
 
-template <bool FULLFORM>
+// STAGED (round 4, the zero-copy host path): the workgroup's 256 states (24 KB, contiguous) go through an LDS tile with
+// coalesced 16-byte loads and stores -- 1 KB per wave instruction -- instead of six 16-byte accesses per lane at a 96-byte pitch.
+// In HBM the two are equivalent (counter traffic 1.004 x algorithmic either way); over PCIe the per-lane form splits every
+// 128-byte line over several instructions.  Tile: 25 dwords per lane (24 + 1 pad: conflict-free per-lane reads).  Needs a
+// 16-byte aligned `states`.
+template <bool FULLFORM, bool STAGED = false>
 __global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D, PoseidonT3Consts C, Fr* states, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
     Fr* st = states + idx * 3;
-    FP s0, s1, s2;
-    if (FULLFORM) {  // the full form takes the wire value x * 2^256 as it is
-        s0 = f29_unpack<AKP_PS>(load_fr_global(st));
-        s1 = f29_unpack<AKP_PS>(load_fr_global(st + 1));
-        s2 = f29_unpack<AKP_PS>(load_fr_global(st + 2));
-    } else {
-        s0 = f29_from_wire<AKP_PS>(load_fr_global(st));
-        s1 = f29_from_wire<AKP_PS>(load_fr_global(st + 1));
-        s2 = f29_from_wire<AKP_PS>(load_fr_global(st + 2));
+    Fr w0, w1, w2;
+#if defined(__HIPCC__)
+    extern __shared__ u32 t3_tile[];
+    const size_t first = (size_t)blockIdx.x * blockDim.x;
+    const u32 cnt = (u32)(n - first < blockDim.x ? n - first : blockDim.x);
+    u32* mine = t3_tile + threadIdx.x * 25u;
+    if (STAGED) {
+        const uint4* g = reinterpret_cast<const uint4*>(states + first * 3);
+        for (u32 k = threadIdx.x; k < cnt * 6u; k += blockDim.x) {
+            const uint4 v = g[k];
+            u32* w = t3_tile + (k / 6u) * 25u + (k % 6u) * 4u;
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        }
+        __syncthreads();
+        if (idx < n) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { w0.l[i] = mine[i]; w1.l[i] = mine[8 + i]; w2.l[i] = mine[16 + i]; }
+        }
+    } else
+#endif
+    {
+        if (idx >= n) return;
+        w0 = load_fr_global(st);
+        w1 = load_fr_global(st + 1);
+        w2 = load_fr_global(st + 2);
     }
-    poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2);
-    if (FULLFORM) {  // the lanes already hold x * 2^256
-        store_fr_global(st, f29_canonical_pack(s0));
-        store_fr_global(st + 1, f29_canonical_pack(s1));
-        store_fr_global(st + 2, f29_canonical_pack(s2));
+    if (idx < n) {
+        FP s0, s1, s2;
+        if (FULLFORM) {  // the full form takes the wire value x * 2^256 as it is
+            s0 = f29_unpack<AKP_PS>(w0);
+            s1 = f29_unpack<AKP_PS>(w1);
+            s2 = f29_unpack<AKP_PS>(w2);
+        } else {
+            s0 = f29_from_wire<AKP_PS>(w0);
+            s1 = f29_from_wire<AKP_PS>(w1);
+            s2 = f29_from_wire<AKP_PS>(w2);
+        }
+        poseidon_permute_t3<FULLFORM>(D, C, s0, s1, s2);
+        if (FULLFORM) {  // the lanes already hold x * 2^256
+            w0 = f29_canonical_pack(s0);
+            w1 = f29_canonical_pack(s1);
+            w2 = f29_canonical_pack(s2);
+        } else {
+            w0 = f29_to_wire(s0);
+            w1 = f29_to_wire(s1);
+            w2 = f29_to_wire(s2);
+        }
+    }
+#if defined(__HIPCC__)
+    if (STAGED) {
+        if (idx < n) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { mine[i] = w0.l[i]; mine[8 + i] = w1.l[i]; mine[16 + i] = w2.l[i]; }
+        }
+        __syncthreads();
+        uint4* g = reinterpret_cast<uint4*>(states + first * 3);
+        for (u32 k = threadIdx.x; k < cnt * 6u; k += blockDim.x) {
+            const u32* w = t3_tile + (k / 6u) * 25u + (k % 6u) * 4u;
+            g[k] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
         return;
     }
-    store_fr_global(st, f29_to_wire(s0));
-    store_fr_global(st + 1, f29_to_wire(s1));
-    store_fr_global(st + 2, f29_to_wire(s2));
+#endif
+    store_fr_global(st, w0);
+    store_fr_global(st + 1, w1);
+    store_fr_global(st + 2, w2);
 }
 template <bool FULLFORM>
 __global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, PoseidonT3Consts C, const Fr* __restrict__ in0,
