@@ -363,9 +363,9 @@ int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s, b
         // A/B against six 16-byte accesses per lane (profiles/r04_s6/poseidon_hostpath_staged_ab.txt): 2^20 states 3.10 -> 3.01 ms,
         // 2^22 states 10.85 -> 10.11 ms (37 -> 40 GB/s in each direction at once: the duplex limit of the link).
         if (host_memory && ((uintptr_t)d_states & 15u) == 0) {
-            if (c.scaled == 3u) hipLaunchKernelGGL((poseidon_permute_t3_kernel<true, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s,
+            if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_permute_t3_staged_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s,
                     p->dims, c, d_states, n);
-            else hipLaunchKernelGGL((poseidon_permute_t3_kernel<false, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims, c,
+            else hipLaunchKernelGGL(poseidon_permute_t3_staged_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), t3_lds_cap(), s, p->dims, c,
                     d_states, n);
             HIP_TRY(hipGetLastError());
             return AKP_OK;

