@@ -7,11 +7,11 @@ import subprocess
 ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODMUL_PER_PERM_REF = 626        # reference-shaped count
-# HBM bytes per permutation from PMC passes of an earlier session (NOT measured in this run; see `static_from`):
-# (2 * 49 583.19 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B); re-collected in round 3 on the
-# four-unit library: FETCH_SIZE 49 583 KB, WRITE_SIZE 98 304 KB, SQ_INSTS_VALU 1 224 736 768, VALUBusy 95.6-96.1 %
-PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49583.1875 + 98304.0) * 1024 / (1 << 20)
-PMC_TRAFFIC_SOURCE = "profiles/r03_s11/pmc_counters_poseidon.txt"
+# HBM bytes per permutation from PMC passes of an earlier session of THIS round (NOT measured in this run; see `static_from`):
+# (2 * 49 585.3 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B); FETCH_SIZE 49 582.8 / 49 587.8 KB,
+# WRITE_SIZE 98 304 KB, SQ_INSTS_VALU 1 224 736 768, VALUBusy 93.6-93.9 % (tools/gpu_pmc_r4.sh; round 3: the same to four digits)
+PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49585.3 + 98304.0) * 1024 / (1 << 20)
+PMC_TRAFFIC_SOURCE = "profiles/r04_s8/pmc_poseidon.txt"
 NOMINAL_SCLK_MHZ = 2400.0
 CYCLES_PER_WAVE_MAD = 4.0        # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
 SIMDS = 256 * 4
@@ -23,14 +23,15 @@ def valu_peak_wave_instr(sclk_mhz=NOMINAL_SCLK_MHZ):
 
 
 VALU_PEAK_WAVE_INSTR = valu_peak_wave_instr()
-# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r03_s4/pmc_te_line128.txt: rocprofv3 --pmc, one counter per pass;
-# NOT measured in this run).  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B): with it the
-# accumulate kernels fetch ~1.07 x the table bytes they gather -- every table line comes from the Infinity Cache / HBM, the L2 only
-# serves the second half of a line (TCC_HIT = TCC_MISS: two 64-byte requests per 128-byte entry, the first misses, the second hits).
-PMC_TE = {"source": "profiles/r03_s4/pmc_te_line128.txt",
-          "pedersen_128B": {"fetch_kb": 4520651 + 164359, "write_kb": 147466 + 114688, "valu_instr": 1531920384 + 47370240},  # accumulate<2> + finalize<0>
-          "bh_32B": {"fetch_kb": 957788 + 163841, "write_kb": 147473 + 81920, "valu_instr": 421838848 + 38817792},          # accumulate<1> + finalize<1>
-          "bh_70B": {"fetch_kb": 2267504 + 163841, "write_kb": 147473 + 81920, "valu_instr": 936509440 + 38817792, "steps": 39}}
+# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r04_s8/pmc_te.txt: rocprofv3 --pmc, one counter per pass, the
+# round-4 kernels with LDS-staged message reads; NOT measured in this run).  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950
+# (128-byte requests tallied at 64 B): with it the accumulate kernels fetch ~0.9 x the table bytes they gather (round 3, with 64
+# scattered message loads per hash: 1.07 x) -- every table line comes from the Infinity Cache / HBM, the L2 only serves the second
+# half of a line.
+PMC_TE = {"source": "profiles/r04_s8/pmc_te.txt",
+          "pedersen_128B": {"fetch_kb": 3777620 + 164360, "write_kb": 147480 + 114688, "valu_instr": 1545830000 + 47370200},  # accumulate_lds<2> + finalize<0>
+          "bh_32B": {"fetch_kb": 883472 + 163439, "write_kb": 147571 + 81920, "valu_instr": 425820000 + 38817800},          # accumulate_lds<1> + finalize<1>
+          "bh_70B": {"fetch_kb": 1936305 + 165085, "write_kb": 147484 + 81921, "valu_instr": 945103000 + 38817800, "steps": 39}}
 MADS_PER_PRODUCT = 153           # multiply-adds of one field product (81 limb products + 72 reduction products)
 MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
 # (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:
