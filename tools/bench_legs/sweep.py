@@ -1,5 +1,5 @@
-"""`sweep`: north_star's "synthetic 2^20 - 2^26 leaf batches" on ONE GPU -- permutations/s and Poseidon-tree leaves/s at 2^20, 2^22,
-2^24, 2^26 with the HBM fraction of each point.  Inputs are generated on the device (a 2^20-element random block tiled: the
+"""`sweep`: north_star's "synthetic 2^20 - 2^26 leaf batches" on ONE GPU -- permutations/s, Poseidon-tree leaves/s and Bowe-Hopwood
+63x9-tree leaves/s (32-byte leaves) at 2^20, 2^22, 2^24, 2^26 with the HBM fraction of each point.  Inputs are generated on the device (a 2^20-element random block tiled: the
 kernels are data-independent; parity is what the headline probe, the merkle leg and the test-suite establish at these sizes),
 three launches per point after one warm-up, device time between events on the launch stream."""
 from .common import ALGO_BYTES_PER_PERM, HBM_PEAK_GBS
@@ -23,6 +23,12 @@ def run(env, sizes=(20, 22, 24, 26)):
         torch.cuda.synchronize(env.dev)
         ms = sorted(a.elapsed_time(b) for a, b in evs)
         return ms[1]
+    hb = None
+    if env.args.bh_merkle_log2:  # BASELINE configs[4]'s hash pair over the same sizes (2^26 = its stated size, here on ONE GPU)
+        from crypto_primitives_amd import params as cparams
+        from crypto_primitives_amd.crh import bowe_hopwood
+        hb = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)).handle(env.ctx)
+        bblock = torch.from_numpy(np.random.default_rng(0xA5A50032).integers(0, 256, size=(1 << 20, 32), dtype=np.uint8)).to(env.dev)
     for lg in sizes:
         n = 1 << lg
         point = {}
@@ -40,7 +46,15 @@ def run(env, sizes=(20, 22, 24, 26)):
             point["tree_leaves_per_s"] = n / (ms / 1e3)
             point["tree_ms"] = ms
             point["tree_hbm_frac"] = 160.0 * n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS  # 32 B leaf in, 2 x 32 B digests out, 2 x 32 B re-read per inner node
-            del leaves, ln, nl
+            del leaves
+            if hb is not None:
+                bl = bblock.repeat(n >> 20, 1) if lg > 20 else bblock
+                ms = timed(lambda: check(lib.akp_merkle_build_te_dev(hb.h, hb.h, bl.data_ptr(), n, 32, ln.data_ptr(), nl.data_ptr(), env.stream)))
+                point["bh_tree_leaves_per_s"] = n / (ms / 1e3)
+                point["bh_tree_ms"] = ms
+                point["bh_tree_hbm_frac"] = 160.0 * n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                del bl
+            del ln, nl
         except Exception as exc:  # pragma: no cover - a crowded device: report what fitted
             point["error"] = repr(exc)[:200]
             torch.cuda.empty_cache()
