@@ -326,3 +326,49 @@ def test_crh_t3_latency_kernel_disabled_matches(cpa, tmp_path):
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, AKP_POSEIDON_COOP_MAX="0"), timeout=300)
     assert np.array_equal(np.load(tmp_path / "o.npy"), pcrh.TwoToOneCRH.compress_batch(c, l, r))
     assert np.array_equal(np.load(tmp_path / "o.npy"), ora.two_to_one_batch(l, r, threads=8))
+
+
+@pytest.mark.parametrize("case", ["near_mds_dense", "alpha3_no_roots", "alpha5_full_form", "different_leaf_and_two_to_one", "mixed_forms_decline", "rate1_declines"])
+def test_path_verify_walk_kernel_on_custom_parameter_sets(cpa, case):
+    """Path::verify for > 2^15 paths (the one-launch kernel in which each lane walks its path) with parameter sets that take its
+    other instantiation or make it decline: a near-MDS matrix whose partial-round block is singular (dense rounds), alpha = 3
+    (gcd(3, p - 1) = 3: no alpha-th roots, no re-parameterised forms), alpha = 5 (full form), DIFFERENT leaf and two-to-one
+    parameters, a full-form set mixed with a plain one and a rate-1 set (both outside the kernel: level by level).  Flags against
+    paths built from the oracle's tree; corruptions must fail exactly their own path."""
+    from crypto_primitives_amd._lib import lib, check
+    near = [[1, 0, 1], [1, 1, 0], [0, 1, 1]]
+    rnd = [rand_fr(3, 170 + i) for i in range(3)]
+    mk = {"near": lambda s: _custom_cfg(cpa, 2, 1, 8, 29, 17, near, s), "a3": lambda s: _custom_cfg(cpa, 2, 1, 4, 11, 3, rnd, s),
+          "a5": lambda s: _custom_cfg(cpa, 2, 1, 8, 22, 5, rnd, s), "r1": lambda s: _custom_cfg(cpa, 1, 2, 8, 12, 5, rnd, s)}
+    (cl, ol), (ct, ot) = {"near_mds_dense": (mk["near"](1), mk["near"](1)), "alpha3_no_roots": (mk["a3"](2), mk["a3"](2)),
+                          "alpha5_full_form": (mk["a5"](3), mk["a5"](3)), "different_leaf_and_two_to_one": (mk["a5"](4), mk["a5"](5)),
+                          "mixed_forms_decline": (mk["a5"](6), mk["a3"](7)), "rate1_declines": (mk["r1"](8), mk["r1"](8))}[case]
+    oral, orat = cref_poseidon(ol), cref_poseidon(ot)
+    n, m, leaf_len = 256, 33000, 2 if case != "rate1_declines" else 1
+    depth = 8 - 1
+    leaves = rand_fr_array(n * leaf_len, 31).reshape(n, leaf_len, 4)
+    # the oracle's tree with the two parameter sets: leaf digests, then level by level
+    level = np.asarray(oral.crh_batch(np.ascontiguousarray(leaves), leaf_len, threads=4)).reshape(n, 4)
+    ln, inner = level, []
+    while len(level) > 1:
+        level = np.asarray(orat.two_to_one_batch(np.ascontiguousarray(level[0::2]), np.ascontiguousarray(level[1::2]), threads=4)).reshape(-1, 4)
+        inner.append(level)
+    nl = np.concatenate(inner[::-1])  # heap order: root first
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, n, size=m).astype(np.uint64)
+    sib, auth = np.empty((m, 4), np.uint64), np.empty((m, depth, 4), np.uint64)
+    check(lib.akp_merkle_gather_paths(np.ascontiguousarray(ln).ctypes.data, np.ascontiguousarray(nl).ctypes.data, n, 1, idx.ctypes.data, m, sib.ctypes.data,
+                                      auth.ctypes.data))
+    lv = np.ascontiguousarray(leaves[idx.astype(np.int64)])
+    want = np.ones(m, np.uint8)
+    bad = rng.choice(m, size=4, replace=False)
+    lv[bad[0], leaf_len - 1, 1] ^= 2
+    sib[bad[1], 0] ^= 1
+    auth[bad[2], 0, 3] ^= 1
+    auth[bad[3], depth - 1, 0] ^= 4
+    want[bad] = 0
+    ok = np.zeros(m, np.uint8)
+    root = np.ascontiguousarray(nl[0])
+    check(lib.akp_merkle_verify_paths_poseidon(cl.handle().h, ct.handle().h, root.ctypes.data, lv.ctypes.data, m, leaf_len, idx.ctypes.data, sib.ctypes.data,
+                                               auth.ctypes.data, depth, ok.ctypes.data))
+    assert np.array_equal(ok, want), (case, np.flatnonzero(ok != want)[:8])
