@@ -63,6 +63,8 @@ def _load():
         "akp_ctx_create": (i32, [i32, pp]),
         "akp_ctx_destroy": (None, [vp]),
         "akp_ctx_synchronize": (i32, [vp]),
+        "akp_ctx_set_table_budget": (i32, [vp, sz]),
+        "akp_ctx_table_budget": (sz, [vp]),
         "akp_ctx_stream": (vp, [vp]),
         "akp_clock_probe_dev": (i32, [vp, u32, u64p, vp]),
         "akp_fr_to_mont": (i32, [u64p, u64p, sz]),
@@ -87,6 +89,7 @@ def _load():
         "akp_sponge_get_state": (i32, [vp, u64p, C.POINTER(i32), C.POINTER(u32)]),
         "akp_sponge_set_state": (i32, [vp, u64p, i32, u32]),
         "akp_te_params_create": (i32, [vp, i32, u32, u32, u64p, pp]),
+        "akp_te_params_create_shaped": (i32, [vp, i32, u32, u32, u64p, u32, pp]),
         "akp_te_params_destroy": (None, [vp]),
         "akp_te_params_info": (i32, [vp, vp, vp, vp, sz, vp]),
         "akp_te_entry_bytes": (u32, []),
@@ -194,6 +197,14 @@ class Context:
 
     def synchronize(self):
         check(lib.akp_ctx_synchronize(self.h))
+
+    def set_table_budget(self, nbytes):
+        """HBM one precomputed Pedersen / Bowe-Hopwood table may take on this device (akp_ctx_set_table_budget); 0 = the default
+        (a quarter of the device's memory, at most half of what is free)"""
+        check(lib.akp_ctx_set_table_budget(self.h, int(nbytes)))
+
+    def table_budget(self):
+        return int(lib.akp_ctx_table_budget(self.h))
 
     def close(self):
         if getattr(self, "h", None):

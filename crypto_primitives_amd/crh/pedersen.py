@@ -17,29 +17,34 @@ class Window:
 
 class Parameters:
     """pedersen::Parameters<C> / bowe_hopwood::Parameters<P> { generators } (pedersen/mod.rs:28-31).
-    generators: wire-format affine points [NUM_WINDOWS, WINDOW_SIZE, 2, 4], used verbatim."""
+    generators: wire-format affine points [NUM_WINDOWS, WINDOW_SIZE, 2, 4], used verbatim.
+    table_shape: digit width (Pedersen, 2..24) / chunks per table step (Bowe-Hopwood, 1..8) of the device tables built for
+    these generators; 0 = the widest the context's table budget admits (akp_te_params_create_shaped).  A tuning choice: the
+    digests do not depend on it."""
 
     _KIND = TE_PEDERSEN
 
-    def __init__(self, generators, window_size=None, num_windows=None):
+    def __init__(self, generators, window_size=None, num_windows=None, table_shape=0):
         g = np.ascontiguousarray(generators, dtype=np.uint64)
         if g.ndim == 4:
             num_windows, window_size = g.shape[0], g.shape[1]
         self.generators = g.reshape(num_windows, window_size, 2, 4)
         self.window_size, self.num_windows = window_size, num_windows
+        self.table_shape = int(table_shape)
         self._handles = {}
 
-    def handle(self, ctx=None, kind=None):
+    def handle(self, ctx=None, kind=None, shape=None):
         """device tables of these generators for one kernel kind (default: the kind of this Parameters class).  In the
         reference pedersen::Parameters serve both pedersen::CRH and the TECompressor types (injective_map/mod.rs:45,77), so
         the CRH class -- not the parameter object -- decides the digest width: callers go through `te_handle`."""
         ctx = ctx or default_context()
         kind = self._KIND if kind is None else kind
-        key = (id(ctx), kind)
+        shape = self.table_shape if shape is None else shape
+        key = (id(ctx), kind, int(shape))
         if key not in self._handles:
             h = C.c_void_p()
-            check(lib.akp_te_params_create(ctx.h, kind, self.window_size, self.num_windows,
-                                           self.generators.ctypes.data, C.byref(h)))
+            check(lib.akp_te_params_create_shaped(ctx.h, kind, self.window_size, self.num_windows,
+                                                  self.generators.ctypes.data, int(shape), C.byref(h)))
             self._handles[key] = _TeHandle(h, ctx, kind)
         return self._handles[key]
 

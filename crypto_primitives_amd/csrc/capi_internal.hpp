@@ -66,6 +66,8 @@ struct akp_ctx {
     // calls fail cleanly until then (handles created on akp_multi_ctx may outlive akp_multi_destroy without touching freed memory)
     int live_handles = 0;
     bool dead = false;
+    // HBM one precomputed curve table may take (akp_ctx_set_table_budget); 0: a quarter of the device's memory, at most half of what is free
+    size_t table_budget = 0;
 };
 void ctx_handle_released(akp_ctx* c);
 // scratch slot `slot` with at least `bytes`, to be used on stream `s` (ordered behind the slot's last use on another stream)
@@ -232,12 +234,22 @@ struct akp_te_params {
     int kind = 0;
     u32 W = 0, N = 0;
     u32 n_gen = 0;             // W * N flat generators
-    u32 digit_bits = 0;        // Pedersen: table digit width D (1..8)
-    u32 group = 1;             // Bowe-Hopwood: chunks per table step (1..4)
+    u32 digit_bits = 0;        // Pedersen: table digit width D (2..24; plain table 1..14)
+    u32 group = 1;             // Bowe-Hopwood: chunks per table step (1..8)
     TeEntry* d_lut = nullptr;    // Pedersen: [ceil(n_gen/D)][2^D] (signed-subset table: [ceil(n_gen/D)][2^(D-1)]); BH: group table
     TeEntry* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]; Pedersen signed-subset: cprefix [n_digits + 1]
     TeEntry* d_tail = nullptr;  // BH: sum of G[c] over the zero-padded tail chunks [tail_from, tail_to) of the last compress shape
     u32 tail_from = 0, tail_to = 0;
+    // BH: the < G chunks a message length leaves after its last full group are ONE more table step: a table of 2^(3r-1) entries for
+    // the r chunks starting at chunk `first`, built on the first use of that length (a parameter set sees a handful of lengths)
+    struct Remainder {
+        u32 first = 0, r = 0;
+        TeEntry* d = nullptr;
+    };
+    static constexpr int MAX_REMAINDERS = 8;
+    Remainder rem[MAX_REMAINDERS];
+    int n_rem = 0;
+    Fr* d_gens = nullptr;  // BH: the generators (affine, wire form), kept for the remainder tables
     bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
     int pins = 0;                // as akp_poseidon::pins
     bool destroy_pending = false;

@@ -6,17 +6,90 @@
 
 // ------------------------------------------------------------------------------------------
 // Pedersen / Bowe-Hopwood
-// largest precomputed table, bytes: the digit width / chunk grouping is reduced until the table fits.  Pedersen: 320 MiB
-// admits 16-bit digits for the 4 x 256 window of BASELINE config 4 (64 steps x 2^15 entries x 128 B = 268 MB; measured on
-// MI355X, 2^20 x 128 B: 15 bits / 145 MB 3.37 ms, 16 bits 3.25 ms, 17 bits / 512 MB 3.28 ms -- past the 256 MiB Infinity
-// Cache the gather costs what the shorter sum saves).  Bowe-Hopwood: 256 MiB admits groups of five chunks for the 63 x 9
-// window of config 5 (113 groups x 2^14 entries x 128 B = 237 MB, of which the 64-byte inputs of a tree touch the first
-// 73 MB; 2.16 -> 1.78 ms per 2^20 two-to-one hashes against groups of four).  (Round 2 swept them through AKP_TE_TABLE_MB; the knob is gone.)
-static size_t te_table_cap(bool bowe_hopwood = false) {
-    return (size_t)(bowe_hopwood ? 256u : 320u) << 20;
+// Width of the precomputed tables.  A hash is one 7-product curve addition per table step, so the only way to shorten it is
+// to make a step cover more message bits -- each extra bit doubles the table.  Rounds 1-3 kept the tables inside the 256 MiB
+// Infinity Cache (Pedersen 4x256: 16-bit digits, 64 steps, 268 MB; Bowe-Hopwood 63x9: groups of 5 chunks, 237 MB).  Round 4
+// measured what the 288 GB of HBM buy (profiles/r04_s10): a step whose entry comes from HBM instead of the cache costs
+// 49 -> 57 us per 2^20 hashes, and there are fewer of them --
+//   Pedersen 4x256, 2^20 x 128 B:  D = 16 / 20 / 22 / 24:  3.16 / 2.84 / 2.62 / 2.43 ms  (268 MB / 3.5 / 12.6 / 46 GB)
+//   Bowe-Hopwood 63x9, 2^20 x 64 B: G = 5 / 6 / 7 / 8:     1.81 / 1.73 / 1.57 / 1.44 ms  (237 MB / 1.6 / 10.9 / 75 GB)
+// The width is therefore the widest the context's TABLE BUDGET admits (akp_ctx_set_table_budget; default: a quarter of the
+// device's memory, at most half of what is free -- 72 GiB on an idle MI355X), or the explicit shape of
+// akp_te_params_create_shaped.  Digits up to 24 bits / groups up to 8 chunks (the message window of a step is one 32-bit word).
+static size_t te_table_budget(const akp_ctx* ctx) {
+    if (ctx->table_budget) return ctx->table_budget;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return (size_t)320 << 20;
+    }
+    return std::max<size_t>(std::min(total_b / 4, free_b / 2), (size_t)64 << 20);
+}
+extern "C" int32_t akp_ctx_set_table_budget(akp_ctx* ctx, size_t bytes) {
+    if (!ctx) return fail(AKP_ERR_BAD_PARAMS, "NULL context");
+    ctx->table_budget = bytes;
+    return AKP_OK;
+}
+extern "C" size_t akp_ctx_table_budget(const akp_ctx* ctx) {
+    if (!ctx || ctx->dead) return 0;
+    (void)hipSetDevice(ctx->device);
+    return te_table_budget(ctx);
+}
+constexpr u32 TE_MAX_DIGIT = 24, TE_MAX_GROUP = 8;
+static inline size_t te_pedersen_entries(size_t n_gen, u32 D) { return ((n_gen + D - 1) / D) << (D - 1); }
+static inline size_t te_bh_entries(size_t n_gen, u32 G) { return (n_gen / G) << (3 * G - 1); }
+// two-part construction of a wide table (te_kernels.hpp): part tables entry by entry, then one addition per wide entry.
+// KIND 2: Pedersen signed-subset table of W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of
+// `units` groups of W chunks, the first group at chunk `first`, consecutive groups `stride` chunks apart, generators `src`.
+template <int KIND>
+static hipError_t te_build_wide(akp_ctx* ctx, const void* src, u32 n_gen, u32 W, u32 units, u32 first, u32 stride, TeEntry* lut, size_t entries) {
+    const u32 k_lo = KIND == 2 ? (W - 1) / 2 : W / 2;
+    const size_t n_lo = KIND == 2 ? (size_t)units << k_lo : (size_t)units << (3 * k_lo - 1);
+    const size_t n_hi = KIND == 2 ? (size_t)units << (W - 1 - k_lo) : (size_t)units << (3 * (W - k_lo));
+    TeEntry *lo = nullptr, *hi = nullptr;
+    hipError_t e = hipMalloc(&lo, n_lo * sizeof(TeEntry));
+    if (e == hipSuccess) e = hipMalloc(&hi, n_hi * sizeof(TeEntry));
+    if (e == hipSuccess) {
+        const unsigned pgrid = (unsigned)((n_lo + n_hi + 63) / 64);
+        if (KIND == 2)
+            hipLaunchKernelGGL(te_build_pedersen_sparts, dim3(pgrid), dim3(64), 0, ctx->stream, (const NielsPad*)src, n_gen, W, units, k_lo, lo, hi);
+        else
+            hipLaunchKernelGGL(te_build_bh_parts, dim3(pgrid), dim3(64), 0, ctx->stream, (const Fr*)src, first, stride, W, k_lo, units, lo, hi);
+        const unsigned cgrid = (unsigned)((entries + 256 * AKP_TE_BUILD_RUN - 1) / (256 * AKP_TE_BUILD_RUN));
+        hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), 0, ctx->stream, lo, hi, W, k_lo, entries, lut);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+#if defined(AKP_TEST_HOOKS)
+    // AKP_TE_TABLE_CHECK=k: every k-th entry of the table against the per-entry definition (group tables at chunk 0 only)
+    const size_t step = env_size("AKP_TE_TABLE_CHECK", 0);
+    if (e == hipSuccess && step && first == 0 && (KIND == 2 || stride == W)) {
+        u32* d_bad = nullptr;
+        u32 bad = 0;
+        e = hipMalloc(&d_bad, sizeof(u32));
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), ctx->stream);
+        if (e == hipSuccess) {
+            const size_t cnt = (entries + step - 1) / step;
+            hipLaunchKernelGGL(te_check_table_kernel<KIND>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, src, n_gen, W, entries, (size_t)0, step,
+                    lut, d_bad);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (d_bad) (void)hipFree(d_bad);
+        if (e == hipSuccess && bad) {
+            fprintf(stderr, "akp: AKP_TE_TABLE_CHECK: %u of the sampled table entries differ from the per-entry definition\n", bad);
+            e = hipErrorAssert;
+        }
+    }
+#endif
+    if (lo) (void)hipFree(lo);
+    if (hi) (void)hipFree(hi);
+    return e;
 }
 extern "C" void akp_te_params_destroy(akp_te_params* p);
-extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
+extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, uint32_t shape,
+        akp_te_params** out) {
     if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
     if (!out || !gens) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
     if (kind != AKP_TE_PEDERSEN && kind != AKP_TE_BOWE_HOPWOOD && kind != AKP_TE_PEDERSEN_X) return fail(AKP_ERR_BAD_PARAMS,
@@ -24,23 +97,29 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     if (W == 0 || N == 0) return fail(AKP_ERR_BAD_PARAMS, "empty window");
     if (kind == AKP_TE_BOWE_HOPWOOD && W > 63) return fail(AKP_ERR_BAD_PARAMS,
             "Bowe-Hopwood window size %u > 63 (bowe_hopwood/mod.rs:81-101)", W);
+    if (shape > (kind == AKP_TE_BOWE_HOPWOOD ? TE_MAX_GROUP : TE_MAX_DIGIT) || (shape == 1 && kind != AKP_TE_BOWE_HOPWOOD))
+        return fail(AKP_ERR_BAD_PARAMS, "table shape %u: Pedersen digits have 2..%u bits, Bowe-Hopwood groups 1..%u chunks (0: from the table budget)",
+                shape, TE_MAX_DIGIT, TE_MAX_GROUP);
     const size_t n_gen = (size_t)W * N;
     if (n_gen > (1u << 22)) return fail(AKP_ERR_BAD_PARAMS, "window %ux%u too large", W, N);
     for (size_t i = 0; i < 2 * n_gen; ++i)
         if (!fr_words_reduced(gens + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "generator coordinate %zu not reduced", i);
     HIP_TRY(hipSetDevice(ctx->device));
+#if defined(AKP_TEST_HOOKS)
+    if (!shape) shape = kind == AKP_TE_BOWE_HOPWOOD ? env_u32("AKP_BH_GROUP", 0, 1, TE_MAX_GROUP) : env_u32("AKP_PEDERSEN_DIGIT_BITS", 0, 1, TE_MAX_DIGIT);
+#endif
     akp_te_params* p = new akp_te_params();
     p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
     ++ctx->live_handles;
+    const size_t budget = te_table_budget(ctx);
+    constexpr size_t max_entries = (size_t)1 << 32;  // entry indices are 32-bit in the kernels
     Fr* d_g = nullptr;
     hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
     if (kind == AKP_TE_PEDERSEN || kind == AKP_TE_PEDERSEN_X) {
         // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
-        // stores 2^(D-1) entries per digit.  Default D = 15: 4x256 is 69 steps over a 163 MB table.  Measured on MI355X, 2^20 x 128 B
-        // (profiles/r02_s9): signed D = 13 / 14 / 15: 2.70 / 2.75 / 2.88e8 hashes/s; plain table D = 13: 2.56e8.
-        // The plain table stays as the fallback for generators outside the subgroup; as an A/B arm (AKP_PEDERSEN_PLAIN=1) it is
-        // selectable only in the test build (-DAKP_TEST_HOOKS).
+        // stores 2^(D-1) entries per digit.  The plain table stays as the fallback for generators outside the subgroup; as an A/B
+        // arm (AKP_PEDERSEN_PLAIN=1) it is selectable only in the test build (-DAKP_TEST_HOOKS).
         NielsPad* d_half = nullptr;
         u32* d_bad = nullptr;
         u32 bad = 1;
@@ -62,34 +141,32 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
         if (e == hipSuccess && bad == 0) {
-            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 16, 2, 17);
-            while (D > 2 && ((n_gen + D - 1) / D) * ((size_t)1 << (D - 1)) * sizeof(TeEntry) > te_table_cap()) --D;
-            size_t n_digits = (n_gen + D - 1) / D, entries = n_digits << (D - 1);
-            e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
-            while (e == hipErrorOutOfMemory && D > 8) {  // a crowded device: a narrower digit needs half the table
+            u32 D = shape ? std::max(shape, 2u) : TE_MAX_DIGIT;
+            if (!shape)
+                while (D > 2 && (te_pedersen_entries(n_gen, D) * sizeof(TeEntry) > budget || te_pedersen_entries(n_gen, D) >= max_entries)) --D;
+            if (te_pedersen_entries(n_gen, D) >= max_entries) e = hipErrorInvalidValue;
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut, te_pedersen_entries(n_gen, D) * sizeof(TeEntry));
+            while (e == hipErrorOutOfMemory && D > 8 && !shape) {  // a crowded device: a narrower digit needs half the table
                 (void)hipGetLastError();
                 --D;
-                n_digits = (n_gen + D - 1) / D;
-                entries = n_digits << (D - 1);
-                e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+                e = hipMalloc(&p->d_lut, te_pedersen_entries(n_gen, D) * sizeof(TeEntry));
             }
+            const size_t n_digits = (n_gen + D - 1) / D;
             p->digit_bits = D;
             p->signed_subset = true;
             if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
+            if (e == hipSuccess) e = te_build_wide<2>(ctx, d_half, (u32)n_gen, D, (u32)n_digits, 0, D, p->d_lut, te_pedersen_entries(n_gen, D));
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(te_build_pedersen_slut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
-                        (u32)n_gen, D, (u32)entries, p->d_lut);
                 hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
                         (u32)n_gen, D, (u32)n_digits, p->d_lut1);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         } else if (e == hipSuccess) {
-            // plain table.  digit width: 13 bits (4x256: 79 steps, 93 MB table, served from the 256 MB Infinity Cache) unless the table
-            // would exceed 192 MB; AKP_PEDERSEN_DIGIT_BITS overrides (1..14).  Measured 2^20 x 128 B on MI355X:
-            // D = 4: 73 M/s, 8: 151, 10: 177, 12: 199, 13: 209, 14: 220 (175 MB table; round 2: 13 beats 14, profiles/r02_s8).
-            u32 D = env_u32("AKP_PEDERSEN_DIGIT_BITS", 13, 1, 14);
-            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(TeEntry) > te_table_cap()) --D;
+            // plain table (generators outside the prime-order subgroup: never what `setup` produces): entry by entry, digits of
+            // at most 14 bits (4x256: 13 bits, 79 steps, 93 MB)
+            u32 D = shape ? std::min(shape, 14u) : 13;
+            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(TeEntry) > std::min(budget, (size_t)192 << 20) && !shape) --D;
             p->digit_bits = D;
             const size_t entries = ((n_gen + D - 1) / D) << D;
             e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
@@ -102,9 +179,11 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
         if (d_half) (void)hipFree(d_half);
         if (d_bad) (void)hipFree(d_bad);
     } else {
-        u32 G = env_u32("AKP_BH_GROUP", 5, 1, 5);
-        while (G > 1 && (n_gen < G || (n_gen / G) * ((size_t)1 << (3 * G - 1)) * sizeof(TeEntry) > te_table_cap(true))) --G;
-        p->group = G;
+        u32 G = shape ? shape : TE_MAX_GROUP;
+        if (!shape)
+            while (G > 1 && (n_gen < G || te_bh_entries(n_gen, G) * sizeof(TeEntry) > budget || te_bh_entries(n_gen, G) >= max_entries)) --G;
+        if (n_gen < G) G = (u32)n_gen;
+        if (G > 1 && te_bh_entries(n_gen, G) >= max_entries) e = hipErrorInvalidValue;
         if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(TeEntry));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
@@ -112,21 +191,17 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
             e = hipGetLastError();
         }
         if (G > 1) {
-            size_t entries = (n_gen / G) << (3 * G - 1);
-            if (e == hipSuccess) e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
-            while (e == hipErrorOutOfMemory && G > 2) {  // a crowded device: a smaller group needs an eighth of the table
+            if (e == hipSuccess) e = hipMalloc(&p->d_lut, te_bh_entries(n_gen, G) * sizeof(TeEntry));
+            while (e == hipErrorOutOfMemory && G > 2 && !shape) {  // a crowded device: a smaller group needs an eighth of the table
                 (void)hipGetLastError();
                 --G;
-                p->group = G;
-                entries = (n_gen / G) << (3 * G - 1);
-                e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+                e = hipMalloc(&p->d_lut, te_bh_entries(n_gen, G) * sizeof(TeEntry));
             }
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(te_build_bh_lutg, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, G, (u32)entries,
-                        p->d_lut);
-                e = hipGetLastError();
-            }
+            if (e == hipSuccess) e = te_build_wide<1>(ctx, d_g, (u32)n_gen, G, (u32)(n_gen / G), 0, G, p->d_lut, te_bh_entries(n_gen, G));
         }
+        p->group = G;
+        p->d_gens = d_g;  // kept: the remainder tables of later message lengths are built from them (te_bh_remainder)
+        d_g = nullptr;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_g) (void)hipFree(d_g);
@@ -138,6 +213,9 @@ extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, 
     }
     *out = p;
     return AKP_OK;
+}
+extern "C" int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, akp_te_params** out) {
+    return akp_te_params_create_shaped(ctx, kind, W, N, gens, 0, out);
 }
 extern "C" uint32_t akp_te_entry_bytes(void) { return (uint32_t)sizeof(TeEntry); }
 void te_unpin(akp_te_params* p) {
@@ -154,6 +232,9 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
     if (p->d_lut) (void)hipFree(p->d_lut);
     if (p->d_lut1) (void)hipFree(p->d_lut1);
     if (p->d_tail) (void)hipFree(p->d_tail);
+    if (p->d_gens) (void)hipFree(p->d_gens);
+    for (int i = 0; i < p->n_rem; ++i)
+        if (p->rem[i].d) (void)hipFree(p->rem[i].d);
     ctx_handle_released(p->ctx);
     delete p;
 }
@@ -192,12 +273,14 @@ extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bi
             entries = p->signed_subset ? (n_digits << (p->digit_bits - 1)) + n_digits + 1 : n_digits << p->digit_bits;
         } else {
             entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)(p->n_gen / p->group) << (3 * p->group - 1)) : 0);
+            for (int i = 0; i < p->n_rem; ++i) entries += (size_t)1 << (3 * p->rem[i].r - 1);
         }
         *table_bytes = entries * sizeof(TeEntry);
     }
     if (steps) {
         u32 g = 0, st = 0;
         te_steps(p, msg_len, &g, &st);
+        if (!ped && p->group > 1 && st > g) st = g + 1;  // the chunks after the last full group are one step (te_bh_remainder)
         *steps = st;
     }
     return AKP_OK;
@@ -240,6 +323,33 @@ struct TePipe {
     hipStream_t cin, side;
     hipEvent_t ev_in, ev_acc;
 };
+// Bowe-Hopwood: table of the r (2 .. 7) chunks starting at chunk `first` -- what a message length leaves after its last full
+// group -- so that they are ONE table step instead of r; built on the first use of that length (2^(3r-1) entries: at most
+// 134 MB, milliseconds).  *out stays NULL when the handle's slots are taken or memory is short: the chunks are then single
+// steps from the one-chunk table, as before round 4.  Measured (profiles/r04_s10): a 63x9 tree node of 64 B is 21 + 1 steps
+// instead of 21 + 3 with groups of eight, a 32-byte leaf 10 + 1 instead of 10 + 6.
+static int32_t te_bh_remainder(akp_te_params* p, u32 first, u32 r, const TeEntry** out) {
+    *out = nullptr;
+    for (int i = 0; i < p->n_rem; ++i)
+        if (p->rem[i].first == first && p->rem[i].r == r) {
+            *out = p->rem[i].d;
+            return AKP_OK;
+        }
+    if (p->n_rem == akp_te_params::MAX_REMAINDERS || !p->d_gens) return AKP_OK;
+    const size_t entries = (size_t)1 << (3 * r - 1);
+    TeEntry* d = nullptr;
+    hipError_t e = hipMalloc(&d, entries * sizeof(TeEntry));
+    if (e == hipSuccess) e = te_build_wide<1>(p->ctx, p->d_gens, p->n_gen, r, 1, first, 0, d, entries);  // waits for the context's stream
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (d) (void)hipFree(d);
+        if (e == hipErrorOutOfMemory) return AKP_OK;
+        return fail(AKP_ERR_HIP, "Bowe-Hopwood remainder table: %s", hipGetErrorString(e));
+    }
+    p->rem[p->n_rem++] = akp_te_params::Remainder{first, r, d};
+    *out = d;
+    return AKP_OK;
+}
 static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len,
         const TePipe* pipe);
 int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len) {
@@ -255,6 +365,18 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (data_len > msg_len || !tail_on) data_len = msg_len;
     u32 groups = 0, steps = 0;
     te_steps(p, data_len, &groups, &steps);
+    // what the kernels call D: the digit width, or the chunks per group with the size of the remainder step above it (te_bh_rem)
+    u32 shape = te_is_pedersen(p) ? p->digit_bits : p->group;
+    const TeEntry* lut1 = p->d_lut1;
+    if (p->kind == AKP_TE_BOWE_HOPWOOD && p->group > 1 && steps - groups >= 2) {
+        const TeEntry* rem = nullptr;
+        if (int32_t rc = te_bh_remainder(p, p->group * groups, steps - groups, &rem)) return rc;
+        if (rem) {
+            shape |= (steps - groups) << 8;
+            lut1 = rem;
+            steps = groups + 1;
+        }
+    }
     const TeEntry* tail = nullptr;
     if (p->kind == AKP_TE_BOWE_HOPWOOD && data_len < msg_len) {
         const u32 from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, p->n_gen), to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3,
@@ -290,18 +412,18 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         const unsigned sgrid = (unsigned)((n + 63) / 64);
         const bool xy = p->kind == AKP_TE_PEDERSEN;  // digest = (x, y); otherwise x only
         if (te_is_pedersen(p) && p->signed_subset) {
-            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<2, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
-                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
-            else hipLaunchKernelGGL((te_crh_small_kernel<2, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
-                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<2, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+                    d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
+            else hipLaunchKernelGGL((te_crh_small_kernel<2, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+                    d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
         } else if (te_is_pedersen(p)) {
-            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<0, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
-                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
-            else hipLaunchKernelGGL((te_crh_small_kernel<0, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1,
-                    d_msgs, data_len, stride, p->digit_bits, groups, steps, tail, d_out, n);
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<0, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+                    d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
+            else hipLaunchKernelGGL((te_crh_small_kernel<0, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+                    d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
         } else {
-            hipLaunchKernelGGL((te_crh_small_kernel<1, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, p->d_lut1, d_msgs,
-                    data_len, stride, p->group, groups, steps, tail, d_out, n);
+            hipLaunchKernelGGL((te_crh_small_kernel<1, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1, d_msgs,
+                    data_len, stride, shape, groups, steps, tail, d_out, n);
         }
         HIP_TRY(hipGetLastError());
         return AKP_OK;
@@ -321,26 +443,26 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
             const unsigned lgrid = (unsigned)((cnt + block - 1) / block);
             const size_t shm = te_lds_image_bytes(block, data_len, stride);
             if (te_is_pedersen(p) && p->signed_subset)
-                hipLaunchKernelGGL(te_accumulate_lds_kernel<2>, dim3(lgrid), dim3(block), shm, st, p->d_lut, p->d_lut1, m, data_len, stride,
-                        p->digit_bits, groups, steps, tail, x, cnt);
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<2>, dim3(lgrid), dim3(block), shm, st, p->d_lut, lut1, m, data_len, stride,
+                        shape, groups, steps, tail, x, cnt);
             else if (te_is_pedersen(p))
-                hipLaunchKernelGGL(te_accumulate_lds_kernel<0>, dim3(lgrid), dim3(block), shm, st, p->d_lut, p->d_lut1, m, data_len, stride,
-                        p->digit_bits, groups, steps, tail, x, cnt);
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<0>, dim3(lgrid), dim3(block), shm, st, p->d_lut, lut1, m, data_len, stride,
+                        shape, groups, steps, tail, x, cnt);
             else
-                hipLaunchKernelGGL(te_accumulate_lds_kernel<1>, dim3(lgrid), dim3(block), shm, st, p->d_lut, p->d_lut1, m, data_len, stride,
-                        p->group, groups, steps, tail, x, cnt);
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<1>, dim3(lgrid), dim3(block), shm, st, p->d_lut, lut1, m, data_len, stride,
+                        shape, groups, steps, tail, x, cnt);
             HIP_TRY(hipGetLastError());
             return AKP_OK;
         }
         const unsigned grid = (unsigned)((cnt + 255) / 256);
         if (te_is_pedersen(p) && p->signed_subset)
-            hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, st, p->d_lut, p->d_lut1, m, data_len, stride, p->digit_bits,
+            hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, st, p->d_lut, lut1, m, data_len, stride, shape,
                     groups, steps, tail, x, cnt);
         else if (te_is_pedersen(p))
-            hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, st, p->d_lut, p->d_lut1, m, data_len, stride, p->digit_bits,
+            hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, st, p->d_lut, lut1, m, data_len, stride, shape,
                     groups, steps, tail, x, cnt);
         else
-            hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, st, p->d_lut, p->d_lut1, m, data_len, stride, p->group,
+            hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, st, p->d_lut, lut1, m, data_len, stride, shape,
                     groups, steps, tail, x, cnt);
         HIP_TRY(hipGetLastError());
         return AKP_OK;

@@ -271,6 +271,136 @@ __global__ void te_build_pedersen_cprefix(const NielsPad* __restrict__ half, u32
     store_niels(cprefix + k, te_pedersen_cprefix_entry(half, n_gen, D, k));
 }
 
+// ---- two-part construction of the wide tables (round 4) -----------------------------------------------------------
+// The per-entry builders above spend D additions and one inversion on every entry: ~500 field products, 2 s for the 46 GB
+// table of 24-bit digits.  A wide entry is the sum of two NARROW ones -- the digit's low bits and its high bits select
+// independent subsets of the same generators -- so the wide table is built from two small part tables per digit / group
+// (a few thousand entries each, built entry by entry as before) with ONE mixed addition per entry, and the conversion to
+// affine shares one inversion among the AKP_TE_BUILD_RUN entries of a lane (Montgomery's trick; the extended point waits
+// in the entry's own 128-byte slot meanwhile): ~17 products + 1/16 inversion per entry.
+//   Pedersen, signed-subset table of D-bit digits: entry index v' has D - 1 bits (the top bit of the digit is set);
+//     lo part: bits [0, k_lo) of the digit, 2^k_lo entries;   hi part: bits [k_lo, D), 2^(D-1-k_lo) entries.
+//   Bowe-Hopwood, groups of G chunks: lo part: chunks [0, G_lo) (magnitudes k_0.. and relative signs r_1..: 2^(3 G_lo - 1)
+//     entries);   hi part: chunks [G_lo, G) with a relative sign each: 2^(3 (G - G_lo)) entries.
+constexpr u32 AKP_TE_BUILD_RUN = 16;
+// sum over the bits b in [b0, b1) of digit u of (v_b ? +H : -H)[uD + b]  (generators past n_gen are absent)
+AKP_HD Niels te_pedersen_spart_entry(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 u, u32 b0, u32 b1, u32 v) {
+    Ext acc = ext_identity();
+#pragma unroll 1
+    for (u32 b = b0; b < b1; ++b) {
+        const u32 g = u * D + b;
+        if (g >= n_gen) break;
+        const Niels h = load_niels(half + g);
+        acc = te_madd(acc, ((v >> b) & 1u) ? h : niels_neg(h));
+    }
+    return niels_of_ext(acc);
+}
+// lo[u][w]: bits [0, k_lo) = w;   hi[u][w]: bits [k_lo, D - 1) = w, bit D - 1 set
+__global__ void te_build_pedersen_sparts(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_digits, u32 k_lo, TeEntry* __restrict__ lo,
+                                         TeEntry* __restrict__ hi) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n_lo = n_digits << k_lo, k_hi = D - 1u - k_lo, n_hi = n_digits << k_hi;
+    if (idx < n_lo) {
+        const u32 u = idx >> k_lo, w = idx & ((1u << k_lo) - 1u);
+        store_niels(lo + idx, te_pedersen_spart_entry(half, n_gen, D, u, 0u, k_lo, w));
+    } else if (idx - n_lo < n_hi) {
+        const u32 j = idx - n_lo, u = j >> k_hi, w = j & ((1u << k_hi) - 1u);
+        store_niels(hi + j, te_pedersen_spart_entry(half, n_gen, D, u, k_lo, D, (w << k_lo) | (1u << (D - 1u))));
+    }
+}
+// sum_{i < cnt} (-1)^{r_i} (k_i + 1) G[first + i],  k_i = bits [2i, 2i + 2) of kbits, r_i = bit i of rbits
+AKP_HD Niels te_bh_part_entry(const Fr* __restrict__ gens_affine, size_t first, u32 cnt, u32 kbits, u32 rbits) {
+    Ext acc = ext_identity();
+#pragma unroll 1
+    for (u32 i = 0; i < cnt; ++i) {
+        Niels gn = te_niels_of_gen(gens_affine, first + i);
+        if ((rbits >> i) & 1u) gn = niels_neg(gn);
+        const u32 k = (kbits >> (2u * i)) & 3u;
+#pragma unroll 1
+        for (u32 j = 0; j <= k; ++j) acc = te_madd(acc, gn);
+    }
+    return niels_of_ext(acc);
+}
+// parts of the group table: chunks [first + Gu, .. + G_lo) (lo; chunk 0 carries no sign bit) and the G - G_lo chunks after them (hi).
+// `stride` is the distance in chunks between the groups (G for the group table; 0 with n_groups = 1 for a remainder table).
+__global__ void te_build_bh_parts(const Fr* __restrict__ gens_affine, u32 first, u32 stride, u32 G, u32 G_lo, u32 n_groups, TeEntry* __restrict__ lo,
+                                  TeEntry* __restrict__ hi) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 G_hi = G - G_lo, lo_bits = 3u * G_lo - 1u, hi_bits = 3u * G_hi;
+    const u32 n_lo = n_groups << lo_bits, n_hi = G_hi ? n_groups << hi_bits : 0u;
+    if (idx < n_lo) {
+        const u32 u = idx >> lo_bits, w = idx & ((1u << lo_bits) - 1u);
+        store_niels(lo + idx, te_bh_part_entry(gens_affine, (size_t)first + (size_t)stride * u, G_lo, w & ((1u << (2u * G_lo)) - 1u), (w >> (2u * G_lo)) << 1));
+    } else if (idx - n_lo < n_hi) {
+        const u32 j = idx - n_lo, u = j >> hi_bits, w = j & ((1u << hi_bits) - 1u);
+        store_niels(hi + j, te_bh_part_entry(gens_affine, (size_t)first + (size_t)stride * u + G_lo, G_hi, w & ((1u << (2u * G_hi)) - 1u), w >> (2u * G_hi)));
+    }
+}
+// indices of the two parts of wide entry `idx`.  KIND 2: Pedersen signed-subset (W = D, k_lo bits in the lo part);
+// KIND 1: Bowe-Hopwood group table (W = G, k_lo = G_lo chunks in the lo part; index layout of te_bh_lutg_entry)
+template <int KIND>
+AKP_HD void te_build_split(u32 W, u32 k_lo, u32 idx, u32* lo_idx, u32* hi_idx) {
+    if (KIND == 2) {
+        const u32 u = idx >> (W - 1u), v = idx & ((1u << (W - 1u)) - 1u);
+        *lo_idx = (u << k_lo) | (v & ((1u << k_lo) - 1u));
+        *hi_idx = (u << (W - 1u - k_lo)) | (v >> k_lo);
+    } else {
+        const u32 G = W, G_lo = k_lo, G_hi = G - G_lo, bits = 3u * G - 1u;
+        const u32 u = idx >> bits, v = idx & ((1u << bits) - 1u);
+        const u32 kk = v & ((1u << (2u * G)) - 1u), rr = v >> (2u * G);  // rr: r_1 .. r_{G-1}
+        *lo_idx = (u << (3u * G_lo - 1u)) | (kk & ((1u << (2u * G_lo)) - 1u)) | ((rr & ((1u << (G_lo - 1u)) - 1u)) << (2u * G_lo));
+        *hi_idx = (u << (3u * G_hi)) | (kk >> (2u * G_lo)) | ((rr >> (G_lo - 1u)) << (2u * G_hi));
+    }
+}
+// lut[idx] = hi part + lo part, affine.  One lane builds AKP_TE_BUILD_RUN entries, 256 apart (coalesced across the lanes).
+template <int KIND>
+__global__ void __launch_bounds__(256) te_build_combine_kernel(const TeEntry* __restrict__ lo, const TeEntry* __restrict__ hi, u32 W, u32 k_lo,
+                                                              size_t n_entries, TeEntry* __restrict__ lut) {
+    const size_t base = (size_t)blockIdx.x * (256u * AKP_TE_BUILD_RUN) + threadIdx.x;
+    FS pre[AKP_TE_BUILD_RUN];
+    FS run = f29_one<true>();
+    u32 cnt = 0;
+#pragma unroll 1
+    for (u32 j = 0; j < AKP_TE_BUILD_RUN; ++j) {
+        const size_t e = base + (size_t)j * 256u;
+        if (e >= n_entries) break;
+        u32 li, hi_i;
+        te_build_split<KIND>(W, k_lo, (u32)e, &li, &hi_i);
+        const Ext s = te_madd(ext_from_niels(load_niels(hi + hi_i)), load_niels(lo + li));
+        store_niels(lut + e, Niels{s.X, s.Y, s.Z});  // parked in its own slot until the shared inversion is known
+        pre[j] = run;
+        run = f29_mul(run, s.Z);
+        cnt = j + 1u;
+    }
+    if (cnt == 0) return;
+    FS inv = f29_inv(run);  // Z != 0 always (complete formulas)
+#pragma unroll 1
+    for (u32 j = cnt; j-- > 0;) {
+        const size_t e = base + (size_t)j * 256u;
+        const Niels xyz = load_niels(lut + e);
+        const FS zi = f29_mul(inv, pre[j]);
+        inv = f29_mul(inv, xyz.dxy);
+        store_niels(lut + e, niels_from_affine(f29_mul(xyz.ypx, zi), f29_mul(xyz.ymx, zi)));
+    }
+}
+// test build: the wide table against the per-entry definition (canonical values), mismatches counted
+template <int KIND>
+__global__ void te_check_table_kernel(const void* __restrict__ src /* NielsPad* half (KIND 2) or Fr* generators (KIND 1) */, u32 n_gen, u32 W,
+                                      size_t n_entries, size_t first, size_t step, const TeEntry* __restrict__ lut, u32* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t e = first + i * step;
+    if (e >= n_entries) return;
+    const Niels want = KIND == 2 ? te_pedersen_slut_entry(reinterpret_cast<const NielsPad*>(src), n_gen, W, (u32)e)
+                                 : te_bh_lutg_entry(reinterpret_cast<const Fr*>(src), W, (u32)e);
+    const Niels got = load_niels(lut + e);
+    const Fr a = f29_to_wire(want.ypx), b = f29_to_wire(want.ymx), c = f29_to_wire(want.dxy);
+    const Fr x = f29_to_wire(got.ypx), y = f29_to_wire(got.ymx), z = f29_to_wire(got.dxy);
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) same = same && a.l[k] == x.l[k] && b.l[k] == y.l[k] && c.l[k] == z.l[k];
+    if (!same) atomicAdd(bad, 1u);
+}
+
 // ---- message bit access -----------------------------------------------------------------------
 // bits [o, o+w) (w <= 16) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
 // bits past the end read as zero (Pedersen zero padding :91-99 / Bowe-Hopwood chunk padding :131-138).
@@ -352,6 +482,23 @@ AKP_HD Niels niels_apply(const NielsSel& s) {
     }
     return r;
 }
+// kind 1: `D` packs the group size G (bits 0-7) and the size R of the remainder group (bits 8-15).  R = 0: the chunks a message
+// leaves after its last full group are single steps from lut1.  R >= 2: they are ONE step, and lut1 points to the table of
+// that remainder (2^(3R-1) entries, index layout of a group; capi_te.hip te_bh_remainder).
+AKP_HD u32 te_bh_group(u32 D) { return D & 0xffu; }
+AKP_HD u32 te_bh_rem(u32 D) { return D >> 8; }
+// table index of a group of G chunks from its 3G message bits (layout of te_bh_lutg_entry); *s0 = sign bit of chunk 0
+AKP_HD u32 te_bh_group_index(u32 bits, u32 G, u32* s0) {
+    const u32 s = (bits >> 2) & 1u;
+    u32 idx = bits & 3u;
+#pragma unroll 1
+    for (u32 i = 1; i < G; ++i) {
+        idx |= ((bits >> (3u * i)) & 3u) << (2u * i);
+        idx |= (((bits >> (3u * i + 2u)) & 1u) ^ s) << (2u * G + i - 1u);
+    }
+    *s0 = s;
+    return idx;
+}
 // bit offset and width of step u's message bits
 template <int KIND>
 AKP_HD size_t te_step_offset(u32 D, u32 n_groups, u32 u, u32* width) {
@@ -359,10 +506,14 @@ AKP_HD size_t te_step_offset(u32 D, u32 n_groups, u32 u, u32* width) {
         *width = D;
         return (size_t)u * D;
     }
-    const u32 G = D;  // chunks per group step
+    const u32 G = te_bh_group(D), R = te_bh_rem(D);  // chunks per group step; chunks of the remainder step
     if (u < n_groups) {
         *width = 3u * G;
         return (size_t)u * 3u * G;
+    }
+    if (R) {
+        *width = 3u * R;
+        return (size_t)G * n_groups * 3u;
     }
     *width = 3u;
     return (size_t)(G * n_groups + (u - n_groups)) * 3u;
@@ -453,16 +604,16 @@ AKP_HD NielsSel te_step_fetch(const TeEntry* __restrict__ lut, const TeEntry* __
         const u32 top = (bits >> (D - 1u)) & 1u;
         return NielsSel{load_niels(lut + (((size_t)u << (D - 1u)) | ((top ? bits : ~bits) & half_mask))), top ^ 1u};
     }
-    const u32 G = D;
+    const u32 G = te_bh_group(D), R = te_bh_rem(D);
     if (u < n_groups) {
-        const u32 s0 = (bits >> 2) & 1u;
-        u32 idx = bits & 3u;
-#pragma unroll 1
-        for (u32 i = 1; i < G; ++i) {
-            idx |= ((bits >> (3u * i)) & 3u) << (2u * i);
-            idx |= (((bits >> (3u * i + 2u)) & 1u) ^ s0) << (2u * G + i - 1u);
-        }
+        u32 s0;
+        const u32 idx = te_bh_group_index(bits, G, &s0);
         return NielsSel{load_niels(lut + ((size_t)u << (3u * G - 1u)) + idx), s0};
+    }
+    if (R) {
+        u32 s0;
+        const u32 idx = te_bh_group_index(bits, R, &s0);
+        return NielsSel{load_niels(lut1 + idx), s0};
     }
     const u32 c = G * n_groups + (u - n_groups);
     return NielsSel{load_niels(lut1 + (size_t)c * 4u + (bits & 3u)), (bits >> 2) & 1u};
@@ -484,16 +635,15 @@ AKP_HD void te_step_address(const TeEntry* __restrict__ lut, const TeEntry* __re
         f.idx = (u << (D - 1u)) | ((top ? bits : ~bits) & half_mask);
         f.neg = top ^ 1u;
     } else {
-        const u32 G = D;
+        const u32 G = te_bh_group(D), R = te_bh_rem(D);
         if (u < n_groups) {
-            const u32 s0 = (bits >> 2) & 1u;
-            u32 idx = bits & 3u;
-#pragma unroll 1
-            for (u32 i = 1; i < G; ++i) {
-                idx |= ((bits >> (3u * i)) & 3u) << (2u * i);
-                idx |= (((bits >> (3u * i + 2u)) & 1u) ^ s0) << (2u * G + i - 1u);
-            }
-            f.idx = (u << (3u * G - 1u)) + idx;
+            u32 s0;
+            f.idx = (u << (3u * G - 1u)) + te_bh_group_index(bits, G, &s0);
+            f.neg = s0;
+        } else if (R) {
+            u32 s0;
+            f.base = lut1;
+            f.idx = te_bh_group_index(bits, R, &s0);
             f.neg = s0;
         } else {
             const u32 c = G * n_groups + (u - n_groups);

@@ -70,6 +70,13 @@ int32_t akp_device_count(void);
 int32_t akp_ctx_create(int32_t device_id, akp_ctx** out);
 void akp_ctx_destroy(akp_ctx* ctx);
 int32_t akp_ctx_synchronize(akp_ctx* ctx);
+/* HBM that ONE precomputed curve table (akp_te_params_create) may occupy on this context's device, bytes.  0 (the default)
+ * = a quarter of the device's memory, but at most half of what is free when the handle is created (72 GiB on an idle
+ * 288 GB MI355X).  A host that wants the memory for its own data sets a smaller budget (320 MiB keeps the tables inside the
+ * Infinity Cache: the shapes of rounds 1-3); handles that exist keep their tables.  akp_ctx_table_budget returns the value
+ * the next handle would be created with. */
+int32_t akp_ctx_set_table_budget(akp_ctx* ctx, size_t bytes);
+size_t akp_ctx_table_budget(const akp_ctx* ctx);
 /* the hipStream_t (as void*) the HOST-POINTER entry points of this context enqueue their kernels and copies on: lets a caller
  * bracket such a call with its own events (bench.py times the device side of the proof / update entry points this way) or
  * order its own work behind it.  NULL for a NULL context.  The stream belongs to the context. */
@@ -177,6 +184,15 @@ int32_t akp_sponge_set_state(akp_sponge* s, const uint64_t* state, int32_t mode,
  * For AKP_TE_BOWE_HOPWOOD window_size must be <= 63 (setup bound, bowe_hopwood/mod.rs:81-101). */
 int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
                              const uint64_t* generators_affine, akp_te_params** out);
+/* The handle holds a precomputed table in HBM (no counterpart in the reference, which adds generators bit by bit): a hash is one
+ * curve addition per table step, a step covers `digit_bits` message bits (Pedersen) / `group` 3-bit chunks (Bowe-Hopwood), and
+ * every extra bit doubles the table -- memory for time.  akp_te_params_create picks the widest table the context's table
+ * budget admits (akp_ctx_set_table_budget below; on an idle MI355X: 24-bit digits = 46 GB for a 4x256 window, 43 steps per
+ * 128-byte message instead of the 64 of the 268 MB table that fits the Infinity Cache, -23 % time; groups of 8 chunks = 75 GB
+ * for a 63x9 window).  This form fixes the shape instead: digit_bits 2..24 / group 1..8, 0 = from the budget.  The digests do
+ * not depend on the shape.  Building takes milliseconds to ~0.2 s (the widest tables). */
+int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
+                                    const uint64_t* generators_affine, uint32_t digit_bits_or_group, akp_te_params** out);
 void akp_te_params_destroy(akp_te_params* p);
 /* Tuning facts of a handle (any pointer may be NULL): digit width of the Pedersen table / chunks per table step of the
  * Bowe-Hopwood table, whether the Pedersen table is the signed-subset one, bytes of precomputed tables in HBM, and the

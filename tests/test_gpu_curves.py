@@ -167,31 +167,68 @@ def test_setup_generators(cpa):
 
 
 def test_table_variants_agree(cpa):
-    """the table digit width (Pedersen) / chunk grouping (Bowe-Hopwood) are tuning knobs: every setting must give
-    the same digests (AKP_PEDERSEN_DIGIT_BITS / AKP_BH_GROUP are read when the parameter handle is created)."""
-    import os
+    """the table digit width (Pedersen) / chunk grouping (Bowe-Hopwood) are tuning choices (akp_te_params_create_shaped): every
+    shape must give the same digests -- narrow ones, the widths the table budget picks on a 288 GB device (24-bit digits, groups
+    of 8 chunks: built from two part tables, te_build_combine_kernel) and every message length, so that the remainder step of
+    the Bowe-Hopwood tables (the < G chunks after the last full group) is exercised for every remainder size."""
     from crypto_primitives_amd.crh import pedersen, bowe_hopwood
     g = jj.pedersen_generators(77, 5, 13)   # 65 generators: not a multiple of any digit width
     gb = jj.bowe_hopwood_generators(78, 7, 5)  # 35 chunks: not a multiple of 3
     m = _msgs(40, 8, 5)
     mb = _msgs(40, 13, 6)
     ref_p = ref_b = None
+    for D, grp in ((12, 4), (8, 3), (4, 1), (7, 2), (2, 1), (3, 3), (13, 4), (15, 5), (20, 6), (24, 8), (23, 7), (0, 0)):
+        dp = pedersen.CRH.evaluate_batch(pedersen.Parameters(gens_array(g), table_shape=D), m)
+        db = bowe_hopwood.CRH.evaluate_batch(bowe_hopwood.Parameters(gens_array(gb), table_shape=grp), mb)
+        if ref_p is None:
+            ref_p, ref_b = dp, db
+            for i in range(0, 40, 13):
+                assert tuple(ints(dp[i])) == opd.evaluate(g, 5, 13, bytes(m[i]))
+                assert ints(db[i])[0] == obh.evaluate(gb, 7, 5, bytes(mb[i]))
+        assert np.array_equal(dp, ref_p) and np.array_equal(db, ref_b), (D, grp)
+    # every message length 0 .. 13 bytes (0 .. 35 chunks) at every group size: all remainders 0 .. G - 1, more lengths than a
+    # handle keeps remainder tables for (the later ones walk the chunks one by one), against the oracle
+    for grp in (8, 7, 5, 3, 2):
+        B = bowe_hopwood.Parameters(gens_array(gb), table_shape=grp)
+        for L in range(0, 14):
+            ml = _msgs(5, L, 90 + L) if L else np.zeros((5, 0), np.uint8)
+            d = bowe_hopwood.CRH.evaluate_batch(B, ml)
+            for i in (0, 4):
+                assert ints(d[i])[0] == obh.evaluate(gb, 7, 5, bytes(ml[i])), (grp, L, i)
+        assert B.handle().info(13)["digit_bits_or_group"] == grp
+    # (the plain table of round 1 as an arm of its own: tests/test_gpu_multi_slots.py, test build only; here it runs as the
+    # fallback for generators outside the prime subgroup, test_pedersen_generators_outside_the_prime_subgroup)
+
+
+def test_table_budget_picks_the_shape(cpa):
+    """akp_ctx_set_table_budget: the handle gets the widest table that fits (4x256 Pedersen: 268 MB for 16-bit digits, 3.5 GB
+    for 20), the default follows the device's memory, and the digests do not change"""
+    from crypto_primitives_amd import params as cparams
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    ctx = cpa.default_context(0)
+    gens = cparams.pedersen_generators(0xA5A50004, 4, 256)
+    bgens = cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    m = _msgs(300, 128, 11)
+    mb = _msgs(300, 64, 12)
+    out = {}
     try:
-        for D, grp in ((12, 4), (8, 3), (4, 1), (7, 2), (1, 1), (3, 3), (13, 4), (15, 5)):
-            os.environ["AKP_PEDERSEN_DIGIT_BITS"], os.environ["AKP_BH_GROUP"] = str(D), str(grp)
-            dp = pedersen.CRH.evaluate_batch(pedersen.Parameters(gens_array(g)), m)
-            db = bowe_hopwood.CRH.evaluate_batch(bowe_hopwood.Parameters(gens_array(gb)), mb)
-            if ref_p is None:
-                ref_p, ref_b = dp, db
-                for i in range(0, 40, 13):
-                    assert tuple(ints(dp[i])) == opd.evaluate(g, 5, 13, bytes(m[i]))
-                    assert ints(db[i])[0] == obh.evaluate(gb, 7, 5, bytes(mb[i]))
-            assert np.array_equal(dp, ref_p) and np.array_equal(db, ref_b), (D, grp)
-        # (the plain table of round 1 as an arm of its own: tests/test_gpu_multi_slots.py, test build only; here it runs as the
-        # fallback for generators outside the prime subgroup, test_pedersen_generators_outside_the_prime_subgroup)
+        for budget, want_d, want_g in ((320 << 20, 16, 5), (4 << 30, 20, 6), (16 << 30, 22, 7)):
+            ctx.set_table_budget(budget)
+            assert ctx.table_budget() == budget
+            P, B = pedersen.Parameters(gens), bowe_hopwood.Parameters(bgens)
+            ip, ib = P.handle(ctx).info(128), B.handle(ctx).info(64)
+            assert ip["digit_bits_or_group"] == want_d and ip["table_bytes"] <= budget + (1 << 20), ip
+            assert ib["digit_bits_or_group"] == want_g and ib["table_bytes"] <= budget + (1 << 20), ib
+            assert ip["steps"] == -(-1024 // want_d) and ib["steps"] == 171 // want_g + 1
+            out[budget] = (pedersen.CRH.evaluate_batch(P, m), bowe_hopwood.CRH.evaluate_batch(B, mb))
+            assert B.handle(ctx).info(64)["table_bytes"] > ib["table_bytes"] or 171 % want_g < 2  # the remainder table of 64-byte messages
+            del P, B
     finally:
-        os.environ.pop("AKP_PEDERSEN_DIGIT_BITS", None)
-        os.environ.pop("AKP_BH_GROUP", None)
+        ctx.set_table_budget(0)
+    assert ctx.table_budget() >= 64 << 20
+    a = out[320 << 20]
+    for b in out.values():
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 def test_upstream_jubjub_kat_on_the_gpu(cpa, jubjub_kat):
@@ -280,17 +317,33 @@ def test_split_kernel_disabled_matches(cpa, ped, bhp, tmp_path):
 
 
 def test_table_info_of_the_baseline_windows(cpa):
-    """akp_te_params_info: the shapes bench.py quotes -- Pedersen 4x256 with 16-bit signed digits (64 steps, one 128-byte
-    line per entry), Bowe-Hopwood 63x9 with five chunks per step (18 steps per 32-byte leaf, 39 per 70-byte inner node)"""
+    """akp_te_params_info for the BASELINE windows.  With a 320 MiB table budget (the tables of rounds 1-3, inside the Infinity
+    Cache): Pedersen 4x256 with 16-bit signed digits (64 steps, one 128-byte line per entry), Bowe-Hopwood 63x9 with five chunks
+    per step.  With the default budget on a 288 GB device: 24-bit digits (43 steps, 46 GB) and groups of eight chunks (75 GB);
+    the chunks a message length leaves after its last full group are one more step."""
     from crypto_primitives_amd import params as cparams
     from crypto_primitives_amd.crh import pedersen, bowe_hopwood
-    hp = pedersen.Parameters(cparams.pedersen_generators(0xA5A50004, 4, 256)).handle()
-    i = hp.info(128)
-    assert i == {"digit_bits_or_group": 16, "signed_subset": True, "table_bytes": ((64 << 15) + 65) * 128, "steps": 64}
-    assert hp.info(32)["steps"] == 16 and hp.info(0)["steps"] == 0
-    hb = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)).handle()
-    assert hb.info(32) == {"digit_bits_or_group": 5, "signed_subset": False, "table_bytes": (567 * 4 + (113 << 14)) * 128, "steps": 18}
-    assert hb.info(70)["steps"] == 39 and hb.info(64)["steps"] == 35
+    ctx = cpa.default_context(0)
+    pg, bg = cparams.pedersen_generators(0xA5A50004, 4, 256), cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    ctx.set_table_budget(320 << 20)
+    try:
+        hp = pedersen.Parameters(pg).handle()
+        i = hp.info(128)
+        assert i == {"digit_bits_or_group": 16, "signed_subset": True, "table_bytes": ((64 << 15) + 65) * 128, "steps": 64}
+        assert hp.info(32)["steps"] == 16 and hp.info(0)["steps"] == 0
+        hb = bowe_hopwood.Parameters(bg).handle()
+        assert hb.info(32) == {"digit_bits_or_group": 5, "signed_subset": False, "table_bytes": (567 * 4 + (113 << 14)) * 128, "steps": 18}
+        assert hb.info(70)["steps"] == 38 and hb.info(64)["steps"] == 35  # 187 = 37 * 5 + 2 chunks: the two left over are one step
+        del hp, hb
+    finally:
+        ctx.set_table_budget(0)
+    if ctx.table_budget() >= 76 << 30:  # an idle 288 GB device
+        hp = pedersen.Parameters(pg).handle()
+        assert hp.info(128) == {"digit_bits_or_group": 24, "signed_subset": True, "table_bytes": ((43 << 23) + 44) * 128, "steps": 43}
+        assert hp.info(32)["steps"] == 11
+        hb = bowe_hopwood.Parameters(bg).handle()
+        assert hb.info(32) == {"digit_bits_or_group": 8, "signed_subset": False, "table_bytes": (567 * 4 + (70 << 23)) * 128, "steps": 11}
+        assert hb.info(64)["steps"] == 22 and hb.info(70)["steps"] == 24  # 171 = 21 * 8 + 3 chunks, 187 = 23 * 8 + 3
 
 
 @pytest.mark.parametrize("W,N", [(63, 9), (40, 14), (63, 13), (30, 19)])

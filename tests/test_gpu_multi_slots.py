@@ -312,3 +312,24 @@ def test_config5_shape_sharded_resident_tree_2pow26_over_8_slots(cpa, monkeypatc
     st.close()
     ref.close()
     mg.close()
+
+
+@needs_hooks
+def test_two_part_table_construction_equals_the_per_entry_definition(cpa, monkeypatch):
+    """the wide tables are built from two part tables with one addition per entry and a shared inversion
+    (te_build_combine_kernel); AKP_TE_TABLE_CHECK=k (test build) recomputes every k-th entry by the per-entry definition
+    (te_pedersen_slut_entry / te_bh_lutg_entry: D additions + an inversion of its own) and fails the creation on any
+    difference of the canonical values.  Every entry for the narrow shapes, a sample for the wide ones."""
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    g = gens_array(jj.pedersen_generators(0x52, 5, 13))        # 65 generators: the last digit is clipped at every width
+    gb = gens_array(jj.bowe_hopwood_generators(0x53, 7, 5))    # 35 chunks
+    monkeypatch.setenv("AKP_TE_TABLE_CHECK", "1")
+    for D in (2, 3, 4, 5, 8, 11, 13, 16):
+        assert pedersen.Parameters(g, table_shape=D).handle().info()["digit_bits_or_group"] == D
+    for G in (2, 3, 4, 5):
+        assert bowe_hopwood.Parameters(gb, table_shape=G).handle().info()["digit_bits_or_group"] == G
+    monkeypatch.setenv("AKP_TE_TABLE_CHECK", "4099")
+    for D in (20, 24):
+        assert pedersen.Parameters(g, table_shape=D).handle().info()["digit_bits_or_group"] == D
+    for G in (6, 7, 8):
+        assert bowe_hopwood.Parameters(gb, table_shape=G).handle().info()["digit_bits_or_group"] == G
