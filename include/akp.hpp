@@ -51,6 +51,10 @@ class Context {
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     akp_ctx* get() const { return h_; }
+    // HBM one precomputed Pedersen / Bowe-Hopwood table may take on this device (akp_ctx_set_table_budget; 0 = the default: a
+    // quarter of the device's memory, at most half of what is free)
+    void set_table_budget(size_t bytes) { check(akp_ctx_set_table_budget(h_, bytes)); }
+    size_t table_budget() const { return akp_ctx_table_budget(h_); }
 
   private:
     akp_ctx* h_ = nullptr;
@@ -157,10 +161,12 @@ struct AffineWire { FrWire x, y; };  // ark_ed_on_bls12_381::EdwardsAffine coord
 template <int KIND>
 class TeParameters {  // pedersen::Parameters / bowe_hopwood::Parameters { generators } as affine points [N][W]
   public:
-    TeParameters(const Context& ctx, uint32_t window_size, uint32_t num_windows, const std::vector<AffineWire>& generators)
+    // table_shape: digit width (Pedersen, 2..24) / chunks per table step (Bowe-Hopwood, 1..8) of the device table; 0 = the widest
+    // the context's table budget admits (akp_te_params_create_shaped).  The digests do not depend on it.
+    TeParameters(const Context& ctx, uint32_t window_size, uint32_t num_windows, const std::vector<AffineWire>& generators, uint32_t table_shape = 0)
         : window_size(window_size), num_windows(num_windows) {
         if (generators.size() != (size_t)window_size * num_windows) throw Error(AKP_ERR_BAD_PARAMS, "Incorrect pp size for window params");
-        check(akp_te_params_create(ctx.get(), KIND, window_size, num_windows, generators[0].x.data(), &h_));
+        check(akp_te_params_create_shaped(ctx.get(), KIND, window_size, num_windows, generators[0].x.data(), table_shape, &h_));
     }
     ~TeParameters() { akp_te_params_destroy(h_); }
     TeParameters(const TeParameters&) = delete;

@@ -140,12 +140,23 @@ impl ThreadRuntime {
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { ffi::akp_ctx_create(dev, &mut ctx) };
         assert_eq!(rc, ffi::AKP_OK, "akp_ctx_create({dev}) failed: there is no CPU fallback");
-        // Poseidon constants are a few KB per set; a curve-hash set owns up to ~270 MB of tables
+        // Poseidon constants are a few KB per set; a curve-hash set owns a precomputed table sized by the context's table budget
+        // (default: up to a quarter of the device's memory -- 46 GB for a 4x256 Pedersen window on an idle MI355X).  A host that
+        // needs the HBM for its own data lowers it: AKP_TABLE_BUDGET_MB here, or `set_table_budget` before the first curve hash.
+        if let Some(mb) = std::env::var("AKP_TABLE_BUDGET_MB").ok().and_then(|s| s.parse::<usize>().ok()) {
+            let rc = unsafe { ffi::akp_ctx_set_table_budget(ctx, mb << 20) };
+            assert_eq!(rc, ffi::AKP_OK);
+        }
         Self { poseidon: HandleCache::new(64, ffi::akp_poseidon_params_destroy), te: HandleCache::new(4, ffi::akp_te_params_destroy), ctx: CtxGuard(ctx) }
     }
 }
 thread_local! {
     static RT: RefCell<Option<ThreadRuntime>> = const { RefCell::new(None) };
+}
+/// HBM one precomputed Pedersen / Bowe-Hopwood table may take on this thread's device (`akp_ctx_set_table_budget`; 0 = the
+/// library's default).  Handles that exist keep their tables; the next `setup` / first use of new generators follows the budget.
+pub fn set_table_budget(bytes: usize) -> Result<(), Error> {
+    with_runtime(|rt| check(unsafe { ffi::akp_ctx_set_table_budget(rt.ctx.0, bytes) }, 0))
 }
 /// run `f` with this thread's runtime (created on first use)
 pub fn with_runtime<R>(f: impl FnOnce(&mut ThreadRuntime) -> R) -> R {

@@ -40,6 +40,17 @@ static int te_cases(const Context& ctx, const char* path) {
             catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_LENGTH); }  // the reference panics (:82-89)
             auto batch = pedersen::CRH::evaluate_batch(P, std::vector<uint8_t>(msg), L);
             REQUIRE(batch.size() == 1 && batch[0].x == want.x);
+            // the table shape is a tuning choice: an explicit digit width and a small table budget give the same digest
+            pedersen::Parameters P5(ctx, W, N, gens, 5);
+            REQUIRE(P5.info().digit_bits_or_group == 5 && pedersen::CRH::evaluate(P5, msg).x == want.x);
+            const_cast<Context&>(ctx).set_table_budget((size_t)8 << 20);
+            REQUIRE(ctx.table_budget() == ((size_t)8 << 20));
+            {
+                pedersen::Parameters Pb(ctx, W, N, gens);
+                REQUIRE(Pb.info().table_bytes <= ((size_t)8 << 20) + 65536 && pedersen::CRH::evaluate(Pb, msg).y == want.y);
+            }
+            const_cast<Context&>(ctx).set_table_budget(0);
+            REQUIRE(ctx.table_budget() >= ((size_t)64 << 20));
             // crh/injective_map/mod.rs: PedersenCRHCompressor with TECompressor = x of the same hash; compress of two Fq
             // digests = evaluate on their 32-byte canonical serialisations
             injective_map::Parameters X(ctx, W, N, gens);
@@ -56,6 +67,8 @@ static int te_cases(const Context& ctx, const char* path) {
             REQUIRE(std::fread(&want, sizeof want, 1, f) == 1);
             bowe_hopwood::Parameters B(ctx, W, N, gens);
             REQUIRE(bowe_hopwood::CRH::evaluate(B, msg) == want);
+            bowe_hopwood::Parameters B3(ctx, W, N, gens, 3);  // groups of three chunks (+ the remainder step)
+            REQUIRE(B3.info().digit_bits_or_group == 3 && bowe_hopwood::CRH::evaluate(B3, msg) == want);
             REQUIRE(fr_to_canonical({bowe_hopwood::CRH::evaluate(B, {})})[0] == (FrWire{0, 0, 0, 0}));  // empty message: x of the identity
             try { bowe_hopwood::TwoToOneCRH::evaluate(B, lo, std::vector<uint8_t>(lo.size() + 1)); REQUIRE(false); }
             catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_LENGTH); }

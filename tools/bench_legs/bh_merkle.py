@@ -37,7 +37,7 @@ def run(env):
                               "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                               "table": h.info(32),
-                              "traffic": te_counters("bh_32B", per)["traffic"] + te_counters("bh_70B", per - 1, (h.info(64)["steps"] + 1) / 39.0)["traffic"],
+                              "traffic": te_counters("bh_32B", per, h.info(32)["steps"])["traffic"] + te_counters("bh_70B", per - 1, h.info(64)["steps"] + 1)["traffic"],
                               "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_lds_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
                                                      "for the leaf level and 2^20 x 70 B scaled to the inner nodes' table steps; levels of <= 2^14 nodes run the split kernel; "
                                                      "NOT measured in this run)",

@@ -23,15 +23,16 @@ def valu_peak_wave_instr(sclk_mhz=NOMINAL_SCLK_MHZ):
 
 
 VALU_PEAK_WAVE_INSTR = valu_peak_wave_instr()
-# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r04_s8/pmc_te.txt: rocprofv3 --pmc, one counter per pass, the
-# round-4 kernels with LDS-staged message reads; NOT measured in this run).  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950
-# (128-byte requests tallied at 64 B): with it the accumulate kernels fetch ~0.9 x the table bytes they gather (round 3, with 64
-# scattered message loads per hash: 1.07 x) -- every table line comes from the Infinity Cache / HBM, the L2 only serves the second
-# half of a line.
-PMC_TE = {"source": "profiles/r04_s8/pmc_te.txt",
-          "pedersen_128B": {"fetch_kb": 3777620 + 164360, "write_kb": 147480 + 114688, "valu_instr": 1545830000 + 47370200},  # accumulate_lds<2> + finalize<0>
-          "bh_32B": {"fetch_kb": 883472 + 163439, "write_kb": 147571 + 81920, "valu_instr": 425820000 + 38817800},          # accumulate_lds<1> + finalize<1>
-          "bh_70B": {"fetch_kb": 1936305 + 165085, "write_kb": 147484 + 81921, "valu_instr": 945103000 + 38817800, "steps": 39}}
+# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r04_s11/pmc_te.txt: rocprofv3 --pmc, one counter per pass, the
+# round-4 kernels with the HBM-sized tables -- 24-bit Pedersen digits, 8-chunk Bowe-Hopwood groups + remainder step; NOT measured
+# in this run).  `steps` is the table-step count of that launch: a run whose handles got another shape (smaller table budget)
+# scales the gather-proportional parts by its own step count.  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950 (128-byte
+# requests tallied at 64 B): with it the accumulate kernels fetch ~1.0 x the table bytes they gather -- every table line comes
+# from HBM, the L2 only serves the second half of a line.  (The 268 MB / 237 MB tables of rounds 1-3: profiles/r04_s8/pmc_te.txt.)
+PMC_TE = {"source": "profiles/r04_s11/pmc_te.txt",
+          "pedersen_128B": {"fetch_kb": 2881640 + 164360, "write_kb": 147480 + 114690, "valu_instr": 1040370000 + 47370200, "steps": 43},  # accumulate_lds<2> + finalize<0>
+          "bh_32B": {"fetch_kb": 734736 + 164936, "write_kb": 147497 + 81920, "valu_instr": 258785000 + 38817800, "steps": 11},          # accumulate_lds<1> + finalize<1>
+          "bh_70B": {"fetch_kb": 1546125 + 164612, "write_kb": 147489 + 81920, "valu_instr": 584163000 + 38817800, "steps": 24}}
 MADS_PER_PRODUCT = 153           # multiply-adds of one field product (81 limb products + 72 reduction products)
 MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
 # (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:
@@ -39,9 +40,11 @@ MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) 
 # last one dot2 + one product; no conversion products.
 
 
-def te_counters(key, hashes, steps_scale=1.0):
-    """bytes / instructions for `hashes` hashes from the per-2^20 PMC figures (gather-proportional parts scaled by steps_scale)"""
+def te_counters(key, hashes, steps=None):
+    """bytes / instructions for `hashes` hashes from the per-2^20 PMC figures; the gather-proportional parts are scaled to `steps`
+    table steps per hash when the run's table shape differs from the profiled one"""
     c = PMC_TE[key]
+    steps_scale = 1.0 if steps is None else steps / float(c["steps"])
     per = hashes / float(1 << 20)
     return {"traffic": (2.0 * c["fetch_kb"] * steps_scale + c["write_kb"]) * 1024.0 * per, "valu_instr": c["valu_instr"] * steps_scale * per}
 

@@ -1,7 +1,7 @@
 """`pedersen`: BASELINE configs[3] -- pedersen::CRH over Jubjub, window 4 x 256, 2^20 messages of 128 bytes per GPU, resident"""
 import time
 
-from .common import HBM_PEAK_GBS, MADS_PER_PRODUCT, PMC_TE, VALU_PEAK_WAVE_INSTR, gpu_clock_mhz, gpu_sensors, te_counters
+from .common import HBM_PEAK_GBS, MADS_PER_PRODUCT, PMC_TE, VALU_PEAK_WAVE_INSTR, ClockProbe, gpu_clock_mhz, gpu_sensors, te_counters, valu_peak_wave_instr
 
 
 def run(env):
@@ -35,7 +35,7 @@ def run(env):
     kavg = sum(kms) / len(kms) / 1e3
     pinfo = hP.info(128)
     psteps = pinfo["steps"]
-    tc = te_counters("pedersen_128B", npd)
+    tc = te_counters("pedersen_128B", npd, psteps)
     pedersen = {"config": "BASELINE configs[3]: pedersen::CRH, Jubjub, window 4x256, 128-byte messages", "messages_per_gpu": npd,
                 "hashes_per_s": npd * env.world * reps / psec, "ms_per_batch": psec / reps * 1e3,
                 "roofline": {"bound": "hbm", "kernels": "te_accumulate_lds_kernel<2> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
@@ -47,26 +47,38 @@ def run(env):
                              "gather_over_algorithmic": psteps * int(lib.akp_te_entry_bytes()) / 192.0,
                              "table": pinfo,
                              "valu": {"table_steps_per_hash": psteps, "field_products_per_step": 7,
-                                      "valu_instructions_per_hash": te_counters("pedersen_128B", 1)["valu_instr"],
+                                      "valu_instructions_per_hash": te_counters("pedersen_128B", 1, psteps)["valu_instr"],
                                       "v_mad_per_s": (psteps * 7 + 6) * MADS_PER_PRODUCT * npd / kavg,
                                       "frac_of_mad_issue_peak": (psteps * 7 + 6) * MADS_PER_PRODUCT * npd / kavg / (VALU_PEAK_WAVE_INSTR * 64),
-                                      "v_mad_note": "7 products per table step + ~6 per hash in the shared-inversion pass, 153 multiply-adds each; peak at the nominal 2.4 GHz",
-                                      "note": "VALU-issue bound like the permutation: one mixed addition of 7 products per table step (signed-subset table); "
-                                              "message bits come from an LDS image of the workgroup's messages (round 4, -3 %: profiles/r04_s1); one 128-byte line "
-                                              "per table entry, gathered through L2 / Infinity Cache / HBM: 0.18 ms of a 3.19 ms launch for presenting 64 distinct "
-                                              "lines per load, 0.32 ms for the lines that miss L2 (profiles/r04_s1/README.md; counters profiles/r03_s4)"}}}
+                                      "v_mad_note": "7 products per table step + ~6 per hash in the shared-inversion pass, 153 multiply-adds each; peak at the nominal 2.4 GHz "
+                                                    "(`sustained.frac_of_mad_issue_peak_at_effective_sclk`: at the clock the board actually holds under this kernel)",
+                                      "note": "VALU-issue bound like the permutation (VALUBusy 88-95 %, 4.4-4.6 cycles per wave instruction at the effective clock: "
+                                              "profiles/r04_s10, r04_s11): one mixed addition of 7 products per table step, so the lever is the NUMBER of steps -- the table "
+                                              "is sized for HBM, not for the Infinity Cache (24-bit digits, 46 GB: 43 steps instead of the 64 of the 268 MB table; "
+                                              "3.16 -> 2.43 ms per 2^20 hashes although a step from HBM takes 49 -> 55 us, half of that a 4 % lower clock at the power "
+                                              "cap).  Message bits come from an LDS image of the workgroup's messages; one 128-byte line per table entry"}}}
     if args.sustain_seconds > 0:  # clock / power under the gather-heavy kernel (the permutation's figures are in `sustained`)
         count = int(min(2000, max(8, 0.5 * args.sustain_seconds / max(kavg, 1e-4))))
+        probe = ClockProbe(env)  # effective shader clock under THIS kernel (one wave on a side stream beside every 1/8 of the loop)
         torch.cuda.synchronize(env.dev)
         s0 = time.perf_counter()
-        for _ in range(count):
+        for i in range(count):
+            if i % max(1, count // 8) == max(1, count // 16):
+                probe.launch()
             ped_step()
         time.sleep(min(0.25, 0.25 * count * kavg))  # sample while the queue is still draining
         cmid, sens = gpu_clock_mhz(env.local_rank), gpu_sensors()
         torch.cuda.synchronize(env.dev)
         ssec = time.perf_counter() - s0
-        pedersen["sustained"] = {"launches": count, "seconds": ssec, "hashes_per_s": npd * count / ssec, "sclk_level_mhz_during": cmid, "power_w_during": sens["power_w"],
-                                 "power_cap_w": sens["power_cap_w"], "temp_c_max_during": sens["temp_c_max"]}
+        mhz = [p["mhz"] for p in probe.read()]
+        eff = sum(mhz) / len(mhz) if mhz else None
+        mads = (psteps * 7 + 6) * MADS_PER_PRODUCT * npd * count / ssec
+        pedersen["sustained"] = {"launches": count, "seconds": ssec, "hashes_per_s": npd * count / ssec, "sclk_level_mhz_during": cmid,
+                                 "effective_sclk_mhz": eff, "effective_sclk_mhz_min_max": [min(mhz), max(mhz)] if mhz else None,
+                                 "frac_of_mad_issue_peak_at_effective_sclk": mads / (valu_peak_wave_instr(eff) * 64) if eff else None,
+                                 "power_w_during": sens["power_w"], "power_cap_w": sens["power_cap_w"], "temp_c_max_during": sens["temp_c_max"],
+                                 "note": "the curve kernels hold the board at its power cap: the effective clock under them is ~2.0 GHz against ~2.3 GHz under the "
+                                         "permutation kernel (profiles/r04_s10/te_clock_vs_table.txt)"}
     if env.rank == 0:
         from oracle import cref
         cur = cref.CurveParams(4, 256, gens)

@@ -3,9 +3,9 @@
 # no trace domains), on tools/prof_driver.py.  Every launch is listed (the te driver launches 128-byte, 32-byte and 70-byte batches).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r04_pmc}; mkdir -p $OUT
 export TMPDIR=/tmp
-for W in te poseidon; do
+for W in ${2:-te poseidon}; do
   : > $OUT/pmc_$W.txt
-  for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU VALUBusy; do
+  for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU VALUBusy}; do
     (cd /tmp && PROF_REPS=2 timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/p_${W}_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/prof_driver.py $W > $OUT/p_${W}_$C.log 2>&1)
     F=$(find $OUT/p_${W}_$C -name "*counter_collection.csv" | head -1)
     [ -n "$F" ] && python - "$F" "$C" >> $OUT/pmc_$W.txt <<'PY'

@@ -221,5 +221,26 @@ s29)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_s29; mkdir -p $OUT
 AKP_LIB=$GRAFT_REPO_ROOT/crypto_primitives_amd/lib/libakp_testhooks.so timeout 900 python -m pytest tests/test_gpu_multi_slots.py -m gpu -x -q -p no:cacheprovider --durations=15 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | tail -24 | tee $OUT/pytest_hooks_child.txt
 ;;
-*) echo "usage: $0 s1 .. s29"; exit 2;;
+s32)
+# wide curve tables (24-bit digits / 8-chunk groups): full suite, counters of the curve kernels, bench.py alone and under rocprofv3
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_s32; mkdir -p $OUT
+(timeout 3000 python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | tail -12) > $OUT/pytest_gpu_full.txt; tail -3 $OUT/pytest_gpu_full.txt
+PMC_COUNTERS="FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU VALUBusy MemUnitStalled" bash tools/gpu_pmc_r4.sh r04_s32 te > /dev/null 2>&1; cat $OUT/pmc_te.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-path --sustain-seconds 0 --no-sweep --proofs-log2 0 > $OUT/bench_under_rocprofv3.json 2> $OUT/bench_under_rocprofv3.err
+f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/rocprof_kernel_stats_bench_py.csv; head -8 $f | cut -c1-200; rm -rf $OUT/prof
+cd $GRAFT_REPO_ROOT
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -2 $OUT/bench.err
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r04_s32/bench.json') if l.startswith('{')][-1])
+r=d['roofline']
+print('value %.4g ms/step %.3f eff %.1f power %s' % (d['value'], d['ms_per_step'], r['effective_sclk_mhz'] or 0, r['power_w_under_load']))
+print('pedersen', d['pedersen']['hashes_per_s'], d['pedersen']['ms_per_batch'], json.dumps(d['pedersen']['roofline']['table']), d['pedersen'].get('sustained'))
+print('bh', d['bh_merkle']['seconds'], d['bh_merkle']['leaves_per_s'])
+print('proofs bh', json.dumps(d['proofs']['bh'])[:700])
+print('host', {k: v.get('ms_per_batch') for k, v in d['host_path'].items() if isinstance(v, dict)})
+PY
+;;
+*) echo "usage: $0 s1 .. s32"; exit 2;;
 esac

@@ -17,7 +17,7 @@ from crypto_primitives_amd.crh import pedersen, bowe_hopwood  # noqa: E402
 dev = torch.device("cuda", 0)
 ctx = cpa.default_context(0)
 st = torch.cuda.current_stream().cuda_stream
-n = 1 << int(os.environ.get("LOG2_N", "20"))
+n = int(os.environ["N"]) if os.environ.get("N") else 1 << int(os.environ.get("LOG2_N", "20"))
 ped_gens = cparams.pedersen_generators(0xA5A50004, 4, 256)
 bh_gens = cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
 
