@@ -350,13 +350,15 @@ static int32_t te_bh_remainder(akp_te_params* p, u32 first, u32 r, const TeEntry
     *out = d;
     return AKP_OK;
 }
+// `pitch`: distance in bytes between consecutive messages in d_msgs (0: msg_len); a pitch below msg_len is legal when the bytes
+// past data_len are the implied zero padding (te_compress_dev packs the digest pairs without it)
 static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len,
-        const TePipe* pipe);
+        const TePipe* pipe, size_t pitch = 0);
 int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len) {
     return te_crh_run(p, d_msgs, n, msg_len, d_out, s, data_len, nullptr);
 }
 static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len,
-        const TePipe* pipe) {
+        const TePipe* pipe, size_t pitch) {
     if (msg_len * 8 > te_input_bits(p))
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
     if (n == 0) return AKP_OK;
@@ -396,7 +398,7 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
             tail = p->d_tail;
         }
     }
-    size_t stride = msg_len;
+    size_t stride = pitch ? pitch : msg_len;
     if (data_len > 0 && data_len < 4) {  // the kernels fetch message bits with one 32-bit load: pad 1..3-byte messages to four bytes
         void* pad = nullptr;
         if (int32_t rc = ctx_scratch(p->ctx, SCR_L, n * 4, &pad, s)) return rc;
@@ -667,10 +669,15 @@ int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_right, s
     void* dbuf = nullptr;
     if (int32_t rc = ctx_scratch(p->ctx, SCR_D, n * buflen, &dbuf, s)) return rc;
     const size_t work = n * 2 * fe;
+    const bool tail_on = te_zero_tail_on();
+    if (used == (size_t)2 * fe * 32 && tail_on) {  // both digests fit: packed at a pitch of `used` bytes, the padding is never materialised
+        hipLaunchKernelGGL(te_serialize_pairs_vec_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, d_left, d_right, fe, (uint8_t*)dbuf, n);
+        HIP_TRY(hipGetLastError());
+        return te_crh_run(p, (const uint8_t*)dbuf, n, buflen, d_out, s, used, nullptr, used);
+    }
     hipLaunchKernelGGL(te_serialize_pairs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, d_left, d_right, fe, buflen,
             (uint8_t*)dbuf, n);
     HIP_TRY(hipGetLastError());
-    const bool tail_on = te_zero_tail_on();
     if (used < buflen && !tail_on) {  // with the zero-tail shortcut the padding bytes are never read
         const size_t tw = n * (buflen - used);
         hipLaunchKernelGGL(te_zero_tail_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, s, (uint8_t*)dbuf, buflen, used, n);

@@ -939,6 +939,24 @@ __global__ void te_serialize_pairs_kernel(const Fr* __restrict__ left, const Fr*
     if (t >= n * 2 * (size_t)fe_per_digest) return;
     te_serialize_pair_fe(left, right, fe_per_digest, buflen, buf, t);
 }
+// The same for buffers that hold the two digests completely (2 * fe_per_digest * 32 <= buflen): only the data bytes are written, at a
+// pitch of exactly 64 * fe_per_digest bytes and with two 16-byte stores per field element -- the hash kernels are told the pitch and
+// never read the zero padding (its contribution is a constant).  (The byte-wise kernel above took 1.7 ms of a 2^23-leaf
+// Bowe-Hopwood tree's 18.8 ms: profiles/r04_s11.)
+__global__ void __launch_bounds__(256) te_serialize_pairs_vec_kernel(const Fr* __restrict__ left, const Fr* __restrict__ right, u32 fe_per_digest,
+                                                                    uint8_t* __restrict__ buf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = 2 * (size_t)fe_per_digest;
+    if (t >= n * per) return;
+    const size_t i = t / per, k = t % per;
+    const Fr* src;
+    if (right == nullptr) src = left + t;
+    else src = (k < fe_per_digest) ? (left + i * fe_per_digest + k) : (right + i * fe_per_digest + (k - fe_per_digest));
+    const Fr c = f29_to_canonical_int(f29_from_wire<true>(load_fr_g(src)));
+    uint4* dst = reinterpret_cast<uint4*>(buf + t * 32);
+    dst[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+    dst[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+}
 // messages of 1..3 bytes, zero-padded to four (the accumulate kernels read message bits with one 32-bit load)
 __global__ void te_pad4_kernel(const uint8_t* __restrict__ msgs, size_t stride, u32 len, uint8_t* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
