@@ -142,8 +142,11 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
         }
         if (e == hipSuccess && bad == 0) {
             u32 D = shape ? std::max(shape, 2u) : TE_MAX_DIGIT;
-            if (!shape)
+            if (!shape) {
                 while (D > 2 && (te_pedersen_entries(n_gen, D) * sizeof(TeEntry) > budget || te_pedersen_entries(n_gen, D) >= max_entries)) --D;
+                // the narrowest digit with the same number of table steps (64 generators: 22 bits give the 3 steps that 24 bits give)
+                while (D > 2 && (n_gen + D - 2) / (D - 1) == (n_gen + D - 1) / D) --D;
+            }
             if (te_pedersen_entries(n_gen, D) >= max_entries) e = hipErrorInvalidValue;
             if (e == hipSuccess) e = hipMalloc(&p->d_lut, te_pedersen_entries(n_gen, D) * sizeof(TeEntry));
             while (e == hipErrorOutOfMemory && D > 8 && !shape) {  // a crowded device: a narrower digit needs half the table
