@@ -574,7 +574,11 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
         }
         for (int i = 0; i < 8; ++i)
             if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
-        const TePipe pipe{chunk /* 2^16 / 2^18 / 2^19 measured slower, profiles/r04_s3 */, msgs, out, c->pipe[0], c->pipe[4], c->chunk_event[0], c->chunk_event[1]};
+        size_t pchunk = chunk;
+#if defined(AKP_TEST_HOOKS)
+        pchunk = env_size("AKP_TE_PIPE_CHUNK", chunk);
+#endif
+        const TePipe pipe{pchunk /* 2^16 / 2^18 / 2^19 measured slower, profiles/r04_s3 */, msgs, out, c->pipe[0], c->pipe[4], c->chunk_event[0], c->chunk_event[1]};
         if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
         if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
         HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
