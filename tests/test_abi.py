@@ -105,6 +105,20 @@ def test_params_validation_without_device():
     cpa.lib.akp_poseidon_params_destroy(h)
 
 
+def test_table_budget_and_shaped_create_argument_checks_without_device():
+    """the table-shape entry points (akp.h: akp_ctx_set_table_budget, akp_te_params_create_shaped) reject NULL contexts and report no
+    budget for them; curve tables are built on the GPU, so a create without a context is AKP_ERR_HIP, never a host-side table"""
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import field
+    assert cpa.lib.akp_ctx_set_table_budget(None, 1 << 30) == 2
+    assert cpa.lib.akp_ctx_table_budget(None) == 0
+    gens = field.fr([0, 1] * 8).reshape(2, 4, 2, 4)
+    h = C.c_void_p()
+    for shape in (0, 5, 24):
+        assert cpa.lib.akp_te_params_create_shaped(None, 0, 4, 2, gens.ctypes.data, shape, C.byref(h)) == 3
+        assert b"device context is required" in cpa.lib.akp_last_error()
+
+
 def test_no_device_means_loud_failure():
     import crypto_primitives_amd as cpa
     if cpa.lib.akp_device_count() > 0:

@@ -226,6 +226,14 @@ def test_table_budget_picks_the_shape(cpa):
     finally:
         ctx.set_table_budget(0)
     assert ctx.table_budget() >= 64 << 20
+    # shapes outside 2..24 bits / 1..8 chunks are the caller's error
+    import ctypes as C
+    from crypto_primitives_amd._lib import lib, AKP_ERR_BAD_PARAMS
+    h = C.c_void_p()
+    g = np.ascontiguousarray(gens)
+    for kind, shape in ((0, 25), (0, 1), (2, 99), (1, 9)):
+        assert lib.akp_te_params_create_shaped(ctx.h, kind, 4 if kind != 1 else 63, 256 if kind != 1 else 9, (g if kind != 1 else np.ascontiguousarray(bgens)).ctypes.data,
+                                               shape, C.byref(h)) == AKP_ERR_BAD_PARAMS, (kind, shape)
     a = out[320 << 20]
     for b in out.values():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
