@@ -240,10 +240,11 @@ struct akp_te_params {
     TeEntry* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]; Pedersen signed-subset: cprefix [n_digits + 1]
     TeEntry* d_tail = nullptr;  // BH: sum of G[c] over the zero-padded tail chunks [tail_from, tail_to) of the last compress shape
     u32 tail_from = 0, tail_to = 0;
-    // BH: the < G chunks a message length leaves after its last full group are ONE more table step: a table of 2^(3r-1) entries for
-    // the r chunks starting at chunk `first`, built on the first use of that length (a parameter set sees a handful of lengths)
+    // BH: the < G chunks a message shape leaves after its last full group are ONE more table step: a table of 2^(3r) entries for
+    // the r chunks starting at chunk `first`, with the constant of the zero-padded tail chunks [tail_from, tail_to) folded in;
+    // built on the first use of that shape (a parameter set sees a handful of shapes)
     struct Remainder {
-        u32 first = 0, r = 0;
+        u32 first = 0, r = 0, tail_from = 0, tail_to = 0;
         TeEntry* d = nullptr;
     };
     static constexpr int MAX_REMAINDERS = 8;

@@ -276,7 +276,7 @@ extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bi
             entries = p->signed_subset ? (n_digits << (p->digit_bits - 1)) + n_digits + 1 : n_digits << p->digit_bits;
         } else {
             entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)(p->n_gen / p->group) << (3 * p->group - 1)) : 0);
-            for (int i = 0; i < p->n_rem; ++i) entries += (size_t)1 << (3 * p->rem[i].r - 1);
+            for (int i = 0; i < p->n_rem; ++i) entries += (size_t)1 << (3 * p->rem[i].r);
         }
         *table_bytes = entries * sizeof(TeEntry);
     }
@@ -326,30 +326,45 @@ struct TePipe {
     hipStream_t cin, side;
     hipEvent_t ev_in, ev_acc;
 };
-// Bowe-Hopwood: table of the r (2 .. 7) chunks starting at chunk `first` -- what a message length leaves after its last full
-// group -- so that they are ONE table step instead of r; built on the first use of that length (2^(3r-1) entries: at most
-// 134 MB, milliseconds).  *out stays NULL when the handle's slots are taken or memory is short: the chunks are then single
-// steps from the one-chunk table, as before round 4.  Measured (profiles/r04_s10): a 63x9 tree node of 64 B is 21 + 1 steps
-// instead of 21 + 3 with groups of eight, a 32-byte leaf 10 + 1 instead of 10 + 6.
-static int32_t te_bh_remainder(akp_te_params* p, u32 first, u32 r, const TeEntry** out) {
+// Bowe-Hopwood: table of the r (1 .. 7) chunks starting at chunk `first` -- what a message shape leaves after its last full
+// group -- with the constant of the zero-padded tail chunks [tail_from, tail_to) folded into every entry, so that those chunks AND
+// the tail are ONE table step instead of r + 1 additions; built on the first use of the shape (2^(3r) entries: at most 268 MB,
+// milliseconds).  *out stays NULL when the handle's slots are taken or memory is short: the chunks are then single steps
+// from the one-chunk table and the tail its own addition, as before round 4.  A 63x9 tree node of 64 data bytes is 21 + 1
+// additions instead of 21 + 3 + 1 with groups of eight, a 32-byte leaf 10 + 1 instead of 10 + 6.
+static int32_t te_bh_remainder(akp_te_params* p, u32 first, u32 r, u32 tail_from, u32 tail_to, const TeEntry** out) {
     *out = nullptr;
+    if (tail_from >= tail_to) tail_from = tail_to = 0;
     for (int i = 0; i < p->n_rem; ++i)
-        if (p->rem[i].first == first && p->rem[i].r == r) {
+        if (p->rem[i].first == first && p->rem[i].r == r && p->rem[i].tail_from == tail_from && p->rem[i].tail_to == tail_to) {
             *out = p->rem[i].d;
             return AKP_OK;
         }
     if (p->n_rem == akp_te_params::MAX_REMAINDERS || !p->d_gens) return AKP_OK;
-    const size_t entries = (size_t)1 << (3 * r - 1);
-    TeEntry* d = nullptr;
+    const size_t entries = (size_t)1 << (3 * r);
+    akp_ctx* c = p->ctx;
+    TeEntry *d = nullptr, *d_t = nullptr;
     hipError_t e = hipMalloc(&d, entries * sizeof(TeEntry));
-    if (e == hipSuccess) e = te_build_wide<1>(p->ctx, p->d_gens, p->n_gen, r, 1, first, 0, d, entries);  // waits for the context's stream
+    if (e == hipSuccess && tail_from < tail_to) {
+        e = hipMalloc(&d_t, sizeof(TeEntry));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, c->stream, p->d_lut1, tail_from, tail_to, d_t);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(te_build_bh_remainder, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, c->stream, p->d_gens, first, r, d_t, (u32)entries, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_t) (void)hipFree(d_t);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (d) (void)hipFree(d);
         if (e == hipErrorOutOfMemory) return AKP_OK;
         return fail(AKP_ERR_HIP, "Bowe-Hopwood remainder table: %s", hipGetErrorString(e));
     }
-    p->rem[p->n_rem++] = akp_te_params::Remainder{first, r, d};
+    p->rem[p->n_rem++] = akp_te_params::Remainder{first, r, tail_from, tail_to, d};
     *out = d;
     return AKP_OK;
 }
@@ -373,33 +388,37 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     // what the kernels call D: the digit width, or the chunks per group with the size of the remainder step above it (te_bh_rem)
     u32 shape = te_is_pedersen(p) ? p->digit_bits : p->group;
     const TeEntry* lut1 = p->d_lut1;
-    if (p->kind == AKP_TE_BOWE_HOPWOOD && p->group > 1 && steps - groups >= 2) {
+    const TeEntry* tail = nullptr;
+    u32 tail_from = 0, tail_to = 0;
+    if (p->kind == AKP_TE_BOWE_HOPWOOD && data_len < msg_len) {
+        tail_from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, p->n_gen);
+        tail_to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3, p->n_gen);
+    }
+    bool tail_folded = false;
+    if (p->kind == AKP_TE_BOWE_HOPWOOD && p->group > 1 && steps > groups) {  // chunks after the last full group: one step, tail included
         const TeEntry* rem = nullptr;
-        if (int32_t rc = te_bh_remainder(p, p->group * groups, steps - groups, &rem)) return rc;
+        if (int32_t rc = te_bh_remainder(p, p->group * groups, steps - groups, tail_from, tail_to, &rem)) return rc;
         if (rem) {
             shape |= (steps - groups) << 8;
             lut1 = rem;
             steps = groups + 1;
+            tail_folded = true;
         }
     }
-    const TeEntry* tail = nullptr;
-    if (p->kind == AKP_TE_BOWE_HOPWOOD && data_len < msg_len) {
-        const u32 from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, p->n_gen), to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3,
-                p->n_gen);
-        if (from < to) {
-            if (!p->d_tail) HIP_TRY(hipMalloc(&p->d_tail, sizeof(TeEntry)));
-            // stream-ordered: later launches on other streams go through ctx_scratch-style events below
-            if (p->tail_from != from || p->tail_to != to) {
-                // an earlier shape's constant may still be in use (rare: one shape per parameter set)
-                HIP_TRY(hipStreamSynchronize(s));
-                hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, s, p->d_lut1, from, to, p->d_tail);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(s));
-                p->tail_from = from;
-                p->tail_to = to;
-            }
-            tail = p->d_tail;
+    if (tail_from < tail_to && !tail_folded) {
+        const u32 from = tail_from, to = tail_to;
+        if (!p->d_tail) HIP_TRY(hipMalloc(&p->d_tail, sizeof(TeEntry)));
+        // stream-ordered: later launches on other streams go through ctx_scratch-style events below
+        if (p->tail_from != from || p->tail_to != to) {
+            // an earlier shape's constant may still be in use (rare: one shape per parameter set)
+            HIP_TRY(hipStreamSynchronize(s));
+            hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, s, p->d_lut1, from, to, p->d_tail);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            p->tail_from = from;
+            p->tail_to = to;
         }
+        tail = p->d_tail;
     }
     size_t stride = pitch ? pitch : msg_len;
     if (data_len > 0 && data_len < 4) {  // the kernels fetch message bits with one 32-bit load: pad 1..3-byte messages to four bytes

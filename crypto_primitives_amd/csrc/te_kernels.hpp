@@ -336,6 +336,25 @@ __global__ void te_build_bh_parts(const Fr* __restrict__ gens_affine, u32 first,
         store_niels(hi + j, te_bh_part_entry(gens_affine, (size_t)first + (size_t)stride * u + G_lo, G_hi, w & ((1u << (2u * G_hi)) - 1u), w >> (2u * G_hi)));
     }
 }
+// remainder table of the r chunks starting at chunk `first`: entry[bits] = sum_i (-1)^{s_i} (k_i + 1) G[first + i] (+ tail), the
+// chunk bits in message order (k_i = bits [3i, 3i + 2), s_i = bit 3i + 2).  `tail`: the constant of the zero-padded chunks
+// behind the data (te_bh_tail_kernel) or NULL.  Entry by entry: at most 2^21 entries, once per message shape.
+__global__ void te_build_bh_remainder(const Fr* __restrict__ gens_affine, u32 first, u32 r, const TeEntry* __restrict__ tail, u32 n_entries,
+                                      TeEntry* __restrict__ out) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_entries) return;
+    Ext acc = ext_identity();
+#pragma unroll 1
+    for (u32 i = 0; i < r; ++i) {
+        Niels gn = te_niels_of_gen(gens_affine, (size_t)first + i);
+        if ((idx >> (3u * i + 2u)) & 1u) gn = niels_neg(gn);
+        const u32 k = (idx >> (3u * i)) & 3u;
+#pragma unroll 1
+        for (u32 j = 0; j <= k; ++j) acc = te_madd(acc, gn);
+    }
+    if (tail) acc = te_madd(acc, load_niels(tail));
+    store_niels(out + idx, niels_of_ext(acc));
+}
 // indices of the two parts of wide entry `idx`.  KIND 2: Pedersen signed-subset (W = D, k_lo bits in the lo part);
 // KIND 1: Bowe-Hopwood group table (W = G, k_lo = G_lo chunks in the lo part; index layout of te_bh_lutg_entry)
 template <int KIND>
@@ -483,10 +502,11 @@ AKP_HD Niels niels_apply(const NielsSel& s) {
     return r;
 }
 // kind 1: `D` packs the group size G (bits 0-7) and the size R of the remainder group (bits 8-15).  R = 0: the chunks a message
-// leaves after its last full group are single steps from lut1.  R >= 2: they are ONE step, and lut1 points to the table of
-// that remainder (2^(3R-1) entries, index layout of a group; capi_te.hip te_bh_remainder).
+// leaves after its last full group are single steps from lut1.  R >= 1: they are ONE step, and lut1 points to the table of
+// that remainder: 2^(3R) entries indexed by the 3R message bits as they are (no sign symmetry: the constant of a
+// zero-padded tail is folded into every entry, so the step also replaces the tail addition; te_build_bh_remainder).
 AKP_HD u32 te_bh_group(u32 D) { return D & 0xffu; }
-AKP_HD u32 te_bh_rem(u32 D) { return D >> 8; }
+AKP_HD u32 te_bh_rem(u32 D) { return (D >> 8) & 0xffu; }
 // table index of a group of G chunks from its 3G message bits (layout of te_bh_lutg_entry); *s0 = sign bit of chunk 0
 AKP_HD u32 te_bh_group_index(u32 bits, u32 G, u32* s0) {
     const u32 s = (bits >> 2) & 1u;
@@ -610,11 +630,7 @@ AKP_HD NielsSel te_step_fetch(const TeEntry* __restrict__ lut, const TeEntry* __
         const u32 idx = te_bh_group_index(bits, G, &s0);
         return NielsSel{load_niels(lut + ((size_t)u << (3u * G - 1u)) + idx), s0};
     }
-    if (R) {
-        u32 s0;
-        const u32 idx = te_bh_group_index(bits, R, &s0);
-        return NielsSel{load_niels(lut1 + idx), s0};
-    }
+    if (R) return NielsSel{load_niels(lut1 + bits), 0u};
     const u32 c = G * n_groups + (u - n_groups);
     return NielsSel{load_niels(lut1 + (size_t)c * 4u + (bits & 3u)), (bits >> 2) & 1u};
 }
@@ -641,10 +657,9 @@ AKP_HD void te_step_address(const TeEntry* __restrict__ lut, const TeEntry* __re
             f.idx = (u << (3u * G - 1u)) + te_bh_group_index(bits, G, &s0);
             f.neg = s0;
         } else if (R) {
-            u32 s0;
             f.base = lut1;
-            f.idx = te_bh_group_index(bits, R, &s0);
-            f.neg = s0;
+            f.idx = bits;
+            f.neg = 0u;
         } else {
             const u32 c = G * n_groups + (u - n_groups);
             f.base = lut1;

@@ -205,9 +205,10 @@ uint32_t akp_te_entry_bytes(void);
 /* pedersen::CRH::evaluate (crh/pedersen/mod.rs:76-129) / bowe_hopwood::CRH::evaluate
  * (crh/bowe_hopwood/mod.rs:114-186): n messages of msg_len bytes each ->
  * n digests (2 Fr for Pedersen, 1 Fr for Bowe-Hopwood).
- * Bowe-Hopwood: the FIRST call with a new message length may build one more small table (the chunks that length leaves after
- * its last full group: <= 134 MB, milliseconds, kept in the handle; up to eight lengths) -- that call waits for the context's
- * own stream once; every later call with the length only enqueues. */
+ * Bowe-Hopwood: the FIRST call with a new message shape (length, and for two-to-one buffers the length of the zero padding) may
+ * build one more small table (the chunks the shape leaves after its last full group, with the padding's constant folded in:
+ * <= 268 MB, milliseconds, kept in the handle; up to eight shapes) -- that call waits for the context's own stream once; every
+ * later call with the shape only enqueues. */
 int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_t n, size_t msg_len, uint64_t* out);
 int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out,
                              void* stream);

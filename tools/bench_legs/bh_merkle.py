@@ -31,20 +31,25 @@ def run(env):
     bsec = env.max_over_ranks(time.perf_counter() - m0) / reps
     dev_ms = sum(a.elapsed_time(b) for a, b in evs) / reps
     h = B.handle(env.ctx)
+    grp = h.info()["digit_bits_or_group"]
+    # additions per inner node: the table steps of the 64 data bytes; the constant of the zero-padded tail (a zero chunk adds +g) is
+    # folded into the remainder step when the 171 data chunks leave one (groups of 8: 21 + 1), else it is one more addition
+    inner_adds = h.info(64)["steps"] + (0 if grp > 1 and 171 % grp else 1)
     bh_merkle = {"config": "BASELINE configs[4]: MerkleTree::new, Bowe-Hopwood 63x9 over Jubjub, 32-byte leaves, ByteDigestConverter",
                  "leaves": total, "leaves_per_gpu": per, "seconds": bsec, "leaves_per_s": total / bsec, "scaling": "weak",
                  "roofline": {"bound": "hbm", "kernels": "te_accumulate_lds_kernel<1> + te_finalize_kernel<1> + te_serialize_pairs_kernel per level",
                               "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                               "table": h.info(32),
-                              "traffic": te_counters("bh_32B", per, h.info(32)["steps"])["traffic"] + te_counters("bh_70B", per - 1, h.info(64)["steps"] + 1)["traffic"],
+                              "traffic": te_counters("bh_32B", per, h.info(32)["steps"])["traffic"] + te_counters("bh_70B", per - 1, inner_adds)["traffic"],
                               "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_lds_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
                                                      "for the leaf level and 2^20 x 70 B scaled to the inner nodes' table steps; levels of <= 2^14 nodes run the split kernel; "
                                                      "NOT measured in this run)",
                               "valu": {"table_steps_per_leaf_hash": h.info(32)["steps"],
-                                       "table_steps_per_inner_node": h.info(64)["steps"] + 1,
-                                       "inner_node_note": "64 bytes of digests in a 70-byte buffer: the table steps of the 64 data bytes + one constant "
-                                                          "entry for the zero-padded tail (a zero chunk adds +g); %d steps if the padding is walked" % h.info(70)["steps"],
+                                       "table_steps_per_inner_node": inner_adds,
+                                       "inner_node_note": "64 bytes of digests in a 70-byte buffer: the table steps of the 64 data bytes, the last of them a "
+                                                          "remainder entry with the constant of the zero-padded tail folded in (a zero chunk adds +g); "
+                                                          "%d steps if the padding is walked" % h.info(70)["steps"],
                                        "field_products_per_step": 7}}}
     rfb = bh_merkle["roofline"]
     rfb["traffic_over_algorithmic"] = rfb["traffic"] / (160.0 * per)
