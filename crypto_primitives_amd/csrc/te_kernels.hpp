@@ -8,17 +8,18 @@
 //   Pedersen:  message bit g selects generators[g / W][g % W], i.e. FLAT generator index g, so the window
 //              structure is irrelevant to evaluation and the digit width D is a free tuning parameter:
 //              H(m) = sum over digits u of LUT[u][digit_u],  digit_u = message bits [uD, uD + D),
-//              LUT[u][v] = sum_b v_b * G[uD + b]   (valid for arbitrary generators; D = 13 by default, so a
-//              4x256 hash is 79 mixed additions instead of the reference's ~512 conditional + 255 window adds)
+//              LUT[u][v] = sum_b v_b * G[uD + b]   (valid for arbitrary generators; with the signed-subset table below and
+//              24-bit digits a 4x256 hash is 43 mixed additions instead of the reference's ~512 conditional + 255 window adds)
 //   Bowe-Hopwood: chunk c (3 bits) uses flat generator G[c]; digit = (1 + b0 + 2 b1) * (-1)^b2 (zero chunk = +g, :167).
-//              G chunks per step (G = 4 by default): sum_i (-1)^{s_i} (k_i+1) G[Gu+i] = (-1)^{s_0} * LUTG[u][k_0..k_{G-1}, s_i^s_0]
+//              G chunks per step (G up to 8): sum_i (-1)^{s_i} (k_i+1) G[Gu+i] = (-1)^{s_0} * LUTG[u][k_0..k_{G-1}, s_i^s_0]
 //              (2^(3G-1) entries per group); the < G chunks left over at the end of a message use LUT1[c][k] = (k+1) G[c].
 // LUT entries are precomputed once per parameter set in halved "Niels" form ((y+x)/2, (y-x)/2, d*x*y),
 // so one step is a 7-product mixed addition (madd-2008-hwcd-3, a = -1, complete on Jubjub because d is a
 // non-square; every coordinate comes out scaled by 1/4, which the projective form absorbs and which
-// removes the doubling of Z).  One message per lane; the tables (tens of MB) live in L2 / the 256 MB Infinity
-// Cache -- per step a wavefront gathers 64 x 128 B (the entry of step u+1 is fetched before the addition of step u)
-// against ~1900 VALU instructions, so the path stays integer-ALU bound.
+// removes the doubling of Z).  One message per lane; the tables are sized for HBM (capi_te.hip: tens of GB when the
+// table budget allows, 268 / 237 MB when it is set to keep them in the 256 MB Infinity Cache) -- per step a wavefront gathers
+// 64 x 128 B (the entry of step u+1 is fetched before the addition of step u) against ~1480 VALU instructions, and the path
+// stays integer-ALU bound at either size (VALUBusy 88-95 %).
 // Arithmetic: signed lazy radix-2^29 form (f29.hpp, FS): subtraction is limb-wise, no reduction anywhere.
 // The projective -> affine conversion (crh/pedersen/mod.rs:128, bowe_hopwood/mod.rs:185) is one field
 // inversion per message in the reference; here a separate pass shares one inversion among up to 64 messages
