@@ -15,7 +15,9 @@
 //   Bowe-Hopwood 63x9, 2^20 x 64 B: G = 5 / 6 / 7 / 8:     1.81 / 1.73 / 1.57 / 1.44 ms  (237 MB / 1.6 / 10.9 / 75 GB)
 // The width is therefore the widest the context's TABLE BUDGET admits (akp_ctx_set_table_budget; default: a quarter of the
 // device's memory, at most half of what is free -- 72 GiB on an idle MI355X), or the explicit shape of
-// akp_te_params_create_shaped.  Digits up to 24 bits / groups up to 8 chunks (the message window of a step is one 32-bit word).
+// akp_te_params_create_shaped.  Digits up to 24 bits / groups up to 8 chunks: 25-bit digits (the 32-bit message window of a step
+// would admit them: 41 steps, 88 GB) were measured SLOWER, 2.65 against 2.41 ms -- a digit's region of the table is then 2 GB
+// and the gather leaves the TLB reach (64.6 against 55.9 us per step; profiles/r04_s10/digit25_rejected.txt, gather_probe.txt).
 static size_t te_table_budget(const akp_ctx* ctx) {
     if (ctx->table_budget) return ctx->table_budget;
     size_t free_b = 0, total_b = 0;
