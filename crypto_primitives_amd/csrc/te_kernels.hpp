@@ -831,25 +831,50 @@ __global__ void te_bh_tail_kernel(const TeEntry* __restrict__ lut1, u32 from, u3
 template <int KIND>
 AKP_HD void te_finalize_lane(const F29Pad* __restrict__ xyz, F29Pad* __restrict__ prefix, Fr* __restrict__ out, size_t n,
                              size_t lanes, size_t l) {
+    // Both passes are chains of dependent products with one wave per SIMD, so a load that is issued where its value is needed
+    // costs its full latency 2 x (elements per lane) times: every load is issued one iteration ahead of its use.
     FS run = f29_one<true>();
     size_t cnt = 0;
+    if (l >= n) return;
+    FS z = f29_load_pad<true>(xyz + l * 3 + 2);
 #pragma unroll 1
     for (size_t e = l; e < n; e += lanes, ++cnt) {
+        FS zn = z;
+        if (e + lanes < n) zn = f29_load_pad<true>(xyz + (e + lanes) * 3 + 2);
         f29_store_pad(prefix + e, run);  // product of the earlier Z's of this lane
-        run = f29_mul(run, f29_load_pad<true>(xyz + e * 3 + 2));
+        run = f29_mul(run, z);
+        z = zn;
     }
     FS inv = f29_inv(run);  // Z != 0 always (complete formulas)
+    size_t k = cnt - 1, e = l + k * lanes;
+    FS p = f29_load_pad<true>(prefix + e), x = f29_load_pad<true>(xyz + e * 3), y = x;
+    z = f29_load_pad<true>(xyz + e * 3 + 2);
+    if (KIND != 1) y = f29_load_pad<true>(xyz + e * 3 + 1);
 #pragma unroll 1
-    for (size_t k = cnt; k-- > 0;) {
-        const size_t e = l + k * lanes;
-        const FS zi = f29_mul(inv, f29_load_pad<true>(prefix + e));
-        inv = f29_mul(inv, f29_load_pad<true>(xyz + e * 3 + 2));
-        if (KIND != 1) {
-            store_fr_g(out + e * 2, f29_to_wire(f29_mul(f29_load_pad<true>(xyz + e * 3), zi)));
-            store_fr_g(out + e * 2 + 1, f29_to_wire(f29_mul(f29_load_pad<true>(xyz + e * 3 + 1), zi)));
-        } else {
-            store_fr_g(out + e, f29_to_wire(f29_mul(f29_load_pad<true>(xyz + e * 3), zi)));
+    for (;;) {
+        FS pn = p, zn = z, xn = x, yn = y;
+        if (k > 0) {
+            const size_t en = e - lanes;
+            pn = f29_load_pad<true>(prefix + en);
+            zn = f29_load_pad<true>(xyz + en * 3 + 2);
+            xn = f29_load_pad<true>(xyz + en * 3);
+            if (KIND != 1) yn = f29_load_pad<true>(xyz + en * 3 + 1);
         }
+        const FS zi = f29_mul(inv, p);
+        inv = f29_mul(inv, z);
+        if (KIND != 1) {
+            store_fr_g(out + e * 2, f29_to_wire(f29_mul(x, zi)));
+            store_fr_g(out + e * 2 + 1, f29_to_wire(f29_mul(y, zi)));
+        } else {
+            store_fr_g(out + e, f29_to_wire(f29_mul(x, zi)));
+        }
+        if (k == 0) break;
+        --k;
+        e -= lanes;
+        p = pn;
+        z = zn;
+        x = xn;
+        y = yn;
     }
 }
 template <int KIND>
