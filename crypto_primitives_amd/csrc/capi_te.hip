@@ -41,10 +41,10 @@ constexpr u32 TE_MAX_DIGIT = 24, TE_MAX_GROUP = 8;
 static inline size_t te_pedersen_entries(size_t n_gen, u32 D) { return ((n_gen + D - 1) / D) << (D - 1); }
 static inline size_t te_bh_entries(size_t n_gen, u32 G) { return (n_gen / G) << (3 * G - 1); }
 // two-part construction of a wide table (te_kernels.hpp): part tables entry by entry, then one addition per wide entry.
-// KIND 2: Pedersen signed-subset table of W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of
-// `units` groups of W chunks, the first group at chunk `first`, consecutive groups `stride` chunks apart, generators `src`.
+// KIND 2: Pedersen signed-subset table of `units` W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of
+// `units` groups of W chunks, generators `src`.
 template <int KIND>
-static hipError_t te_build_wide(akp_ctx* ctx, const void* src, u32 n_gen, u32 W, u32 units, u32 first, u32 stride, TeEntry* lut, size_t entries) {
+static hipError_t te_build_wide(akp_ctx* ctx, const void* src, u32 n_gen, u32 W, u32 units, TeEntry* lut, size_t entries) {
     const u32 k_lo = KIND == 2 ? (W - 1) / 2 : W / 2;
     const size_t n_lo = KIND == 2 ? (size_t)units << k_lo : (size_t)units << (3 * k_lo - 1);
     const size_t n_hi = KIND == 2 ? (size_t)units << (W - 1 - k_lo) : (size_t)units << (3 * (W - k_lo));
@@ -56,16 +56,16 @@ static hipError_t te_build_wide(akp_ctx* ctx, const void* src, u32 n_gen, u32 W,
         if (KIND == 2)
             hipLaunchKernelGGL(te_build_pedersen_sparts, dim3(pgrid), dim3(64), 0, ctx->stream, (const NielsPad*)src, n_gen, W, units, k_lo, lo, hi);
         else
-            hipLaunchKernelGGL(te_build_bh_parts, dim3(pgrid), dim3(64), 0, ctx->stream, (const Fr*)src, first, stride, W, k_lo, units, lo, hi);
+            hipLaunchKernelGGL(te_build_bh_parts, dim3(pgrid), dim3(64), 0, ctx->stream, (const Fr*)src, W, k_lo, units, lo, hi);
         const unsigned cgrid = (unsigned)((entries + 256 * AKP_TE_BUILD_RUN - 1) / (256 * AKP_TE_BUILD_RUN));
         hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), 0, ctx->stream, lo, hi, W, k_lo, entries, lut);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 #if defined(AKP_TEST_HOOKS)
-    // AKP_TE_TABLE_CHECK=k: every k-th entry of the table against the per-entry definition (group tables at chunk 0 only)
+    // AKP_TE_TABLE_CHECK=k: every k-th entry of the table against the per-entry definition
     const size_t step = env_size("AKP_TE_TABLE_CHECK", 0);
-    if (e == hipSuccess && step && first == 0 && (KIND == 2 || stride == W)) {
+    if (e == hipSuccess && step) {
         u32* d_bad = nullptr;
         u32 bad = 0;
         e = hipMalloc(&d_bad, sizeof(u32));
@@ -160,7 +160,7 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
             p->digit_bits = D;
             p->signed_subset = true;
             if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
-            if (e == hipSuccess) e = te_build_wide<2>(ctx, d_half, (u32)n_gen, D, (u32)n_digits, 0, D, p->d_lut, te_pedersen_entries(n_gen, D));
+            if (e == hipSuccess) e = te_build_wide<2>(ctx, d_half, (u32)n_gen, D, (u32)n_digits, p->d_lut, te_pedersen_entries(n_gen, D));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
                         (u32)n_gen, D, (u32)n_digits, p->d_lut1);
@@ -202,7 +202,7 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
                 --G;
                 e = hipMalloc(&p->d_lut, te_bh_entries(n_gen, G) * sizeof(TeEntry));
             }
-            if (e == hipSuccess) e = te_build_wide<1>(ctx, d_g, (u32)n_gen, G, (u32)(n_gen / G), 0, G, p->d_lut, te_bh_entries(n_gen, G));
+            if (e == hipSuccess) e = te_build_wide<1>(ctx, d_g, (u32)n_gen, G, (u32)(n_gen / G), p->d_lut, te_bh_entries(n_gen, G));
         }
         p->group = G;
         p->d_gens = d_g;  // kept: the remainder tables of later message lengths are built from them (te_bh_remainder)

@@ -322,19 +322,17 @@ AKP_HD Niels te_bh_part_entry(const Fr* __restrict__ gens_affine, size_t first, 
     }
     return niels_of_ext(acc);
 }
-// parts of the group table: chunks [first + Gu, .. + G_lo) (lo; chunk 0 carries no sign bit) and the G - G_lo chunks after them (hi).
-// `stride` is the distance in chunks between the groups (G for the group table; 0 with n_groups = 1 for a remainder table).
-__global__ void te_build_bh_parts(const Fr* __restrict__ gens_affine, u32 first, u32 stride, u32 G, u32 G_lo, u32 n_groups, TeEntry* __restrict__ lo,
-                                  TeEntry* __restrict__ hi) {
+// parts of the group table: chunks [Gu, Gu + G_lo) (lo; chunk 0 carries no sign bit) and the G - G_lo chunks after them (hi)
+__global__ void te_build_bh_parts(const Fr* __restrict__ gens_affine, u32 G, u32 G_lo, u32 n_groups, TeEntry* __restrict__ lo, TeEntry* __restrict__ hi) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 G_hi = G - G_lo, lo_bits = 3u * G_lo - 1u, hi_bits = 3u * G_hi;
-    const u32 n_lo = n_groups << lo_bits, n_hi = G_hi ? n_groups << hi_bits : 0u;
+    const u32 n_lo = n_groups << lo_bits, n_hi = n_groups << hi_bits;
     if (idx < n_lo) {
         const u32 u = idx >> lo_bits, w = idx & ((1u << lo_bits) - 1u);
-        store_niels(lo + idx, te_bh_part_entry(gens_affine, (size_t)first + (size_t)stride * u, G_lo, w & ((1u << (2u * G_lo)) - 1u), (w >> (2u * G_lo)) << 1));
+        store_niels(lo + idx, te_bh_part_entry(gens_affine, (size_t)G * u, G_lo, w & ((1u << (2u * G_lo)) - 1u), (w >> (2u * G_lo)) << 1));
     } else if (idx - n_lo < n_hi) {
         const u32 j = idx - n_lo, u = j >> hi_bits, w = j & ((1u << hi_bits) - 1u);
-        store_niels(hi + j, te_bh_part_entry(gens_affine, (size_t)first + (size_t)stride * u + G_lo, G_hi, w & ((1u << (2u * G_hi)) - 1u), w >> (2u * G_hi)));
+        store_niels(hi + j, te_bh_part_entry(gens_affine, (size_t)G * u + G_lo, G_hi, w & ((1u << (2u * G_hi)) - 1u), w >> (2u * G_hi)));
     }
 }
 // remainder table of the r chunks starting at chunk `first`: entry[bits] = sum_i (-1)^{s_i} (k_i + 1) G[first + i] (+ tail), the
