@@ -250,7 +250,13 @@ struct akp_te_params {
     static constexpr int MAX_REMAINDERS = 8;
     Remainder rem[MAX_REMAINDERS];
     int n_rem = 0;
-    Fr* d_gens = nullptr;  // BH: the generators (affine, wire form), kept for the remainder tables
+    Fr* d_gens = nullptr;  // BH: the generators (affine, wire form), kept for the group / remainder tables built later
+    // The wide table is built FOR THE MESSAGE LENGTHS THAT ARRIVE: d_lut covers the first `units_built` of `units_total` digits
+    // (Pedersen signed-subset table) / chunk groups (Bowe-Hopwood); a longer message extends it (te_ensure_table).  A handle that
+    // only ever hashes 32- and 64-byte tree nodes holds a third of the 63x9 table.
+    u32 units_total = 0, units_built = 0;
+    bool shape_auto = true;  // the shape came from the table budget (not from akp_te_params_create_shaped): it may narrow when memory is short
+    NielsPad* d_half = nullptr;  // Pedersen signed-subset table: the halved generators it is built from
     bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
     int pins = 0;                // as akp_poseidon::pins
     bool destroy_pending = false;

@@ -112,6 +112,7 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
 #endif
     akp_te_params* p = new akp_te_params();
     p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
+    p->shape_auto = shape == 0;
     ++ctx->live_handles;
     const size_t budget = te_table_budget(ctx);
     constexpr size_t max_entries = (size_t)1 << 32;  // entry indices are 32-bit in the kernels
@@ -150,23 +151,19 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
                 while (D > 2 && (n_gen + D - 2) / (D - 1) == (n_gen + D - 1) / D) --D;
             }
             if (te_pedersen_entries(n_gen, D) >= max_entries) e = hipErrorInvalidValue;
-            if (e == hipSuccess) e = hipMalloc(&p->d_lut, te_pedersen_entries(n_gen, D) * sizeof(TeEntry));
-            while (e == hipErrorOutOfMemory && D > 8 && !shape) {  // a crowded device: a narrower digit needs half the table
-                (void)hipGetLastError();
-                --D;
-                e = hipMalloc(&p->d_lut, te_pedersen_entries(n_gen, D) * sizeof(TeEntry));
-            }
             const size_t n_digits = (n_gen + D - 1) / D;
             p->digit_bits = D;
             p->signed_subset = true;
+            p->units_total = (u32)n_digits;  // the table itself is built for the message lengths that arrive (te_ensure_table)
             if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
-            if (e == hipSuccess) e = te_build_wide<2>(ctx, d_half, (u32)n_gen, D, (u32)n_digits, p->d_lut, te_pedersen_entries(n_gen, D));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
                         (u32)n_gen, D, (u32)n_digits, p->d_lut1);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            p->d_half = d_half;
+            d_half = nullptr;
         } else if (e == hipSuccess) {
             // plain table (generators outside the prime-order subgroup: never what `setup` produces): entry by entry, digits of
             // at most 14 bits (4x256: 13 bits, 79 steps, 93 MB)
@@ -195,15 +192,7 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
                     p->d_lut1);
             e = hipGetLastError();
         }
-        if (G > 1) {
-            if (e == hipSuccess) e = hipMalloc(&p->d_lut, te_bh_entries(n_gen, G) * sizeof(TeEntry));
-            while (e == hipErrorOutOfMemory && G > 2 && !shape) {  // a crowded device: a smaller group needs an eighth of the table
-                (void)hipGetLastError();
-                --G;
-                e = hipMalloc(&p->d_lut, te_bh_entries(n_gen, G) * sizeof(TeEntry));
-            }
-            if (e == hipSuccess) e = te_build_wide<1>(ctx, d_g, (u32)n_gen, G, (u32)(n_gen / G), p->d_lut, te_bh_entries(n_gen, G));
-        }
+        if (G > 1) p->units_total = (u32)(n_gen / G);  // the group table is built for the message lengths that arrive (te_ensure_table)
         p->group = G;
         p->d_gens = d_g;  // kept: the remainder tables of later message lengths are built from them (te_bh_remainder)
         d_g = nullptr;
@@ -238,6 +227,7 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
     if (p->d_lut1) (void)hipFree(p->d_lut1);
     if (p->d_tail) (void)hipFree(p->d_tail);
     if (p->d_gens) (void)hipFree(p->d_gens);
+    if (p->d_half) (void)hipFree(p->d_half);
     for (int i = 0; i < p->n_rem; ++i)
         if (p->rem[i].d) (void)hipFree(p->rem[i].d);
     ctx_handle_released(p->ctx);
@@ -275,9 +265,9 @@ extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bi
         size_t entries;
         if (ped) {
             const size_t n_digits = (p->n_gen + p->digit_bits - 1) / p->digit_bits;
-            entries = p->signed_subset ? (n_digits << (p->digit_bits - 1)) + n_digits + 1 : n_digits << p->digit_bits;
+            entries = p->signed_subset ? ((size_t)p->units_built << (p->digit_bits - 1)) + n_digits + 1 : n_digits << p->digit_bits;
         } else {
-            entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)(p->n_gen / p->group) << (3 * p->group - 1)) : 0);
+            entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)p->units_built << (3 * p->group - 1)) : 0);
             for (int i = 0; i < p->n_rem; ++i) entries += (size_t)1 << (3 * p->rem[i].r);
         }
         *table_bytes = entries * sizeof(TeEntry);
@@ -328,6 +318,85 @@ struct TePipe {
     hipStream_t cin, side;
     hipEvent_t ev_in, ev_acc;
 };
+static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32* n_steps);
+// A handle whose shape came from the table budget narrows it when the device cannot hold the table after all (other handles
+// were created or built in the meantime): one bit / one chunk less, everything that depends on the shape rebuilt.
+static hipError_t te_narrow(akp_te_params* p) {
+    akp_ctx* c = p->ctx;
+    if (te_is_pedersen(p)) {
+        const u32 D = --p->digit_bits;
+        const size_t n_digits = ((size_t)p->n_gen + D - 1) / D;
+        p->units_total = (u32)n_digits;
+        if (p->d_lut1) (void)hipFree(p->d_lut1);
+        p->d_lut1 = nullptr;
+        hipError_t e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, c->stream, p->d_half, p->n_gen, D,
+                (u32)n_digits, p->d_lut1);
+        e = hipGetLastError();
+        return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+    }
+    --p->group;
+    p->units_total = p->n_gen / p->group;
+    for (int i = 0; i < p->n_rem; ++i)
+        if (p->rem[i].d) (void)hipFree(p->rem[i].d);  // their first chunk follows the group size
+    p->n_rem = 0;
+    return hipSuccess;
+}
+// The wide table covers the digits / chunk groups [0, units_built); a message that needs more extends it: the old table is
+// released (after the device has drained: launches already enqueued on any stream may still read it) and a new one is built for
+// max(needed, twice the old coverage) units -- 0.1 s for the 46 GB of a whole 4x256 table, milliseconds for the prefix a tree's
+// 32- and 64-byte nodes use.  Happens once or twice in the life of a handle; every other call only enqueues.  Returns the
+// table steps of a data_len-byte message (te_steps) for the shape the handle ends up with.
+static int32_t te_ensure_table(akp_te_params* p, size_t data_len, u32* groups, u32* steps) {
+    const bool ped = te_is_pedersen(p);
+    akp_ctx* c = p->ctx;
+    for (;;) {
+        te_steps(p, data_len, groups, steps);
+        const u32 needed = ped ? *steps : *groups;
+        if (needed <= p->units_built || (ped ? !p->signed_subset : p->group <= 1)) return AKP_OK;  // (plain table / single chunks: complete)
+        const u32 shape = ped ? p->digit_bits : p->group;
+        const bool can_narrow = p->shape_auto && shape > (ped ? 8u : 2u);
+        auto bytes_of = [&](u32 units) { return ((size_t)units << (ped ? shape - 1 : 3 * shape - 1)) * sizeof(TeEntry); };
+        u32 target = std::min(p->units_total, std::max(needed, 2 * p->units_built));
+        if (p->d_lut) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(p->d_lut));
+            p->d_lut = nullptr;
+            p->units_built = 0;
+        }
+        hipError_t e = hipSuccess;
+        if (p->shape_auto) {  // the rule of creation, applied to what is about to be built: at most half of what is free now
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                if (bytes_of(target) > free_b / 2) target = needed;
+                if (bytes_of(target) > free_b / 2 && can_narrow) e = hipErrorOutOfMemory;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (e == hipSuccess) e = hipMalloc(&p->d_lut, bytes_of(target));
+        if (e == hipErrorOutOfMemory && can_narrow) {
+            (void)hipGetLastError();
+            p->d_lut = nullptr;
+            HIP_TRY(hipDeviceSynchronize());  // the constants / remainder tables of the old shape may be in use
+            e = te_narrow(p);
+            if (e == hipSuccess) continue;
+        }
+        if (e == hipSuccess)
+            e = ped ? te_build_wide<2>(c, p->d_half, p->n_gen, p->digit_bits, target, p->d_lut, bytes_of(target) / sizeof(TeEntry))
+                    : te_build_wide<1>(c, p->d_gens, p->n_gen, p->group, target, p->d_lut, bytes_of(target) / sizeof(TeEntry));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (p->d_lut) (void)hipFree(p->d_lut);
+            p->d_lut = nullptr;
+            return fail(AKP_ERR_HIP, "curve table of %zu MB (%u of %u %s): %s -- lower akp_ctx_set_table_budget and create the handle again",
+                    bytes_of(target) >> 20, target, p->units_total, ped ? "digits" : "chunk groups", hipGetErrorString(e));
+        }
+        p->units_built = target;
+        return AKP_OK;
+    }
+}
 // Bowe-Hopwood: table of the r (1 .. 7) chunks starting at chunk `first` -- what a message shape leaves after its last full
 // group -- with the constant of the zero-padded tail chunks [tail_from, tail_to) folded into every entry, so that those chunks AND
 // the tail are ONE table step instead of r + 1 additions; built on the first use of the shape (2^(3r) entries: at most 268 MB,
@@ -386,7 +455,7 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     const bool tail_on = te_zero_tail_on();
     if (data_len > msg_len || !tail_on) data_len = msg_len;
     u32 groups = 0, steps = 0;
-    te_steps(p, data_len, &groups, &steps);
+    if (int32_t rc = te_ensure_table(p, data_len, &groups, &steps)) return rc;
     // what the kernels call D: the digit width, or the chunks per group with the size of the remainder step above it (te_bh_rem)
     u32 shape = te_is_pedersen(p) ? p->digit_bits : p->group;
     const TeEntry* lut1 = p->d_lut1;

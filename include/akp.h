@@ -190,7 +190,11 @@ int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t window_size, u
  * budget admits (akp_ctx_set_table_budget below; on an idle MI355X: 24-bit digits = 46 GB for a 4x256 window, 43 steps per
  * 128-byte message instead of the 64 of the 268 MB table that fits the Infinity Cache, -23 % time; groups of 8 chunks = 75 GB
  * for a 63x9 window).  This form fixes the shape instead: digit_bits 2..24 / group 1..8, 0 = from the budget.  The digests do
- * not depend on the shape.  Building takes milliseconds to ~0.2 s (the widest tables). */
+ * not depend on the shape.
+ * The table is BUILT FOR THE MESSAGE LENGTHS THAT ARRIVE: creation allocates kilobytes, the first hash of a length builds the
+ * digits / groups that length touches (a 63x9 handle that only hashes a tree's 32- and 64-byte nodes holds 22.5 of the 75 GB),
+ * a longer message later extends the table (the device is drained once, the old table released, the new one built: ~0.1 s
+ * for the widest complete table).  akp_te_params_info reports what the handle holds at the moment. */
 int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
                                     const uint64_t* generators_affine, uint32_t digit_bits_or_group, akp_te_params** out);
 void akp_te_params_destroy(akp_te_params* p);
@@ -205,6 +209,7 @@ uint32_t akp_te_entry_bytes(void);
 /* pedersen::CRH::evaluate (crh/pedersen/mod.rs:76-129) / bowe_hopwood::CRH::evaluate
  * (crh/bowe_hopwood/mod.rs:114-186): n messages of msg_len bytes each ->
  * n digests (2 Fr for Pedersen, 1 Fr for Bowe-Hopwood).
+ * The FIRST call with a longer message than any before may extend the handle's table (see akp_te_params_create_shaped).
  * Bowe-Hopwood: the FIRST call with a new message shape (length, and for two-to-one buffers the length of the zero padding) may
  * build one more small table (the chunks the shape leaves after its last full group, with the padding's constant folded in:
  * <= 268 MB, milliseconds, kept in the handle; up to eight shapes) -- that call waits for the context's own stream once; every

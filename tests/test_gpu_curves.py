@@ -328,30 +328,79 @@ def test_table_info_of_the_baseline_windows(cpa):
     """akp_te_params_info for the BASELINE windows.  With a 320 MiB table budget (the tables of rounds 1-3, inside the Infinity
     Cache): Pedersen 4x256 with 16-bit signed digits (64 steps, one 128-byte line per entry), Bowe-Hopwood 63x9 with five chunks
     per step.  With the default budget on a 288 GB device: 24-bit digits (43 steps, 46 GB) and groups of eight chunks (75 GB);
-    the chunks a message length leaves after its last full group are one more step."""
+    the chunks a message length leaves after its last full group are one more step.  `table_bytes` is what the handle HOLDS: the
+    wide table is built for the message lengths that arrive (here: after one message of the maximum length)."""
     from crypto_primitives_amd import params as cparams
     from crypto_primitives_amd.crh import pedersen, bowe_hopwood
     ctx = cpa.default_context(0)
     pg, bg = cparams.pedersen_generators(0xA5A50004, 4, 256), cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    longest_p, longest_b = _msgs(1, 128, 1), _msgs(1, 212, 2)
     ctx.set_table_budget(320 << 20)
     try:
-        hp = pedersen.Parameters(pg).handle()
-        i = hp.info(128)
-        assert i == {"digit_bits_or_group": 16, "signed_subset": True, "table_bytes": ((64 << 15) + 65) * 128, "steps": 64}
+        P, B = pedersen.Parameters(pg), bowe_hopwood.Parameters(bg)
+        hp, hb = P.handle(), B.handle()
+        assert hp.info(128) == {"digit_bits_or_group": 16, "signed_subset": True, "table_bytes": 65 * 128, "steps": 64}  # nothing hashed yet
+        pedersen.CRH.evaluate_batch(P, longest_p)
+        assert hp.info(128) == {"digit_bits_or_group": 16, "signed_subset": True, "table_bytes": ((64 << 15) + 65) * 128, "steps": 64}
         assert hp.info(32)["steps"] == 16 and hp.info(0)["steps"] == 0
-        hb = bowe_hopwood.Parameters(bg).handle()
-        assert hb.info(32) == {"digit_bits_or_group": 5, "signed_subset": False, "table_bytes": (567 * 4 + (113 << 14)) * 128, "steps": 18}
+        assert hb.info(32) == {"digit_bits_or_group": 5, "signed_subset": False, "table_bytes": 567 * 4 * 128, "steps": 18}
+        bowe_hopwood.CRH.evaluate_batch(B, longest_b)
+        assert hb.info(32) == {"digit_bits_or_group": 5, "signed_subset": False, "table_bytes": (567 * 4 + (113 << 14) + 8) * 128, "steps": 18}  # + the 1-chunk remainder of 212 bytes
         assert hb.info(70)["steps"] == 38 and hb.info(64)["steps"] == 35  # 187 = 37 * 5 + 2 chunks: the two left over are one step
-        del hp, hb
+        del hp, hb, P, B
     finally:
         ctx.set_table_budget(0)
     if ctx.table_budget() >= 76 << 30:  # an idle 288 GB device
-        hp = pedersen.Parameters(pg).handle()
+        P, B = pedersen.Parameters(pg), bowe_hopwood.Parameters(bg)
+        hp, hb = P.handle(), B.handle()
+        pedersen.CRH.evaluate_batch(P, longest_p)
         assert hp.info(128) == {"digit_bits_or_group": 24, "signed_subset": True, "table_bytes": ((43 << 23) + 44) * 128, "steps": 43}
         assert hp.info(32)["steps"] == 11
-        hb = bowe_hopwood.Parameters(bg).handle()
-        assert hb.info(32) == {"digit_bits_or_group": 8, "signed_subset": False, "table_bytes": (567 * 4 + (70 << 23)) * 128, "steps": 11}
+        bowe_hopwood.CRH.evaluate_batch(B, _msgs(1, 64, 3))  # a tree node: 21 of the 70 groups + the 3-chunk remainder
+        assert hb.info(32) == {"digit_bits_or_group": 8, "signed_subset": False, "table_bytes": (567 * 4 + (21 << 23) + 512) * 128, "steps": 11}
         assert hb.info(64)["steps"] == 22 and hb.info(70)["steps"] == 24  # 171 = 21 * 8 + 3 chunks, 187 = 23 * 8 + 3
+
+
+def test_tables_grow_with_the_message_lengths(cpa):
+    """the wide table covers the digits / chunk groups the messages so far needed (te_ensure_units): every length against the
+    oracle while the table grows underneath, `table_bytes` never shrinks, and a resident tree that pinned the handle keeps
+    working after a longer message replaced the table it was built with"""
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    from crypto_primitives_amd import merkle_tree as mt
+    g = jj.pedersen_generators(0x61, 8, 40)   # 320 generators: 14 digits of 24 bits
+    gb = jj.bowe_hopwood_generators(0x62, 20, 12)  # 240 chunks: 30 groups of 8
+    P, B = pedersen.Parameters(gens_array(g), table_shape=24), bowe_hopwood.Parameters(gens_array(gb), table_shape=8)
+    seen_p = seen_b = 0
+    for L in (3, 4, 11, 12, 7, 25, 40):
+        m = _msgs(3, L, 300 + L)
+        dp = pedersen.CRH.evaluate_batch(P, m)
+        assert tuple(ints(dp[1])) == opd.evaluate(g, 8, 40, bytes(m[1])), L
+        tb = P.handle().info()["table_bytes"]
+        assert tb >= seen_p
+        seen_p = tb
+    assert seen_p == ((14 << 23) + 15) * 128
+    for L in (2, 9, 10, 33, 20, 64, 90):
+        m = _msgs(3, L, 400 + L)
+        db = bowe_hopwood.CRH.evaluate_batch(B, m)
+        assert ints(db[2])[0] == obh.evaluate(gb, 20, 12, bytes(m[2])), L
+        tb = B.handle().info()["table_bytes"]
+        assert tb >= seen_b
+        seen_b = tb
+    # a RESIDENT byte tree over 32-byte leaves pins the handle; a 90-byte hash on the same handle replaces the table it was built
+    # with; updates and proofs of the old tree then run on the new table and must agree with a tree built afterwards
+    B2 = bowe_hopwood.Parameters(gens_array(gb), table_shape=8)
+    leaves = _msgs(64, 32, 77)
+    tree = cpa.GpuMerkleTree.new(cpa.BoweHopwoodByteConfig, B2, B2, leaves)
+    before = B2.handle().info()["table_bytes"]
+    bowe_hopwood.CRH.evaluate_batch(B2, _msgs(2, 90, 5))
+    assert B2.handle().info()["table_bytes"] > before
+    new_leaf = _msgs(1, 32, 78)
+    tree.update_batch([5], new_leaf)
+    leaves[5] = new_leaf[0]
+    fresh = cpa.GpuMerkleTree.new(cpa.BoweHopwoodByteConfig, B2, B2, leaves)
+    assert np.array_equal(np.asarray(tree.root()), np.asarray(fresh.root()))
+    pa, pb = tree.generate_proof(9), fresh.generate_proof(9)
+    assert np.array_equal(np.asarray(pa.auth_path), np.asarray(pb.auth_path)) and pa.verify(B2, B2, tree.root(), leaves[9])
 
 
 @pytest.mark.parametrize("W,N", [(63, 9), (40, 14), (63, 13), (30, 19)])
