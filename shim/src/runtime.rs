@@ -141,7 +141,8 @@ impl ThreadRuntime {
         let rc = unsafe { ffi::akp_ctx_create(dev, &mut ctx) };
         assert_eq!(rc, ffi::AKP_OK, "akp_ctx_create({dev}) failed: there is no CPU fallback");
         // Poseidon constants are a few KB per set; a curve-hash set owns a precomputed table sized by the context's table budget
-        // (default: up to a quarter of the device's memory -- 46 GB for a 4x256 Pedersen window on an idle MI355X).  A host that
+        // (default: up to a quarter of the device's memory -- 46 GB for a 4x256 Pedersen window on an idle MI355X --, built for the
+        // message lengths that arrive).  A host that
         // needs the HBM for its own data lowers it: AKP_TABLE_BUDGET_MB here, or `set_table_budget` before the first curve hash.
         if let Some(mb) = std::env::var("AKP_TABLE_BUDGET_MB").ok().and_then(|s| s.parse::<usize>().ok()) {
             let rc = unsafe { ffi::akp_ctx_set_table_budget(ctx, mb << 20) };
