@@ -286,5 +286,27 @@ print('host', {k: v.get('ms_per_batch') for k, v in d['host_path'].items() if is
 print('predicted', json.dumps(d['predicted_scaling']['bh_merkle_weak'])[:400])
 PY
 ;;
-*) echo "usage: $0 s1 .. s39"; exit 2;;
+s40)
+# final state of round 4 (tables built for the message lengths that arrive): full suite, bench.py alone and under rocprofv3
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_s40; mkdir -p $OUT
+(timeout 3000 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED|^E  " | tail -12) > $OUT/pytest_gpu_full.txt; tail -3 $OUT/pytest_gpu_full.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-path --sustain-seconds 0 --no-sweep --proofs-log2 0 > $OUT/bench_under_rocprofv3.json 2> $OUT/bench_under_rocprofv3.err
+f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/rocprof_kernel_stats_bench_py.csv; rm -rf $OUT/prof
+cd $GRAFT_REPO_ROOT
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -2 $OUT/bench.err
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r04_s40/bench.json') if l.startswith('{')][-1])
+r=d['roofline']
+print('value %.4g ms/step %.3f eff %.1f power %s' % (d['value'], d['ms_per_step'], r['effective_sclk_mhz'] or 0, r['power_w_under_load']))
+p=d['pedersen']; print('pedersen', p['hashes_per_s'], p['ms_per_batch'], p['roofline']['traffic_over_algorithmic'], p['roofline']['valu']['frac_of_mad_issue_peak'], json.dumps(p.get('sustained')))
+b=d['bh_merkle']; print('bh', b['seconds'], b['leaves_per_s'], b['roofline']['traffic_over_algorithmic'], b['roofline']['valu']['frac_of_mad_issue_peak'])
+print('sweep', {k: (round(v['bh_tree_ms'],2), round(v['tree_ms'],2)) for k, v in d['sweep']['points'].items()})
+print('host', {k: v.get('ms_per_batch') for k, v in d['host_path'].items() if isinstance(v, dict)})
+print('predicted', json.dumps(d['predicted_scaling']['bh_merkle_weak'])[:400])
+PY
+;;
+*) echo "usage: $0 s1 .. s40"; exit 2;;
 esac
