@@ -3,6 +3,7 @@
 // point (a missing device is AKP_ERR_HIP).
 #include "capi_internal.hpp"
 #include "te_kernels.hpp"
+#include "te_shape.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Pedersen / Bowe-Hopwood
@@ -37,9 +38,9 @@ extern "C" size_t akp_ctx_table_budget(const akp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     return te_table_budget(ctx);
 }
-constexpr u32 TE_MAX_DIGIT = 24, TE_MAX_GROUP = 8;
-static inline size_t te_pedersen_entries(size_t n_gen, u32 D) { return ((n_gen + D - 1) / D) << (D - 1); }
-static inline size_t te_bh_entries(size_t n_gen, u32 G) { return (n_gen / G) << (3 * G - 1); }
+constexpr u32 TE_MAX_DIGIT = te_shape::MAX_DIGIT, TE_MAX_GROUP = te_shape::MAX_GROUP;
+static inline size_t te_pedersen_entries(size_t n_gen, u32 D) { return te_shape::pedersen_entries(n_gen, D); }
+static inline size_t te_bh_entries(size_t n_gen, u32 G) { return te_shape::bh_entries(n_gen, G); }
 // two-part construction of a wide table (te_kernels.hpp): part tables entry by entry, then one addition per wide entry.
 // KIND 2: Pedersen signed-subset table of `units` W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of
 // `units` groups of W chunks, generators `src`.
@@ -144,12 +145,7 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
         if (e == hipSuccess && bad == 0) {
-            u32 D = shape ? std::max(shape, 2u) : TE_MAX_DIGIT;
-            if (!shape) {
-                while (D > 2 && (te_pedersen_entries(n_gen, D) * sizeof(TeEntry) > budget || te_pedersen_entries(n_gen, D) >= max_entries)) --D;
-                // the narrowest digit with the same number of table steps (64 generators: 22 bits give the 3 steps that 24 bits give)
-                while (D > 2 && (n_gen + D - 2) / (D - 1) == (n_gen + D - 1) / D) --D;
-            }
+            const u32 D = shape ? std::max(shape, 2u) : te_shape::pick_digit(n_gen, budget, sizeof(TeEntry));
             if (te_pedersen_entries(n_gen, D) >= max_entries) e = hipErrorInvalidValue;
             const size_t n_digits = (n_gen + D - 1) / D;
             p->digit_bits = D;
@@ -181,9 +177,7 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
         if (d_half) (void)hipFree(d_half);
         if (d_bad) (void)hipFree(d_bad);
     } else {
-        u32 G = shape ? shape : TE_MAX_GROUP;
-        if (!shape)
-            while (G > 1 && (n_gen < G || te_bh_entries(n_gen, G) * sizeof(TeEntry) > budget || te_bh_entries(n_gen, G) >= max_entries)) --G;
+        u32 G = shape ? shape : te_shape::pick_group(n_gen, budget, sizeof(TeEntry));
         if (n_gen < G) G = (u32)n_gen;
         if (G > 1 && te_bh_entries(n_gen, G) >= max_entries) e = hipErrorInvalidValue;
         if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(TeEntry));
@@ -238,20 +232,11 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
 // bytes (those digits select the identity); Bowe-Hopwood stops at ceil(bits/3) chunks = `groups` triples +
 // left-over singles.
 static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32* n_steps) {
-    const size_t bits = msg_len * 8;
     if (te_is_pedersen(p)) {
-        const size_t used = std::min<size_t>(bits, p->n_gen);
         *n_groups = 0;
-        *n_steps = (u32)((used + p->digit_bits - 1) / p->digit_bits);
-        return;
-    }
-    const size_t chunks = std::min<size_t>((bits + 2) / 3, (size_t)p->n_gen);
-    if (p->group > 1) {
-        *n_groups = (u32)(chunks / p->group);
-        *n_steps = (u32)(chunks / p->group + chunks % p->group);
+        te_shape::pedersen_steps(p->n_gen, p->digit_bits, msg_len, n_steps);
     } else {
-        *n_groups = 0;
-        *n_steps = (u32)chunks;
+        te_shape::bh_steps(p->n_gen, p->group, msg_len, n_groups, n_steps);
     }
 }
 extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset, size_t* table_bytes,
@@ -358,7 +343,7 @@ static int32_t te_ensure_table(akp_te_params* p, size_t data_len, u32* groups, u
         const u32 shape = ped ? p->digit_bits : p->group;
         const bool can_narrow = p->shape_auto && shape > (ped ? 8u : 2u);
         auto bytes_of = [&](u32 units) { return ((size_t)units << (ped ? shape - 1 : 3 * shape - 1)) * sizeof(TeEntry); };
-        u32 target = std::min(p->units_total, std::max(needed, 2 * p->units_built));
+        u32 target = te_shape::grow_target(needed, p->units_built, p->units_total);
         if (p->d_lut) {
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipFree(p->d_lut));

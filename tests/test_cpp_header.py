@@ -92,3 +92,11 @@ def test_cpp_serialize_wrappers_against_the_oracle_bytes(tmp_path):
     out = p.stdout.splitlines()
     assert out[0] == "path depth 4 index 11" and out[1] == "path depth 0 index 0" and out[2] == "multipath m 3 suffix digests 6"
     assert out[3] == out[4] == "parameters 3 x 2" and out[5] == want_cfg and out[-1] == "OK %d cases" % len(cases)
+
+
+def test_te_shape_arithmetic():
+    """csrc/te_shape.hpp (what capi_te.hip decides table shapes, step counts and table growth with) against brute force: host only"""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_te_shape")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "test_te_shape.cpp"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "OK", p.stdout + p.stderr
