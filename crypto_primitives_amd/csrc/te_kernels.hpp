@@ -297,9 +297,8 @@ AKP_HD Niels te_pedersen_spart_entry(const NielsPad* __restrict__ half, u32 n_ge
     return niels_of_ext(acc);
 }
 // lo[u][w]: bits [0, k_lo) = w;   hi[u][w]: bits [k_lo, D - 1) = w, bit D - 1 set
-__global__ void te_build_pedersen_sparts(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_digits, u32 k_lo, TeEntry* __restrict__ lo,
-                                         TeEntry* __restrict__ hi) {
-    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+AKP_HD void te_pedersen_sparts_item(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_digits, u32 k_lo, TeEntry* __restrict__ lo,
+                                    TeEntry* __restrict__ hi, u32 idx) {
     const u32 n_lo = n_digits << k_lo, k_hi = D - 1u - k_lo, n_hi = n_digits << k_hi;
     if (idx < n_lo) {
         const u32 u = idx >> k_lo, w = idx & ((1u << k_lo) - 1u);
@@ -308,6 +307,10 @@ __global__ void te_build_pedersen_sparts(const NielsPad* __restrict__ half, u32 
         const u32 j = idx - n_lo, u = j >> k_hi, w = j & ((1u << k_hi) - 1u);
         store_niels(hi + j, te_pedersen_spart_entry(half, n_gen, D, u, k_lo, D, (w << k_lo) | (1u << (D - 1u))));
     }
+}
+__global__ void te_build_pedersen_sparts(const NielsPad* __restrict__ half, u32 n_gen, u32 D, u32 n_digits, u32 k_lo, TeEntry* __restrict__ lo,
+                                         TeEntry* __restrict__ hi) {
+    te_pedersen_sparts_item(half, n_gen, D, n_digits, k_lo, lo, hi, blockIdx.x * blockDim.x + threadIdx.x);
 }
 // sum_{i < cnt} (-1)^{r_i} (k_i + 1) G[first + i],  k_i = bits [2i, 2i + 2) of kbits, r_i = bit i of rbits
 AKP_HD Niels te_bh_part_entry(const Fr* __restrict__ gens_affine, size_t first, u32 cnt, u32 kbits, u32 rbits) {
@@ -323,8 +326,7 @@ AKP_HD Niels te_bh_part_entry(const Fr* __restrict__ gens_affine, size_t first, 
     return niels_of_ext(acc);
 }
 // parts of the group table: chunks [Gu, Gu + G_lo) (lo; chunk 0 carries no sign bit) and the G - G_lo chunks after them (hi)
-__global__ void te_build_bh_parts(const Fr* __restrict__ gens_affine, u32 G, u32 G_lo, u32 n_groups, TeEntry* __restrict__ lo, TeEntry* __restrict__ hi) {
-    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+AKP_HD void te_bh_parts_item(const Fr* __restrict__ gens_affine, u32 G, u32 G_lo, u32 n_groups, TeEntry* __restrict__ lo, TeEntry* __restrict__ hi, u32 idx) {
     const u32 G_hi = G - G_lo, lo_bits = 3u * G_lo - 1u, hi_bits = 3u * G_hi;
     const u32 n_lo = n_groups << lo_bits, n_hi = n_groups << hi_bits;
     if (idx < n_lo) {
@@ -335,13 +337,13 @@ __global__ void te_build_bh_parts(const Fr* __restrict__ gens_affine, u32 G, u32
         store_niels(hi + j, te_bh_part_entry(gens_affine, (size_t)G * u + G_lo, G_hi, w & ((1u << (2u * G_hi)) - 1u), w >> (2u * G_hi)));
     }
 }
+__global__ void te_build_bh_parts(const Fr* __restrict__ gens_affine, u32 G, u32 G_lo, u32 n_groups, TeEntry* __restrict__ lo, TeEntry* __restrict__ hi) {
+    te_bh_parts_item(gens_affine, G, G_lo, n_groups, lo, hi, blockIdx.x * blockDim.x + threadIdx.x);
+}
 // remainder table of the r chunks starting at chunk `first`: entry[bits] = sum_i (-1)^{s_i} (k_i + 1) G[first + i] (+ tail), the
 // chunk bits in message order (k_i = bits [3i, 3i + 2), s_i = bit 3i + 2).  `tail`: the constant of the zero-padded chunks
 // behind the data (te_bh_tail_kernel) or NULL.  Entry by entry: at most 2^21 entries, once per message shape.
-__global__ void te_build_bh_remainder(const Fr* __restrict__ gens_affine, u32 first, u32 r, const TeEntry* __restrict__ tail, u32 n_entries,
-                                      TeEntry* __restrict__ out) {
-    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_entries) return;
+AKP_HD Niels te_bh_remainder_entry(const Fr* __restrict__ gens_affine, u32 first, u32 r, const TeEntry* __restrict__ tail, u32 idx) {
     Ext acc = ext_identity();
 #pragma unroll 1
     for (u32 i = 0; i < r; ++i) {
@@ -352,7 +354,13 @@ __global__ void te_build_bh_remainder(const Fr* __restrict__ gens_affine, u32 fi
         for (u32 j = 0; j <= k; ++j) acc = te_madd(acc, gn);
     }
     if (tail) acc = te_madd(acc, load_niels(tail));
-    store_niels(out + idx, niels_of_ext(acc));
+    return niels_of_ext(acc);
+}
+__global__ void te_build_bh_remainder(const Fr* __restrict__ gens_affine, u32 first, u32 r, const TeEntry* __restrict__ tail, u32 n_entries,
+                                      TeEntry* __restrict__ out) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_entries) return;
+    store_niels(out + idx, te_bh_remainder_entry(gens_affine, first, r, tail, idx));
 }
 // indices of the two parts of wide entry `idx`.  KIND 2: Pedersen signed-subset (W = D, k_lo bits in the lo part);
 // KIND 1: Bowe-Hopwood group table (W = G, k_lo = G_lo chunks in the lo part; index layout of te_bh_lutg_entry)
@@ -370,17 +378,17 @@ AKP_HD void te_build_split(u32 W, u32 k_lo, u32 idx, u32* lo_idx, u32* hi_idx) {
         *hi_idx = (u << (3u * G_hi)) | (kk >> (2u * G_lo)) | ((rr >> (G_lo - 1u)) << (2u * G_hi));
     }
 }
-// lut[idx] = hi part + lo part, affine.  One lane builds AKP_TE_BUILD_RUN entries, 256 apart (coalesced across the lanes).
+// lut[idx] = hi part + lo part, affine.  One lane builds AKP_TE_BUILD_RUN entries, `stride` apart starting at `base` (the kernel:
+// stride 256 = the workgroup, coalesced across the lanes).
 template <int KIND>
-__global__ void __launch_bounds__(256) te_build_combine_kernel(const TeEntry* __restrict__ lo, const TeEntry* __restrict__ hi, u32 W, u32 k_lo,
-                                                              size_t n_entries, TeEntry* __restrict__ lut) {
-    const size_t base = (size_t)blockIdx.x * (256u * AKP_TE_BUILD_RUN) + threadIdx.x;
+AKP_HD void te_build_combine_lane(const TeEntry* __restrict__ lo, const TeEntry* __restrict__ hi, u32 W, u32 k_lo, size_t n_entries,
+                                  TeEntry* __restrict__ lut, size_t base, size_t stride) {
     FS pre[AKP_TE_BUILD_RUN];
     FS run = f29_one<true>();
     u32 cnt = 0;
 #pragma unroll 1
     for (u32 j = 0; j < AKP_TE_BUILD_RUN; ++j) {
-        const size_t e = base + (size_t)j * 256u;
+        const size_t e = base + (size_t)j * stride;
         if (e >= n_entries) break;
         u32 li, hi_i;
         te_build_split<KIND>(W, k_lo, (u32)e, &li, &hi_i);
@@ -394,12 +402,17 @@ __global__ void __launch_bounds__(256) te_build_combine_kernel(const TeEntry* __
     FS inv = f29_inv(run);  // Z != 0 always (complete formulas)
 #pragma unroll 1
     for (u32 j = cnt; j-- > 0;) {
-        const size_t e = base + (size_t)j * 256u;
+        const size_t e = base + (size_t)j * stride;
         const Niels xyz = load_niels(lut + e);
         const FS zi = f29_mul(inv, pre[j]);
         inv = f29_mul(inv, xyz.dxy);
         store_niels(lut + e, niels_from_affine(f29_mul(xyz.ypx, zi), f29_mul(xyz.ymx, zi)));
     }
+}
+template <int KIND>
+__global__ void __launch_bounds__(256) te_build_combine_kernel(const TeEntry* __restrict__ lo, const TeEntry* __restrict__ hi, u32 W, u32 k_lo,
+                                                              size_t n_entries, TeEntry* __restrict__ lut) {
+    te_build_combine_lane<KIND>(lo, hi, W, k_lo, n_entries, lut, (size_t)blockIdx.x * (256u * AKP_TE_BUILD_RUN) + threadIdx.x, 256u);
 }
 // test build: the wide table against the per-entry definition (canonical values), mismatches counted
 template <int KIND>

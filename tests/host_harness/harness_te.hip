@@ -49,6 +49,46 @@ void hh_te_crh(int kind, const TeEntry* lut, const TeEntry* lut1, const uint8_t*
         else te_finalize_lane<1>(xyz.data(), prefix.data(), out, n, lanes, l);
     }
 }
+// The two-part construction of the wide tables exactly as capi_te.hip's te_build_wide launches it (part tables, then one addition
+// per entry with the inversion shared by the AKP_TE_BUILD_RUN entries of a lane), for `units` digits (kind 2, shape = D) / chunk
+// groups (kind 1, shape = G): lut gets units << (D - 1) / units << (3G - 1) entries.
+void hh_te_build_wide(int kind, const Fr* gens, uint32_t W, uint32_t N, uint32_t shape, uint32_t units, TeEntry* lut) {
+    const u32 n_gen = W * N;
+    const u32 k_lo = kind == 2 ? (shape - 1) / 2 : shape / 2;
+    const size_t n_lo = kind == 2 ? (size_t)units << k_lo : (size_t)units << (3 * k_lo - 1);
+    const size_t n_hi = kind == 2 ? (size_t)units << (shape - 1 - k_lo) : (size_t)units << (3 * (shape - k_lo));
+    const size_t entries = kind == 2 ? (size_t)units << (shape - 1) : (size_t)units << (3 * shape - 1);
+    std::vector<TeEntry> lo(n_lo), hi(n_hi);
+    if (kind == 2) {
+        std::vector<NielsPad> half(n_gen);
+        for (u32 g = 0; g < n_gen; ++g) {
+            Niels h;
+            (void)te_half_generator(gens, g, h);
+            store_niels(&half[g], h);
+        }
+        for (size_t i = 0; i < n_lo + n_hi; ++i) te_pedersen_sparts_item(half.data(), n_gen, shape, units, k_lo, lo.data(), hi.data(), (u32)i);
+    } else {
+        for (size_t i = 0; i < n_lo + n_hi; ++i) te_bh_parts_item(gens, shape, k_lo, units, lo.data(), hi.data(), (u32)i);
+    }
+    const size_t per_block = 256 * (size_t)AKP_TE_BUILD_RUN;
+    for (size_t block = 0; block * per_block < entries; ++block)
+        for (size_t lane = 0; lane < 256; ++lane) {
+            if (kind == 2) te_build_combine_lane<2>(lo.data(), hi.data(), shape, k_lo, entries, lut, block * per_block + lane, 256);
+            else te_build_combine_lane<1>(lo.data(), hi.data(), shape, k_lo, entries, lut, block * per_block + lane, 256);
+        }
+}
+// Bowe-Hopwood remainder table (te_build_bh_remainder): the r chunks from chunk `first`, indexed by the raw message bits, with the
+// constant of the zero-padded tail chunks [tail_from, tail_to) folded in (tail_from >= tail_to: none); lut1 = the one-chunk table
+void hh_te_build_remainder(const Fr* gens, const TeEntry* lut1, uint32_t first, uint32_t r, uint32_t tail_from, uint32_t tail_to, TeEntry* out) {
+    TeEntry tail;
+    const bool has_tail = tail_from < tail_to;
+    if (has_tail) {
+        Ext acc = ext_from_niels(load_niels(lut1 + (size_t)tail_from * 4u));
+        for (u32 c = tail_from + 1; c < tail_to; ++c) acc = te_madd(acc, load_niels(lut1 + (size_t)c * 4u));
+        store_niels(&tail, niels_of_ext(acc));
+    }
+    for (u32 i = 0; i < (1u << (3 * r)); ++i) store_niels(out + i, te_bh_remainder_entry(gens, first, r, has_tail ? &tail : nullptr, i));
+}
 // the small-batch kernel's arithmetic (te_crh_small_kernel) on the CPU: `split` strided partial sums, a binary tree of
 // full additions, one inversion per message
 void hh_te_crh_split(int kind, const TeEntry* lut, const TeEntry* lut1, const uint8_t* msgs, size_t n, size_t msg_len, uint32_t D,

@@ -30,6 +30,8 @@ def H():
     h.hh_te_in_subgroup.restype = C.c_int
     h.hh_te_serialize_pairs.argtypes = [vp, vp, C.c_uint32, C.c_size_t, vp, C.c_size_t]
     h.hh_fr_pow.argtypes = [vp, C.c_uint64, vp]
+    h.hh_te_build_wide.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    h.hh_te_build_remainder.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     return h
 
 
@@ -338,6 +340,99 @@ def test_bowe_hopwood_table_path(H, W, N, group):
             out2 = np.zeros_like(out)
             H.hh_te_crh_split(1, P(lut3), P(lut1), P(m), n, L, group, groups, steps, split, P(out2))
             assert np.array_equal(out2, out), (W, N, group, L, split)
+
+
+def _canon(H, tbl, n):
+    """the first n table entries (128 bytes each: three lazy radix-2^29 values of nine limbs + padding) as canonical integers:
+    equal points <=> equal rows"""
+    t = np.ascontiguousarray(tbl, dtype=np.uint32).reshape(-1)[: n * 32].reshape(n, 32)
+    out = []
+    for row in t:
+        vals = []
+        for k in range(3):
+            v = 0
+            for i in range(9):
+                v += int(np.int32(row[9 * k + i])) << (29 * i)
+            vals.append(v % ofr.P)
+        out.append(tuple(vals))
+    return out
+
+
+@pytest.mark.parametrize("kind,W,N,shape", [(2, 5, 13, 7), (2, 5, 13, 10), (2, 4, 4, 2), (2, 4, 4, 3), (2, 3, 7, 12), (1, 7, 5, 2), (1, 7, 5, 3), (1, 7, 5, 4)])
+def test_two_part_table_construction_equals_the_per_entry_definition(H, kind, W, N, shape):
+    """te_build_wide as capi_te.hip launches it (round 4: two narrow part tables per digit / chunk group, ONE mixed addition per wide
+    entry, the inversion shared by the 16 entries of a lane) against the per-entry definition of rounds 1-3 (D additions and an
+    inversion of its own per entry) -- every entry, as canonical field values; also a table that covers only the first digits /
+    groups (what a handle builds for short messages) is the prefix of the complete one"""
+    if os.environ.get("AKP_HARNESS_SO") and kind == 1 and shape >= 4:
+        pytest.skip("2^11-entry groups: minutes under a sanitizer; the smaller shapes run there")
+    g = jj.pedersen_generators(40 + shape, W, N) if kind == 2 else jj.bowe_hopwood_generators(41 + shape, W, N)
+    G = gens_array(g)
+    n_gen = W * N
+    units = (n_gen + shape - 1) // shape if kind == 2 else n_gen // shape
+    per = 1 << (shape - 1) if kind == 2 else 1 << (3 * shape - 1)
+    ref = np.zeros((units * per, 36), np.uint32)
+    aux = np.zeros(((units + 1) if kind == 2 else n_gen * 4, 36), np.uint32)
+    H.hh_te_build_lut(kind, P(G), W, N, shape if kind == 2 else 0, shape if kind == 1 else 1, P(ref), P(aux))
+    wide = np.zeros_like(ref)
+    H.hh_te_build_wide(kind, P(G), W, N, shape, units, P(wide))
+    assert _canon(H, wide, units * per) == _canon(H, ref, units * per)
+    part = np.zeros(((units - 1) * per, 36), np.uint32) if units > 1 else None
+    if part is not None:
+        H.hh_te_build_wide(kind, P(G), W, N, shape, units - 1, P(part))
+        assert _canon(H, part, (units - 1) * per) == _canon(H, ref, (units - 1) * per)
+
+
+@pytest.mark.parametrize("W,N,group", [(13, 1, 7), (7, 5, 6), (7, 5, 5), (7, 5, 3), (20, 2, 6)])
+def test_bowe_hopwood_remainder_step_and_folded_tail(H, W, N, group):
+    """the chunks a message leaves after its last full group as ONE table step (te_build_bh_remainder: entries indexed by the raw
+    message bits), with the constant of a zero-padded tail folded in: every message length against the oracle, through the
+    software-pipelined accumulation and the split kernel's arithmetic; the two-to-one shape (data bytes + zero padding) against the
+    oracle on the padded buffer"""
+    if os.environ.get("AKP_HARNESS_SO") and group >= 6:
+        pytest.skip("2^17-entry groups and more: minutes under a sanitizer; groups of 3 and 5 run there")
+    g = jj.bowe_hopwood_generators(60 + group, W, N)
+    G = gens_array(g)
+    n_gen = W * N
+    n_groups_all = n_gen // group
+    lut1 = np.zeros((n_gen * 4, 36), np.uint32)
+    small = np.zeros((1, 36), np.uint32)
+    H.hh_te_build_lut(1, P(G), W, N, 0, 1, P(small), P(lut1))
+    lut = np.zeros((n_groups_all << (3 * group - 1), 36), np.uint32)
+    H.hh_te_build_wide(1, P(G), W, N, group, n_groups_all, P(lut))
+    maxL = n_gen * 3 // 8
+    n = 3
+    for L in range(1, maxL + 1):
+        chunks = min((8 * L + 2) // 3, n_gen)
+        groups, r = chunks // group, chunks % group
+        m = np.frombuffer(ofr.SplitMix64(7 * L + group).bytes(L * n), dtype=np.uint8).copy()
+        out = np.zeros((n, 4), np.uint64)
+        if r == 0:
+            H.hh_te_crh(1, P(lut), P(lut1), P(m), n, L, group, groups, groups, 2, P(out))
+        else:
+            rem = np.zeros((1 << (3 * r), 36), np.uint32)
+            H.hh_te_build_remainder(P(G), P(lut1), group * groups, r, 0, 0, P(rem))
+            H.hh_te_crh(1, P(lut), P(rem), P(m), n, L, group | (r << 8), groups, groups + 1, 2, P(out))
+            out2 = np.zeros_like(out)
+            H.hh_te_crh_split(1, P(lut), P(rem), P(m), n, L, group | (r << 8), groups, groups + 1, 4, P(out2))
+            assert np.array_equal(out2, out), (group, L)
+        for i in range(n):
+            assert ints(out[i])[0] == bh.evaluate(g, W, N, bytes(m[i * L:(i + 1) * L])), (W, N, group, L, r)
+    # two-to-one shape: `data` bytes followed by zero padding up to the buffer length; the padding's chunks are a constant in the remainder entries
+    for data, buflen in ((4, maxL), (6, maxL), (maxL - 3, maxL), (5, 9)):
+        chunks = min((8 * data + 2) // 3, n_gen)
+        groups, r = chunks // group, chunks % group
+        if r == 0 or buflen > maxL or data >= buflen or data < 1:
+            continue
+        tail_to = min((8 * buflen + 2) // 3, n_gen)
+        rem = np.zeros((1 << (3 * r), 36), np.uint32)
+        H.hh_te_build_remainder(P(G), P(lut1), group * groups, r, chunks, tail_to, P(rem))
+        m = np.frombuffer(ofr.SplitMix64(90 + data).bytes(data * n), dtype=np.uint8).copy()
+        out = np.zeros((n, 4), np.uint64)
+        H.hh_te_crh(1, P(lut), P(rem), P(m), n, data, group | (r << 8), groups, groups + 1, 2, P(out))
+        for i in range(n):
+            padded = bytes(m[i * data:(i + 1) * data]) + bytes(buflen - data)
+            assert ints(out[i])[0] == bh.evaluate(g, W, N, padded), (group, data, buflen)
 
 
 def test_digest_serialisation(H):
