@@ -106,6 +106,8 @@ void hh_te_crh_split(int kind, const TeEntry* lut, const TeEntry* lut1, const ui
         else out[i] = f29_to_wire(f29_mul(part[0].X, zi));
     }
 }
+// the w message bits at bit offset o as a table step reads them: ONE 32-bit window (msg_load) and a shift (msg_combine)
+uint32_t hh_te_window(const uint8_t* msg, size_t len, size_t o, uint32_t w) { return msg_combine(msg_load(msg, len, o), len, o, w); }
 // 1 when the generator is in the prime-order subgroup (2 * (G / 2) == G)
 int hh_te_in_subgroup(const Fr* gen_affine) {
     Niels h;

@@ -30,6 +30,8 @@ def H():
     h.hh_te_in_subgroup.restype = C.c_int
     h.hh_te_serialize_pairs.argtypes = [vp, vp, C.c_uint32, C.c_size_t, vp, C.c_size_t]
     h.hh_fr_pow.argtypes = [vp, C.c_uint64, vp]
+    h.hh_te_window.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_uint32]
+    h.hh_te_window.restype = C.c_uint32
     h.hh_te_build_wide.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     h.hh_te_build_remainder.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     return h
@@ -340,6 +342,23 @@ def test_bowe_hopwood_table_path(H, W, N, group):
             out2 = np.zeros_like(out)
             H.hh_te_crh_split(1, P(lut3), P(lut1), P(m), n, L, group, groups, steps, split, P(out2))
             assert np.array_equal(out2, out), (W, N, group, L, split)
+
+
+def test_message_window_of_a_table_step_for_every_digit_width(H):
+    """a table step reads its message bits through one unaligned 32-bit word whose address is pulled back at the end of the message
+    (msg_load / msg_combine): digits of 1 .. 24 bits (groups of up to eight 3-bit chunks) at every bit offset of messages of 4 .. 19
+    bytes equal the bits of the little-endian integer, and read as zero past the end"""
+    rng = ofr.SplitMix64(2024)
+    for L in list(range(4, 20)) + [32, 70, 128]:
+        msg = np.frombuffer(rng.bytes(L), dtype=np.uint8).copy()
+        val = int.from_bytes(bytes(msg), "little")
+        for w in (1, 3, 8, 13, 16, 17, 20, 21, 23, 24):
+            for u in range(0, (8 * L) // w + 2):
+                o = u * w
+                if o >= 8 * L + w:
+                    break
+                want = (val >> o) & ((1 << w) - 1) if o < 8 * L else 0
+                assert H.hh_te_window(P(msg), L, o, w) == want, (L, w, u)
 
 
 def _canon(H, tbl, n):
