@@ -323,13 +323,21 @@ def test_two_part_table_construction_equals_the_per_entry_definition(cpa, monkey
     from crypto_primitives_amd.crh import pedersen, bowe_hopwood
     g = gens_array(jj.pedersen_generators(0x52, 5, 13))        # 65 generators: the last digit is clipped at every width
     gb = gens_array(jj.bowe_hopwood_generators(0x53, 7, 5))    # 35 chunks
+    mp, mbh = np.frombuffer(ofr.SplitMix64(9).bytes(8), dtype=np.uint8).reshape(1, 8).copy(), np.frombuffer(ofr.SplitMix64(10).bytes(13), dtype=np.uint8).reshape(1, 13).copy()
+
+    def built(P, m, cls):  # the table is built by the first hash: a message of the maximum length builds (and checks) all of it
+        cls.evaluate_batch(P, m)
+        return P.handle().info()
+
     monkeypatch.setenv("AKP_TE_TABLE_CHECK", "1")
     for D in (2, 3, 4, 5, 8, 11, 13, 16):
-        assert pedersen.Parameters(g, table_shape=D).handle().info()["digit_bits_or_group"] == D
+        i = built(pedersen.Parameters(g, table_shape=D), mp, pedersen.CRH)
+        assert i["digit_bits_or_group"] == D and i["table_bytes"] >= (-(-64 // D) << (D - 1)) * 128  # the digits 64 message bits reach
     for G in (2, 3, 4, 5):
-        assert bowe_hopwood.Parameters(gb, table_shape=G).handle().info()["digit_bits_or_group"] == G
+        i = built(bowe_hopwood.Parameters(gb, table_shape=G), mbh, bowe_hopwood.CRH)
+        assert i["digit_bits_or_group"] == G and i["table_bytes"] >= ((35 // G) << (3 * G - 1)) * 128
     monkeypatch.setenv("AKP_TE_TABLE_CHECK", "4099")
     for D in (20, 24):
-        assert pedersen.Parameters(g, table_shape=D).handle().info()["digit_bits_or_group"] == D
+        assert built(pedersen.Parameters(g, table_shape=D), mp, pedersen.CRH)["digit_bits_or_group"] == D
     for G in (6, 7, 8):
-        assert bowe_hopwood.Parameters(gb, table_shape=G).handle().info()["digit_bits_or_group"] == G
+        assert built(bowe_hopwood.Parameters(gb, table_shape=G), mbh, bowe_hopwood.CRH)["digit_bits_or_group"] == G
