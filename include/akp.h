@@ -369,7 +369,11 @@ int32_t akp_serialize_digests(const uint64_t* digests, size_t n, uint32_t fe_per
                               size_t out_cap, size_t* out_len);
 int32_t akp_deserialize_digests(const uint8_t* in, size_t in_len, size_t n, uint32_t fe_per_digest, int32_t compress,
                                 int32_t validate, uint64_t* digests);
-/* PoseidonConfig: both modes write the same bytes.  The reader builds a handle (ctx may be NULL: host-only handle). */
+/* PoseidonConfig: both modes write the same bytes.  The reader builds a handle (ctx may be NULL: host-only handle) and therefore
+ * refuses (AKP_ERR_BAD_PARAMS) field values no handle can be built from -- ark rows != full + partial rounds, a row or mds not
+ * t = rate + capacity wide, odd full_rounds, alpha 0 -- which the reference's derive reads without complaint and panics on at the
+ * first permutation.  Likewise akp_deserialize_multipath wants its four vectors of one length and akp_deserialize_te_parameters
+ * windows of one size (tests/test_serialize_fuzz.py pins these differences against the oracle reader). */
 int32_t akp_serialize_poseidon_config(const akp_poseidon* p, uint8_t* out, size_t out_cap, size_t* out_len);
 int32_t akp_deserialize_poseidon_config(akp_ctx* ctx, const uint8_t* in, size_t in_len, akp_poseidon** out);
 /* Parameters { generators: Vec<Vec<C>> }: generators_affine is [num_windows][window_size] points as in akp_te_params_create.

@@ -50,7 +50,8 @@ def _have_xdist():
 def _sanitizer_builds():
     """the three sanitizer builds side by side (2.5 min + 40 s + 2 s when nothing is built yet; no-ops afterwards)"""
     jobs = [subprocess.Popen(["make", "-C", HARNESS, "-s", "asan"]), subprocess.Popen(["make", "-C", HARNESS, "-s", "ubsan"]),
-            subprocess.Popen(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"], stderr=subprocess.DEVNULL)]
+            subprocess.Popen(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"], stderr=subprocess.DEVNULL),
+            subprocess.Popen(["make", "-C", os.path.join(ROOT, "crypto_primitives_amd", "csrc"), "-s", "asan"], stdout=subprocess.DEVNULL)]
     for j in jobs:
         assert j.wait() == 0, "a sanitizer build failed"
 
@@ -109,3 +110,26 @@ def test_c_oracle_under_sanitizers():
     env = {"LD_PRELOAD": _rt("libclang_rt.asan-x86_64.so"), "ASAN_OPTIONS": "detect_leaks=0", "UBSAN_OPTIONS": "halt_on_error=1", "AKP_ORACLE_SO": so}
     cp = _child(env, ["tests/test_oracle_poseidon.py", "tests/test_oracle_curves.py", "tests/test_reference_vectors.py", "-m", "not gpu"])
     _assert_clean(cp, "C oracle (ASan + UBSan)")
+
+
+def test_byte_format_readers_of_the_library_under_address_sanitizer():
+    """libakp_asan.so (`make -C crypto_primitives_amd/csrc asan`: the product library with AddressSanitizer on its host code) behind
+    the byte-format tests: every struct against the oracle's bytes, the rejection cases, and the mutation fuzz of
+    tests/test_serialize_fuzz.py -- akp_deserialize_* is the one place where the library parses bytes it did not produce"""
+    so = os.path.join(ROOT, "crypto_primitives_amd", "lib", "libakp_asan.so")
+    env = {"LD_PRELOAD": _rt("libclang_rt.asan-x86_64.so"), "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "AKP_LIB": so}
+    cp = _child(env, ["tests/test_serialize_cpu.py", "tests/test_serialize_fuzz.py"], timeout=1500)
+    _assert_clean(cp, "byte-format readers (ASan)")
+    # the sanitizer is live in THAT library: a digest array one element too short for akp_deserialize_digests -> heap-buffer-overflow
+    code = ("import ctypes as C, numpy as np\n"
+            "L = C.CDLL(%r)\n"
+            "vp = C.c_void_p\n"
+            "L.akp_deserialize_digests.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, vp]\n"
+            "src = np.zeros(4096 * 32, np.uint8)\n"
+            "dst = np.empty((4095, 4), np.uint64)\n"   # 4096 field elements need 4096 x 4 words
+            "rc = L.akp_deserialize_digests(src.ctypes.data, src.size, 4096, 1, 0, 1, dst.ctypes.data)\n"
+            "print('not caught', rc)\n") % so
+    e = dict(os.environ)
+    e.update(env)
+    cp = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert cp.returncode != 0 and "AddressSanitizer" in cp.stderr and "not caught" not in cp.stdout, cp.stderr[-1500:]
