@@ -118,7 +118,8 @@ def test_byte_format_readers_of_the_library_under_address_sanitizer():
     tests/test_serialize_fuzz.py -- akp_deserialize_* is the one place where the library parses bytes it did not produce"""
     so = os.path.join(ROOT, "crypto_primitives_amd", "lib", "libakp_asan.so")
     env = {"LD_PRELOAD": _rt("libclang_rt.asan-x86_64.so"), "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "AKP_LIB": so}
-    cp = _child(env, ["tests/test_serialize_cpu.py", "tests/test_serialize_fuzz.py"], timeout=1500)
+    # (+ tests/test_abi.py: the other host-only entry points -- parameter generation, MultiPath encode / decode, path gathering)
+    cp = _child(env, ["tests/test_serialize_cpu.py", "tests/test_serialize_fuzz.py", "tests/test_abi.py"], timeout=1500)
     _assert_clean(cp, "byte-format readers (ASan)")
     # the sanitizer is live in THAT library: a digest array one element too short for akp_deserialize_digests -> heap-buffer-overflow
     code = ("import ctypes as C, numpy as np\n"
