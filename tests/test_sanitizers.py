@@ -51,7 +51,8 @@ def _sanitizer_builds():
     """the three sanitizer builds side by side (2.5 min + 40 s + 2 s when nothing is built yet; no-ops afterwards)"""
     jobs = [subprocess.Popen(["make", "-C", HARNESS, "-s", "asan"]), subprocess.Popen(["make", "-C", HARNESS, "-s", "ubsan"]),
             subprocess.Popen(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"], stderr=subprocess.DEVNULL),
-            subprocess.Popen(["make", "-C", os.path.join(ROOT, "crypto_primitives_amd", "csrc"), "-s", "asan"], stdout=subprocess.DEVNULL)]
+            subprocess.Popen(["make", "-C", os.path.join(ROOT, "crypto_primitives_amd", "csrc"), "-s", "asan"], stdout=subprocess.DEVNULL),
+            subprocess.Popen(["make", "-C", os.path.join(ROOT, "crypto_primitives_amd", "csrc"), "-s", "ubsan"], stdout=subprocess.DEVNULL)]
     for j in jobs:
         assert j.wait() == 0, "a sanitizer build failed"
 
@@ -112,7 +113,7 @@ def test_c_oracle_under_sanitizers():
     _assert_clean(cp, "C oracle (ASan + UBSan)")
 
 
-def test_byte_format_readers_of_the_library_under_address_sanitizer():
+def test_byte_format_readers_of_the_library_under_sanitizers():
     """libakp_asan.so (`make -C crypto_primitives_amd/csrc asan`: the product library with AddressSanitizer on its host code) behind
     the byte-format tests: every struct against the oracle's bytes, the rejection cases, and the mutation fuzz of
     tests/test_serialize_fuzz.py -- akp_deserialize_* is the one place where the library parses bytes it did not produce"""
@@ -134,3 +135,9 @@ def test_byte_format_readers_of_the_library_under_address_sanitizer():
     e.update(env)
     cp = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
     assert cp.returncode != 0 and "AddressSanitizer" in cp.stderr and "not caught" not in cp.stdout, cp.stderr[-1500:]
+    # the same tests against libakp_ubsan.so (`make ... ubsan`): signed overflow, shifts, alignment and bounds in the host code --
+    # the field arithmetic of the point decoders (square roots, curve and subgroup checks) and the cursor arithmetic of the readers
+    so = os.path.join(ROOT, "crypto_primitives_amd", "lib", "libakp_ubsan.so")
+    env = {"LD_PRELOAD": _rt("libclang_rt.ubsan_standalone-x86_64.so"), "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=0", "AKP_LIB": so}
+    cp = _child(env, ["tests/test_serialize_cpu.py", "tests/test_serialize_fuzz.py", "tests/test_abi.py"], timeout=1500)
+    _assert_clean(cp, "byte-format readers (UBSan)")
