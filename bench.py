@@ -334,11 +334,11 @@ def main():
     if world == 1:
         out["predicted_scaling"] = scaling.predict(merkle, bh_merkle)
     elif args.merkle_log2 == 24 and args.bh_merkle_log2 == 23:
-        # N > 1: the model calibrated on the committed one-GPU line (profiles/r04_s7/bench.json), so that THIS run's measured tree times
+        # N > 1: the model calibrated on the committed one-GPU line (profiles/r04_s14/bench.json), so that THIS run's measured tree times
         # stand next to what the design implied for them
-        ref = scaling.predict({"leaves": 1 << 24, "seconds": 0.0641}, {"leaves_per_gpu": 1 << 23, "seconds": 0.0246})
+        ref = scaling.predict({"leaves": 1 << 24, "seconds": 0.0656}, {"leaves_per_gpu": 1 << 23, "seconds": 0.0170})
         key = "%d_gpus" % world
-        out["predicted_scaling"] = {"calibrated_on": "profiles/r04_s7/bench.json (one GPU: Poseidon 2^24 leaves 0.0641 s, Bowe-Hopwood 2^23 leaves 0.0246 s)",
+        out["predicted_scaling"] = {"calibrated_on": "profiles/r04_s14/bench.json (one GPU: Poseidon 2^24 leaves 0.0656 s, Bowe-Hopwood 2^23 leaves 0.0170 s)",
                                     "model": ref["model"],
                                     "merkle_strong": {"predicted": ref["merkle_strong"].get(key), "measured_seconds": merkle["seconds"] if merkle else None},
                                     "bh_merkle_weak": {"predicted": ref["bh_merkle_weak"].get(key), "measured_seconds": bh_merkle["seconds"] if bh_merkle else None}}

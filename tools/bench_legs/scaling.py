@@ -25,10 +25,11 @@ def _tree_time(per_device_leaves, hash_rate, narrow_ms, exchange_ms, log2g):
     return wide_s + (narrow_levels + log2g) * narrow_ms / 1e3 + (exchange_ms / 1e3 if log2g else 0.0)
 
 
-def predict(merkle, bh_merkle, narrow_poseidon_ms=0.098, narrow_bh_ms=0.081):
+def predict(merkle, bh_merkle, narrow_poseidon_ms=0.098, narrow_bh_ms=0.092):
     out = {"model": "t(G) = wide levels at the measured one-GPU hash rate + 16 narrow levels per device + log2 G top levels at one launch latency each "
                     "+ one latency-bound all-gather; tools/bench_legs/scaling.py",
-           "narrow_level_ms": {"poseidon": narrow_poseidon_ms, "bowe_hopwood": narrow_bh_ms, "source": "profiles/r03_s7/level_gaps.txt, DESIGN.md section 6"}}
+           "narrow_level_ms": {"poseidon": narrow_poseidon_ms, "bowe_hopwood": narrow_bh_ms, "source": "Poseidon: profiles/r03_s7/level_gaps.txt; Bowe-Hopwood: 73 us split kernel + 19 us pair serialisation per level, "
+                                                "profiles/r04_s13/rocprof_kernel_stats_bench_py.csv"}}
     if merkle and merkle.get("seconds"):
         n = merkle["leaves"]
         leg = merkle.get("one_process_c_abi") or {}
