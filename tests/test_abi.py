@@ -188,6 +188,52 @@ def test_multipath_encode_decode_host(derived):
     assert cpa.lib.akp_merkle_multipath_decode(pre.ctypes.data, suf.ctypes.data, cnt.value, m, depth, 1, back.ctypes.data) == 2
 
 
+def test_multipath_encode_decode_random_and_hostile_inputs():
+    """akp_merkle_multipath_encode / _decode (host only) on random path sets against a direct restatement of prefix_encode_path /
+    prefix_decode_path (merkle_tree/mod.rs:795-817), then the decoder on hostile inputs -- prefix lengths beyond the depth or near
+    2^64, a first path with a prefix, too few / too many suffix digests: a status code, nothing written past the buffers
+    (tests/test_sanitizers.py runs this against the ASan / UBSan builds of the library)"""
+    import ctypes as C
+    import crypto_primitives_amd as cpa
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        m, depth, fe = int(rng.integers(1, 9)), int(rng.integers(0, 7)), int(rng.integers(1, 3))
+        auth = rng.integers(0, 1 << 62, size=(m, max(depth, 1), fe * 4), dtype=np.uint64)[:, :depth]
+        for i in range(1, m):  # share a random prefix with the previous path
+            k = int(rng.integers(0, depth + 1))
+            auth[i, :k] = auth[i - 1, :k]
+        auth = np.ascontiguousarray(auth)
+        want_pre, want_suf = [], []
+        for i in range(m):
+            k = 0
+            if i:
+                while k < depth and np.array_equal(auth[i, k], auth[i - 1, k]):
+                    k += 1
+            want_pre.append(k)
+            want_suf.extend(auth[i, k:].reshape(-1, fe * 4))
+        pre = np.zeros(m, np.uint64)
+        suf = np.zeros((max(m * depth, 1), fe * 4), np.uint64)
+        cnt = C.c_size_t()
+        assert cpa.lib.akp_merkle_multipath_encode(auth.ctypes.data if auth.size else None, m, depth, fe, pre.ctypes.data, suf.ctypes.data, C.byref(cnt)) == 0
+        assert pre.tolist() == want_pre and cnt.value == len(want_suf)
+        assert cnt.value == 0 or np.array_equal(suf[:cnt.value], np.asarray(want_suf))
+        back = np.full_like(auth, 7) if auth.size else auth
+        assert cpa.lib.akp_merkle_multipath_decode(pre.ctypes.data, suf.ctypes.data, cnt.value, m, depth, fe, back.ctypes.data if back.size else None) == 0
+        assert np.array_equal(back, auth)
+        # hostile decodes: never a crash, never success
+        guard = np.full((m * max(depth, 1) + 2, fe * 4), 0xA5A5A5A5A5A5A5A5, np.uint64)  # the output buffer with two digests of canary behind it
+        out = guard[: m * max(depth, 1)]
+        for bad_pre, bad_cnt in ((pre.copy(), cnt.value + 1), (pre.copy(), max(cnt.value, 1) - 1 if cnt.value else 1),
+                                 (np.where(np.arange(m) == m - 1, depth + 1, pre).astype(np.uint64), cnt.value),
+                                 (np.where(np.arange(m) == 0, 1, pre).astype(np.uint64), cnt.value),
+                                 (np.full(m, (1 << 64) - 1, np.uint64), cnt.value), (np.full(m, 1 << 63, np.uint64), 0)):
+            if depth == 0 and bad_cnt == cnt.value and np.array_equal(bad_pre, pre):
+                continue
+            rc = cpa.lib.akp_merkle_multipath_decode(bad_pre.ctypes.data, suf.ctypes.data, bad_cnt, m, depth, fe, out.ctypes.data)
+            assert rc in (1, 2), (trial, m, depth, bad_pre.tolist(), bad_cnt, rc)
+            assert np.all(guard[m * max(depth, 1):] == 0xA5A5A5A5A5A5A5A5)
+
+
 def test_multi_device_and_tree_entry_points_fail_loudly_without_gpu():
     import ctypes as C
     import crypto_primitives_amd as cpa
