@@ -47,6 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+from bench_legs.line import compact  # noqa: E402
 from bench_legs.common import (ALGO_BYTES_PER_PERM, HBM_PEAK_GBS, MADS_PER_PERM, MODMUL_PER_PERM_REF, NOMINAL_SCLK_MHZ, PMC_TRAFFIC_BYTES_PER_PERM,  # noqa: E402
                                PMC_TRAFFIC_SOURCE, ClockProbe, Env, gpu_clock_mhz, gpu_sensors, measure_hbm_copy, valu_peak_wave_instr)
 
@@ -301,6 +302,7 @@ def main():
         "curve_parity": curve_parity_status(),
         "roofline": {"bound": "hbm", "kernel": parity["probe_kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_PERM * n,
+                     "traffic_source": PMC_TRAFFIC_SOURCE,
                      "traffic_static_from": PMC_TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                             "correction; NOT measured in this run)",
                      "peak_measured_copy": hbm_copy_gbs, "frac_of_measured_copy": achieved / hbm_copy_gbs if hbm_copy_gbs else None,
@@ -344,7 +346,12 @@ def main():
                                     "bh_merkle_weak": {"predicted": ref["bh_merkle_weak"].get(key), "measured_seconds": bh_merkle["seconds"] if bh_merkle else None}}
     if not args.no_cpu_baseline and world == 1:
         cpu_leg.run(env, out, host_states, n, value, pedersen, bh_merkle)
-    print(json.dumps(out))
+    # the full record goes to a file; stdout gets ONE short line (tools/bench_legs/line.py: < 6 KB, the driver parses its last line)
+    full_path = os.environ.get("AKP_BENCH_FULL", os.path.join(ROOT, "bench_full.json"))
+    with open(full_path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    sys.stdout.flush()
+    print(json.dumps(compact(out, os.path.basename(full_path))), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -44,3 +44,40 @@ def test_bench_curve_parity_string_and_help():
     assert s.startswith("unpinned (emitter not run)") or s.startswith("pinned by")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "--sweep-max-log2" in p.stdout and "--gpus" in p.stdout
+
+
+def test_compact_line_of_committed_full_records_is_short_and_complete():
+    """tools/bench_legs/line.py on every full record committed under profiles/ (round 4's 22 KB line among them): the printed line
+    stays under the limit, carries the contract keys with scalar-only legs, and agrees with the record it was cut from"""
+    import glob
+    from bench_legs import line as line_mod
+    recs = [p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]_*", "bench*.json"))]
+    assert recs
+    seen = 0
+    for p in recs:
+        try:
+            full = json.load(open(p))
+        except ValueError:
+            continue
+        if not isinstance(full, dict) or "roofline" not in full or "parity" not in full or "timed_buffer_states_checked" not in full["parity"]:
+            continue
+        ln = line_mod.compact(full)
+        s = json.dumps(ln)
+        assert len(s) < line_mod.LIMIT == 6000, (p, len(s))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config", "roofline", "cpu_baseline", "legs", "full"):
+            assert k in ln, (p, k)
+        assert ln["value"] == full["value"] and set(ln["config"]) == {"workload", "states_per_gpu", "parallelism"}
+        assert all(not isinstance(v, (dict, list)) for v in ln["legs"].values())
+        assert all(not isinstance(v, (dict, list)) for v in ln["roofline"].values())
+        if full.get("cpu_baseline"):
+            assert ln["cpu_baseline"]["value"] > 0 and ln["cpu_baseline"]["kind"] in ("port", "reference")
+        else:
+            assert ln["cpu_baseline"] is None
+        seen += 1
+    assert seen >= 1
+    # N > 1 shape: no cpu_baseline in the record -> an explicit null in the line
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_s14", "bench.json")))
+    full.pop("cpu_baseline"), full.pop("gpu_over_cpu")
+    full["n_gpus"] = 8
+    assert line_mod.compact(full)["cpu_baseline"] is None

@@ -44,6 +44,7 @@ def run(env, out, host_states, n, value, pedersen, bh_merkle):
     out["cpu_baseline"] = {"value": rate_n, "unit": "permutations/s", "cores": eff_cores, "cores_basis": basis, "kind": "port",
                            "threads_used": threads, "rate_1_thread": rate1, "effective_cores": rate_n / rate1,
                            "hardware_threads": hw, **info,
+                           "sample_short": "%d permutations of the timed 2^%d states, oracle/c/akp_oracle.c (reference-shaped port), %d pthreads" % (sample, args.log2_states, threads),
                            "sample": "%d permutations over the same 2^%d states, reference-shaped C restatement (oracle/c/akp_oracle.c: "
                                      "dense MDS, square-and-multiply, one permutation per call as the reference), %d pthreads (best of a "
                                      "thread-count sweep); `cores` = min(affinity, cgroup quota, hardware threads) = what this container "
