@@ -154,6 +154,11 @@ def main():
     from bench_legs import bh_merkle as bh_leg, cpu_baseline as cpu_leg, host_path as host_leg, merkle as merkle_leg, pedersen as ped_leg, scaling, sustained as sus_leg, sweep as sweep_leg
 
     ctx = cpa.default_context(local_rank)
+    # curve tables: the library's default is the cache-sized table (fast from cold); the warm legs below opt into the HBM-sized ones
+    # (AKP_TABLE_BUDGET_DEVICE), and the pedersen / bh_merkle legs report BOTH, cold and warm.  Ranks that share one GPU (test hook)
+    # keep the default: every process would build tables of its own.
+    if not shared_gpu:
+        ctx.set_table_budget(cpa._lib.TABLE_BUDGET_DEVICE)
     cfg = cpa.get_default_poseidon_parameters(2, False)
     ph = cfg.handle(ctx)
     n = 1 << args.log2_states
@@ -289,7 +294,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "i32 limbs (255-bit Montgomery integers, radix 2^29 x 9, 64-bit v_mad_i64_i32 accumulation)",
+        "dtype": "i32",
+        "dtype_detail": "255-bit Montgomery integers as 9 limbs of 29 bits in 32-bit registers, 64-bit v_mad_i64_i32 accumulation",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batched Poseidon permutation, BLS12-381 Fr, t=3 rate=2 alpha=17 RF=8 RP=31 "
                                "(default Grain-LFSR parameters), 2^%d states per GPU, in place in HBM" % args.log2_states,
@@ -300,6 +306,8 @@ def main():
         "parity_probe_bit_exact": parity["bit_exact"],
         "parity": parity,
         "curve_parity": curve_parity_status(),
+        "curve_tables": "warm curve-hash legs run with akp_ctx_set_table_budget(AKP_TABLE_BUDGET_DEVICE) (HBM-sized tables, opt-in); the library default is the "
+                        "cache-sized table: pedersen.tables / bh_merkle.tables hold cold-start and warm figures of both" if not shared_gpu else "library default (cache-sized)",
         "roofline": {"bound": "hbm", "kernel": parity["probe_kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_PERM * n,
                      "traffic_source": PMC_TRAFFIC_SOURCE,

@@ -19,7 +19,7 @@ class Parameters:
     """pedersen::Parameters<C> / bowe_hopwood::Parameters<P> { generators } (pedersen/mod.rs:28-31).
     generators: wire-format affine points [NUM_WINDOWS, WINDOW_SIZE, 2, 4], used verbatim.
     table_shape: digit width (Pedersen, 2..24) / chunks per table step (Bowe-Hopwood, 1..8) of the device tables built for
-    these generators; 0 = the widest the context's table budget admits (akp_te_params_create_shaped).  A tuning choice: the
+    these generators; 0 = the widest the context's table budget admits (akp_te_params_create_shaped; by default the cache-sized tables).  A tuning choice: the
     digests do not depend on it."""
 
     _KIND = TE_PEDERSEN
@@ -73,6 +73,20 @@ class _TeHandle:
         d, sg, tb, st = C.c_uint32(), C.c_int32(), C.c_size_t(), C.c_uint32()
         check(lib.akp_te_params_info(self.h, C.byref(d), C.byref(sg), C.byref(tb), msg_len, C.byref(st)))
         return {"digit_bits_or_group": d.value, "signed_subset": bool(sg.value), "table_bytes": tb.value, "steps": st.value}
+
+    def prepare(self, msg_len=None, compress=False):
+        """build the device tables now (akp_te_params_prepare / _prepare_compress) instead of inside the first hash"""
+        if msg_len is not None:
+            check(lib.akp_te_params_prepare(self.h, int(msg_len)))
+        if compress:
+            check(lib.akp_te_params_prepare_compress(self.h))
+
+    def table_info(self):
+        """the shared table behind this handle (akp_te_params_table_info): id (equal for handles that share), handles attached,
+        wide-table builds so far"""
+        tid, refs, builds = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        check(lib.akp_te_params_table_info(self.h, C.byref(tid), C.byref(refs), C.byref(builds)))
+        return {"table_id": tid.value, "handles_attached": refs.value, "wide_builds": builds.value}
 
     def __del__(self):
         try:

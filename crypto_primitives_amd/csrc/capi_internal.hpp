@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -66,7 +67,8 @@ struct akp_ctx {
     // calls fail cleanly until then (handles created on akp_multi_ctx may outlive akp_multi_destroy without touching freed memory)
     int live_handles = 0;
     bool dead = false;
-    // HBM one precomputed curve table may take (akp_ctx_set_table_budget); 0: a quarter of the device's memory, at most half of what is free
+    // HBM one precomputed curve table may take (akp_ctx_set_table_budget); 0: 320 MiB (cache-sized tables); AKP_TABLE_BUDGET_DEVICE: a
+    // quarter of the device's memory, at most half of what is free
     size_t table_budget = 0;
 };
 void ctx_handle_released(akp_ctx* c);
@@ -229,17 +231,32 @@ int32_t launch_verify_paths_t3(akp_poseidon* leafp, akp_poseidon* two, const Fr*
         const Fr* d_auth, size_t depth, const Fr* d_root, uint8_t* d_ok, size_t m, hipStream_t s, bool* done);
 
 // ---- Pedersen / Bowe-Hopwood parameter handle (capi_te.hip) -------------------------------------------------------------
-struct akp_te_params {
-    akp_ctx* ctx = nullptr;
-    int kind = 0;
+// The precomputed tables of one parameter set on one DEVICE (round 5).  In the reference a `Parameters` value is `Sync` and every
+// rayon worker borrows the same one (crh/mod.rs:22, merkle_tree/mod.rs:417,458,494); here every worker thread has a context of its
+// own, so the tables -- up to 46 / 75 GB -- cannot belong to a handle: handles created with the same generators, window and table
+// shape on contexts of the same device ATTACH to one TeTable (process-wide store in capi_te.hip, reference-counted; the last handle
+// frees it).  `mu` serialises everything that reads or changes the table's pointers with the kernel launches that use them: a
+// launch is enqueued under the lock, an extension (free + rebuild) drains the device under the lock -- every launch that could
+// still read the old table was enqueued before the drain, whichever context or stream it came from.
+struct TeTable {
+    std::mutex mu;
+    int device = 0;
+    bool pedersen = false;     // Pedersen arithmetic (AKP_TE_PEDERSEN and AKP_TE_PEDERSEN_X share a table), else Bowe-Hopwood
     u32 W = 0, N = 0;
     u32 n_gen = 0;             // W * N flat generators
     u32 digit_bits = 0;        // Pedersen: table digit width D (2..24; plain table 1..14)
     u32 group = 1;             // Bowe-Hopwood: chunks per table step (1..8)
     TeEntry* d_lut = nullptr;    // Pedersen: [ceil(n_gen/D)][2^D] (signed-subset table: [ceil(n_gen/D)][2^(D-1)]); BH: group table
     TeEntry* d_lut1 = nullptr;  // BH: single-chunk table [n_gen][4]; Pedersen signed-subset: cprefix [n_digits + 1]
-    TeEntry* d_tail = nullptr;  // BH: sum of G[c] over the zero-padded tail chunks [tail_from, tail_to) of the last compress shape
-    u32 tail_from = 0, tail_to = 0;
+    // BH: sum of G[c] over the zero-padded tail chunks [from, to) of a two-to-one shape that has no remainder table: one entry per
+    // shape, computed once (a table is shared by streams of several contexts: nothing is ever recomputed in place)
+    struct Tail {
+        u32 from = 0, to = 0;
+        TeEntry* d = nullptr;
+    };
+    static constexpr int MAX_TAILS = 8;
+    Tail tails[MAX_TAILS];
+    int n_tails = 0;
     // BH: the < G chunks a message shape leaves after its last full group are ONE more table step: a table of 2^(3r) entries for
     // the r chunks starting at chunk `first`, with the constant of the zero-padded tail chunks [tail_from, tail_to) folded in;
     // built on the first use of that shape (a parameter set sees a handful of shapes)
@@ -251,14 +268,27 @@ struct akp_te_params {
     Remainder rem[MAX_REMAINDERS];
     int n_rem = 0;
     Fr* d_gens = nullptr;  // BH: the generators (affine, wire form), kept for the group / remainder tables built later
-    // The wide table is built FOR THE MESSAGE LENGTHS THAT ARRIVE: d_lut covers the first `units_built` of `units_total` digits
-    // (Pedersen signed-subset table) / chunk groups (Bowe-Hopwood); a longer message extends it (te_ensure_table).  A handle that
-    // only ever hashes 32- and 64-byte tree nodes holds a third of the 63x9 table.
+    // The wide table is built FOR THE MESSAGE LENGTHS THAT ARRIVE (or that akp_te_params_prepare names): d_lut covers the first
+    // `units_built` of `units_total` digits (Pedersen signed-subset table) / chunk groups (Bowe-Hopwood); a longer message extends
+    // it (te_ensure_table).  A table that only ever hashes 32- and 64-byte tree nodes holds a third of the 63x9 table.
     u32 units_total = 0, units_built = 0;
     bool shape_auto = true;  // the shape came from the table budget (not from akp_te_params_create_shaped): it may narrow when memory is short
     NielsPad* d_half = nullptr;  // Pedersen signed-subset table: the halved generators it is built from
     bool signed_subset = false;  // Pedersen: d_lut holds the signed-subset table (te_kernels.hpp), d_lut1 its constants
-    int pins = 0;                // as akp_poseidon::pins
+    // store bookkeeping (under the store's mutex): handles attached, the key the table is filed under
+    int refs = 0;
+    bool in_store = false;
+    u32 key_shape = 0;               // the shape it was created with (a narrowed table leaves the store: its shape no longer says what was asked)
+    std::vector<uint64_t> gens;      // host copy of the generators (key comparison; 64 KB for a 4x256 window)
+    uint64_t builds = 0;             // wide-table builds so far (akp_te_params_table_info: a test can see that eight handles built once)
+};
+struct akp_te_params {
+    akp_ctx* ctx = nullptr;
+    int kind = 0;
+    u32 W = 0, N = 0;
+    u32 n_gen = 0;             // W * N flat generators
+    TeTable* t = nullptr;      // shared with every handle of the same parameters on this device
+    int pins = 0;              // as akp_poseidon::pins
     bool destroy_pending = false;
 };
 static inline void te_pin(akp_te_params* p) { if (p) ++p->pins; }
@@ -279,6 +309,8 @@ static inline size_t te_input_bits(const akp_te_params* p) {  // max message bit
 // n messages of msg_len bytes (device) -> n digests; data_len < msg_len: the bytes past data_len are zero padding (two-to-one buffers)
 int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s,
         size_t data_len = (size_t)-1);
+// akp_te_params_prepare_compress without the argument checks (the tree builders call it)
+int32_t te_prepare_compress(akp_te_params* p);
 // TwoToOneCRH::compress on device digests (d_right == nullptr: pairs d_left[2i], d_left[2i + 1], a tree level)
 int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_right, size_t n, Fr* d_out, hipStream_t s);
 

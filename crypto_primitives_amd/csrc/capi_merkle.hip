@@ -305,12 +305,13 @@ extern "C" int32_t akp_merkle_verify_paths_poseidon(akp_poseidon* leafp, akp_pos
     if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "parameters belong to different contexts");
     if (m && !leaves && leaf_len) return fail(AKP_ERR_BAD_PARAMS, "leaves is NULL");
     akp_ctx* c = leafp->ctx;
+    bool leaves_uploaded = false;  // the one-launch attempt below uploads the leaves into SCR_A; when it declines (small batch, shape), the level-by-level path reuses them
     return verify_paths_common(
         c, 1, root, m, idx, sibs, auth, depth, ok_out,
         [&](Fr* d_cur, hipStream_t s) -> int32_t {
             void* dl = nullptr;
             if (int32_t rc = ctx_scratch(c, SCR_A, m * leaf_len * sizeof(Fr), &dl, s)) return rc;
-            if (leaf_len) HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
+            if (leaf_len && !leaves_uploaded) HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
             return launch_crh(leafp, (const Fr*)dl, nullptr, leaf_len, d_cur, m, s);
         },
         [&](const Fr* l, const Fr* r, Fr* out, hipStream_t s) -> int32_t { return launch_crh(two, l, r, 2, out, m, s); },
@@ -320,6 +321,7 @@ extern "C" int32_t akp_merkle_verify_paths_poseidon(akp_poseidon* leafp, akp_pos
             void* dl = nullptr;
             if (int32_t rc = ctx_scratch(c, SCR_A, m * leaf_len * sizeof(Fr), &dl, s)) return rc;
             HIP_TRY(hipMemcpyAsync(dl, leaves, m * leaf_len * sizeof(Fr), hipMemcpyHostToDevice, s));
+            leaves_uploaded = true;
             return launch_verify_paths_t3(leafp, two, (const Fr*)dl, leaf_len, d_idx, d_sib, d_auth, depth, d_root, d_ok, m, s, done);
         });
 }

@@ -20,7 +20,8 @@
 // would admit them: 41 steps, 88 GB) were measured SLOWER, 2.65 against 2.41 ms -- a digit's region of the table is then 2 GB
 // and the gather leaves the TLB reach (64.6 against 55.9 us per step; profiles/r04_s10/digit25_rejected.txt, gather_probe.txt).
 static size_t te_table_budget(const akp_ctx* ctx) {
-    if (ctx->table_budget) return ctx->table_budget;
+    if (ctx->table_budget && ctx->table_budget != AKP_TABLE_BUDGET_DEVICE) return ctx->table_budget;
+    if (!ctx->table_budget) return (size_t)320 << 20;  // the default: tables that stay inside the 256 MiB Infinity Cache and build in milliseconds
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
         (void)hipGetLastError();
@@ -90,37 +91,40 @@ static hipError_t te_build_wide(akp_ctx* ctx, const void* src, u32 n_gen, u32 W,
     if (hi) (void)hipFree(hi);
     return e;
 }
-extern "C" void akp_te_params_destroy(akp_te_params* p);
-extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, uint32_t shape,
-        akp_te_params** out) {
-    if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
-    if (!out || !gens) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
-    if (kind != AKP_TE_PEDERSEN && kind != AKP_TE_BOWE_HOPWOOD && kind != AKP_TE_PEDERSEN_X) return fail(AKP_ERR_BAD_PARAMS,
-            "unknown kind %d", kind);
-    if (W == 0 || N == 0) return fail(AKP_ERR_BAD_PARAMS, "empty window");
-    if (kind == AKP_TE_BOWE_HOPWOOD && W > 63) return fail(AKP_ERR_BAD_PARAMS,
-            "Bowe-Hopwood window size %u > 63 (bowe_hopwood/mod.rs:81-101)", W);
-    if (shape > (kind == AKP_TE_BOWE_HOPWOOD ? TE_MAX_GROUP : TE_MAX_DIGIT) || (shape == 1 && kind != AKP_TE_BOWE_HOPWOOD))
-        return fail(AKP_ERR_BAD_PARAMS, "table shape %u: Pedersen digits have 2..%u bits, Bowe-Hopwood groups 1..%u chunks (0: from the table budget)",
-                shape, TE_MAX_DIGIT, TE_MAX_GROUP);
-    const size_t n_gen = (size_t)W * N;
-    if (n_gen > (1u << 22)) return fail(AKP_ERR_BAD_PARAMS, "window %ux%u too large", W, N);
-    for (size_t i = 0; i < 2 * n_gen; ++i)
-        if (!fr_words_reduced(gens + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "generator coordinate %zu not reduced", i);
-    HIP_TRY(hipSetDevice(ctx->device));
-#if defined(AKP_TEST_HOOKS)
-    if (!shape) shape = kind == AKP_TE_BOWE_HOPWOOD ? env_u32("AKP_BH_GROUP", 0, 1, TE_MAX_GROUP) : env_u32("AKP_PEDERSEN_DIGIT_BITS", 0, 1, TE_MAX_DIGIT);
-#endif
-    akp_te_params* p = new akp_te_params();
-    p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
-    p->shape_auto = shape == 0;
-    ++ctx->live_handles;
-    const size_t budget = te_table_budget(ctx);
+// ---- the process-wide table store (TeTable, capi_internal.hpp) ---------------------------------------------------------------
+static std::mutex g_store_mu;
+static std::vector<TeTable*> g_store;
+static void te_table_free(TeTable* t) {  // refs == 0: no handle, no launch can name it any more
+    (void)hipSetDevice(t->device);
+    (void)hipDeviceSynchronize();
+    if (t->d_lut) (void)hipFree(t->d_lut);
+    if (t->d_lut1) (void)hipFree(t->d_lut1);
+    if (t->d_gens) (void)hipFree(t->d_gens);
+    if (t->d_half) (void)hipFree(t->d_half);
+    for (int i = 0; i < t->n_tails; ++i)
+        if (t->tails[i].d) (void)hipFree(t->tails[i].d);
+    for (int i = 0; i < t->n_rem; ++i)
+        if (t->rem[i].d) (void)hipFree(t->rem[i].d);
+    delete t;
+}
+static void te_table_release(TeTable* t) {
+    if (!t) return;
+    {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        if (--t->refs > 0) return;
+        g_store.erase(std::remove(g_store.begin(), g_store.end(), t), g_store.end());
+    }
+    te_table_free(t);
+}
+// everything a fresh table needs before its first hash: kilobytes and a few small kernels (the wide table itself is built by
+// te_ensure_table for the message lengths that arrive or that akp_te_params_prepare names)
+static hipError_t te_table_init(akp_ctx* ctx, TeTable* t, const uint64_t* gens, u32 shape, size_t budget) {
+    const size_t n_gen = t->n_gen;
     constexpr size_t max_entries = (size_t)1 << 32;  // entry indices are 32-bit in the kernels
     Fr* d_g = nullptr;
     hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
-    if (kind == AKP_TE_PEDERSEN || kind == AKP_TE_PEDERSEN_X) {
+    if (t->pedersen) {
         // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
         // stores 2^(D-1) entries per digit.  The plain table stays as the fallback for generators outside the subgroup; as an A/B
         // arm (AKP_PEDERSEN_PLAIN=1) it is selectable only in the test build (-DAKP_TEST_HOOKS).
@@ -145,60 +149,118 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
         if (e == hipSuccess && bad == 0) {
-            const u32 D = shape ? std::max(shape, 2u) : te_shape::pick_digit(n_gen, budget, sizeof(TeEntry));
+            const u32 D = shape;
             if (te_pedersen_entries(n_gen, D) >= max_entries) e = hipErrorInvalidValue;
             const size_t n_digits = (n_gen + D - 1) / D;
-            p->digit_bits = D;
-            p->signed_subset = true;
-            p->units_total = (u32)n_digits;  // the table itself is built for the message lengths that arrive (te_ensure_table)
-            if (e == hipSuccess) e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
+            t->digit_bits = D;
+            t->signed_subset = true;
+            t->units_total = (u32)n_digits;
+            if (e == hipSuccess) e = hipMalloc(&t->d_lut1, (n_digits + 1) * sizeof(TeEntry));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
-                        (u32)n_gen, D, (u32)n_digits, p->d_lut1);
+                        (u32)n_gen, D, (u32)n_digits, t->d_lut1);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            p->d_half = d_half;
+            t->d_half = d_half;
             d_half = nullptr;
         } else if (e == hipSuccess) {
             // plain table (generators outside the prime-order subgroup: never what `setup` produces): entry by entry, digits of
             // at most 14 bits (4x256: 13 bits, 79 steps, 93 MB)
-            u32 D = shape ? std::min(shape, 14u) : 13;
-            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(TeEntry) > std::min(budget, (size_t)192 << 20) && !shape) --D;
-            p->digit_bits = D;
+            u32 D = t->shape_auto ? 13 : std::min(shape, 14u);
+            while (D > 1 && ((n_gen + D - 1) / D) * ((size_t)1 << D) * sizeof(TeEntry) > std::min(budget, (size_t)192 << 20) && t->shape_auto) --D;
+            t->digit_bits = D;
             const size_t entries = ((n_gen + D - 1) / D) << D;
-            e = hipMalloc(&p->d_lut, entries * sizeof(TeEntry));
+            e = hipMalloc(&t->d_lut, entries * sizeof(TeEntry));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
-                        D, (u32)entries, p->d_lut);
+                        D, (u32)entries, t->d_lut);
                 e = hipGetLastError();
             }
         }
         if (d_half) (void)hipFree(d_half);
         if (d_bad) (void)hipFree(d_bad);
     } else {
-        u32 G = shape ? shape : te_shape::pick_group(n_gen, budget, sizeof(TeEntry));
-        if (n_gen < G) G = (u32)n_gen;
+        const u32 G = shape;
         if (G > 1 && te_bh_entries(n_gen, G) >= max_entries) e = hipErrorInvalidValue;
-        if (e == hipSuccess) e = hipMalloc(&p->d_lut1, n_gen * 4 * sizeof(TeEntry));
+        if (e == hipSuccess) e = hipMalloc(&t->d_lut1, n_gen * 4 * sizeof(TeEntry));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
-                    p->d_lut1);
+                    t->d_lut1);
             e = hipGetLastError();
         }
-        if (G > 1) p->units_total = (u32)(n_gen / G);  // the group table is built for the message lengths that arrive (te_ensure_table)
-        p->group = G;
-        p->d_gens = d_g;  // kept: the remainder tables of later message lengths are built from them (te_bh_remainder)
+        if (G > 1) t->units_total = (u32)(n_gen / G);
+        t->group = G;
+        t->d_gens = d_g;  // kept: the group table and the remainder tables of later message lengths are built from them
         d_g = nullptr;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_g) (void)hipFree(d_g);
-    if (e != hipSuccess) {
-        const std::string why = hipGetErrorString(e);
-        (void)hipGetLastError();
-        akp_te_params_destroy(p);  // frees whatever was allocated and gives the context its handle count back
-        return fail(AKP_ERR_HIP, "akp_te_params_create: %s", why.c_str());
+    return e;
+}
+extern "C" void akp_te_params_destroy(akp_te_params* p);
+extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, uint32_t shape,
+        akp_te_params** out) {
+    if (!ctx) return fail(AKP_ERR_HIP, "akp_te_params_create: a device context is required (tables are built on the GPU)");
+    if (!out || !gens) return fail(AKP_ERR_BAD_PARAMS, "NULL argument");
+    if (ctx->dead) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_create: the context was destroyed");
+    if (kind != AKP_TE_PEDERSEN && kind != AKP_TE_BOWE_HOPWOOD && kind != AKP_TE_PEDERSEN_X) return fail(AKP_ERR_BAD_PARAMS,
+            "unknown kind %d", kind);
+    if (W == 0 || N == 0) return fail(AKP_ERR_BAD_PARAMS, "empty window");
+    if (kind == AKP_TE_BOWE_HOPWOOD && W > 63) return fail(AKP_ERR_BAD_PARAMS,
+            "Bowe-Hopwood window size %u > 63 (bowe_hopwood/mod.rs:81-101)", W);
+    if (shape > (kind == AKP_TE_BOWE_HOPWOOD ? TE_MAX_GROUP : TE_MAX_DIGIT) || (shape == 1 && kind != AKP_TE_BOWE_HOPWOOD))
+        return fail(AKP_ERR_BAD_PARAMS, "table shape %u: Pedersen digits have 2..%u bits, Bowe-Hopwood groups 1..%u chunks (0: from the table budget)",
+                shape, TE_MAX_DIGIT, TE_MAX_GROUP);
+    const size_t n_gen = (size_t)W * N;
+    if (n_gen > (1u << 22)) return fail(AKP_ERR_BAD_PARAMS, "window %ux%u too large", W, N);
+    for (size_t i = 0; i < 2 * n_gen; ++i)
+        if (!fr_words_reduced(gens + 4 * i)) return fail(AKP_ERR_BAD_PARAMS, "generator coordinate %zu not reduced", i);
+    HIP_TRY(hipSetDevice(ctx->device));
+#if defined(AKP_TEST_HOOKS)
+    if (!shape) shape = kind == AKP_TE_BOWE_HOPWOOD ? env_u32("AKP_BH_GROUP", 0, 1, TE_MAX_GROUP) : env_u32("AKP_PEDERSEN_DIGIT_BITS", 0, 1, TE_MAX_DIGIT);
+#endif
+    const bool ped = kind != AKP_TE_BOWE_HOPWOOD;
+    const bool shape_auto = shape == 0;
+    const size_t budget = te_table_budget(ctx);
+    // the shape the table is filed under: what was asked for, or what the budget admits at this moment
+    u32 key_shape = ped ? (shape ? std::max(shape, 2u) : te_shape::pick_digit(n_gen, budget, sizeof(TeEntry)))
+                        : (shape ? shape : te_shape::pick_group(n_gen, budget, sizeof(TeEntry)));
+    if (!ped && n_gen < key_shape) key_shape = (u32)n_gen;
+    akp_te_params* p = new akp_te_params();
+    p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
+    const size_t words = n_gen * 8;
+    {
+        // creation is serialised process-wide: two threads that ask for the same parameters at the same moment must end up with ONE
+        // table, and a fresh table costs kilobytes and microseconds (the wide table is built later, under the table's own lock)
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        for (TeTable* t : g_store)
+            if (t->device == ctx->device && t->pedersen == ped && t->W == W && t->N == N && t->key_shape == key_shape && t->shape_auto == shape_auto &&
+                t->gens.size() == words && memcmp(t->gens.data(), gens, words * sizeof(uint64_t)) == 0) {
+                ++t->refs;
+                p->t = t;
+                break;
+            }
+        if (!p->t) {
+            TeTable* t = new TeTable();
+            t->device = ctx->device; t->pedersen = ped; t->W = W; t->N = N; t->n_gen = (u32)n_gen;
+            t->shape_auto = shape_auto; t->key_shape = key_shape;
+            t->gens.assign(gens, gens + words);
+            const hipError_t e = te_table_init(ctx, t, gens, key_shape, budget);
+            if (e != hipSuccess) {
+                const std::string why = hipGetErrorString(e);
+                (void)hipGetLastError();
+                te_table_free(t);
+                delete p;
+                return fail(AKP_ERR_HIP, "akp_te_params_create: %s", why.c_str());
+            }
+            t->refs = 1;
+            t->in_store = true;
+            g_store.push_back(t);
+            p->t = t;
+        }
     }
+    ++ctx->live_handles;
     *out = p;
     return AKP_OK;
 }
@@ -215,15 +277,7 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
         p->destroy_pending = true;
         return;
     }
-    (void)hipSetDevice(p->ctx->device);
-    (void)hipDeviceSynchronize();
-    if (p->d_lut) (void)hipFree(p->d_lut);
-    if (p->d_lut1) (void)hipFree(p->d_lut1);
-    if (p->d_tail) (void)hipFree(p->d_tail);
-    if (p->d_gens) (void)hipFree(p->d_gens);
-    if (p->d_half) (void)hipFree(p->d_half);
-    for (int i = 0; i < p->n_rem; ++i)
-        if (p->rem[i].d) (void)hipFree(p->rem[i].d);
+    te_table_release(p->t);  // the tables go with the LAST handle attached to them (device drained first)
     ctx_handle_released(p->ctx);
     delete p;
 }
@@ -231,37 +285,55 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
 // table steps a message of msg_len bytes touches (later digits are zero / absent): Pedersen pads with zero
 // bytes (those digits select the identity); Bowe-Hopwood stops at ceil(bits/3) chunks = `groups` triples +
 // left-over singles.
-static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32* n_steps) {
-    if (te_is_pedersen(p)) {
+static void te_steps(const TeTable* t, size_t msg_len, u32* n_groups, u32* n_steps) {
+    if (t->pedersen) {
         *n_groups = 0;
-        te_shape::pedersen_steps(p->n_gen, p->digit_bits, msg_len, n_steps);
+        te_shape::pedersen_steps(t->n_gen, t->digit_bits, msg_len, n_steps);
     } else {
-        te_shape::bh_steps(p->n_gen, p->group, msg_len, n_groups, n_steps);
+        te_shape::bh_steps(t->n_gen, t->group, msg_len, n_groups, n_steps);
     }
+}
+static size_t te_table_bytes(const TeTable* t) {
+    size_t entries;
+    if (t->pedersen) {
+        const size_t n_digits = (t->n_gen + t->digit_bits - 1) / t->digit_bits;
+        entries = t->signed_subset ? ((size_t)t->units_built << (t->digit_bits - 1)) + n_digits + 1 : n_digits << t->digit_bits;
+    } else {
+        entries = (size_t)t->n_gen * 4 + (t->group > 1 ? ((size_t)t->units_built << (3 * t->group - 1)) : 0);
+        for (int i = 0; i < t->n_rem; ++i) entries += (size_t)1 << (3 * t->rem[i].r);
+        entries += t->n_tails;
+    }
+    return entries * sizeof(TeEntry);
 }
 extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset, size_t* table_bytes,
         size_t msg_len,
                                       uint32_t* steps) {
     if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_info: params is NULL");
-    const bool ped = te_is_pedersen(p);
-    if (digit_bits_or_group) *digit_bits_or_group = ped ? p->digit_bits : p->group;
-    if (signed_subset) *signed_subset = ped && p->signed_subset ? 1 : 0;
-    if (table_bytes) {
-        size_t entries;
-        if (ped) {
-            const size_t n_digits = (p->n_gen + p->digit_bits - 1) / p->digit_bits;
-            entries = p->signed_subset ? ((size_t)p->units_built << (p->digit_bits - 1)) + n_digits + 1 : n_digits << p->digit_bits;
-        } else {
-            entries = (size_t)p->n_gen * 4 + (p->group > 1 ? ((size_t)p->units_built << (3 * p->group - 1)) : 0);
-            for (int i = 0; i < p->n_rem; ++i) entries += (size_t)1 << (3 * p->rem[i].r);
-        }
-        *table_bytes = entries * sizeof(TeEntry);
-    }
+    TeTable* t = p->t;
+    std::lock_guard<std::mutex> lk(t->mu);
+    const bool ped = t->pedersen;
+    if (digit_bits_or_group) *digit_bits_or_group = ped ? t->digit_bits : t->group;
+    if (signed_subset) *signed_subset = ped && t->signed_subset ? 1 : 0;
+    if (table_bytes) *table_bytes = te_table_bytes(t);
     if (steps) {
         u32 g = 0, st = 0;
-        te_steps(p, msg_len, &g, &st);
-        if (!ped && p->group > 1 && st > g) st = g + 1;  // the chunks after the last full group are one step (te_bh_remainder)
+        te_steps(t, msg_len, &g, &st);
+        if (!ped && t->group > 1 && st > g) st = g + 1;  // the chunks after the last full group are one step (te_bh_remainder)
         *steps = st;
+    }
+    return AKP_OK;
+}
+extern "C" int32_t akp_te_params_table_info(const akp_te_params* p, uint64_t* table_id, uint32_t* handles_attached, uint64_t* wide_builds) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_table_info: params is NULL");
+    TeTable* t = p->t;
+    if (table_id) *table_id = (uint64_t)(uintptr_t)t;
+    if (handles_attached) {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        *handles_attached = (uint32_t)t->refs;
+    }
+    if (wide_builds) {
+        std::lock_guard<std::mutex> lk(t->mu);
+        *wide_builds = t->builds;
     }
     return AKP_OK;
 }
@@ -303,55 +375,76 @@ struct TePipe {
     hipStream_t cin, side;
     hipEvent_t ev_in, ev_acc;
 };
-static void te_steps(const akp_te_params* p, size_t msg_len, u32* n_groups, u32* n_steps);
-// A handle whose shape came from the table budget narrows it when the device cannot hold the table after all (other handles
-// were created or built in the meantime): one bit / one chunk less, everything that depends on the shape rebuilt.
-static hipError_t te_narrow(akp_te_params* p) {
-    akp_ctx* c = p->ctx;
-    if (te_is_pedersen(p)) {
-        const u32 D = --p->digit_bits;
-        const size_t n_digits = ((size_t)p->n_gen + D - 1) / D;
-        p->units_total = (u32)n_digits;
-        if (p->d_lut1) (void)hipFree(p->d_lut1);
-        p->d_lut1 = nullptr;
-        hipError_t e = hipMalloc(&p->d_lut1, (n_digits + 1) * sizeof(TeEntry));
+// Table work on the slow path (build / extend / remainder / tail constant) allocates, drains the device and waits: legal from any
+// entry point EXCEPT while the caller's stream is being captured into a graph -- there the caller must have prepared the table
+// (akp_te_params_prepare) before capture began.
+static int32_t te_slow_path_allowed(hipStream_t s, const char* what) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return AKP_OK;
+    }
+    if (st == hipStreamCaptureStatusActive)
+        return fail(AKP_ERR_BAD_PARAMS, "%s needs a table that is not built and the stream is being captured: call akp_te_params_prepare before the capture", what);
+    return AKP_OK;
+}
+// A table whose shape came from the table budget narrows it when the device cannot hold the table after all (other tables
+// were created or built in the meantime): one bit / one chunk less, everything that depends on the shape rebuilt.  The narrowed
+// table leaves the store (its shape no longer says what a new handle with this budget would get); the handles attached keep it.
+// Caller holds t->mu and has drained the device.
+static hipError_t te_narrow(akp_ctx* c, TeTable* t) {
+    {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        if (t->in_store) {
+            g_store.erase(std::remove(g_store.begin(), g_store.end(), t), g_store.end());
+            t->in_store = false;
+        }
+    }
+    if (t->pedersen) {
+        const u32 D = --t->digit_bits;
+        const size_t n_digits = ((size_t)t->n_gen + D - 1) / D;
+        t->units_total = (u32)n_digits;
+        if (t->d_lut1) (void)hipFree(t->d_lut1);
+        t->d_lut1 = nullptr;
+        hipError_t e = hipMalloc(&t->d_lut1, (n_digits + 1) * sizeof(TeEntry));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, c->stream, p->d_half, p->n_gen, D,
-                (u32)n_digits, p->d_lut1);
+        hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, c->stream, t->d_half, t->n_gen, D,
+                (u32)n_digits, t->d_lut1);
         e = hipGetLastError();
         return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
     }
-    --p->group;
-    p->units_total = p->n_gen / p->group;
-    for (int i = 0; i < p->n_rem; ++i)
-        if (p->rem[i].d) (void)hipFree(p->rem[i].d);  // their first chunk follows the group size
-    p->n_rem = 0;
+    --t->group;
+    t->units_total = t->n_gen / t->group;
+    for (int i = 0; i < t->n_rem; ++i)
+        if (t->rem[i].d) (void)hipFree(t->rem[i].d);  // their first chunk follows the group size
+    t->n_rem = 0;
     return hipSuccess;
 }
 // The wide table covers the digits / chunk groups [0, units_built); a message that needs more extends it: the old table is
-// released (after the device has drained: launches already enqueued on any stream may still read it) and a new one is built for
-// max(needed, twice the old coverage) units -- 0.1 s for the 46 GB of a whole 4x256 table, milliseconds for the prefix a tree's
-// 32- and 64-byte nodes use.  Happens once or twice in the life of a handle; every other call only enqueues.  Returns the
-// table steps of a data_len-byte message (te_steps) for the shape the handle ends up with.
-static int32_t te_ensure_table(akp_te_params* p, size_t data_len, u32* groups, u32* steps) {
-    const bool ped = te_is_pedersen(p);
-    akp_ctx* c = p->ctx;
+// released (after the device has drained: launches already enqueued on any stream of any context may still read it -- they were
+// all enqueued under t->mu, which the caller holds) and a new one is built for max(needed, twice the old coverage) units -- 0.1 s
+// for the 46 GB of a whole 4x256 table, milliseconds for the cache-sized default or the prefix a tree's 32- and 64-byte nodes use.
+// Happens once or twice in the life of a table; every other call only enqueues.  Returns the table steps of a data_len-byte
+// message (te_steps) for the shape the table ends up with.  `c`: the calling handle's context (its stream runs the build).
+static int32_t te_ensure_table(akp_ctx* c, TeTable* t, size_t data_len, u32* groups, u32* steps, hipStream_t s) {
+    const bool ped = t->pedersen;
     for (;;) {
-        te_steps(p, data_len, groups, steps);
+        te_steps(t, data_len, groups, steps);
         const u32 needed = ped ? *steps : *groups;
-        if (needed <= p->units_built || (ped ? !p->signed_subset : p->group <= 1)) return AKP_OK;  // (plain table / single chunks: complete)
-        const u32 shape = ped ? p->digit_bits : p->group;
-        const bool can_narrow = p->shape_auto && shape > (ped ? 8u : 2u);
+        if (needed <= t->units_built || (ped ? !t->signed_subset : t->group <= 1)) return AKP_OK;  // (plain table / single chunks: complete)
+        if (int32_t rc = te_slow_path_allowed(s, "the curve hash")) return rc;
+        const u32 shape = ped ? t->digit_bits : t->group;
+        const bool can_narrow = t->shape_auto && shape > (ped ? 8u : 2u);
         auto bytes_of = [&](u32 units) { return ((size_t)units << (ped ? shape - 1 : 3 * shape - 1)) * sizeof(TeEntry); };
-        u32 target = te_shape::grow_target(needed, p->units_built, p->units_total);
-        if (p->d_lut) {
+        u32 target = te_shape::grow_target(needed, t->units_built, t->units_total);
+        if (t->d_lut) {
             HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(p->d_lut));
-            p->d_lut = nullptr;
-            p->units_built = 0;
+            HIP_TRY(hipFree(t->d_lut));
+            t->d_lut = nullptr;
+            t->units_built = 0;
         }
         hipError_t e = hipSuccess;
-        if (p->shape_auto) {  // the rule of creation, applied to what is about to be built: at most half of what is free now
+        if (t->shape_auto) {  // the rule of creation, applied to what is about to be built: at most half of what is free now
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 if (bytes_of(target) > free_b / 2) target = needed;
@@ -360,56 +453,57 @@ static int32_t te_ensure_table(akp_te_params* p, size_t data_len, u32* groups, u
                 (void)hipGetLastError();
             }
         }
-        if (e == hipSuccess) e = hipMalloc(&p->d_lut, bytes_of(target));
+        if (e == hipSuccess) e = hipMalloc(&t->d_lut, bytes_of(target));
         if (e == hipErrorOutOfMemory && can_narrow) {
             (void)hipGetLastError();
-            p->d_lut = nullptr;
+            t->d_lut = nullptr;
             HIP_TRY(hipDeviceSynchronize());  // the constants / remainder tables of the old shape may be in use
-            e = te_narrow(p);
+            e = te_narrow(c, t);
             if (e == hipSuccess) continue;
         }
         if (e == hipSuccess)
-            e = ped ? te_build_wide<2>(c, p->d_half, p->n_gen, p->digit_bits, target, p->d_lut, bytes_of(target) / sizeof(TeEntry))
-                    : te_build_wide<1>(c, p->d_gens, p->n_gen, p->group, target, p->d_lut, bytes_of(target) / sizeof(TeEntry));
+            e = ped ? te_build_wide<2>(c, t->d_half, t->n_gen, t->digit_bits, target, t->d_lut, bytes_of(target) / sizeof(TeEntry))
+                    : te_build_wide<1>(c, t->d_gens, t->n_gen, t->group, target, t->d_lut, bytes_of(target) / sizeof(TeEntry));
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            if (p->d_lut) (void)hipFree(p->d_lut);
-            p->d_lut = nullptr;
+            if (t->d_lut) (void)hipFree(t->d_lut);
+            t->d_lut = nullptr;
             return fail(AKP_ERR_HIP, "curve table of %zu MB (%u of %u %s): %s -- lower akp_ctx_set_table_budget and create the handle again",
-                    bytes_of(target) >> 20, target, p->units_total, ped ? "digits" : "chunk groups", hipGetErrorString(e));
+                    bytes_of(target) >> 20, target, t->units_total, ped ? "digits" : "chunk groups", hipGetErrorString(e));
         }
-        p->units_built = target;
+        t->units_built = target;
+        ++t->builds;
         return AKP_OK;
     }
 }
 // Bowe-Hopwood: table of the r (1 .. 7) chunks starting at chunk `first` -- what a message shape leaves after its last full
 // group -- with the constant of the zero-padded tail chunks [tail_from, tail_to) folded into every entry, so that those chunks AND
 // the tail are ONE table step instead of r + 1 additions; built on the first use of the shape (2^(3r) entries: at most 268 MB,
-// milliseconds).  *out stays NULL when the handle's slots are taken or memory is short: the chunks are then single steps
+// milliseconds).  *out stays NULL when the table's slots are taken or memory is short: the chunks are then single steps
 // from the one-chunk table and the tail its own addition, as before round 4.  A 63x9 tree node of 64 data bytes is 21 + 1
-// additions instead of 21 + 3 + 1 with groups of eight, a 32-byte leaf 10 + 1 instead of 10 + 6.
-static int32_t te_bh_remainder(akp_te_params* p, u32 first, u32 r, u32 tail_from, u32 tail_to, const TeEntry** out) {
+// additions instead of 21 + 3 + 1 with groups of eight, a 32-byte leaf 10 + 1 instead of 10 + 6.  Caller holds t->mu.
+static int32_t te_bh_remainder(akp_ctx* c, TeTable* t, u32 first, u32 r, u32 tail_from, u32 tail_to, const TeEntry** out, hipStream_t s) {
     *out = nullptr;
     if (tail_from >= tail_to) tail_from = tail_to = 0;
-    for (int i = 0; i < p->n_rem; ++i)
-        if (p->rem[i].first == first && p->rem[i].r == r && p->rem[i].tail_from == tail_from && p->rem[i].tail_to == tail_to) {
-            *out = p->rem[i].d;
+    for (int i = 0; i < t->n_rem; ++i)
+        if (t->rem[i].first == first && t->rem[i].r == r && t->rem[i].tail_from == tail_from && t->rem[i].tail_to == tail_to) {
+            *out = t->rem[i].d;
             return AKP_OK;
         }
-    if (p->n_rem == akp_te_params::MAX_REMAINDERS || !p->d_gens) return AKP_OK;
+    if (t->n_rem == TeTable::MAX_REMAINDERS || !t->d_gens) return AKP_OK;
+    if (int32_t rc = te_slow_path_allowed(s, "the Bowe-Hopwood hash of a new message shape")) return rc;
     const size_t entries = (size_t)1 << (3 * r);
-    akp_ctx* c = p->ctx;
     TeEntry *d = nullptr, *d_t = nullptr;
     hipError_t e = hipMalloc(&d, entries * sizeof(TeEntry));
     if (e == hipSuccess && tail_from < tail_to) {
         e = hipMalloc(&d_t, sizeof(TeEntry));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, c->stream, p->d_lut1, tail_from, tail_to, d_t);
+            hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, c->stream, t->d_lut1, tail_from, tail_to, d_t);
             e = hipGetLastError();
         }
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(te_build_bh_remainder, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, c->stream, p->d_gens, first, r, d_t, (u32)entries, d);
+        hipLaunchKernelGGL(te_build_bh_remainder, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, c->stream, t->d_gens, first, r, d_t, (u32)entries, d);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -420,9 +514,92 @@ static int32_t te_bh_remainder(akp_te_params* p, u32 first, u32 r, u32 tail_from
         if (e == hipErrorOutOfMemory) return AKP_OK;
         return fail(AKP_ERR_HIP, "Bowe-Hopwood remainder table: %s", hipGetErrorString(e));
     }
-    p->rem[p->n_rem++] = akp_te_params::Remainder{first, r, tail_from, tail_to, d};
+    t->rem[t->n_rem++] = TeTable::Remainder{first, r, tail_from, tail_to, d};
     *out = d;
     return AKP_OK;
+}
+// Bowe-Hopwood: the constant of the zero-padded tail chunks [from, to) as ONE entry (shapes without a remainder table); one entry per
+// shape, computed once and never rewritten.  Caller holds t->mu.
+static int32_t te_bh_tail(akp_ctx* c, TeTable* t, u32 from, u32 to, const TeEntry** out, hipStream_t s) {
+    for (int i = 0; i < t->n_tails; ++i)
+        if (t->tails[i].from == from && t->tails[i].to == to) {
+            *out = t->tails[i].d;
+            return AKP_OK;
+        }
+    if (int32_t rc = te_slow_path_allowed(s, "the Bowe-Hopwood hash of a new two-to-one shape")) return rc;
+    if (t->n_tails == TeTable::MAX_TAILS) {  // more shapes than slots (no real parameter set does this): start over once the device has drained
+        HIP_TRY(hipDeviceSynchronize());
+        for (int i = 0; i < t->n_tails; ++i) (void)hipFree(t->tails[i].d);
+        t->n_tails = 0;
+    }
+    TeEntry* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(TeEntry)));
+    hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, c->stream, t->d_lut1, from, to, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(AKP_ERR_HIP, "Bowe-Hopwood tail constant: %s", hipGetErrorString(e));
+    }
+    t->tails[t->n_tails++] = TeTable::Tail{from, to, d};
+    *out = d;
+    return AKP_OK;
+}
+// What one launch needs from the table for messages of msg_len bytes of which the first data_len carry data: built on demand
+// (slow path) or looked up.  Caller holds t->mu and keeps it until the kernels that use these pointers are enqueued.
+struct TeResolved {
+    u32 shape = 0, groups = 0, steps = 0;
+    const TeEntry *lut = nullptr, *lut1 = nullptr, *tail = nullptr;
+};
+static int32_t te_resolve(akp_te_params* p, size_t msg_len, size_t data_len, hipStream_t s, TeResolved* r) {
+    TeTable* t = p->t;
+    akp_ctx* c = p->ctx;
+    if (int32_t rc = te_ensure_table(c, t, data_len, &r->groups, &r->steps, s)) return rc;
+    // what the kernels call D: the digit width, or the chunks per group with the size of the remainder step above it (te_bh_rem)
+    r->shape = t->pedersen ? t->digit_bits : t->group;
+    r->lut = t->d_lut;
+    r->lut1 = t->d_lut1;
+    r->tail = nullptr;
+    u32 tail_from = 0, tail_to = 0;
+    if (!t->pedersen && data_len < msg_len) {
+        tail_from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, t->n_gen);
+        tail_to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3, t->n_gen);
+    }
+    bool tail_folded = false;
+    if (!t->pedersen && t->group > 1 && r->steps > r->groups) {  // chunks after the last full group: one step, tail included
+        const TeEntry* rem = nullptr;
+        if (int32_t rc = te_bh_remainder(c, t, t->group * r->groups, r->steps - r->groups, tail_from, tail_to, &rem, s)) return rc;
+        if (rem) {
+            r->shape |= (r->steps - r->groups) << 8;
+            r->lut1 = rem;
+            r->steps = r->groups + 1;
+            tail_folded = true;
+        }
+    }
+    if (tail_from < tail_to && !tail_folded)
+        if (int32_t rc = te_bh_tail(c, t, tail_from, tail_to, &r->tail, s)) return rc;
+    return AKP_OK;
+}
+// akp_te_params_prepare: build now what hashing msg_len-byte messages will need, at a time of the host's choosing
+extern "C" int32_t akp_te_params_prepare(akp_te_params* p, size_t msg_len) {
+    NEED_TE(p, "akp_te_params_prepare");
+    if (msg_len * 8 > te_input_bits(p))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
+    std::lock_guard<std::mutex> lk(p->t->mu);
+    TeResolved r;
+    return te_resolve(p, msg_len, msg_len, p->ctx->stream, &r);
+}
+// ... and what TwoToOneCRH::compress / the inner levels of a tree will need: two serialised digests in the (W*N)/8-byte buffer
+int32_t te_prepare_compress(akp_te_params* p) {
+    const size_t buflen = ((size_t)p->W * p->N) / 8;
+    const size_t used = std::min<size_t>(buflen, (size_t)2 * te_fe_per_digest(p) * 32);
+    std::lock_guard<std::mutex> lk(p->t->mu);
+    TeResolved r;
+    return te_resolve(p, buflen, te_zero_tail_on() ? used : buflen, p->ctx->stream, &r);
+}
+extern "C" int32_t akp_te_params_prepare_compress(akp_te_params* p) {
+    NEED_TE(p, "akp_te_params_prepare_compress");
+    return te_prepare_compress(p);
 }
 // `pitch`: distance in bytes between consecutive messages in d_msgs (0: msg_len); a pitch below msg_len is legal when the bytes
 // past data_len are the implied zero padding (te_compress_dev packs the digest pairs without it)
@@ -439,43 +616,15 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (n > ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32", n);
     const bool tail_on = te_zero_tail_on();
     if (data_len > msg_len || !tail_on) data_len = msg_len;
-    u32 groups = 0, steps = 0;
-    if (int32_t rc = te_ensure_table(p, data_len, &groups, &steps)) return rc;
-    // what the kernels call D: the digit width, or the chunks per group with the size of the remainder step above it (te_bh_rem)
-    u32 shape = te_is_pedersen(p) ? p->digit_bits : p->group;
-    const TeEntry* lut1 = p->d_lut1;
-    const TeEntry* tail = nullptr;
-    u32 tail_from = 0, tail_to = 0;
-    if (p->kind == AKP_TE_BOWE_HOPWOOD && data_len < msg_len) {
-        tail_from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, p->n_gen);
-        tail_to = (u32)std::min<size_t>((msg_len * 8 + 2) / 3, p->n_gen);
-    }
-    bool tail_folded = false;
-    if (p->kind == AKP_TE_BOWE_HOPWOOD && p->group > 1 && steps > groups) {  // chunks after the last full group: one step, tail included
-        const TeEntry* rem = nullptr;
-        if (int32_t rc = te_bh_remainder(p, p->group * groups, steps - groups, tail_from, tail_to, &rem)) return rc;
-        if (rem) {
-            shape |= (steps - groups) << 8;
-            lut1 = rem;
-            steps = groups + 1;
-            tail_folded = true;
-        }
-    }
-    if (tail_from < tail_to && !tail_folded) {
-        const u32 from = tail_from, to = tail_to;
-        if (!p->d_tail) HIP_TRY(hipMalloc(&p->d_tail, sizeof(TeEntry)));
-        // stream-ordered: later launches on other streams go through ctx_scratch-style events below
-        if (p->tail_from != from || p->tail_to != to) {
-            // an earlier shape's constant may still be in use (rare: one shape per parameter set)
-            HIP_TRY(hipStreamSynchronize(s));
-            hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, s, p->d_lut1, from, to, p->d_tail);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(s));
-            p->tail_from = from;
-            p->tail_to = to;
-        }
-        tail = p->d_tail;
-    }
+    TeTable* t = p->t;
+    // the table's pointers are read and the kernels that use them enqueued under its lock (TeTable, capi_internal.hpp): handles of
+    // other contexts share the table, and one of them may be extending it right now
+    std::lock_guard<std::mutex> table_lock(t->mu);
+    TeResolved rs;
+    if (int32_t rc = te_resolve(p, msg_len, data_len, s, &rs)) return rc;
+    const u32 shape = rs.shape, groups = rs.groups, steps = rs.steps;
+    const TeEntry *lut = rs.lut, *lut1 = rs.lut1, *tail = rs.tail;
+    const bool signed_subset = t->signed_subset;
     size_t stride = pitch ? pitch : msg_len;
     if (data_len > 0 && data_len < 4) {  // the kernels fetch message bits with one 32-bit load: pad 1..3-byte messages to four bytes
         void* pad = nullptr;
@@ -491,18 +640,18 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (n <= te_split_max) {
         const unsigned sgrid = (unsigned)((n + 63) / 64);
         const bool xy = p->kind == AKP_TE_PEDERSEN;  // digest = (x, y); otherwise x only
-        if (te_is_pedersen(p) && p->signed_subset) {
-            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<2, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+        if (te_is_pedersen(p) && signed_subset) {
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<2, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, lut, lut1,
                     d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
-            else hipLaunchKernelGGL((te_crh_small_kernel<2, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+            else hipLaunchKernelGGL((te_crh_small_kernel<2, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, lut, lut1,
                     d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
         } else if (te_is_pedersen(p)) {
-            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<0, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+            if (xy) hipLaunchKernelGGL((te_crh_small_kernel<0, false>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, lut, lut1,
                     d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
-            else hipLaunchKernelGGL((te_crh_small_kernel<0, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1,
+            else hipLaunchKernelGGL((te_crh_small_kernel<0, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, lut, lut1,
                     d_msgs, data_len, stride, shape, groups, steps, tail, d_out, n);
         } else {
-            hipLaunchKernelGGL((te_crh_small_kernel<1, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, p->d_lut, lut1, d_msgs,
+            hipLaunchKernelGGL((te_crh_small_kernel<1, true>), dim3(sgrid), dim3(64 * AKP_TE_SPLIT), 0, s, lut, lut1, d_msgs,
                     data_len, stride, shape, groups, steps, tail, d_out, n);
         }
         HIP_TRY(hipGetLastError());
@@ -522,27 +671,27 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         if (block) {
             const unsigned lgrid = (unsigned)((cnt + block - 1) / block);
             const size_t shm = te_lds_image_bytes(block, data_len, stride);
-            if (te_is_pedersen(p) && p->signed_subset)
-                hipLaunchKernelGGL(te_accumulate_lds_kernel<2>, dim3(lgrid), dim3(block), shm, st, p->d_lut, lut1, m, data_len, stride,
+            if (te_is_pedersen(p) && signed_subset)
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<2>, dim3(lgrid), dim3(block), shm, st, lut, lut1, m, data_len, stride,
                         shape, groups, steps, tail, x, cnt);
             else if (te_is_pedersen(p))
-                hipLaunchKernelGGL(te_accumulate_lds_kernel<0>, dim3(lgrid), dim3(block), shm, st, p->d_lut, lut1, m, data_len, stride,
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<0>, dim3(lgrid), dim3(block), shm, st, lut, lut1, m, data_len, stride,
                         shape, groups, steps, tail, x, cnt);
             else
-                hipLaunchKernelGGL(te_accumulate_lds_kernel<1>, dim3(lgrid), dim3(block), shm, st, p->d_lut, lut1, m, data_len, stride,
+                hipLaunchKernelGGL(te_accumulate_lds_kernel<1>, dim3(lgrid), dim3(block), shm, st, lut, lut1, m, data_len, stride,
                         shape, groups, steps, tail, x, cnt);
             HIP_TRY(hipGetLastError());
             return AKP_OK;
         }
         const unsigned grid = (unsigned)((cnt + 255) / 256);
-        if (te_is_pedersen(p) && p->signed_subset)
-            hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, st, p->d_lut, lut1, m, data_len, stride, shape,
+        if (te_is_pedersen(p) && signed_subset)
+            hipLaunchKernelGGL(te_accumulate_kernel<2>, dim3(grid), dim3(256), 0, st, lut, lut1, m, data_len, stride, shape,
                     groups, steps, tail, x, cnt);
         else if (te_is_pedersen(p))
-            hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, st, p->d_lut, lut1, m, data_len, stride, shape,
+            hipLaunchKernelGGL(te_accumulate_kernel<0>, dim3(grid), dim3(256), 0, st, lut, lut1, m, data_len, stride, shape,
                     groups, steps, tail, x, cnt);
         else
-            hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, st, p->d_lut, lut1, m, data_len, stride, shape,
+            hipLaunchKernelGGL(te_accumulate_kernel<1>, dim3(grid), dim3(256), 0, st, lut, lut1, m, data_len, stride, shape,
                     groups, steps, tail, x, cnt);
         HIP_TRY(hipGetLastError());
         return AKP_OK;

@@ -51,7 +51,7 @@ extern "C" {
 #define AKP_ERR_RCCL 4 /* RCCL could not be loaded / a collective of the multi-device entry points failed */
 #define AKP_ERR_NOT_POW2 5
 
-#define AKP_ABI_VERSION 3
+#define AKP_ABI_VERSION 4
 
 typedef struct akp_ctx akp_ctx;
 typedef struct akp_poseidon akp_poseidon; /* PoseidonConfig<Fr>, sponge/poseidon/mod.rs:27-45 */
@@ -70,11 +70,16 @@ int32_t akp_device_count(void);
 int32_t akp_ctx_create(int32_t device_id, akp_ctx** out);
 void akp_ctx_destroy(akp_ctx* ctx);
 int32_t akp_ctx_synchronize(akp_ctx* ctx);
-/* HBM that ONE precomputed curve table (akp_te_params_create) may occupy on this context's device, bytes.  0 (the default)
- * = a quarter of the device's memory, but at most half of what is free when the handle is created (72 GiB on an idle
- * 288 GB MI355X).  A host that wants the memory for its own data sets a smaller budget (320 MiB keeps the tables inside the
- * Infinity Cache: the shapes of rounds 1-3); handles that exist keep their tables.  akp_ctx_table_budget returns the value
- * the next handle would be created with. */
+/* HBM that ONE precomputed curve table (akp_te_params_create) may occupy on this context's device, bytes.
+ *   0 (the default)           320 MiB: the tables stay inside the 256 MiB Infinity Cache (4x256 Pedersen: 16-bit digits, 268 MB;
+ *                             63x9 Bowe-Hopwood: groups of 5 chunks, 237 MB) and are built in milliseconds -- the faster choice
+ *                             for a host that hashes ONE batch or builds ONE tree (cold figures: profiles/r05_*);
+ *   AKP_TABLE_BUDGET_DEVICE   a quarter of the device's memory, but at most half of what is free when the handle is created
+ *                             (72 GiB on an idle 288 GB MI355X: 24-bit digits = 46 GB, groups of 8 chunks = 75 GB): -23 % time per
+ *                             hash once the table exists, ~0.1 s to build it -- for a host that keeps hashing with one parameter set;
+ *   any other value           that many bytes.
+ * Handles that exist keep their tables.  akp_ctx_table_budget returns the value the next handle would be created with. */
+#define AKP_TABLE_BUDGET_DEVICE ((size_t)-1)
 int32_t akp_ctx_set_table_budget(akp_ctx* ctx, size_t bytes);
 size_t akp_ctx_table_budget(const akp_ctx* ctx);
 /* the hipStream_t (as void*) the HOST-POINTER entry points of this context enqueue their kernels and copies on: lets a caller
@@ -181,15 +186,19 @@ int32_t akp_sponge_set_state(akp_sponge* s, const uint64_t* state, int32_t mode,
 /* Parameters { generators } (crh/pedersen/mod.rs:28-31, crh/bowe_hopwood/mod.rs:33-37):
  * generators is [num_windows][window_size] affine points (x||y, Fr wire format), used verbatim
  * (no assumption that generators[i][j] is a multiple of generators[i][0]).
- * For AKP_TE_BOWE_HOPWOOD window_size must be <= 63 (setup bound, bowe_hopwood/mod.rs:81-101). */
+ * For AKP_TE_BOWE_HOPWOOD window_size must be <= 63 (setup bound, bowe_hopwood/mod.rs:81-101).
+ * SHARED TABLES (the reference's `Parameters: Sync`, crh/mod.rs:22 -- one value borrowed by every rayon worker,
+ * merkle_tree/mod.rs:417,458,494): handles created with the same generators, window and table shape on contexts of the SAME
+ * device attach to ONE set of precomputed tables in that device's HBM (process-wide, reference-counted, freed with the last
+ * handle; thread-safe).  N worker threads with a context each hold one table, built once, whoever hashes first. */
 int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
                              const uint64_t* generators_affine, akp_te_params** out);
 /* The handle holds a precomputed table in HBM (no counterpart in the reference, which adds generators bit by bit): a hash is one
  * curve addition per table step, a step covers `digit_bits` message bits (Pedersen) / `group` 3-bit chunks (Bowe-Hopwood), and
  * every extra bit doubles the table -- memory for time.  akp_te_params_create picks the widest table the context's table
- * budget admits (akp_ctx_set_table_budget below; on an idle MI355X: 24-bit digits = 46 GB for a 4x256 window, 43 steps per
- * 128-byte message instead of the 64 of the 268 MB table that fits the Infinity Cache, -23 % time; groups of 8 chunks = 75 GB
- * for a 63x9 window).  This form fixes the shape instead: digit_bits 2..24 / group 1..8, 0 = from the budget.  The digests do
+ * budget admits (akp_ctx_set_table_budget above: by default the 268 MB / 237 MB tables that fit the Infinity Cache; with
+ * AKP_TABLE_BUDGET_DEVICE on an idle MI355X 24-bit digits = 46 GB for a 4x256 window, 43 steps per 128-byte message instead of
+ * 64, -23 % time; groups of 8 chunks = 75 GB for a 63x9 window).  This form fixes the shape instead: digit_bits 2..24 / group 1..8, 0 = from the budget.  The digests do
  * not depend on the shape.
  * The table is BUILT FOR THE MESSAGE LENGTHS THAT ARRIVE: creation allocates kilobytes, the first hash of a length builds the
  * digits / groups that length touches (a 63x9 handle that only hashes a tree's 32- and 64-byte nodes holds 22.5 of the 75 GB),
@@ -198,6 +207,18 @@ int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t window_size, u
 int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
                                     const uint64_t* generators_affine, uint32_t digit_bits_or_group, akp_te_params** out);
 void akp_te_params_destroy(akp_te_params* p);
+/* Build NOW what hashing messages of msg_len bytes needs (the wide table up to that length; for Bowe-Hopwood also the remainder
+ * table of that length), on the context's stream, and wait for it: the host chooses the moment of the 0.1 s an HBM-sized table
+ * takes (milliseconds for the default budget) instead of meeting it inside its first hash.  akp_te_params_prepare_compress does
+ * the same for TwoToOneCRH::compress / the inner levels of a tree (two serialised digests in the (W*N)/8-byte buffer).
+ * Without it the table work happens lazily inside the first call that needs it -- also a `_dev`
+ * call, which then allocates, drains the device and waits ONCE (never while its stream is being captured into a graph: that
+ * call fails with AKP_ERR_BAD_PARAMS and names this function). */
+int32_t akp_te_params_prepare(akp_te_params* p, size_t msg_len);
+int32_t akp_te_params_prepare_compress(akp_te_params* p);
+/* the shared table behind a handle (any pointer may be NULL): an identifier that is equal for two handles iff they use the same
+ * tables, the number of handles attached to it, and how often its wide table has been built or extended so far */
+int32_t akp_te_params_table_info(const akp_te_params* p, uint64_t* table_id, uint32_t* handles_attached, uint64_t* wide_builds);
 /* Tuning facts of a handle (any pointer may be NULL): digit width of the Pedersen table / chunks per table step of the
  * Bowe-Hopwood table, whether the Pedersen table is the signed-subset one, bytes of precomputed tables in HBM, and the
  * number of table steps (curve additions + 1) an input of msg_len bytes takes. */
@@ -445,7 +466,8 @@ int32_t akp_multi_tree_build_poseidon_dev(akp_multi* m, akp_poseidon* const* lea
                                           const uint64_t* const* d_leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
 int32_t akp_multi_tree_build_te_dev(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
                                     const uint8_t* const* d_leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
-void akp_multi_tree_destroy(akp_multi_tree* t); /* before akp_multi_destroy(m) */
+/* The tree keeps its akp_multi alive: akp_multi_destroy(m) with live trees is deferred to the last akp_multi_tree_destroy. */
+void akp_multi_tree_destroy(akp_multi_tree* t);
 int32_t akp_multi_tree_info(const akp_multi_tree* t, size_t* n_leaves, uint32_t* fe_per_digest, size_t* height, int32_t* n_dev);
 /* MerkleTree::root (:526-528), from the replicated top (no device access) */
 int32_t akp_multi_tree_root(akp_multi_tree* t, uint64_t* root_out);
@@ -455,7 +477,9 @@ akp_merkle_tree* akp_multi_tree_shard(akp_multi_tree* t, int32_t r);
  * akp_merkle_tree_gather_paths (auth_paths [m][log2(n) - 1], root side first: log2 G top siblings, then the local path) */
 int32_t akp_multi_tree_gather_paths(akp_multi_tree* t, const uint64_t* leaf_indices, size_t m, uint64_t* leaf_sibling_hashes,
                                     uint64_t* auth_paths);
-/* MerkleTree::update (:692-702), batched as akp_merkle_tree_update_batch: per-shard updates, then the exchange */
+/* MerkleTree::update (:692-702), batched as akp_merkle_tree_update_batch: per-shard updates, then the exchange.  If a device
+ * fails after others have updated, the replicated top is refreshed all the same (root and proofs describe the shards as they are)
+ * and the error says so; if that refresh fails too the tree is marked unusable and every later call returns AKP_ERR_BAD_PARAMS. */
 int32_t akp_multi_tree_update_batch(akp_multi_tree* t, const uint64_t* leaf_indices, const void* new_leaves, size_t m,
                                     size_t leaf_len);
 /* MerkleTree::check_update (:707-725) on the sharded tree: *ok = 1 and the update is kept iff the new root equals asserted_new_root */

@@ -51,8 +51,8 @@ class Context {
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     akp_ctx* get() const { return h_; }
-    // HBM one precomputed Pedersen / Bowe-Hopwood table may take on this device (akp_ctx_set_table_budget; 0 = the default: a
-    // quarter of the device's memory, at most half of what is free)
+    // HBM one precomputed Pedersen / Bowe-Hopwood table may take on this device (akp_ctx_set_table_budget; 0 = the default: 320 MiB,
+    // cache-sized tables; AKP_TABLE_BUDGET_DEVICE = a quarter of the device's memory, at most half of what is free)
     void set_table_budget(size_t bytes) { check(akp_ctx_set_table_budget(h_, bytes)); }
     size_t table_budget() const { return akp_ctx_table_budget(h_); }
 
@@ -184,6 +184,20 @@ class TeParameters {  // pedersen::Parameters / bowe_hopwood::Parameters { gener
         check(akp_te_params_info(h_, &i.digit_bits_or_group, &sg, &i.table_bytes, msg_len, &i.steps));
         i.signed_subset = sg != 0;
         return i;
+    }
+    // build the device tables now instead of inside the first hash (akp_te_params_prepare / _prepare_compress)
+    void prepare(size_t msg_len) const { check(akp_te_params_prepare(h_, msg_len)); }
+    void prepare_compress() const { check(akp_te_params_prepare_compress(h_)); }
+    // the shared per-device table behind this handle (akp_te_params_table_info): handles with equal id share it
+    struct TableInfo {
+        uint64_t table_id = 0;
+        uint32_t handles_attached = 0;
+        uint64_t wide_builds = 0;
+    };
+    TableInfo table_info() const {
+        TableInfo t;
+        check(akp_te_params_table_info(h_, &t.table_id, &t.handles_attached, &t.wide_builds));
+        return t;
     }
     uint32_t window_size, num_windows;
 

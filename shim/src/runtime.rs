@@ -140,13 +140,18 @@ impl ThreadRuntime {
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { ffi::akp_ctx_create(dev, &mut ctx) };
         assert_eq!(rc, ffi::AKP_OK, "akp_ctx_create({dev}) failed: there is no CPU fallback");
-        // Poseidon constants are a few KB per set; a curve-hash set owns a precomputed table sized by the context's table budget
-        // (default: up to a quarter of the device's memory -- 46 GB for a 4x256 Pedersen window on an idle MI355X --, built for the
-        // message lengths that arrive).  A host that
-        // needs the HBM for its own data lowers it: AKP_TABLE_BUDGET_MB here, or `set_table_budget` before the first curve hash.
-        if let Some(mb) = std::env::var("AKP_TABLE_BUDGET_MB").ok().and_then(|s| s.parse::<usize>().ok()) {
-            let rc = unsafe { ffi::akp_ctx_set_table_budget(ctx, mb << 20) };
-            assert_eq!(rc, ffi::AKP_OK);
+        // Poseidon constants are a few KB per set.  The precomputed tables of a curve-hash set live ONCE per device, shared by the
+        // handles of every thread's context (libakp's table store: the analogue of the reference's `&Parameters` borrowed by all
+        // rayon workers, crh/mod.rs:22): this thread's handle attaches to them.  Their size follows the context's table budget --
+        // by default 320 MiB (cache-sized tables, built in milliseconds); AKP_TABLE_BUDGET_MB here (or `set_table_budget` before
+        // the first curve hash) raises it, `AKP_TABLE_BUDGET_MB=device` asks for the HBM-sized tables (46 GB for a 4x256 Pedersen
+        // window: ~0.1 s to build, -23 % per hash afterwards).
+        if let Ok(v) = std::env::var("AKP_TABLE_BUDGET_MB") {
+            let bytes = if v == "device" { Some(usize::MAX) } else { v.parse::<usize>().ok().map(|mb| mb << 20) };
+            if let Some(b) = bytes {
+                let rc = unsafe { ffi::akp_ctx_set_table_budget(ctx, b) };
+                assert_eq!(rc, ffi::AKP_OK);
+            }
         }
         Self { poseidon: HandleCache::new(64, ffi::akp_poseidon_params_destroy), te: HandleCache::new(4, ffi::akp_te_params_destroy), ctx: CtxGuard(ctx) }
     }

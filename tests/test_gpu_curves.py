@@ -225,7 +225,13 @@ def test_table_budget_picks_the_shape(cpa):
             del P, B
     finally:
         ctx.set_table_budget(0)
-    assert ctx.table_budget() >= 64 << 20
+    assert ctx.table_budget() == 320 << 20  # the default: cache-sized tables (round 5; round 4 sized them from the device's memory)
+    from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
+    ctx.set_table_budget(TABLE_BUDGET_DEVICE)
+    try:
+        assert ctx.table_budget() >= 64 << 20 and ctx.table_budget() != TABLE_BUDGET_DEVICE  # a quarter of the device, at most half of what is free
+    finally:
+        ctx.set_table_budget(0)
     # shapes outside 2..24 bits / 1..8 chunks are the caller's error
     import ctypes as C
     from crypto_primitives_amd._lib import lib, AKP_ERR_BAD_PARAMS
@@ -332,8 +338,11 @@ def test_table_info_of_the_baseline_windows(cpa):
     wide table is built for the message lengths that arrive (here: after one message of the maximum length)."""
     from crypto_primitives_amd import params as cparams
     from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
     ctx = cpa.default_context(0)
-    pg, bg = cparams.pedersen_generators(0xA5A50004, 4, 256), cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    # generators of this test's own: tables are shared per device among handles of equal parameters (round 5), and "nothing
+    # hashed yet" below must not meet a table another test's live handle has already built
+    pg, bg = cparams.pedersen_generators(0xB5B50004, 4, 256), cparams.bowe_hopwood_generators(0xB5B50005, 63, 9)
     longest_p, longest_b = _msgs(1, 128, 1), _msgs(1, 212, 2)
     ctx.set_table_budget(320 << 20)
     try:
@@ -350,9 +359,14 @@ def test_table_info_of_the_baseline_windows(cpa):
         del hp, hb, P, B
     finally:
         ctx.set_table_budget(0)
-    if ctx.table_budget() >= 71 << 30:  # an idle 288 GB device
+    ctx.set_table_budget(TABLE_BUDGET_DEVICE)
+    try:
+        wide = ctx.table_budget() >= 71 << 30  # an idle 288 GB device
         P, B = pedersen.Parameters(pg), bowe_hopwood.Parameters(bg)
         hp, hb = P.handle(), B.handle()
+    finally:
+        ctx.set_table_budget(0)
+    if wide:
         pedersen.CRH.evaluate_batch(P, longest_p)
         assert hp.info(128) == {"digit_bits_or_group": 24, "signed_subset": True, "table_bytes": ((43 << 23) + 44) * 128, "steps": 43}
         assert hp.info(32)["steps"] == 11
@@ -388,7 +402,12 @@ def test_tables_grow_with_the_message_lengths(cpa):
         seen_b = tb
     # a RESIDENT byte tree over 32-byte leaves pins the handle; a 90-byte hash on the same handle replaces the table it was built
     # with; updates and proofs of the old tree then run on the new table and must agree with a tree built afterwards
+    full_table = B.handle().table_info()["table_id"]
     B2 = bowe_hopwood.Parameters(gens_array(gb), table_shape=8)
+    assert B2.handle().table_info()["table_id"] == full_table  # same generators, same shape: the handle attaches to B's table (round 5)
+    del B2, B  # ... which goes with its last handle, so that the next one starts from nothing
+    B2 = bowe_hopwood.Parameters(gens_array(gb), table_shape=8)
+    assert B2.handle().table_info()["wide_builds"] == 0
     leaves = _msgs(64, 32, 77)
     tree = cpa.GpuMerkleTree.new(cpa.BoweHopwoodByteConfig, B2, B2, leaves)
     before = B2.handle().info()["table_bytes"]
@@ -501,15 +520,21 @@ def test_budget_chosen_shape_narrows_when_memory_is_taken_after_creation(cpa):
     import torch
     from crypto_primitives_amd import params as cparams
     from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
     ctx = cpa.default_context(0)
-    if ctx.table_budget() < 71 << 30:
-        pytest.skip("needs an idle 288 GB device")
-    pg, bg = cparams.pedersen_generators(0xA5A50004, 4, 256), cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
+    ctx.set_table_budget(TABLE_BUDGET_DEVICE)  # the budget that follows the device's memory (opt-in since round 5)
+    try:
+        if ctx.table_budget() < 71 << 30:
+            pytest.skip("needs an idle 288 GB device")
+        pg, bg = cparams.pedersen_generators(0xB5B50014, 4, 256), cparams.bowe_hopwood_generators(0xB5B50015, 63, 9)
+        P, B, PX = pedersen.Parameters(pg), bowe_hopwood.Parameters(bg), pedersen.Parameters(pg, table_shape=24)
+        hp, hb, hx = P.handle(), B.handle(), PX.handle()
+    finally:
+        ctx.set_table_budget(0)
     m, mb = _msgs(40, 128, 21), _msgs(40, 64, 22)
     want_p = pedersen.CRH.evaluate_batch(pedersen.Parameters(pg, table_shape=12), m)
     want_b = bowe_hopwood.CRH.evaluate_batch(bowe_hopwood.Parameters(bg, table_shape=3), mb)
-    P, B, PX = pedersen.Parameters(pg), bowe_hopwood.Parameters(bg), pedersen.Parameters(pg, table_shape=24)
-    hp, hb, hx = P.handle(), B.handle(), PX.handle()
+    assert hp.table_info()["table_id"] != hx.table_info()["table_id"]  # budget-chosen and explicit shapes are filed apart (only the former may narrow)
     assert hp.info()["digit_bits_or_group"] == 24 and hb.info()["digit_bits_or_group"] == 8
     free, _ = torch.cuda.mem_get_info(0)
     hog = torch.empty(free - (40 << 30), dtype=torch.uint8, device="cuda:0")  # leaves ~40 GB: half of it is below 46 GB and below 22.5 GB

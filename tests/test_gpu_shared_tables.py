@@ -1,0 +1,204 @@
+"""Curve tables are shared per DEVICE (round 5): handles created with the same generators, window and table shape on different
+contexts of one device attach to ONE set of precomputed tables -- the analogue of the reference's `Parameters: Sync`
+(crh/mod.rs:22; one value borrowed by every rayon worker, merkle_tree/mod.rs:417,458,494).  Every digest against the oracle."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import jubjub as jj, fr as ofr, cref  # noqa: E402
+from helpers import gens_array  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import crypto_primitives_amd as m
+    assert m.lib.akp_device_count() >= 1
+    return m
+
+
+def _msgs(n, L, seed):
+    return np.frombuffer(ofr.SplitMix64(seed).bytes(max(n * L, 1)), dtype=np.uint8)[: n * L].reshape(n, L).copy()
+
+
+def _free_bytes():
+    import torch
+    return torch.cuda.mem_get_info(0)[0]
+
+
+def _run_threads(n, fn):
+    errs, out = [], [None] * n
+
+    def body(i):
+        try:
+            out[i] = fn(i)
+        except BaseException as e:  # noqa: BLE001 -- reported below, in the test's thread
+            errs.append((i, repr(e)))
+    ts = [threading.Thread(target=body, args=(i,)) for i in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("budget_name", ["default", "device"])
+def test_eight_threads_own_contexts_same_generators_share_one_table(cpa, budget_name):
+    """8 threads x own context x the same 4x256 Pedersen generators: one table id, built once, device memory grows by ONE table
+    (with the device-sized budget eight tables of 46 GB would not even fit), every thread's digests equal the oracle's"""
+    from crypto_primitives_amd._lib import Context, TABLE_BUDGET_DEVICE
+    from crypto_primitives_amd.crh import pedersen
+    g = gens_array(jj.pedersen_generators(0xC5C50001 + (budget_name == "device"), 4, 256))
+    ora = cref.CurveParams(4, 256, g)
+    budget = TABLE_BUDGET_DEVICE if budget_name == "device" else 0
+    n_thr, n_msg = 8, 3000
+    ctxs = [Context(0) for _ in range(n_thr)]
+    for c in ctxs:
+        c.set_table_budget(budget)
+    if budget_name == "device" and ctxs[0].table_budget() < 71 << 30:
+        pytest.skip("needs an idle 288 GB device")
+    P = pedersen.Parameters(g)
+    free0 = _free_bytes()
+    start = threading.Barrier(n_thr)
+
+    def work(i):
+        h = P.handle(ctxs[i])
+        start.wait()  # all first hashes at the same moment: one thread builds, seven wait on the table's lock and find it built
+        k = n_msg + 17000 * (i % 2)  # odd threads: the accumulate + finalize kernels; even threads: the split kernel of small batches
+        m = _msgs(k, 128, 100 + i)
+        out = np.empty((k, 2, 4), dtype=np.uint64)
+        cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, k, 128, out.ctypes.data))
+        assert np.array_equal(out, ora.pedersen_crh_batch(m, k, 128, threads=2)), "thread %d: digests differ from the oracle" % i
+        return h.table_info(), h.info(128)
+    res = _run_threads(n_thr, work)
+    ids = {r[0]["table_id"] for r in res}
+    assert len(ids) == 1, ids
+    ti = P.handle(ctxs[0]).table_info()
+    assert ti["handles_attached"] == n_thr and ti["wide_builds"] == 1, ti
+    table_bytes = res[0][1]["table_bytes"]
+    want_d = 24 if budget_name == "device" else 16
+    assert res[0][1]["digit_bits_or_group"] == want_d and all(r[1] == res[0][1] for r in res)
+    used = free0 - _free_bytes()
+    # one table + eight contexts' scratch for 3000 messages (a few MB each, allocator granularity included)
+    assert table_bytes <= used < table_bytes + (512 << 20), (used, table_bytes)
+    # the creator goes first -- handle AND context -- and the others keep hashing with the table it built
+    del res
+    P._handles.pop((id(ctxs[0]), P._KIND, 0))
+    ctxs[0].close()
+    m = _msgs(500, 128, 7)
+    out = np.empty((500, 2, 4), dtype=np.uint64)
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(P.handle(ctxs[5]).h, m.ctypes.data, 500, 128, out.ctypes.data))
+    assert np.array_equal(out, ora.pedersen_crh_batch(m, 500, 128, threads=2))
+    assert P.handle(ctxs[5]).table_info()["handles_attached"] == n_thr - 1
+    # ... and the memory comes back with the LAST handle
+    P._handles.clear()
+    for c in ctxs[1:]:
+        c.close()
+    assert free0 - _free_bytes() < 64 << 20
+
+
+def test_table_extends_under_concurrent_hashing(cpa):
+    """threads with contexts of their own hash messages of DIFFERENT lengths through one shared Bowe-Hopwood table while it is
+    extended underneath them (short messages build a prefix of the group table, longer ones release it and build more, new
+    lengths add remainder tables): the launches and the rebuilds are serialised by the table's lock, every digest is the oracle's"""
+    from crypto_primitives_amd._lib import Context
+    from crypto_primitives_amd.crh import bowe_hopwood
+    g = gens_array(jj.bowe_hopwood_generators(0xC5C50003, 63, 9))
+    ora = cref.CurveParams(63, 9, g)
+    lens = [8, 32, 64, 100, 150, 212, 20, 70]
+    ctxs = [Context(0) for _ in lens]
+    B = bowe_hopwood.Parameters(g)
+    start = threading.Barrier(len(lens))
+
+    def work(i):
+        h = B.handle(ctxs[i])
+        L = lens[i]
+        start.wait()
+        for rep in range(6):
+            n = 700 + 50 * rep
+            m = _msgs(n, L, 1000 + 10 * i + rep)
+            out = np.empty((n, 4), dtype=np.uint64)
+            cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, n, L, out.ctypes.data))
+            assert np.array_equal(out, ora.bh_crh_batch(m, n, L, threads=1)), "length %d, repetition %d" % (L, rep)
+        return h.table_info()
+    res = _run_threads(len(lens), work)
+    assert len({r["table_id"] for r in res}) == 1
+    info = B.handle(ctxs[0]).info(212)
+    assert info["digit_bits_or_group"] == 5 and B.handle(ctxs[0]).table_info()["wide_builds"] >= 1
+
+
+def test_pedersen_flavours_and_threads_of_a_tree_share(cpa):
+    """pedersen::CRH (x || y) and the TECompressor flavour (x only) hash with the SAME table (the digest width is the handle's, the
+    table the generators'); different generators, windows or shapes do not share"""
+    from crypto_primitives_amd._lib import Context, TE_PEDERSEN
+    from crypto_primitives_amd.crh import pedersen
+    ga = gens_array(jj.pedersen_generators(0xC5C50005, 4, 64))
+    gb = gens_array(jj.pedersen_generators(0xC5C50006, 4, 64))
+    c1, c2 = Context(0), Context(0)
+    A, A2, Bp, As = pedersen.Parameters(ga), pedersen.Parameters(ga.copy()), pedersen.Parameters(gb), pedersen.Parameters(ga, table_shape=12)
+    TE_PEDERSEN_X = 2
+    h_xy, h_x = A.handle(c1, kind=TE_PEDERSEN), A.handle(c2, kind=TE_PEDERSEN_X)
+    assert h_xy.table_info()["table_id"] == h_x.table_info()["table_id"] == A2.handle(c2).table_info()["table_id"]
+    assert h_xy.table_info()["handles_attached"] == 3
+    assert Bp.handle(c1).table_info()["table_id"] != h_xy.table_info()["table_id"]
+    assert As.handle(c1).table_info()["table_id"] != h_xy.table_info()["table_id"]
+    m = _msgs(300, 32, 3)
+    oxy, ox = np.empty((300, 2, 4), dtype=np.uint64), np.empty((300, 4), dtype=np.uint64)
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(h_xy.h, m.ctypes.data, 300, 32, oxy.ctypes.data))
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(h_x.h, m.ctypes.data, 300, 32, ox.ctypes.data))
+    want = cref.CurveParams(4, 64, ga).pedersen_crh_batch(m, 300, 32, threads=2)
+    assert np.array_equal(oxy, want) and np.array_equal(ox, want[:, 0, :])
+    assert h_xy.table_info()["wide_builds"] == 1  # the second flavour found the table built
+
+
+def test_prepare_builds_at_a_time_of_the_hosts_choosing_and_dev_calls_then_only_enqueue(cpa):
+    """akp_te_params_prepare / _prepare_compress: the table work happens in the call the host names; the `_dev` calls that follow
+    find everything built (wide_builds does not move) -- also inside a stream capture, where an UNPREPARED handle refuses cleanly
+    (AKP_ERR_BAD_PARAMS naming akp_te_params_prepare) instead of allocating and draining the device under the capture"""
+    import torch
+    from crypto_primitives_amd._lib import Context, AKP_ERR_BAD_PARAMS
+    from crypto_primitives_amd.crh import bowe_hopwood
+    g = gens_array(jj.bowe_hopwood_generators(0xC5C50007, 63, 9))
+    ora = cref.CurveParams(63, 9, g)
+    ctx = Context(0)
+    B, B2 = bowe_hopwood.Parameters(g), bowe_hopwood.Parameters(g, table_shape=4)
+    h, h2 = B.handle(ctx), B2.handle(ctx)
+    assert h.table_info()["wide_builds"] == 0 and h.info(32)["table_bytes"] == 567 * 4 * 128
+    h.prepare(32, compress=True)  # a tree's leaf length and its inner nodes
+    ti = h.table_info()
+    assert ti["wide_builds"] == 1 and h.info(32)["table_bytes"] > 567 * 4 * 128
+    n = 20000
+    dev = torch.device("cuda", 0)
+    m = _msgs(n, 32, 9)
+    d_m = torch.from_numpy(m).to(dev)
+    d_out = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        cpa._lib.check(cpa.lib.akp_te_crh_batch_dev(h.h, d_m.data_ptr(), n, 32, d_out.data_ptr(), side.cuda_stream))  # sizes the context's scratch
+        cpa._lib.check(cpa.lib.akp_te_crh_batch_dev(h2.h, d_m.data_ptr(), 16, 8, d_out.data_ptr(), side.cuda_stream))  # (h2: 8-byte messages only)
+    side.synchronize()
+    assert h.table_info()["wide_builds"] == 1  # the hash found its table
+    want = ora.bh_crh_batch(m, n, 32, threads=4)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
+    # the same launch captured into a graph and replayed on new messages
+    graph = torch.cuda.CUDAGraph()
+    d_out.zero_()
+    with torch.cuda.graph(graph, stream=side):
+        rc = cpa.lib.akp_te_crh_batch_dev(h.h, d_m.data_ptr(), n, 32, d_out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        # an unprepared shape under capture: a clean refusal, the capture stays valid
+        rc2 = cpa.lib.akp_te_crh_batch_dev(h2.h, d_m.data_ptr(), n, 32, d_out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        msg2 = cpa.lib.akp_last_error().decode()
+    assert rc == 0 and rc2 == AKP_ERR_BAD_PARAMS and "akp_te_params_prepare" in msg2, (rc, rc2, msg2)
+    m2 = _msgs(n, 32, 10)
+    d_m.copy_(torch.from_numpy(m2))
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), ora.bh_crh_batch(m2, n, 32, threads=4))
+    # oversized lengths are the reference's panic, from prepare as from evaluate
+    with pytest.raises(cpa.IncorrectInputLength):
+        h.prepare(213)
+    assert cpa.lib.akp_te_params_prepare(None, 8) == AKP_ERR_BAD_PARAMS and cpa.lib.akp_te_params_prepare_compress(None) == AKP_ERR_BAD_PARAMS

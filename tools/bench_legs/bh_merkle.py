@@ -14,29 +14,86 @@ def run(env):
     per = 1 << args.bh_merkle_log2
     total = per * env.world
     gens = cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)
-    B = bowe_hopwood.Parameters(gens)
     leaves = np.random.default_rng(0xA5A50005 + env.rank).integers(0, 256, size=(per, 32), dtype=np.uint8)
     d_leaves = torch.from_numpy(leaves).to(env.dev)
-    tb = env.GpuTeBackend(B, B, device=env.dev)
-    env.build_sharded(tb, d_leaves, total, env.dist)  # untimed full-size warm-up (tables, scratch, RCCL)
-    env.barrier()
-    reps = 3
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    m0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        res = env.build_sharded(tb, d_leaves, total, env.dist)
-        b.record()
-    env.barrier()
-    bsec = env.max_over_ranks(time.perf_counter() - m0) / reps
-    dev_ms = sum(a.elapsed_time(b) for a, b in evs) / reps
+    from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
+    budget_before = env.ctx.table_budget_setting
+
+    def fresh(budget, g):
+        env.ctx.set_table_budget(budget)
+        try:
+            Bp = bowe_hopwood.Parameters(g)
+            return Bp, env.GpuTeBackend(Bp, Bp, device=env.dev)
+        finally:
+            env.ctx.set_table_budget(budget_before)
+
+    def one_table(budget):
+        """a FRESH handle under `budget`: the first tree from nothing (tables for 32- and 64-byte nodes + scratch + RCCL warm-up + the
+        tree), then the warm build time"""
+        Bp, tb = fresh(budget, gens)
+        assert Bp.handle(env.ctx).table_info()["wide_builds"] == 0
+        env.barrier()
+        c0 = time.perf_counter()
+        env.build_sharded(tb, d_leaves, total, env.dist)
+        torch.cuda.synchronize(env.dev)
+        cold_ms = env.max_over_ranks(time.perf_counter() - c0) * 1e3
+        env.barrier()
+        reps = 3
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        m0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            res = env.build_sharded(tb, d_leaves, total, env.dist)
+            b.record()
+        env.barrier()
+        bsec = env.max_over_ranks(time.perf_counter() - m0) / reps
+        hh = Bp.handle(env.ctx)
+        return {"B": Bp, "tb": tb, "res": res, "bsec": bsec, "dev_ms": sum(a.elapsed_time(b) for a, b in evs) / reps,
+                "rec": {"group": hh.info()["digit_bits_or_group"], "table_bytes": hh.info(32)["table_bytes"], "steps_leaf": hh.info(32)["steps"],
+                        "steps_inner": hh.info(64)["steps"], "cold_first_tree_ms": cold_ms, "warm_seconds": bsec, "warm_leaves_per_s": total / bsec}}
+    cache = one_table(0)
+    hbm = one_table(TABLE_BUDGET_DEVICE) if not env.shared_gpu else None
+    main = hbm or cache
+    B, res, bsec, dev_ms = main["B"], main["res"], main["bsec"], main["dev_ms"]
+    tables = {"cache_sized": cache["rec"], "library_default": "cache_sized (akp_ctx_set_table_budget 0 = 320 MiB)",
+              "cold_first_tree_ms_means": "fresh handles: tables for the leaf and inner-node lengths + scratch allocation + one tree of %d leaves "
+                                          "per GPU, host wall clock, max over ranks; the cache-sized handle is measured first and also pays the "
+                                          "context's first scratch allocation (and, at N > 1, the first collective)" % per,
+              "headline_table": "hbm_sized (opt-in: AKP_TABLE_BUDGET_DEVICE)" if hbm else "cache_sized"}
+    if hbm:
+        tables["hbm_sized"] = hbm["rec"]
+        d_cold = (hbm["rec"]["cold_first_tree_ms"] - cache["rec"]["cold_first_tree_ms"]) / 1e3
+        d_tree = cache["rec"]["warm_seconds"] - hbm["rec"]["warm_seconds"]
+        tables["break_even_trees"] = 1 + d_cold / d_tree if d_tree > 0 and d_cold > 0 else None
+    # configs[4] as ONE tree of 2^26 leaves on one GPU, from nothing, for both tables (generators of their own: nothing is built yet)
+    if env.world == 1 and not env.shared_gpu and not args.no_sweep and args.sweep_max_log2 >= 26 and args.bh_merkle_log2 >= 20:
+        big = 1 << 26
+        d_big = d_leaves.repeat(big // per, 1) if big > per else d_leaves[:big]
+        g2 = cparams.bowe_hopwood_generators(0xA5A50105, 63, 9)
+        single = {}
+        for name, budget in (("cache_sized", 0), ("hbm_sized", TABLE_BUDGET_DEVICE)):
+            Bp, tb2 = fresh(budget, g2)
+            torch.cuda.synchronize(env.dev)
+            c0 = time.perf_counter()
+            r2 = env.build_sharded(tb2, d_big, big, None)
+            torch.cuda.synchronize(env.dev)
+            cold = time.perf_counter() - c0
+            c0 = time.perf_counter()
+            r2 = env.build_sharded(tb2, d_big, big, None)
+            torch.cuda.synchronize(env.dev)
+            single[name] = {"cold_first_tree_s": cold, "warm_tree_s": time.perf_counter() - c0, "table_bytes": Bp.handle(env.ctx).info(32)["table_bytes"]}
+            del r2, tb2, Bp
+            torch.cuda.empty_cache()
+        tables["single_tree_2p26_one_gpu"] = single
+        del d_big
+        torch.cuda.empty_cache()
     h = B.handle(env.ctx)
     grp = h.info()["digit_bits_or_group"]
     # additions per inner node: the table steps of the 64 data bytes; the constant of the zero-padded tail (a zero chunk adds +g) is
     # folded into the remainder step when the 171 data chunks leave one (groups of 8: 21 + 1), else it is one more addition
     inner_adds = h.info(64)["steps"] + (0 if grp > 1 and 171 % grp else 1)
     bh_merkle = {"config": "BASELINE configs[4]: MerkleTree::new, Bowe-Hopwood 63x9 over Jubjub, 32-byte leaves, ByteDigestConverter",
-                 "leaves": total, "leaves_per_gpu": per, "seconds": bsec, "leaves_per_s": total / bsec, "scaling": "weak",
+                 "leaves": total, "leaves_per_gpu": per, "tables": tables, "seconds": bsec, "leaves_per_s": total / bsec, "scaling": "weak",
                  "roofline": {"bound": "hbm", "kernels": "te_accumulate_lds_kernel<1> + te_finalize_kernel<1> + te_serialize_pairs_kernel per level",
                               "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,

@@ -30,7 +30,7 @@ def compact(full, full_name="bench_full.json"):
     rf = full["roofline"]
     valu = rf.get("valu") or {}
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")}
-    line["dtype"] = "i32"  # 9 x 29-bit limbs in 32-bit registers, 64-bit v_mad_i64_i32 accumulation (bench_full.json: dtype_detail)
+    line["dtype"] = full["dtype"].split(" ")[0]  # "i32": 9 x 29-bit limbs in 32-bit registers, 64-bit multiply-add accumulation (full record: dtype_detail)
     line["data"] = full["data"]
     line["config"] = {k: full["config"][k] for k in ("workload", "states_per_gpu", "parallelism")}
     par = full["parity"]
@@ -56,15 +56,20 @@ def compact(full, full_name="bench_full.json"):
         "merkle_hbm_frac": _get(full, "merkle", "hbm_frac"),
         "pedersen_hashes_per_s": _get(full, "pedersen", "hashes_per_s"),   # configs[3], warm
         "pedersen_hbm_frac": _get(full, "pedersen", "roofline", "frac"),
-        "pedersen_cold_first_call_ms": _get(full, "pedersen", "cold", "default", "first_call_ms"),
-        "pedersen_cold_first_call_ms_cache_table": _get(full, "pedersen", "cold", "cache_sized", "first_call_ms"),
+        "pedersen_default_table_hashes_per_s": _get(full, "pedersen", "tables", "cache_sized", "warm_hashes_per_s"),
+        "pedersen_cold_first_call_ms": _get(full, "pedersen", "tables", "cache_sized", "cold_first_call_ms"),          # library default, from nothing
+        "pedersen_cold_first_call_ms_hbm_table": _get(full, "pedersen", "tables", "hbm_sized", "cold_first_call_ms"),
+        "pedersen_break_even_hashes": _get(full, "pedersen", "tables", "break_even_hashes"),
         "bh_leaves": _get(full, "bh_merkle", "leaves"),
         "bh_s": _get(full, "bh_merkle", "seconds"),                        # configs[4] share: 2^23 leaves per GPU, warm
         "bh_leaves_per_s": _get(full, "bh_merkle", "leaves_per_s"),
         "bh_hbm_frac": _get(full, "bh_merkle", "roofline", "frac"),
-        "bh_cold_first_tree_ms": _get(full, "bh_merkle", "cold", "default", "first_tree_ms"),
-        "bh_cold_first_tree_ms_cache_table": _get(full, "bh_merkle", "cold", "cache_sized", "first_tree_ms"),
-        "bh_2p26_s": _get(full, "sweep", "points", "2^26", "bh_tree_ms"),
+        "bh_default_table_s": _get(full, "bh_merkle", "tables", "cache_sized", "warm_seconds"),
+        "bh_cold_first_tree_ms": _get(full, "bh_merkle", "tables", "cache_sized", "cold_first_tree_ms"),                # library default, from nothing
+        "bh_cold_first_tree_ms_hbm_table": _get(full, "bh_merkle", "tables", "hbm_sized", "cold_first_tree_ms"),
+        "bh_2p26_s": _get(full, "sweep", "points", "2^26", "bh_tree_ms"),                                               # ONE GPU, warm, hbm table
+        "bh_2p26_cold_s": _get(full, "bh_merkle", "tables", "single_tree_2p26_one_gpu", "cache_sized", "cold_first_tree_s"),
+        "bh_2p26_cold_s_hbm_table": _get(full, "bh_merkle", "tables", "single_tree_2p26_one_gpu", "hbm_sized", "cold_first_tree_s"),
         "verify_paths_hashes_per_s": _get(full, "proofs", "poseidon", "verify_all_leaves_dev", "hashes_per_s_device"),
         "update_2p10_leaves_per_s": _get(full, "proofs", "poseidon", "update_batch", "2^10", "leaves_per_s"),
         "host_pinned_perm_per_s": _get(full, "host_path", "pinned", "permutations_per_s"),

@@ -12,31 +12,69 @@ def run(env):
     from crypto_primitives_amd.crh import pedersen as cped
     npd = 1 << args.pedersen_log2
     gens = cparams.pedersen_generators(0xA5A50004, 4, 256)
-    hP = cped.Parameters(gens).handle(env.ctx)
     msgs = np.random.default_rng(0xA5A50004 + env.rank).integers(0, 256, size=(npd, 128), dtype=np.uint8)
     d_msgs = torch.from_numpy(msgs).to(env.dev)
     d_out = torch.empty((npd, 8), dtype=torch.int64, device=env.dev)
+    from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
+    budget_before = env.ctx.table_budget_setting
+    state = {}
 
     def ped_step():
-        check(lib.akp_te_crh_batch_dev(hP.h, d_msgs.data_ptr(), npd, 128, d_out.data_ptr(), env.stream))
-    for _ in range(3):
+        check(lib.akp_te_crh_batch_dev(state["h"].h, d_msgs.data_ptr(), npd, 128, d_out.data_ptr(), env.stream))
+
+    def one_table(budget):
+        """a FRESH handle under `budget` (nothing else in this process holds these generators with that shape, so the table is built
+        here): the first call from nothing (table build + scratch + hash), then the warm rate"""
+        env.ctx.set_table_budget(budget)
+        try:
+            P = cped.Parameters(gens)
+            state["h"] = h = P.handle(env.ctx)
+        finally:
+            env.ctx.set_table_budget(budget_before)
+        assert h.table_info()["wide_builds"] == 0
+        torch.cuda.synchronize(env.dev)
+        c0 = time.perf_counter()
         ped_step()
-    env.barrier()
-    reps = 10
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    p0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        ped_step()
-        b.record()
-    env.barrier()
-    psec = env.max_over_ranks(time.perf_counter() - p0)
-    kms = sorted(a.elapsed_time(b) for a, b in evs)
-    kavg = sum(kms) / len(kms) / 1e3
+        torch.cuda.synchronize(env.dev)
+        cold_ms = (time.perf_counter() - c0) * 1e3
+        for _ in range(3):
+            ped_step()
+        env.barrier()
+        reps = 10
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        p0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            ped_step()
+            b.record()
+        env.barrier()
+        psec = env.max_over_ranks(time.perf_counter() - p0)
+        kms = sorted(a.elapsed_time(b) for a, b in evs)
+        info = h.info(128)
+        return {"P": P, "h": h, "reps": reps, "psec": psec, "kavg": sum(kms) / len(kms) / 1e3,
+                "rec": {"digit_bits": info["digit_bits_or_group"], "table_bytes": info["table_bytes"], "steps": info["steps"],
+                        "cold_first_call_ms": cold_ms, "warm_ms_per_batch": psec / reps * 1e3, "warm_hashes_per_s": npd * env.world * reps / psec}}
+    # the library's default first (cache-sized table), then the HBM-sized table a host opts into -- both from nothing
+    cache = one_table(0)
+    hbm = one_table(TABLE_BUDGET_DEVICE) if not env.shared_gpu else None
+    main = hbm or cache
+    hP, reps, psec, kavg = main["h"], main["reps"], main["psec"], main["kavg"]
+    state["h"] = hP
     pinfo = hP.info(128)
     psteps = pinfo["steps"]
     tc = te_counters("pedersen_128B", npd, psteps)
-    pedersen = {"config": "BASELINE configs[3]: pedersen::CRH, Jubjub, window 4x256, 128-byte messages", "messages_per_gpu": npd,
+    tables = {"cache_sized": cache["rec"], "library_default": "cache_sized (akp_ctx_set_table_budget 0 = 320 MiB)",
+              "cold_first_call_ms_means": "fresh handle: table build + scratch allocation + one batch of %d hashes, host wall clock; the cache-sized "
+                                          "handle is measured first and also pays the context's first scratch allocation" % npd}
+    if hbm:
+        tables["hbm_sized"] = hbm["rec"]
+        d_cold = hbm["rec"]["cold_first_call_ms"] - cache["rec"]["cold_first_call_ms"]
+        d_hash = (cache["rec"]["warm_ms_per_batch"] - hbm["rec"]["warm_ms_per_batch"]) / npd
+        tables["break_even_hashes"] = npd + d_cold / d_hash if d_hash > 0 and d_cold > 0 else None
+        tables["headline_table"] = "hbm_sized (opt-in: AKP_TABLE_BUDGET_DEVICE): `hashes_per_s`, `roofline` and `sustained` of this leg"
+    else:
+        tables["headline_table"] = "cache_sized"
+    pedersen = {"config": "BASELINE configs[3]: pedersen::CRH, Jubjub, window 4x256, 128-byte messages", "messages_per_gpu": npd, "tables": tables,
                 "hashes_per_s": npd * env.world * reps / psec, "ms_per_batch": psec / reps * 1e3,
                 "roofline": {"bound": "hbm", "kernels": "te_accumulate_lds_kernel<2> + te_finalize_kernel<0>", "algorithmic_bytes_per_hash": 192,
                              "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
