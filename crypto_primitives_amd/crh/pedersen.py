@@ -76,10 +76,10 @@ class _TeHandle:
 
     def prepare(self, msg_len=None, compress=False):
         """build the device tables now (akp_te_params_prepare / _prepare_compress) instead of inside the first hash"""
+        if compress:  # first: the two-to-one buffer is usually the longer message, and a longer message later would rebuild the table
+            check(lib.akp_te_params_prepare_compress(self.h))
         if msg_len is not None:
             check(lib.akp_te_params_prepare(self.h, int(msg_len)))
-        if compress:
-            check(lib.akp_te_params_prepare_compress(self.h))
 
     def table_info(self):
         """the shared table behind this handle (akp_te_params_table_info): id (equal for handles that share), handles attached,

@@ -309,6 +309,10 @@ static inline size_t te_input_bits(const akp_te_params* p) {  // max message bit
 // n messages of msg_len bytes (device) -> n digests; data_len < msg_len: the bytes past data_len are zero padding (two-to-one buffers)
 int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s,
         size_t data_len = (size_t)-1);
+// ragged batch on device buffers (item i = bytes [d_offsets[i], d_offsets[i+1]) of d_msgs; max_len bounds the longest) and the host-side
+// check of an offsets array (monotonic, every item inside the window: AKP_ERR_BAD_LENGTH where the reference panics)
+int32_t te_crh_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_t* d_offsets, size_t n, size_t max_len, Fr* d_out, hipStream_t s);
+int32_t te_ragged_check_offsets(const akp_te_params* p, const uint64_t* offsets, size_t n, size_t* max_len);
 // akp_te_params_prepare_compress without the argument checks (the tree builders call it)
 int32_t te_prepare_compress(akp_te_params* p);
 // TwoToOneCRH::compress on device digests (d_right == nullptr: pairs d_left[2i], d_left[2i + 1], a tree level)

@@ -4,6 +4,7 @@
 #include "capi_internal.hpp"
 #include "te_kernels.hpp"
 #include "te_shape.hpp"
+#include "ragged_sort.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Pedersen / Bowe-Hopwood
@@ -601,6 +602,22 @@ extern "C" int32_t akp_te_params_prepare_compress(akp_te_params* p) {
     NEED_TE(p, "akp_te_params_prepare_compress");
     return te_prepare_compress(p);
 }
+// projective -> affine for `cnt` sums.  One inversion is shared among up to 64 messages per lane, but `target` lanes
+// stay busy when the range allows.  Measured at 2^20 Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K /
+// 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 / 3.29 / 3.46 ms for accumulate + finalize (two boxes): one wave
+// per SIMD it is (a compile-time choice since round 3).
+static int32_t te_launch_finalize(const akp_te_params* p, const F29Pad* x, F29Pad* pre, Fr* d_out, size_t cnt, hipStream_t st) {
+    constexpr size_t target = 65536;
+    const size_t chain = std::min<size_t>(64, std::max<size_t>(1, cnt / target));
+    const size_t lanes = (cnt + chain - 1) / chain;
+    const unsigned fgrid = (unsigned)((lanes + 255) / 256);
+    if (p->kind == AKP_TE_PEDERSEN)
+        hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, st, x, pre, d_out, cnt, lanes);
+    else
+        hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, st, x, pre, d_out, cnt, lanes);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
 // `pitch`: distance in bytes between consecutive messages in d_msgs (0: msg_len); a pitch below msg_len is legal when the bytes
 // past data_len are the implied zero padding (te_compress_dev packs the digest pairs without it)
 static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, Fr* d_out, hipStream_t s, size_t data_len,
@@ -696,23 +713,9 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         HIP_TRY(hipGetLastError());
         return AKP_OK;
     };
-    // projective -> affine for the same range.  One inversion is shared among up to 64 messages per lane, but `target` lanes
-    // stay busy when the range allows.  Measured at 2^20 Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K /
-    // 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 / 3.29 / 3.46 ms for accumulate + finalize (two boxes): one wave
-    // per SIMD it is (a compile-time choice since round 3).
+    // projective -> affine for the same range (te_launch_finalize)
     auto finalize = [&](size_t first, size_t cnt, hipStream_t st) -> int32_t {
-        constexpr size_t target = 65536;
-        const size_t chain = std::min<size_t>(64, std::max<size_t>(1, cnt / target));
-        const size_t lanes = (cnt + chain - 1) / chain;
-        const unsigned fgrid = (unsigned)((lanes + 255) / 256);
-        const F29Pad* x = (const F29Pad*)xyz + first * 3;
-        F29Pad* pre = (F29Pad*)prefix + first;
-        if (p->kind == AKP_TE_PEDERSEN)
-            hipLaunchKernelGGL(te_finalize_kernel<0>, dim3(fgrid), dim3(256), 0, st, x, pre, d_out + first * fe, cnt, lanes);
-        else
-            hipLaunchKernelGGL(te_finalize_kernel<1>, dim3(fgrid), dim3(256), 0, st, x, pre, d_out + first * fe, cnt, lanes);
-        HIP_TRY(hipGetLastError());
-        return AKP_OK;
+        return te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, d_out + first * fe, cnt, st);
     };
 #if defined(AKP_TE_SPLIT_FINALIZE)
     // A/B arm (`make splitfin`, round 3): the latency-bound finalize pass of the first half runs on a side stream under the
@@ -860,6 +863,94 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     HIP_TRY(hipStreamSynchronize(cin));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipStreamSynchronize(cout));
+    return AKP_OK;
+}
+// ---- ragged batches: every message has its own length (round 5; crh/pedersen/mod.rs:82-99, crh/bowe_hopwood/mod.rs:121-138,
+// merkle_tree/mod.rs:411-422) ---------------------------------------------------------------------------------------------------
+// item i = bytes [offsets[i], offsets[i+1]) of d_msgs; max_len = a bound on the longest item (the wide table is built for it).
+// Items launch sorted by their number of table steps (ragged_sort.hpp), longest first; scratch: SCR_E / SCR_F as te_crh_run, SCR_H
+// for the sort.  Enqueue only.
+static inline bool te_ragged_sort_on(size_t n) {
+#if defined(AKP_TEST_HOOKS)
+    if (const char* e = getenv("AKP_RAGGED_SORT")) return atoi(e) != 0;  // A/B of the launch order (test build only)
+#endif
+    return n >= 4096;  // below that the three sort launches cost more than the idle lanes
+}
+int32_t te_crh_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_t* d_offsets, size_t n, size_t max_len, Fr* d_out, hipStream_t s) {
+    if (max_len * 8 > te_input_bits(p))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", max_len, p->W, p->N);
+    if (n == 0) return AKP_OK;
+    if (n >= ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32 - 1", n);
+    TeTable* t = p->t;
+    akp_ctx* c = p->ctx;
+    std::lock_guard<std::mutex> table_lock(t->mu);
+    u32 groups = 0, steps = 0;
+    if (int32_t rc = te_ensure_table(c, t, max_len, &groups, &steps, s)) return rc;
+    const u32 D = t->pedersen ? t->digit_bits : t->group;  // Bowe-Hopwood: no remainder table (R = 0): left-over chunks are single steps
+    void *xyz = nullptr, *prefix = nullptr, *work = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
+    const u32* order = nullptr;
+    if (te_ragged_sort_on(n)) {
+        if (int32_t rc = ctx_scratch(c, SCR_H, (2 * n + 2 * RAGGED_MAX_KEYS) * sizeof(u32), &work, s)) return rc;
+        u32* d_order = (u32*)work + n + 2 * RAGGED_MAX_KEYS;
+        const RaggedKey key{t->pedersen ? 0u : 1u, D, t->n_gen};
+        HIP_TRY(ragged_order(d_offsets, n, key, (u32*)work, d_order, s));
+        order = d_order;
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    const u32 built = t->pedersen && !t->signed_subset ? 0xffffffffu : (t->pedersen || t->group > 1 ? t->units_built : 0u);
+    if (t->pedersen && t->signed_subset)
+        hipLaunchKernelGGL(te_accumulate_ragged_kernel<2>, dim3(grid), dim3(256), 0, s, t->d_lut, t->d_lut1, d_msgs, d_offsets, order, D, t->n_gen, built,
+                (F29Pad*)xyz, n);
+    else if (t->pedersen)
+        hipLaunchKernelGGL(te_accumulate_ragged_kernel<0>, dim3(grid), dim3(256), 0, s, t->d_lut, t->d_lut1, d_msgs, d_offsets, order, D, t->n_gen, built,
+                (F29Pad*)xyz, n);
+    else
+        hipLaunchKernelGGL(te_accumulate_ragged_kernel<1>, dim3(grid), dim3(256), 0, s, t->d_lut, t->d_lut1, d_msgs, d_offsets, order, D, t->n_gen, built,
+                (F29Pad*)xyz, n);
+    HIP_TRY(hipGetLastError());
+    return te_launch_finalize(p, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, s);
+}
+// offsets[0 .. n] on the host: non-decreasing, every item within the window; *max_len = the longest item
+int32_t te_ragged_check_offsets(const akp_te_params* p, const uint64_t* offsets, size_t n, size_t* max_len) {
+    size_t mx = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(AKP_ERR_BAD_PARAMS, "offsets[%zu] > offsets[%zu]: offsets must not decrease", i, i + 1);
+        mx = std::max<size_t>(mx, (size_t)(offsets[i + 1] - offsets[i]));
+    }
+    if (mx * 8 > te_input_bits(p))
+        return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", mx, p->W, p->N);
+    *max_len = mx;
+    return AKP_OK;
+}
+extern "C" int32_t akp_te_crh_batch_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_t* d_offsets, size_t n, size_t max_len,
+        uint64_t* d_out, void* stream) {
+    NEED_TE(p, "akp_te_crh_batch_ragged_dev");
+    if (n && (!d_offsets || !d_out)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    return te_crh_ragged_dev(p, d_msgs, d_offsets, n, max_len, (Fr*)d_out, pick_stream(p->ctx, stream));
+}
+extern "C" int32_t akp_te_crh_batch_ragged(akp_te_params* p, const uint8_t* msgs, const uint64_t* offsets, size_t n, uint64_t* out) {
+    NEED_TE(p, "akp_te_crh_batch_ragged");
+    if (n == 0) return AKP_OK;
+    if (!offsets || !out) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    size_t max_len = 0;
+    if (int32_t rc = te_ragged_check_offsets(p, offsets, n, &max_len)) return rc;
+    const size_t total = (size_t)(offsets[n] - offsets[0]);
+    if (total && !msgs) return fail(AKP_ERR_BAD_PARAMS, "msgs is NULL");
+    akp_ctx* c = p->ctx;
+    hipStream_t s = c->stream;
+    const size_t dig = te_fe_per_digest(p) * sizeof(Fr);
+    void *dm = nullptr, *doff = nullptr, *dout = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_A, total + 4, &dm, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_G, (n + 1) * sizeof(uint64_t), &doff, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
+    if (total) HIP_TRY(hipMemcpyAsync(dm, msgs + offsets[0], total, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(doff, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    // the offsets go up as they are: the device base is moved back by offsets[0] instead (never dereferenced below offsets[0])
+    if (int32_t rc = te_crh_ragged_dev(p, (const uint8_t*)dm - offsets[0], (const uint64_t*)doff, n, max_len, (Fr*)dout, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, n * dig, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return AKP_OK;
 }
 extern "C" int32_t akp_te_two_to_one_batch(akp_te_params* p, const uint8_t* left, const uint8_t* right, size_t n, size_t half_len,

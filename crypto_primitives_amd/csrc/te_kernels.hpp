@@ -30,6 +30,7 @@
 #pragma once
 #include "f29.hpp"
 #include "akp_types.hpp"
+#include "te_shape.hpp"
 
 namespace akp {
 
@@ -433,12 +434,13 @@ __global__ void te_check_table_kernel(const void* __restrict__ src /* NielsPad* 
 }
 
 // ---- message bit access -----------------------------------------------------------------------
-// bits [o, o+w) (w <= 16) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
+// bits [o, o+w) (w <= 24 + 1) of a message of `len` bytes, LSB-first per byte (crh/pedersen/mod.rs:200-209);
 // bits past the end read as zero (Pedersen zero padding :91-99 / Bowe-Hopwood chunk padding :131-138).
 // Done in two halves for the software pipeline of te_accumulate_item: msg_load issues ONE unconditional, unaligned
 // 32-bit load that covers the window (so that nothing waits for it here), msg_combine extracts the bits -- it runs one
 // curve addition later.  The load address is pulled back so that the four bytes end inside the message (messages of
-// fewer than four bytes are padded by the host, te_crh_dev); a window of w <= 17 bits starting at bit (o & 7) of its first
+// fewer than four bytes are padded by the host, te_crh_dev); a window of w <= 25 bits (24-bit digits, groups of 8 chunks; static_assert
+// below) starting at bit (o & 7) of its first
 // byte fits the 32 bits, and when the address was pulled back the window reaches past the end of the message, where the
 // bits are zero -- exactly what the right shift of the 32-bit word shifts in.
 struct MsgRaw {
@@ -485,6 +487,25 @@ __device__ __forceinline__ MsgRaw msg_load(const MsgLds& m, size_t len, size_t o
     return MsgRaw{__builtin_amdgcn_alignbit(hi, lo, sh)};
 }
 #endif
+
+// A message of ANY length, also 1..3 bytes (the ragged batches: every lane has a length of its own, nothing was padded by the host).
+// Short messages are assembled from byte loads; everything else is the 32-bit window of msg_load above.
+struct MsgAny {
+    const uint8_t* p;
+};
+AKP_HD MsgRaw msg_load(const MsgAny& m, size_t len, size_t o) {
+    if (len == 0) return MsgRaw{0u};
+    u32 v = 0;
+    if (len < 4) {
+        for (size_t k = 0; k < len; ++k) v |= (u32)m.p[k] << (8 * k);
+        return MsgRaw{v};
+    }
+    __builtin_memcpy(&v, m.p + msg_word_addr(len, o), 4);
+    return MsgRaw{v};
+}
+constexpr u32 te_shape_max_window_bits = te_shape::MAX_DIGIT > 3 * te_shape::MAX_GROUP ? te_shape::MAX_DIGIT : 3 * te_shape::MAX_GROUP;
+// the invariant every window extraction above rests on: a step's bits start at most 7 bits into the 32-bit word
+static_assert(te_shape_max_window_bits + 7 <= 32, "a table step's message bits must fit one 32-bit window that starts inside a byte");
 
 // ---- accumulate: one message per lane ------------------------------------------------------------
 // A step is split into three stages so that no load is consumed in the stage that issues it (the compiler places the
@@ -778,6 +799,56 @@ __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_kernel(co
     if (idx >= n) return;
     Ext acc = te_accumulate_item<KIND>(lut, lut1, msgs + idx * stride, msg_len, D, n_groups, n_steps);
     if (tail) acc = te_madd(acc, load_niels(tail));
+    f29_store_pad(xyz + idx * 3, acc.X);
+    f29_store_pad(xyz + idx * 3 + 1, acc.Y);
+    f29_store_pad(xyz + idx * 3 + 2, acc.Z);
+}
+// ---- ragged batches: every item has its own length (round 5) ---------------------------------------------------------------------
+// The reference hashes each input with ITS length (crh/pedersen/mod.rs:82-99 pads each input to the window; crh/bowe_hopwood/
+// mod.rs:131-138 pads each input to a multiple of 3 bits; MerkleTree::new maps LeafHash::evaluate over any iterator of leaves,
+// merkle_tree/mod.rs:411-422).  Item i is bytes [offsets[i], offsets[i+1]) of `msgs`.  Its table steps follow from its length
+// exactly as te_shape.hpp computes them for a uniform batch -- Bowe-Hopwood: full groups from the wide table, the chunks left
+// over as single steps from the one-chunk table (no remainder tables: those belong to ONE length) -- and te_accumulate_item runs
+// with per-lane step counts.  `order` (may be null): the launch order of the items, sorted by step count so that the 64 lanes of
+// a wave finish together (ragged_sort.hpp); results are stored by ITEM index either way.  `units_built`: digits / groups the wide
+// table covers (the host built it for the longest item; the clamp keeps a lying max_len from reading past the table).
+template <int KIND>
+AKP_HD void te_item_steps(u32 n_gen, u32 D, size_t len, u32 units_built, u32* groups, u32* steps) {
+    if (KIND != 1) {
+        const size_t used = len * 8 < n_gen ? len * 8 : n_gen;
+        u32 st = (u32)((used + D - 1) / D);
+        if (KIND == 2 && st > units_built) st = units_built;
+        *groups = 0;
+        *steps = st;
+        return;
+    }
+    const size_t ch = (len * 8 + 2) / 3;
+    const u32 chunks = (u32)(ch < n_gen ? ch : n_gen);
+    const u32 G = te_bh_group(D);
+    if (G > 1) {
+        u32 g = chunks / G;
+        if (g > units_built) g = units_built;
+        *groups = g;
+        *steps = g + (chunks - g * G < G ? chunks - g * G : chunks % G);
+    } else {
+        *groups = 0;
+        *steps = chunks;
+    }
+}
+template <int KIND>
+__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_ragged_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
+                                                           const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offsets,
+                                                           const u32* __restrict__ order, u32 D, u32 n_gen, u32 units_built,
+                                                           F29Pad* __restrict__ xyz, size_t n) {
+    const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const size_t idx = order ? order[slot] : slot;
+    const uint64_t off = offsets[idx];
+    const size_t len = (size_t)(offsets[idx + 1] - off);
+    u32 groups, steps;
+    te_item_steps<KIND>(n_gen, D, len, units_built, &groups, &steps);
+    const MsgAny m{msgs + off};
+    const Ext acc = te_accumulate_item<KIND>(lut, lut1, m, len, D, groups, steps);
     f29_store_pad(xyz + idx * 3, acc.X);
     f29_store_pad(xyz + idx * 3 + 1, acc.Y);
     f29_store_pad(xyz + idx * 3 + 2, acc.Z);
