@@ -98,6 +98,14 @@ def _load():
         "akp_te_entry_bytes": (u32, []),
         "akp_te_crh_batch": (i32, [vp, u8p, sz, sz, u64p]),
         "akp_te_crh_batch_dev": (i32, [vp, u8p, sz, sz, u64p, vp]),
+        "akp_te_crh_batch_ragged": (i32, [vp, u8p, u64p, sz, u64p]),
+        "akp_te_crh_batch_ragged_dev": (i32, [vp, u8p, u64p, sz, sz, u64p, vp]),
+        "akp_poseidon_crh_batch_ragged": (i32, [vp, u64p, u64p, sz, u64p]),
+        "akp_poseidon_crh_batch_ragged_dev": (i32, [vp, u64p, u64p, sz, u64p, vp]),
+        "akp_merkle_tree_build_poseidon_ragged": (i32, [vp, vp, u64p, u64p, sz, pp]),
+        "akp_merkle_tree_build_te_ragged": (i32, [vp, vp, u8p, u64p, sz, pp]),
+        "akp_multi_tree_build_poseidon_ragged": (i32, [vp, pp, pp, u64p, u64p, sz, pp]),
+        "akp_multi_tree_build_te_ragged": (i32, [vp, pp, pp, u8p, u64p, sz, pp]),
         "akp_te_two_to_one_batch": (i32, [vp, u8p, u8p, sz, sz, u64p]),
         "akp_te_compress_batch": (i32, [vp, u64p, u64p, sz, u64p]),
         "akp_merkle_build_poseidon": (i32, [vp, vp, u64p, sz, sz, u64p, u64p, u64p]),

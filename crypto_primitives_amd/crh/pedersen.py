@@ -97,13 +97,27 @@ class _TeHandle:
             pass
 
 
+def ragged_bytes(msgs):
+    """byte strings of DIFFERENT lengths -> (flat uint8 array, offsets uint64 [n + 1]) for the `_ragged` entry points, or None when
+    `msgs` is an array / a list of equal-length strings (the uniform entry points take those)"""
+    if not isinstance(msgs, (list, tuple)) or not msgs or isinstance(msgs[0], (int, np.integer)):
+        return None
+    lens = [len(x) for x in msgs]
+    if all(L == lens[0] for L in lens):
+        return None
+    offs = np.zeros(len(msgs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(np.asarray(lens, dtype=np.uint64))
+    flat = np.frombuffer(b"".join(bytes(np.asarray(x, dtype=np.uint8)) if not isinstance(x, (bytes, bytearray)) else bytes(x) for x in msgs), dtype=np.uint8)
+    return np.ascontiguousarray(flat), offs
+
+
 def _as_msgs(msgs, n=None, msg_len=None):
     if isinstance(msgs, (bytes, bytearray)):
         m = np.frombuffer(bytes(msgs), dtype=np.uint8)
         return m, 1, len(m)
     if isinstance(msgs, (list, tuple)) and msgs and isinstance(msgs[0], (bytes, bytearray)):
         L = len(msgs[0])
-        assert all(len(x) == L for x in msgs), "batch forms take equal-length inputs"
+        assert all(len(x) == L for x in msgs), "the uniform batch forms take equal-length inputs (evaluate_batch routes others to the ragged entry point)"
         return np.frombuffer(b"".join(bytes(x) for x in msgs), dtype=np.uint8), len(msgs), L
     m = np.ascontiguousarray(msgs, dtype=np.uint8)
     if m.ndim == 1:
@@ -129,7 +143,16 @@ class _TeCRH:
 
     @classmethod
     def evaluate_batch(cls, parameters, msgs, window=None):
+        """n inputs -> n digests.  Inputs of different lengths (a list of byte strings) are hashed each with ITS length, as the
+        reference's per-item evaluate does (akp_te_crh_batch_ragged)."""
         cls._check_window(window, parameters)
+        rg = ragged_bytes(msgs)
+        if rg is not None:
+            flat, offs = rg
+            n = len(offs) - 1
+            out = np.empty((n, cls._FE, 4), dtype=np.uint64)
+            check(lib.akp_te_crh_batch_ragged(te_handle(parameters, cls).h, flat.ctypes.data if flat.size else None, offs.ctypes.data, n, out.ctypes.data))
+            return out if cls._FE == 2 else out.reshape(n, 4)
         m, n, L = _as_msgs(msgs)
         out = np.empty((n, cls._FE, 4), dtype=np.uint64)
         check(lib.akp_te_crh_batch(te_handle(parameters, cls).h, m.ctypes.data if m.size else None, n, L, out.ctypes.data))

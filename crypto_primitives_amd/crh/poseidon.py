@@ -11,6 +11,20 @@ from .._lib import lib, check
 from ..sponge.poseidon import PoseidonConfig
 
 
+def ragged_fr(inputs):
+    """a list of [k_i, 4] wire-format inputs with DIFFERENT k_i -> (flat [sum k_i, 4] array, offsets uint64 [n + 1] in elements);
+    None for an array or a list of equal shapes"""
+    if not isinstance(inputs, (list, tuple)) or not inputs:
+        return None
+    items = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in inputs]
+    lens = [len(x) for x in items]
+    if all(k == lens[0] for k in lens):
+        return None
+    offs = np.zeros(len(items) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(np.asarray(lens, dtype=np.uint64))
+    return np.ascontiguousarray(np.concatenate(items, axis=0)), offs
+
+
 class CRH:
     """poseidon::CRH<Fr>: Input = [Fr], Output = Fr, Parameters = PoseidonConfig<Fr>."""
 
@@ -27,7 +41,15 @@ class CRH:
 
     @staticmethod
     def evaluate_batch(parameters: PoseidonConfig, inputs) -> np.ndarray:
-        """inputs [n, k, 4] -> digests [n, 4].  k may be 0."""
+        """inputs [n, k, 4] -> digests [n, 4].  k may be 0.  A LIST of inputs with different element counts is hashed item by item
+        with its own length (akp_poseidon_crh_batch_ragged), as the reference's evaluate(&[F]) does."""
+        rg = ragged_fr(inputs)
+        if rg is not None:
+            flat, offs = rg
+            n = len(offs) - 1
+            out = np.empty((n, 4), dtype=np.uint64)
+            check(lib.akp_poseidon_crh_batch_ragged(parameters.handle().h, flat.ctypes.data if flat.size else None, offs.ctypes.data, n, out.ctypes.data))
+            return out
         x = np.ascontiguousarray(inputs, dtype=np.uint64)
         n, k = x.shape[0], x.shape[1]
         out = np.empty((n, 4), dtype=np.uint64)

@@ -227,6 +227,8 @@ void poseidon_unpin(akp_poseidon* p);
 // the batch launchers the tree code shares with the batch entry points: route n items to the register / latency / LDS-file kernels
 int32_t launch_permute(akp_poseidon* p, Fr* d_states, size_t n, hipStream_t s, bool host_memory = false);
 int32_t launch_crh(akp_poseidon* p, const Fr* in0, const Fr* in1, size_t k, Fr* d_out, size_t n, hipStream_t s);
+// ragged CRH batch on device buffers (t = 3): item i = elements [d_offsets[i], d_offsets[i+1]) of d_inputs
+int32_t poseidon_crh_ragged_dev(akp_poseidon* p, const Fr* d_inputs, const uint64_t* d_offsets, size_t n, Fr* d_out, hipStream_t s);
 int32_t launch_verify_paths_t3(akp_poseidon* leafp, akp_poseidon* two, const Fr* d_leaves, size_t leaf_len, const uint64_t* d_idx, const Fr* d_sibs,
         const Fr* d_auth, size_t depth, const Fr* d_root, uint8_t* d_ok, size_t m, hipStream_t s, bool* done);
 
@@ -314,7 +316,9 @@ int32_t te_crh_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg
 int32_t te_crh_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_t* d_offsets, size_t n, size_t max_len, Fr* d_out, hipStream_t s);
 int32_t te_ragged_check_offsets(const akp_te_params* p, const uint64_t* offsets, size_t n, size_t* max_len);
 // akp_te_params_prepare_compress without the argument checks (the tree builders call it)
-int32_t te_prepare_compress(akp_te_params* p);
+int32_t te_prepare_compress(akp_te_params* p, hipStream_t s);
+// before a tree build: when leaf and two-to-one hash share a table, build it for the inner nodes first (one build, no extension)
+int32_t te_tree_prepare(akp_te_params* leafp, akp_te_params* two, hipStream_t s);
 // TwoToOneCRH::compress on device digests (d_right == nullptr: pairs d_left[2i], d_left[2i + 1], a tree level)
 int32_t te_compress_dev(akp_te_params* p, const Fr* d_left, const Fr* d_right, size_t n, Fr* d_out, hipStream_t s);
 

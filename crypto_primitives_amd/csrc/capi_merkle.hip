@@ -149,6 +149,7 @@ extern "C" int32_t akp_merkle_build_te_dev(akp_te_params* leafp, akp_te_params* 
     if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "parameters belong to different contexts");
     if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
     hipStream_t s = pick_stream(leafp->ctx, stream);
+    if (int32_t rc = te_tree_prepare(leafp, two, s)) return rc;
     if (int32_t rc = te_crh_dev(leafp, d_leaves, n, leaf_len, (Fr*)d_leaf_nodes, s)) return rc;
     return akp_merkle_inner_te_dev(two, d_leaf_nodes, n, d_non_leaf, (void*)s);
 }
@@ -168,6 +169,7 @@ extern "C" int32_t akp_merkle_build_te(akp_te_params* leafp, akp_te_params* two,
     if (int32_t rc = ctx_scratch(c, SCR_B, n * fe * sizeof(Fr), &dln, c->stream)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_C, (n - 1) * fe * sizeof(Fr), &dnl, c->stream)) return rc;
     if (leafp->kind != two->kind || leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "leaf / two-to-one parameters mismatch");
+    if (int32_t rc = te_tree_prepare(leafp, two, c->stream)) return rc;
     return host_tree_build(
         c, leaves, n, leaf_len, fe * sizeof(Fr), dl, dln, dnl, leaf_nodes, non_leaf, root_out,
         [&](const void* d_chunk, size_t first, size_t cnt, hipStream_t s) -> int32_t {

@@ -4,6 +4,7 @@
 // point (a missing device is AKP_ERR_HIP).
 #include "capi_internal.hpp"
 #include "poseidon_kernels.hpp"
+#include "ragged_sort.hpp"
 #include "poseidon_opt.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -512,6 +513,75 @@ extern "C" int32_t akp_poseidon_crh_batch(akp_poseidon* p, const uint64_t* input
             hipStream_t s) -> int32_t {
         return launch_crh(p, (const Fr*)di[0], nullptr, k, (Fr*)dout, cnt, s);
     });
+}
+// ---- ragged batches: every input has its own number of elements (round 5; crh/poseidon/mod.rs:30-40, merkle_tree/mod.rs:411-422) ----
+// item i = elements [d_offsets[i], d_offsets[i+1]) of d_inputs.  t = 3 parameter sets only (the register kernel with per-lane
+// lengths; other widths go through the host entry point, which groups the items by length).  Scratch: SCR_H for the launch order.
+int32_t poseidon_crh_ragged_dev(akp_poseidon* p, const Fr* d_inputs, const uint64_t* d_offsets, size_t n, Fr* d_out, hipStream_t s) {
+    if (n == 0) return AKP_OK;
+    if (p->dims.t != 3) return fail(AKP_ERR_BAD_PARAMS, "ragged Poseidon batches on device buffers need t = 3 (got t = %u): use akp_poseidon_crh_batch_ragged", p->dims.t);
+    if (n >= ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu items exceeds the supported 2^32 - 1", n);
+    const u32* order = nullptr;
+    if (n >= 4096) {
+        void* work = nullptr;
+        if (int32_t rc = ctx_scratch(p->ctx, SCR_H, (2 * n + 2 * RAGGED_MAX_KEYS) * sizeof(u32), &work, s)) return rc;
+        u32* d_order = (u32*)work + n + 2 * RAGGED_MAX_KEYS;
+        HIP_TRY(ragged_order(d_offsets, n, RaggedKey{2u, p->dims.rate, 0u}, (u32*)work, d_order, s));
+        order = d_order;
+    }
+    const PoseidonConsts c = t3_reg_consts(p);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (c.scaled == 3u) hipLaunchKernelGGL(poseidon_crh_ragged_t3_kernel<true>, grid, dim3(256), t3_lds_cap(), s, p->dims, c, d_inputs, d_offsets, order, d_out, n);
+    else hipLaunchKernelGGL(poseidon_crh_ragged_t3_kernel<false>, grid, dim3(256), t3_lds_cap(), s, p->dims, c, d_inputs, d_offsets, order, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return AKP_OK;
+}
+extern "C" int32_t akp_poseidon_crh_batch_ragged_dev(akp_poseidon* p, const uint64_t* d_inputs, const uint64_t* d_offsets, size_t n, uint64_t* d_out,
+        void* stream) {
+    NEED_DEV(p, "akp_poseidon_crh_batch_ragged_dev");
+    if (n && (!d_offsets || !d_out)) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    return poseidon_crh_ragged_dev(p, (const Fr*)d_inputs, d_offsets, n, (Fr*)d_out, pick_stream(p->ctx, stream));
+}
+extern "C" int32_t akp_poseidon_crh_batch_ragged(akp_poseidon* p, const uint64_t* inputs, const uint64_t* offsets, size_t n, uint64_t* out) {
+    NEED_DEV(p, "akp_poseidon_crh_batch_ragged");
+    if (n == 0) return AKP_OK;
+    if (!offsets || !out) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    for (size_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(AKP_ERR_BAD_PARAMS, "offsets[%zu] > offsets[%zu]: offsets must not decrease", i, i + 1);
+    const size_t total = (size_t)(offsets[n] - offsets[0]);
+    if (total && !inputs) return fail(AKP_ERR_BAD_PARAMS, "inputs is NULL");
+    akp_ctx* c = p->ctx;
+    if (p->dims.t == 3) {
+        hipStream_t s = c->stream;
+        void *di = nullptr, *doff = nullptr, *dout = nullptr;
+        if (int32_t rc = ctx_scratch(c, SCR_A, std::max<size_t>(total, 1) * sizeof(Fr), &di, s)) return rc;
+        if (int32_t rc = ctx_scratch(c, SCR_G, (n + 1) * sizeof(uint64_t), &doff, s)) return rc;
+        if (int32_t rc = ctx_scratch(c, SCR_B, n * sizeof(Fr), &dout, s)) return rc;
+        if (total) HIP_TRY(hipMemcpyAsync(di, inputs + 4 * offsets[0], total * sizeof(Fr), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(doff, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        if (int32_t rc = poseidon_crh_ragged_dev(p, (const Fr*)di - offsets[0], (const uint64_t*)doff, n, (Fr*)dout, s)) return rc;
+        HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return AKP_OK;
+    }
+    // other widths: the items grouped by length on the host, one uniform batch per distinct length (a sponge of rate r sees few)
+    std::vector<std::pair<uint64_t, size_t>> by_len(n);
+    for (size_t i = 0; i < n; ++i) by_len[i] = {offsets[i + 1] - offsets[i], i};
+    std::sort(by_len.begin(), by_len.end());
+    std::vector<uint64_t> in_buf, out_buf;
+    for (size_t a = 0; a < n;) {
+        size_t b = a;
+        while (b < n && by_len[b].first == by_len[a].first) ++b;
+        const size_t k = (size_t)by_len[a].first, cnt = b - a;
+        in_buf.resize(std::max<size_t>(cnt * k * 4, 1));
+        out_buf.resize(cnt * 4);
+        for (size_t j = 0; j < cnt; ++j)
+            if (k) memcpy(in_buf.data() + j * k * 4, inputs + 4 * offsets[by_len[a + j].second], k * sizeof(Fr));
+        if (int32_t rc = akp_poseidon_crh_batch(p, in_buf.data(), cnt, k, out_buf.data())) return rc;
+        for (size_t j = 0; j < cnt; ++j) memcpy(out + 4 * by_len[a + j].second, out_buf.data() + 4 * j, sizeof(Fr));
+        a = b;
+    }
+    return AKP_OK;
 }
 extern "C" int32_t akp_poseidon_two_to_one_batch_dev(akp_poseidon* p, const uint64_t* d_left, const uint64_t* d_right, size_t n,
                                                      uint64_t* d_out, void* stream) {

@@ -591,16 +591,23 @@ extern "C" int32_t akp_te_params_prepare(akp_te_params* p, size_t msg_len) {
     return te_resolve(p, msg_len, msg_len, p->ctx->stream, &r);
 }
 // ... and what TwoToOneCRH::compress / the inner levels of a tree will need: two serialised digests in the (W*N)/8-byte buffer
-int32_t te_prepare_compress(akp_te_params* p) {
+// `s`: the stream the caller is about to enqueue on (only asked whether it is being captured; the build runs on the context stream)
+int32_t te_prepare_compress(akp_te_params* p, hipStream_t s) {
     const size_t buflen = ((size_t)p->W * p->N) / 8;
     const size_t used = std::min<size_t>(buflen, (size_t)2 * te_fe_per_digest(p) * 32);
     std::lock_guard<std::mutex> lk(p->t->mu);
     TeResolved r;
-    return te_resolve(p, buflen, te_zero_tail_on() ? used : buflen, p->ctx->stream, &r);
+    return te_resolve(p, buflen, te_zero_tail_on() ? used : buflen, s, &r);
 }
 extern "C" int32_t akp_te_params_prepare_compress(akp_te_params* p) {
     NEED_TE(p, "akp_te_params_prepare_compress");
-    return te_prepare_compress(p);
+    return te_prepare_compress(p, p->ctx->stream);
+}
+// A tree hashes its leaves first and its (usually longer) two-to-one buffers second: when both hashes share a table, building it
+// for the inner nodes FIRST means one build instead of a build and an extension (the cold first tree: profiles/r05_s2 -> r05_s4).
+int32_t te_tree_prepare(akp_te_params* leafp, akp_te_params* two, hipStream_t s) {
+    if (leafp->t != two->t) return AKP_OK;
+    return te_prepare_compress(two, s);
 }
 // projective -> affine for `cnt` sums.  One inversion is shared among up to 64 messages per lane, but `target` lanes
 // stay busy when the range allows.  Measured at 2^20 Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K /

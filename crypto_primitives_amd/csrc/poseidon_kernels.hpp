@@ -277,6 +277,21 @@ __global__ void __launch_bounds__(256) poseidon_crh_t3_kernel(PoseidonDims D, Po
     store_fr_global(out + idx, poseidon_crh_item_t3<FULLFORM>(D, C, in0, in1, k, idx));
 }
 
+// Ragged batch (round 5): item i = elements [offsets[i], offsets[i+1]) of `in` -- poseidon::CRH::evaluate takes any &[F]
+// (crh/poseidon/mod.rs:30-40) and MerkleTree::new hashes every leaf with its own length (merkle_tree/mod.rs:411-422).  The item's
+// sponge runs ceil(k / rate) permutations (one for the empty slice); `order` (may be null) is the launch order sorted by that
+// count, longest first (ragged_sort.hpp), results are stored by item index.
+template <bool FULLFORM>
+__global__ void __launch_bounds__(256) poseidon_crh_ragged_t3_kernel(PoseidonDims D, PoseidonT3Consts C, const Fr* __restrict__ in,
+                                                                    const uint64_t* __restrict__ offsets, const u32* __restrict__ order,
+                                                                    Fr* __restrict__ out, size_t n) {
+    const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const size_t idx = order ? order[slot] : slot;
+    const uint64_t off = offsets[idx];
+    store_fr_global(out + idx, poseidon_crh_item_t3<FULLFORM>(D, C, in + off, nullptr, (size_t)(offsets[idx + 1] - off), 0));
+}
+
 // Path::verify (merkle_tree/mod.rs:172-212) with each lane walking its OWN path: leaf hash, then depth + 1 two-to-one hashes
 // of (current, sibling) ordered by the index bit of the level (select_left_right_child :367-381), compared with the root.
 // One launch for a whole batch of paths instead of one hash launch + one select launch per level: the chain of a lane

@@ -43,6 +43,8 @@ class PoseidonFieldConfig:
 
     @staticmethod
     def hash_leaves(leaf_params, leaves):
+        if _pos.ragged_fr(leaves) is not None:
+            return _pos.CRH.evaluate_batch(leaf_params, leaves)
         x = np.ascontiguousarray(leaves, dtype=np.uint64)
         n = x.shape[0]
         return _pos.CRH.evaluate_batch(leaf_params, x.reshape(n, -1, 4))
@@ -146,6 +148,11 @@ class PedersenXByteConfig(_ByteConfig):
     digest_shape = (4,)
 
 
+def _ragged_leaves(config, leaves):
+    """(flat, offsets) when `leaves` is a list whose items differ in length, else None (crh.poseidon.ragged_fr / crh.pedersen.ragged_bytes)"""
+    return _pos.ragged_fr(leaves) if config is PoseidonFieldConfig else _ped.ragged_bytes(leaves)
+
+
 # ---- index helpers (:730-786) ---------------------------------------------------------------------
 def tree_height(num_leaves):
     return 1 if num_leaves == 1 else (num_leaves.bit_length() - 1) + 1
@@ -204,6 +211,14 @@ def verify_paths(config, leaf_params, two_params, root_hash, paths, leaves):
     assert all(len(p.auth_path) == depth for p in paths)
     if isinstance(leaves, np.ndarray):
         leaves = [leaves[i] for i in range(n)]
+    if _ragged_leaves(config, list(leaves)) is not None:  # leaves of different lengths: one ABI call per distinct length
+        lens = [len(x) if isinstance(x, (bytes, bytearray)) else len(np.asarray(x).reshape(-1, 4) if config is PoseidonFieldConfig else np.asarray(x).reshape(-1)) for x in leaves]
+        out = [False] * n
+        for L in sorted(set(lens)):
+            sel = [i for i in range(n) if lens[i] == L]
+            for i, v in zip(sel, verify_paths(config, leaf_params, two_params, root_hash, [paths[i] for i in sel], [leaves[i] for i in sel])):
+                out[i] = v
+        return out
     idx = np.array([p.leaf_index for p in paths], dtype=np.uint64)
     sibs = np.ascontiguousarray(np.stack([np.asarray(p.leaf_sibling_hash) for p in paths]), dtype=np.uint64)
     if depth:
@@ -289,10 +304,13 @@ class MerkleTree:
 
     @classmethod
     def new(cls, config, leaf_hash_param, two_to_one_hash_param, leaves):
-        """MerkleTree::new (:411-422): leaves.len() must be a power of two greater than one."""
+        """MerkleTree::new (:411-422): leaves.len() must be a power of two greater than one.  Leaves of different lengths (a list)
+        are hashed each with its own length, as the reference's map over the leaf iterator does."""
         n = len(leaves)
         if n < 2 or n & (n - 1):
             raise NotPowerOfTwo(5, "`leaves.len() should be power of two and greater than one")
+        if _ragged_leaves(config, leaves) is not None:
+            return GpuMerkleTree.new(config, leaf_hash_param, two_to_one_hash_param, leaves).to_host()
         leaf_nodes, non_leaf = config.build(leaf_hash_param, two_to_one_hash_param, leaves)
         return cls(config, leaf_hash_param, two_to_one_hash_param, leaf_nodes, non_leaf)
 
@@ -460,8 +478,15 @@ class GpuMerkleTree:
     @classmethod
     def new(cls, config, leaf_hash_param, two_to_one_hash_param, leaves):
         import ctypes as C
-        x, n, k = cls._leaf_array(config, leaves)
         h = C.c_void_p()
+        rg = _ragged_leaves(config, leaves)
+        if rg is not None:  # leaves of different lengths: akp_merkle_tree_build_*_ragged
+            flat, offs = rg
+            fn = lib.akp_merkle_tree_build_poseidon_ragged if config is PoseidonFieldConfig else lib.akp_merkle_tree_build_te_ragged
+            check(fn(_leaf_handle(config, leaf_hash_param).h, _two_handle(config, two_to_one_hash_param).h, flat.ctypes.data if flat.size else None,
+                     offs.ctypes.data, len(offs) - 1, C.byref(h)))
+            return cls(config, leaf_hash_param, two_to_one_hash_param, h)
+        x, n, k = cls._leaf_array(config, leaves)
         fn = lib.akp_merkle_tree_build_poseidon if config is PoseidonFieldConfig else lib.akp_merkle_tree_build_te
         check(fn(_leaf_handle(config, leaf_hash_param).h, _two_handle(config, two_to_one_hash_param).h, x.ctypes.data if x.size else None, n, k, C.byref(h)))
         return cls(config, leaf_hash_param, two_to_one_hash_param, h)
@@ -620,7 +645,12 @@ class MultiGpu:
         la, ta = self._handles(config, leaf_hash_param, two_to_one_hash_param)
         h = C.c_void_p()
         pos = config is PoseidonFieldConfig
-        if device_leaf_ptrs is None:
+        rg = _ragged_leaves(config, leaves) if device_leaf_ptrs is None else None
+        if rg is not None:
+            flat, offs = rg
+            fn = lib.akp_multi_tree_build_poseidon_ragged if pos else lib.akp_multi_tree_build_te_ragged
+            check(fn(self._h, la, ta, flat.ctypes.data if flat.size else None, offs.ctypes.data, len(offs) - 1, C.byref(h)))
+        elif device_leaf_ptrs is None:
             x, n, k = GpuMerkleTree._leaf_array(config, leaves)
             fn = lib.akp_multi_tree_build_poseidon if pos else lib.akp_multi_tree_build_te
             check(fn(self._h, la, ta, x.ctypes.data if x.size else None, n, k, C.byref(h)))

@@ -145,6 +145,13 @@ int32_t akp_poseidon_crh_batch(akp_poseidon* p, const uint64_t* inputs, size_t n
                                uint64_t* out);
 int32_t akp_poseidon_crh_batch_dev(akp_poseidon* p, const uint64_t* d_inputs, size_t n, size_t elems_per_input,
                                    uint64_t* d_out, void* stream);
+/* The same for inputs of DIFFERENT lengths (crh/poseidon/mod.rs:30-40 takes any &[F]): input i = elements
+ * [offsets[i], offsets[i+1]) of `inputs` (offsets: n + 1 non-decreasing element indices; an empty input is the hash of the empty
+ * slice).  t = 3 parameter sets run one launch with per-lane lengths, the items ordered by their permutation count on the device
+ * so that a wave's lanes finish together; other widths are grouped by length on the host (host entry point only). */
+int32_t akp_poseidon_crh_batch_ragged(akp_poseidon* p, const uint64_t* inputs, const uint64_t* offsets, size_t n, uint64_t* out);
+int32_t akp_poseidon_crh_batch_ragged_dev(akp_poseidon* p, const uint64_t* d_inputs, const uint64_t* d_offsets, size_t n,
+                                          uint64_t* d_out, void* stream);
 /* poseidon::TwoToOneCRH::{evaluate,compress} (crh/poseidon/mod.rs:58-79): out[i] = H(left[i], right[i]). */
 int32_t akp_poseidon_two_to_one_batch(akp_poseidon* p, const uint64_t* left, const uint64_t* right, size_t n,
                                       uint64_t* out);
@@ -238,6 +245,16 @@ uint32_t akp_te_entry_bytes(void);
 int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_t n, size_t msg_len, uint64_t* out);
 int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out,
                              void* stream);
+/* The same for messages of DIFFERENT lengths: the reference hashes every input with ITS length -- Pedersen pads each input with
+ * zero bits to the window (crh/pedersen/mod.rs:82-99: padding does not change the digest), Bowe-Hopwood pads each input to a
+ * multiple of 3 bits only (crh/bowe_hopwood/mod.rs:131-138: the digest DEPENDS on the length, a host cannot pad).  Message i =
+ * bytes [offsets[i], offsets[i+1]) of msgs (offsets: n + 1 non-decreasing byte offsets).  One launch, per-lane step counts; the
+ * items are ordered by step count on the device (counting sort, longest first) so that a wave's lanes finish together.  A message
+ * longer than the window is AKP_ERR_BAD_LENGTH for the whole call (the reference panics on that item).  `_dev`: max_len is the
+ * caller's bound on the longest message (the table is built for it; a longer item is hashed as if truncated to the table). */
+int32_t akp_te_crh_batch_ragged(akp_te_params* p, const uint8_t* msgs, const uint64_t* offsets, size_t n, uint64_t* out);
+int32_t akp_te_crh_batch_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_t* d_offsets, size_t n, size_t max_len,
+                                    uint64_t* d_out, void* stream);
 /* TwoToOneCRH::evaluate (crh/pedersen/mod.rs:158-182, crh/bowe_hopwood/mod.rs:202-227):
  * left/right are n x half_len bytes; buffer = (W*N)/8 zero bytes overwritten by left||right
  * (zip-truncated), then CRH::evaluate. */
@@ -319,6 +336,13 @@ int32_t akp_merkle_tree_build_poseidon(akp_poseidon* leaf_params, akp_poseidon* 
                                        size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
 int32_t akp_merkle_tree_build_te(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* leaves,
                                  size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
+/* MerkleTree::new over leaves of DIFFERENT lengths: the reference maps LeafHash::evaluate over any iterator of leaves
+ * (:411-422), each leaf hashed with its own length (akp_poseidon_crh_batch_ragged / akp_te_crh_batch_ragged for the leaf level).
+ * Leaf i = elements (Poseidon) / bytes (te) [offsets[i], offsets[i+1]) of `leaves`; offsets[0] need not be 0. */
+int32_t akp_merkle_tree_build_poseidon_ragged(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* leaves,
+                                              const uint64_t* offsets, size_t n_leaves, akp_merkle_tree** out);
+int32_t akp_merkle_tree_build_te_ragged(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* leaves,
+                                        const uint64_t* offsets, size_t n_leaves, akp_merkle_tree** out);
 /* the same from leaves that are already in device memory (synchronises the context stream before returning) */
 int32_t akp_merkle_tree_build_poseidon_dev(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* d_leaves,
                                            size_t n_leaves, size_t leaf_len, akp_merkle_tree** out);
@@ -461,6 +485,11 @@ int32_t akp_multi_tree_build_poseidon(akp_multi* m, akp_poseidon* const* leaf_pa
                                       const uint64_t* leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
 int32_t akp_multi_tree_build_te(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
                                 const uint8_t* leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);
+/* leaves of different lengths (akp_merkle_tree_build_*_ragged per device): offsets has n_leaves + 1 entries into the one host array */
+int32_t akp_multi_tree_build_poseidon_ragged(akp_multi* m, akp_poseidon* const* leaf_params, akp_poseidon* const* two_to_one_params,
+                                             const uint64_t* leaves, const uint64_t* offsets, size_t n_leaves, akp_multi_tree** out);
+int32_t akp_multi_tree_build_te_ragged(akp_multi* m, akp_te_params* const* leaf_params, akp_te_params* const* two_to_one_params,
+                                       const uint8_t* leaves, const uint64_t* offsets, size_t n_leaves, akp_multi_tree** out);
 /* the same from leaves that are already resident: d_leaves[r] = device r's n_leaves / G leaves, in ITS memory */
 int32_t akp_multi_tree_build_poseidon_dev(akp_multi* m, akp_poseidon* const* leaf_params, akp_poseidon* const* two_to_one_params,
                                           const uint64_t* const* d_leaves, size_t n_leaves, size_t leaf_len, akp_multi_tree** out);

@@ -20,7 +20,7 @@ use ark_std::{collections::BTreeSet, marker::PhantomData, vec::Vec};
 pub trait GpuConfig: Config {
     /// Fr per digest on the wire: 1 (Poseidon, Bowe-Hopwood) or 2 (Pedersen affine point)
     const FE_PER_DIGEST: usize;
-    /// build the device tree over `leaves` (all leaves must have the same length, as every level is one launch)
+    /// build the device tree over `leaves`, each hashed with its own length (the `_ragged` entry points when the lengths differ)
     fn build(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, leaves: &[&Self::Leaf]) -> Result<*mut ffi::AkpMerkleTree, Error>;
     fn from_digests(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, digests: &[Self::LeafDigest]) -> Result<*mut ffi::AkpMerkleTree, Error>;
     /// flat encoding of leaves for `update` / `check_update`: (buffer, leaf_len in the library's unit)
@@ -33,10 +33,28 @@ pub trait GpuConfig: Config {
 fn fr_of(w: &[u64]) -> Fr {
     fr_from_limbs([w[0], w[1], w[2], w[3]])
 }
+/// `update_batch` hashes its new leaves in one uniform launch (the reference's `update` takes ONE leaf: any batch of one is uniform)
 fn same_len<T: AsRef<[U]> + ?Sized, U>(leaves: &[&T]) -> usize {
     let l = leaves.first().map_or(0, |x| x.as_ref().len());
-    assert!(leaves.iter().all(|x| x.as_ref().len() == l), "the batched tree build takes leaves of equal length");
+    assert!(leaves.iter().all(|x| x.as_ref().len() == l), "update_batch takes new leaves of equal length (call it once per length)");
     l
+}
+/// Leaves as the reference takes them -- each with its own length (`MerkleTree::new` maps `LeafHash::evaluate` over the iterator,
+/// `merkle_tree/mod.rs:411-422`): `Some(len)` when they all agree (the uniform entry points), else the `n + 1` offsets of the
+/// `_ragged` entry points (in elements of the leaf type).
+pub(crate) fn leaf_offsets<T: AsRef<[U]> + ?Sized, U>(leaves: &[&T]) -> (Option<usize>, Vec<u64>) {
+    let l = leaves.first().map_or(0, |x| x.as_ref().len());
+    if leaves.iter().all(|x| x.as_ref().len() == l) {
+        return (Some(l), Vec::new());
+    }
+    let mut offs = Vec::with_capacity(leaves.len() + 1);
+    let mut at = 0u64;
+    offs.push(at);
+    for x in leaves {
+        at += x.as_ref().len() as u64;
+        offs.push(at);
+    }
+    (None, offs)
 }
 
 /// Poseidon field tree: `Leaf = [Fr]`, digests `Fr`, `IdentityDigestConverter`
@@ -52,10 +70,13 @@ impl Config for PoseidonFieldConfig {
 impl GpuConfig for PoseidonFieldConfig {
     const FE_PER_DIGEST: usize = 1;
     fn build(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, leaves: &[&[Fr]]) -> Result<*mut ffi::AkpMerkleTree, Error> {
-        let k = same_len(leaves);
+        let (uniform, offs) = leaf_offsets(leaves);
         let flat: Vec<Fr> = leaves.iter().flat_map(|l| l.iter().copied()).collect();
         let mut t = core::ptr::null_mut();
-        check(unsafe { ffi::akp_merkle_tree_build_poseidon(poseidon::handle(leaf)?, poseidon::handle(two)?, words(&flat), leaves.len(), k, &mut t) }, k)?;
+        match uniform {
+            Some(k) => check(unsafe { ffi::akp_merkle_tree_build_poseidon(poseidon::handle(leaf)?, poseidon::handle(two)?, words(&flat), leaves.len(), k, &mut t) }, k)?,
+            None => check(unsafe { ffi::akp_merkle_tree_build_poseidon_ragged(poseidon::handle(leaf)?, poseidon::handle(two)?, words(&flat), offs.as_ptr(), leaves.len(), &mut t) }, 0)?,
+        }
         Ok(t)
     }
     fn from_digests(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, digests: &[Fr]) -> Result<*mut ffi::AkpMerkleTree, Error> {
@@ -99,6 +120,17 @@ impl<W: Window> Config for PedersenByteConfig<W> {
 fn point_of(w: &[u64]) -> EdwardsAffine {
     EdwardsAffine::new_unchecked(fr_of(&w[0..4]), fr_of(&w[4..8]))
 }
+/// byte-leaf tree build: the uniform entry point when the leaves agree in length, `akp_merkle_tree_build_te_ragged` otherwise
+fn te_tree_build(lh: *mut ffi::AkpTeParams, th: *mut ffi::AkpTeParams, leaves: &[&[u8]]) -> Result<*mut ffi::AkpMerkleTree, Error> {
+    let (uniform, offs) = leaf_offsets(leaves);
+    let flat: Vec<u8> = leaves.iter().flat_map(|x| x.iter().copied()).collect();
+    let mut t = core::ptr::null_mut();
+    match uniform {
+        Some(l) => check(unsafe { ffi::akp_merkle_tree_build_te(lh, th, flat.as_ptr(), leaves.len(), l, &mut t) }, l)?,
+        None => check(unsafe { ffi::akp_merkle_tree_build_te_ragged(lh, th, flat.as_ptr(), offs.as_ptr(), leaves.len(), &mut t) }, 0)?,
+    }
+    Ok(t)
+}
 fn bytes_flat(leaves: &[&[u8]]) -> (Vec<u8>, usize) {
     let l = same_len(leaves);
     (leaves.iter().flat_map(|x| x.iter().copied()).collect(), l)
@@ -106,10 +138,7 @@ fn bytes_flat(leaves: &[&[u8]]) -> (Vec<u8>, usize) {
 impl<W: Window> GpuConfig for PedersenByteConfig<W> {
     const FE_PER_DIGEST: usize = 2;
     fn build(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, leaves: &[&[u8]]) -> Result<*mut ffi::AkpMerkleTree, Error> {
-        let (flat, l) = bytes_flat(leaves);
-        let mut t = core::ptr::null_mut();
-        check(unsafe { ffi::akp_merkle_tree_build_te(te::pedersen_handle(leaf)?, te::pedersen_handle(two)?, flat.as_ptr(), leaves.len(), l, &mut t) }, l)?;
-        Ok(t)
+        te_tree_build(te::pedersen_handle(leaf)?, te::pedersen_handle(two)?, leaves)
     }
     fn from_digests(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, digests: &[EdwardsAffine]) -> Result<*mut ffi::AkpMerkleTree, Error> {
         let flat: Vec<Fr> = digests.iter().flat_map(|p| [p.x, p.y]).collect();
@@ -144,10 +173,7 @@ impl<W: Window> Config for BoweHopwoodByteConfig<W> {
 impl<W: Window> GpuConfig for BoweHopwoodByteConfig<W> {
     const FE_PER_DIGEST: usize = 1;
     fn build(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, leaves: &[&[u8]]) -> Result<*mut ffi::AkpMerkleTree, Error> {
-        let (flat, l) = bytes_flat(leaves);
-        let mut t = core::ptr::null_mut();
-        check(unsafe { ffi::akp_merkle_tree_build_te(te::bowe_hopwood_handle(leaf)?, te::bowe_hopwood_handle(two)?, flat.as_ptr(), leaves.len(), l, &mut t) }, l)?;
-        Ok(t)
+        te_tree_build(te::bowe_hopwood_handle(leaf)?, te::bowe_hopwood_handle(two)?, leaves)
     }
     fn from_digests(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, digests: &[Fr]) -> Result<*mut ffi::AkpMerkleTree, Error> {
         let mut t = core::ptr::null_mut();
@@ -182,10 +208,7 @@ impl<W: Window> Config for PedersenXByteConfig<W> {
 impl<W: Window> GpuConfig for PedersenXByteConfig<W> {
     const FE_PER_DIGEST: usize = 1;
     fn build(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, leaves: &[&[u8]]) -> Result<*mut ffi::AkpMerkleTree, Error> {
-        let (flat, l) = bytes_flat(leaves);
-        let mut t = core::ptr::null_mut();
-        check(unsafe { ffi::akp_merkle_tree_build_te(te::pedersen_x_handle(leaf)?, te::pedersen_x_handle(two)?, flat.as_ptr(), leaves.len(), l, &mut t) }, l)?;
-        Ok(t)
+        te_tree_build(te::pedersen_x_handle(leaf)?, te::pedersen_x_handle(two)?, leaves)
     }
     fn from_digests(leaf: &LeafParam<Self>, two: &TwoToOneParam<Self>, digests: &[Fr]) -> Result<*mut ffi::AkpMerkleTree, Error> {
         let mut t = core::ptr::null_mut();

@@ -59,6 +59,22 @@ pub fn permute_batch(cfg: &PoseidonConfig<Fr>, states: &mut [Fr]) -> Result<(), 
     check(unsafe { ffi::akp_poseidon_permute_batch(h, words_mut(states), states.len() / t) }, t)
 }
 
+/// `CRH::evaluate` over inputs of DIFFERENT lengths in one launch (`akp_poseidon_crh_batch_ragged`; `crh/poseidon/mod.rs:30-40`
+/// takes any `&[F]`)
+pub fn crh_many(cfg: &PoseidonConfig<Fr>, inputs: &[&[Fr]]) -> Result<Vec<Fr>, Error> {
+    let mut offs = Vec::with_capacity(inputs.len() + 1);
+    let mut at = 0u64;
+    offs.push(at);
+    for x in inputs {
+        at += x.len() as u64;
+        offs.push(at);
+    }
+    let flat: Vec<Fr> = inputs.iter().flat_map(|x| x.iter().copied()).collect();
+    let mut out = vec![Fr::zero(); inputs.len()];
+    check(unsafe { ffi::akp_poseidon_crh_batch_ragged(handle(cfg)?, words(&flat), offs.as_ptr(), inputs.len(), words_mut(&mut out)) }, 0)?;
+    Ok(out)
+}
+
 /// `poseidon::CRH<Fr>` (`crh/poseidon/mod.rs:14-41`)
 pub struct CRH;
 impl CRHScheme for CRH {

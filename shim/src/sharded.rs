@@ -101,11 +101,13 @@ impl ShardedGpuConfig for PoseidonFieldConfig {
     fn build_sharded(m: &MultiGpu, leaf: &PoseidonConfig<Fr>, two: &PoseidonConfig<Fr>, leaves: &[&[Fr]]) -> Result<*mut ffi::AkpMultiTree, Error> {
         let (lp, tp) = (poseidon_on_every_device(m, leaf)?, poseidon_on_every_device(m, two)?);
         let (DeviceParams::Poseidon(l), DeviceParams::Poseidon(t)) = (&lp, &tp) else { unreachable!() };
-        let k = leaves.first().map_or(0, |x| x.len());
-        assert!(leaves.iter().all(|x| x.len() == k), "the batched tree build takes leaves of equal length");
+        let (uniform, offs) = crate::merkle::leaf_offsets(leaves);
         let flat: Vec<Fr> = leaves.iter().flat_map(|x| x.iter().copied()).collect();
         let mut out = core::ptr::null_mut();
-        check(unsafe { ffi::akp_multi_tree_build_poseidon(m.h, l.as_ptr(), t.as_ptr(), words(&flat), leaves.len(), k, &mut out) }, k)?;
+        match uniform {
+            Some(k) => check(unsafe { ffi::akp_multi_tree_build_poseidon(m.h, l.as_ptr(), t.as_ptr(), words(&flat), leaves.len(), k, &mut out) }, k)?,
+            None => check(unsafe { ffi::akp_multi_tree_build_poseidon_ragged(m.h, l.as_ptr(), t.as_ptr(), words(&flat), offs.as_ptr(), leaves.len(), &mut out) }, 0)?,
+        }
         Ok(out) // lp / tp dropped here: the tree has pinned the handles
     }
 }
@@ -113,9 +115,13 @@ fn te_build<P: ShardedGpuConfig<Leaf = [u8]>>(m: &MultiGpu, kind: i32, lw: (usiz
                                                -> Result<*mut ffi::AkpMultiTree, Error> {
     let (lp, tp) = (te_on_every_device(m, kind, lw.0, lw.1, &lw.2)?, te_on_every_device(m, kind, tw.0, tw.1, &tw.2)?);
     let (DeviceParams::Te(l), DeviceParams::Te(t)) = (&lp, &tp) else { unreachable!() };
-    let (buf, len) = P::encode_leaves(leaves);
+    let (uniform, offs) = crate::merkle::leaf_offsets(leaves);
+    let buf: Vec<u8> = leaves.iter().flat_map(|x| x.iter().copied()).collect();
     let mut out = core::ptr::null_mut();
-    check(unsafe { ffi::akp_multi_tree_build_te(m.h, l.as_ptr(), t.as_ptr(), buf.as_ptr(), leaves.len(), len, &mut out) }, len)?;
+    match uniform {
+        Some(len) => check(unsafe { ffi::akp_multi_tree_build_te(m.h, l.as_ptr(), t.as_ptr(), buf.as_ptr(), leaves.len(), len, &mut out) }, len)?,
+        None => check(unsafe { ffi::akp_multi_tree_build_te_ragged(m.h, l.as_ptr(), t.as_ptr(), buf.as_ptr(), offs.as_ptr(), leaves.len(), &mut out) }, 0)?,
+    }
     Ok(out)
 }
 impl<W: Window> ShardedGpuConfig for PedersenByteConfig<W> {

@@ -41,6 +41,21 @@ fn two_to_one_words(h: *mut ffi::AkpTeParams, fe: usize, left: &[u8], right: &[u
     check(unsafe { ffi::akp_te_two_to_one_batch(h, left.as_ptr(), right.as_ptr(), 1, left.len(), out.as_mut_ptr()) }, left.len())?;
     Ok(out)
 }
+/// n inputs of DIFFERENT lengths in one launch (`akp_te_crh_batch_ragged`): the analogue of mapping `evaluate` over a slice of inputs,
+/// each hashed with its own length (`crh/pedersen/mod.rs:82-99`, `crh/bowe_hopwood/mod.rs:131-138`)
+fn crh_words_ragged(h: *mut ffi::AkpTeParams, fe: usize, msgs: &[&[u8]]) -> Result<Vec<u64>, Error> {
+    let mut offs = Vec::with_capacity(msgs.len() + 1);
+    let mut at = 0u64;
+    offs.push(at);
+    for m in msgs {
+        at += m.len() as u64;
+        offs.push(at);
+    }
+    let flat: Vec<u8> = msgs.iter().flat_map(|m| m.iter().copied()).collect();
+    let mut out = vec![0u64; msgs.len() * fe * 4];
+    check(unsafe { ffi::akp_te_crh_batch_ragged(h, flat.as_ptr(), offs.as_ptr(), msgs.len(), out.as_mut_ptr()) }, msgs.iter().map(|m| m.len()).max().unwrap_or(0))?;
+    Ok(out)
+}
 fn point(w: &[u64]) -> EdwardsAffine {
     // the library returns a point of the curve (sum of the caller's generators): no curve / subgroup re-check
     EdwardsAffine::new_unchecked(fr_from_limbs([w[0], w[1], w[2], w[3]]), fr_from_limbs([w[4], w[5], w[6], w[7]]))
@@ -53,6 +68,11 @@ impl<W: pedersen::Window> PedersenCRH<W> {
     pub fn evaluate_batch(parameters: &pedersen::Parameters<EdwardsProjective>, msgs: &[u8], msg_len: usize) -> Result<Vec<EdwardsAffine>, Error> {
         let n = if msg_len == 0 { 1 } else { msgs.len() / msg_len };
         let w = crh_words(te_handle(ffi::AKP_TE_PEDERSEN, &parameters.generators)?, 2, msgs, n, msg_len)?;
+        Ok(w.chunks_exact(8).map(point).collect())
+    }
+    /// inputs of different lengths, each hashed as `evaluate` would hash it
+    pub fn evaluate_many(parameters: &pedersen::Parameters<EdwardsProjective>, msgs: &[&[u8]]) -> Result<Vec<EdwardsAffine>, Error> {
+        let w = crh_words_ragged(te_handle(ffi::AKP_TE_PEDERSEN, &parameters.generators)?, 2, msgs)?;
         Ok(w.chunks_exact(8).map(point).collect())
     }
 }
@@ -105,6 +125,11 @@ impl<W: pedersen::Window> BoweHopwoodCRH<W> {
     pub fn evaluate_batch(parameters: &bowe_hopwood::Parameters<EdwardsConfig>, msgs: &[u8], msg_len: usize) -> Result<Vec<Fr>, Error> {
         let n = if msg_len == 0 { 1 } else { msgs.len() / msg_len };
         let w = crh_words(te_handle(ffi::AKP_TE_BOWE_HOPWOOD, &parameters.generators)?, 1, msgs, n, msg_len)?;
+        Ok(w.chunks_exact(4).map(|c| fr_from_limbs([c[0], c[1], c[2], c[3]])).collect())
+    }
+    /// inputs of different lengths, each hashed as `evaluate` would hash it (padded to a multiple of 3 bits only, `:131-138`)
+    pub fn evaluate_many(parameters: &bowe_hopwood::Parameters<EdwardsConfig>, msgs: &[&[u8]]) -> Result<Vec<Fr>, Error> {
+        let w = crh_words_ragged(te_handle(ffi::AKP_TE_BOWE_HOPWOOD, &parameters.generators)?, 1, msgs)?;
         Ok(w.chunks_exact(4).map(|c| fr_from_limbs([c[0], c[1], c[2], c[3]])).collect())
     }
 }

@@ -6,6 +6,7 @@
 #include "../../crypto_primitives_amd/csrc/fr.hpp"
 #include "../../crypto_primitives_amd/csrc/f29.hpp"
 #include "../../crypto_primitives_amd/csrc/te_kernels.hpp"
+#include "../../crypto_primitives_amd/csrc/ragged_sort.hpp"
 using namespace akp;
 
 extern "C" {
@@ -105,6 +106,36 @@ void hh_te_crh_split(int kind, const TeEntry* lut, const TeEntry* lut1, const ui
         if (kind != 1) { out[2 * i] = f29_to_wire(f29_mul(part[0].X, zi)); out[2 * i + 1] = f29_to_wire(f29_mul(part[0].Y, zi)); }
         else out[i] = f29_to_wire(f29_mul(part[0].X, zi));
     }
+}
+// te_accumulate_ragged_kernel's per-item code (round 5): item i = bytes [offsets[i], offsets[i+1]) of msgs, its table steps from its own
+// length (te_item_steps), message bytes through MsgAny (1..3-byte messages are NOT padded by anybody), then the shared finalisation.
+// `msgs` is exactly offsets[n] bytes long in the tests: under ASan every load past an item's end that leaves the buffer is caught.
+void hh_te_crh_ragged(int kind, const TeEntry* lut, const TeEntry* lut1, const uint8_t* msgs, const uint64_t* offsets, size_t n, uint32_t D,
+                      uint32_t n_gen, uint32_t units_built, size_t lanes, Fr* out) {
+    std::vector<F29Pad> xyz(n * 3), prefix(n);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        const MsgAny m{msgs + offsets[i]};
+        u32 groups, steps;
+        Ext a;
+        if (kind == 0) { te_item_steps<0>(n_gen, D, len, units_built, &groups, &steps); a = te_accumulate_item<0>(lut, lut1, m, len, D, groups, steps); }
+        else if (kind == 2) { te_item_steps<2>(n_gen, D, len, units_built, &groups, &steps); a = te_accumulate_item<2>(lut, lut1, m, len, D, groups, steps); }
+        else { te_item_steps<1>(n_gen, D, len, units_built, &groups, &steps); a = te_accumulate_item<1>(lut, lut1, m, len, D, groups, steps); }
+        f29_store_pad(&xyz[3 * i], a.X); f29_store_pad(&xyz[3 * i + 1], a.Y); f29_store_pad(&xyz[3 * i + 2], a.Z);
+    }
+    for (size_t l = 0; l < lanes && l < n; ++l) {
+        if (kind != 1) te_finalize_lane<0>(xyz.data(), prefix.data(), out, n, lanes, l);
+        else te_finalize_lane<1>(xyz.data(), prefix.data(), out, n, lanes, l);
+    }
+}
+// sort key of an item (ragged_sort.hpp) and the step count the kernel computes for it (te_item_steps): must agree
+uint32_t hh_ragged_key(uint32_t mode, uint32_t unit, uint32_t cap, uint64_t len) { return ragged_key_of(RaggedKey{mode, unit, cap}, len); }
+uint32_t hh_te_item_steps(int kind, uint32_t n_gen, uint32_t D, size_t len, uint32_t units_built, uint32_t* groups) {
+    u32 steps;
+    if (kind == 0) te_item_steps<0>(n_gen, D, len, units_built, groups, &steps);
+    else if (kind == 2) te_item_steps<2>(n_gen, D, len, units_built, groups, &steps);
+    else te_item_steps<1>(n_gen, D, len, units_built, groups, &steps);
+    return steps;
 }
 // the w message bits at bit offset o as a table step reads them: ONE 32-bit window (msg_load) and a shift (msg_combine)
 uint32_t hh_te_window(const uint8_t* msg, size_t len, size_t o, uint32_t w) { return msg_combine(msg_load(msg, len, o), len, o, w); }

@@ -62,6 +62,11 @@ def test_eight_threads_own_contexts_same_generators_share_one_table(cpa, budget_
     if budget_name == "device" and ctxs[0].table_budget() < 71 << 30:
         pytest.skip("needs an idle 288 GB device")
     P = pedersen.Parameters(g)
+    # one throw-away hash first: the runtime's own first-use allocations (code objects, queues, signal pools: ~300 MB on this stack) must
+    # not be counted as the table's
+    warm = pedersen.Parameters(gens_array(jj.pedersen_generators(0xC5C500FF, 4, 8)))
+    pedersen.CRH.evaluate_batch(warm, _msgs(20000, 4, 1))
+    del warm
     free0 = _free_bytes()
     start = threading.Barrier(n_thr)
 
@@ -98,7 +103,7 @@ def test_eight_threads_own_contexts_same_generators_share_one_table(cpa, budget_
     P._handles.clear()
     for c in ctxs[1:]:
         c.close()
-    assert free0 - _free_bytes() < 64 << 20
+    assert free0 - _free_bytes() < min(64 << 20, table_bytes // 4), "the table outlived its last handle"
 
 
 def test_table_extends_under_concurrent_hashing(cpa):
@@ -176,10 +181,11 @@ def test_prepare_builds_at_a_time_of_the_hosts_choosing_and_dev_calls_then_only_
     m = _msgs(n, 32, 9)
     d_m = torch.from_numpy(m).to(dev)
     d_out = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    d_tmp = torch.zeros((n, 4), dtype=torch.int64, device=dev)
     side = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(side):
         cpa._lib.check(cpa.lib.akp_te_crh_batch_dev(h.h, d_m.data_ptr(), n, 32, d_out.data_ptr(), side.cuda_stream))  # sizes the context's scratch
-        cpa._lib.check(cpa.lib.akp_te_crh_batch_dev(h2.h, d_m.data_ptr(), 16, 8, d_out.data_ptr(), side.cuda_stream))  # (h2: 8-byte messages only)
+        cpa._lib.check(cpa.lib.akp_te_crh_batch_dev(h2.h, d_m.data_ptr(), 16, 8, d_tmp.data_ptr(), side.cuda_stream))  # (h2: 8-byte messages only)
     side.synchronize()
     assert h.table_info()["wide_builds"] == 1  # the hash found its table
     want = ora.bh_crh_batch(m, n, 32, threads=4)
@@ -190,7 +196,7 @@ def test_prepare_builds_at_a_time_of_the_hosts_choosing_and_dev_calls_then_only_
     with torch.cuda.graph(graph, stream=side):
         rc = cpa.lib.akp_te_crh_batch_dev(h.h, d_m.data_ptr(), n, 32, d_out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         # an unprepared shape under capture: a clean refusal, the capture stays valid
-        rc2 = cpa.lib.akp_te_crh_batch_dev(h2.h, d_m.data_ptr(), n, 32, d_out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        rc2 = cpa.lib.akp_te_crh_batch_dev(h2.h, d_m.data_ptr(), n, 32, d_tmp.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         msg2 = cpa.lib.akp_last_error().decode()
     assert rc == 0 and rc2 == AKP_ERR_BAD_PARAMS and "akp_te_params_prepare" in msg2, (rc, rc2, msg2)
     m2 = _msgs(n, 32, 10)

@@ -34,6 +34,11 @@ def H():
     h.hh_te_window.restype = C.c_uint32
     h.hh_te_build_wide.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     h.hh_te_build_remainder.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    h.hh_te_crh_ragged.argtypes = [C.c_int, vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, vp]
+    h.hh_ragged_key.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    h.hh_ragged_key.restype = C.c_uint32
+    h.hh_te_item_steps.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, vp]
+    h.hh_te_item_steps.restype = C.c_uint32
     return h
 
 
@@ -517,3 +522,57 @@ def test_poseidon_generic_many_partial_rounds(H):
         S = mont([x for s in sts for x in s])
         H.hh_poseidon_permute(rf, rp, alpha, 3, 1, P(ark), P(mds), P(S), 2, mode)
         assert ints(S) == [x for s in sts for x in po.permute(c, s)], mode
+
+
+def _ragged(lengths, seed):
+    """messages of the given lengths back to back in a buffer of EXACTLY their total size + the offsets array"""
+    offs = np.zeros(len(lengths) + 1, np.uint64)
+    offs[1:] = np.cumsum(np.asarray(lengths, dtype=np.uint64))
+    buf = np.frombuffer(ofr.SplitMix64(seed).bytes(max(int(offs[-1]), 1)), dtype=np.uint8)[: int(offs[-1])].copy()
+    return buf, offs
+
+
+@pytest.mark.parametrize("W,N,group", [(63, 9, 5), (63, 9, 1), (7, 3, 2), (6, 2, 4), (7, 3, 5), (5, 3, 3)])
+def test_bowe_hopwood_ragged_items(H, W, N, group):
+    """per-item lengths (crh/bowe_hopwood/mod.rs:131-138 pads EACH input to a multiple of 3 bits): every length 0 .. max in one
+    batch -- empty, 1..3 bytes (no padding by anybody), lengths that end mid-chunk and mid-group, the maximum -- through the
+    ragged kernel's per-item code against the oracle"""
+    g = jj.bowe_hopwood_generators(31, W, N)
+    G = gens_array(g)
+    n_gen = W * N
+    lut1 = np.zeros((n_gen * 4, 36), np.uint32)
+    lut3 = np.zeros((max(n_gen // max(group, 1), 1) << (3 * group - 1), 36), np.uint32)
+    H.hh_te_build_lut(1, P(G), W, N, 0, group, P(lut3), P(lut1))
+    maxL = n_gen * 3 // 8
+    lengths = list(range(0, min(maxL, 40) + 1)) + [maxL, maxL - 1, maxL // 2, 0, 1, maxL]
+    buf, offs = _ragged(lengths, 77 + W)
+    out = np.zeros((len(lengths), 4), np.uint64)
+    H.hh_te_crh_ragged(1, P(lut3), P(lut1), P(buf), P(offs), len(lengths), group, n_gen, n_gen // max(group, 1), 5, P(out))
+    for i, L in enumerate(lengths):
+        assert ints(out[i])[0] == bh.evaluate(g, W, N, bytes(buf[int(offs[i]):int(offs[i + 1])])), (W, N, group, L)
+        grp = C.c_uint32()
+        st = H.hh_te_item_steps(1, n_gen, group, L, n_gen // max(group, 1), C.byref(grp))
+        assert st == H.hh_ragged_key(1, group, n_gen, L)  # the sort key is the step count the kernel runs
+
+
+@pytest.mark.parametrize("W,N,D,kind", [(4, 256, 11, 2), (4, 256, 8, 0), (5, 7, 6, 2), (4, 8, 5, 2), (3, 11, 4, 0)])
+def test_pedersen_ragged_items(H, W, N, D, kind):
+    """Pedersen pads each input with zero bits to the window (crh/pedersen/mod.rs:82-99): the digest of an item equals the digest of
+    its zero-padded form, whatever its length -- signed-subset and plain tables, lengths 0 .. max incl. 1..3 bytes"""
+    g = jj.pedersen_generators(41, W, N)
+    G = gens_array(g)
+    n_gen = W * N
+    n_digits = -(-n_gen // D)
+    if kind == 2:
+        lut, lut1 = np.zeros((n_digits << (D - 1), 36), np.uint32), np.zeros((n_digits + 1, 36), np.uint32)
+    else:
+        lut, lut1 = np.zeros((n_digits << D, 36), np.uint32), np.zeros((1, 36), np.uint32)
+    H.hh_te_build_lut(kind, P(G), W, N, D, 0, P(lut), P(lut1))
+    maxL = n_gen // 8
+    lengths = sorted(set(list(range(0, min(maxL, 9) + 1)) + [maxL, maxL - 1, maxL // 2, maxL // 3])) + [0, maxL, 2]
+    buf, offs = _ragged(lengths, 99 + W)
+    out = np.zeros((len(lengths), 2, 4), np.uint64)
+    H.hh_te_crh_ragged(kind, P(lut), P(lut1), P(buf), P(offs), len(lengths), D, n_gen, n_digits, 3, P(out))
+    for i, L in enumerate(lengths):
+        assert tuple(ints(out[i])) == pd.evaluate(g, W, N, bytes(buf[int(offs[i]):int(offs[i + 1])])), (W, N, D, kind, L)
+        assert H.hh_te_item_steps(kind, n_gen, D, L, n_digits, C.byref(C.c_uint32())) == H.hh_ragged_key(0, D, n_gen, L)
