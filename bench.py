@@ -86,6 +86,7 @@ def main():
                     help="Bowe-Hopwood 63x9 tree: leaves PER GPU (BASELINE config 5 is 2^23 per GPU on 8 GPUs; 0 disables)")
     ap.add_argument("--proofs-log2", type=int, default=20, help="leaves of the HBM-resident trees of the proof / verify / update legs (0 disables)")
     ap.add_argument("--proofs-m-log2", type=int, default=16, help="paths per call of the proof / verify legs")
+    ap.add_argument("--ragged-log2", type=int, default=20, help="items of the ragged (per-item length) batches (0 disables)")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of each sustained loop (0 disables)")
     ap.add_argument("--sustain-log2-big", type=int, default=24, help="second sustained size (0 disables)")
     ap.add_argument("--settle-launches", type=int, default=120, help="untimed launches before the W warm-up steps (clock ramp)")
@@ -151,7 +152,7 @@ def main():
     from crypto_primitives_amd import field
     from crypto_primitives_amd._lib import lib, check
     from crypto_primitives_amd.distributed import GpuPoseidonBackend, GpuTeBackend, build_sharded
-    from bench_legs import bh_merkle as bh_leg, cpu_baseline as cpu_leg, host_path as host_leg, merkle as merkle_leg, pedersen as ped_leg, scaling, sustained as sus_leg, sweep as sweep_leg
+    from bench_legs import bh_merkle as bh_leg, cpu_baseline as cpu_leg, host_path as host_leg, merkle as merkle_leg, pedersen as ped_leg, ragged as ragged_leg, scaling, sustained as sus_leg, sweep as sweep_leg
 
     ctx = cpa.default_context(local_rank)
     # curve tables: the library's default is the cache-sized table (fast from cold); the warm legs below opt into the HBM-sized ones
@@ -214,6 +215,7 @@ def main():
         if not proofs["sponge"]["sampled_parity_bit_exact"]:
             raise SystemExit("sponge leg: sampled squeezes differ from the oracle")
         proofs["profiles"] = "profiles/r04_s4/proofs_poseidon_kernel_stats_walk*.csv, profiles/r03_s6/proofs_* (rocprofv3 --kernel-trace --stats of `python tools/bench_proofs.py`)"
+    ragged = ragged_leg.run(env)        # per-item lengths (the reference's per-leaf evaluate): one launch, lanes ordered by step count
     sweep = sweep_leg.run(env, tuple(lg for lg in (20, 22, 24, 26) if lg <= max(20, args.sweep_max_log2))) if world == 1 else None
 
     # ================= the headline: W warm-up + K timed steps of the 2^20-state permutation ==========================
@@ -338,7 +340,7 @@ def main():
                               "valu_counters_static_from": "profiles/r04_s8/pmc_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy 93.6-93.9 on that box, 96.1 in profiles/r03_s11; NOT measured in this run)"}},
     }
     for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("proofs", proofs), ("host_path", host_path),
-                     ("sweep", sweep)):
+                     ("ragged", ragged), ("sweep", sweep)):
         if leg:
             out[key] = leg
     if world == 1:

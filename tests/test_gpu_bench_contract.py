@@ -16,7 +16,7 @@ ROOFLINE_KEYS = {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic
                  "effective_sclk_mhz", "frac_of_mad_issue_peak"}
 LINE_LIMIT = 6000  # the driver parses the LAST stdout line out of a bounded tail: round 4's 22 KB line was lost
 SMALL = ["--log2-states", "16", "--merkle-log2", "12", "--pedersen-log2", "10", "--bh-merkle-log2", "9", "--sustain-seconds", "0.2",
-         "--sustain-log2-big", "0", "--proofs-log2", "12", "--proofs-m-log2", "8", "--sweep-max-log2", "20"]
+         "--sustain-log2-big", "0", "--proofs-log2", "12", "--proofs-m-log2", "8", "--sweep-max-log2", "20", "--ragged-log2", "13"]
 
 
 def _check(out, full_path):
@@ -58,7 +58,8 @@ def test_bench_single_process(tmp_path):
     lcb = ln["cpu_baseline"]  # in the LINE: what the contract asks for, scalars only
     assert lcb["kind"] == "port" and lcb["cores"] >= 1 and lcb["value"] > 0 and lcb["cpu_model"] and lcb["sample"] and ln["gpu_over_cpu"] > 1
     for k in ("merkle_s", "pedersen_hashes_per_s", "bh_s", "bh_leaves_per_s", "verify_paths_hashes_per_s", "host_pinned_perm_per_s",
-              "pedersen_cold_first_call_ms", "bh_cold_first_tree_ms", "predicted_8gpu_merkle_s", "predicted_8gpu_bh_s"):
+              "pedersen_cold_first_call_ms", "bh_cold_first_tree_ms", "predicted_8gpu_merkle_s", "predicted_8gpu_bh_s", "ragged_bh_hashes_per_s",
+              "ragged_poseidon_hashes_per_s"):
         assert ln["legs"][k] > 0, k
     assert d["n_gpus"] == 1 and d["roofline"]["kernel"] == "poseidon_permute_t3_kernel<true>"  # 2^16 states: the register kernel
     cb = d["cpu_baseline"]

@@ -70,6 +70,9 @@ def compact(full, full_name="bench_full.json"):
         "bh_2p26_s": _get(full, "sweep", "points", "2^26", "bh_tree_ms"),                                               # ONE GPU, warm, hbm table
         "bh_2p26_cold_s": _get(full, "bh_merkle", "tables", "single_tree_2p26_one_gpu", "cache_sized", "cold_first_tree_s"),
         "bh_2p26_cold_s_hbm_table": _get(full, "bh_merkle", "tables", "single_tree_2p26_one_gpu", "hbm_sized", "cold_first_tree_s"),
+        "ragged_bh_hashes_per_s": _get(full, "ragged", "bowe_hopwood_63x9", "hashes_per_s"),          # 2^20 items of 0 .. 64 bytes, one launch
+        "ragged_pedersen_hashes_per_s": _get(full, "ragged", "pedersen_4x256", "hashes_per_s"),
+        "ragged_poseidon_hashes_per_s": _get(full, "ragged", "poseidon_rate2", "hashes_per_s"),
         "verify_paths_hashes_per_s": _get(full, "proofs", "poseidon", "verify_all_leaves_dev", "hashes_per_s_device"),
         "update_2p10_leaves_per_s": _get(full, "proofs", "poseidon", "update_batch", "2^10", "leaves_per_s"),
         "host_pinned_perm_per_s": _get(full, "host_path", "pinned", "permutations_per_s"),
