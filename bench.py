@@ -336,8 +336,8 @@ def main():
                                                   "effective clock unavailable: nominal 2400 MHz",
                               "frac_of_mad_issue_peak": mad_rate / (valu_peak_wave_instr(eff_mhz or NOMINAL_SCLK_MHZ) * 64),
                               "frac_of_mad_issue_peak_at_nominal_2400mhz": mad_rate / (valu_peak_wave_instr() * 64),
-                              "valu_instructions_per_permutation": 1224736768 // 16384, "valu_busy_percent": 93.7,
-                              "valu_counters_static_from": "profiles/r04_s8/pmc_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy 93.6-93.9 on that box, 96.1 in profiles/r03_s11; NOT measured in this run)"}},
+                              "valu_instructions_per_permutation": 1224736768 // 16384, "valu_busy_percent": 97.8,
+                              "valu_counters_static_from": "profiles/r05_s7/pmc_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy 97.8-97.9 on that box; 93.6-96.1 in rounds 3-4; NOT measured in this run)"}},
     }
     for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("proofs", proofs), ("host_path", host_path),
                      ("ragged", ragged), ("sweep", sweep)):

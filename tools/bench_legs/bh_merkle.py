@@ -99,7 +99,8 @@ def run(env):
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                               "table": h.info(32),
                               "traffic": te_counters("bh_32B", per, h.info(32)["steps"])["traffic"] + te_counters("bh_70B", per - 1, inner_adds)["traffic"],
-                              "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_lds_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
+                              "traffic_calibration": PMC_TE["calibration"] + " (FETCH_SIZE x 2 holds for random 128-byte-line gathers: x2 = 1.045 x the distinct line bytes)",
+                             "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_lds_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
                                                      "for the leaf level and 2^20 x 70 B scaled to the inner nodes' table steps; levels of <= 2^14 nodes run the split kernel; "
                                                      "NOT measured in this run)",
                               "valu": {"table_steps_per_leaf_hash": h.info(32)["steps"],
@@ -110,6 +111,9 @@ def run(env):
                                        "field_products_per_step": 7}}}
     rfb = bh_merkle["roofline"]
     rfb["traffic_over_algorithmic"] = rfb["traffic"] / (160.0 * per)
+    rfb["hbm_bytes_moved_per_leaf"] = rfb["traffic"] / per
+    rfb["moved_GBps"] = rfb["traffic"] / (dev_ms / 1e3) / 1e9
+    rfb["moved_frac_of_hbm_peak"] = rfb["moved_GBps"] / HBM_PEAK_GBS
     bh_mads = (per * (rfb["valu"]["table_steps_per_leaf_hash"] * 7 + 6) + (per - 1) * (rfb["valu"]["table_steps_per_inner_node"] * 7 + 6)) * MADS_PER_PRODUCT
     rfb["valu"]["v_mad_per_s"] = bh_mads / (dev_ms / 1e3)
     rfb["valu"]["frac_of_mad_issue_peak"] = bh_mads / (dev_ms / 1e3) / (VALU_PEAK_WAVE_INSTR * 64)

@@ -10,8 +10,8 @@ MODMUL_PER_PERM_REF = 626        # reference-shaped count
 # HBM bytes per permutation from PMC passes of an earlier session of THIS round (NOT measured in this run; see `static_from`):
 # (2 * 49 585.3 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B); FETCH_SIZE 49 582.8 / 49 587.8 KB,
 # WRITE_SIZE 98 304 KB, SQ_INSTS_VALU 1 224 736 768, VALUBusy 93.6-93.9 % (tools/gpu_pmc_r4.sh; round 3: the same to four digits)
-PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49585.3 + 98304.0) * 1024 / (1 << 20)
-PMC_TRAFFIC_SOURCE = "profiles/r04_s8/pmc_poseidon.txt"
+PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49584.7 + 98304.0) * 1024 / (1 << 20)
+PMC_TRAFFIC_SOURCE = "profiles/r05_s7/pmc_poseidon.txt"
 NOMINAL_SCLK_MHZ = 2400.0
 CYCLES_PER_WAVE_MAD = 4.0        # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
 SIMDS = 256 * 4
@@ -23,16 +23,19 @@ def valu_peak_wave_instr(sclk_mhz=NOMINAL_SCLK_MHZ):
 
 
 VALU_PEAK_WAVE_INSTR = valu_peak_wave_instr()
-# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r04_s11/pmc_te.txt: rocprofv3 --pmc, one counter per pass, the
-# round-4 kernels with the HBM-sized tables -- 24-bit Pedersen digits, 8-chunk Bowe-Hopwood groups + remainder step; NOT measured
+# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r05_s7/pmc_te_hbm.txt: rocprofv3 --pmc, one counter per pass, the
+# kernels with the HBM-sized tables -- 24-bit Pedersen digits, 8-chunk Bowe-Hopwood groups + remainder step; NOT measured
 # in this run).  `steps` is the table-step count of that launch: a run whose handles got another shape (smaller table budget)
 # scales the gather-proportional parts by its own step count.  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950 (128-byte
 # requests tallied at 64 B): with it the accumulate kernels fetch ~1.0 x the table bytes they gather -- every table line comes
 # from HBM, the L2 only serves the second half of a line.  (The 268 MB / 237 MB tables of rounds 1-3: profiles/r04_s8/pmc_te.txt.)
-PMC_TE = {"source": "profiles/r04_s11/pmc_te.txt",
-          "pedersen_128B": {"fetch_kb": 2881640 + 164360, "write_kb": 147480 + 114690, "valu_instr": 1040370000 + 47370200, "steps": 43},  # accumulate_lds<2> + finalize<0>
-          "bh_32B": {"fetch_kb": 734736 + 164936, "write_kb": 147497 + 81920, "valu_instr": 258785000 + 38817800, "steps": 11},          # accumulate_lds<1> + finalize<1>
-          "bh_70B": {"fetch_kb": 1546125 + 164612, "write_kb": 147489 + 81920, "valu_instr": 584163000 + 38817800, "steps": 24}}
+PMC_TE = {"source": "profiles/r05_s7/pmc_te_hbm.txt",
+          # FETCH_SIZE x 2 for RANDOM 128-byte-line gathers: calibrated in profiles/r05_s6 (x2 = 1.045 x the distinct line bytes; every
+          # fabric request is a whole line tallied at 64 B, as for streaming reads)
+          "calibration": "profiles/r05_s6/README.md",
+          "pedersen_128B": {"fetch_kb": 2882390 + 164740, "write_kb": 147560 + 114860, "valu_instr": 1040370000 + 48292900, "steps": 43},  # accumulate_lds<2> + finalize<0>
+          "bh_32B": {"fetch_kb": 734823 + 164800, "write_kb": 147483 + 81920, "valu_instr": 257327000 + 39591900, "steps": 11},          # accumulate_lds<1> + finalize<1>
+          "bh_70B": {"fetch_kb": 1547435 + 164780, "write_kb": 147495 + 81920, "valu_instr": 583819000 + 39591900, "steps": 24}}
 MADS_PER_PRODUCT = 153           # multiply-adds of one field product (81 limb products + 72 reduction products)
 MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) + (234 + 153))  # multiply-adds per permutation
 # (45 / 81 / 162 / 243 limb products + 72 reduction products for a square / product / 2-term / 3-term dot) in the full form:

@@ -56,6 +56,7 @@ def compact(full, full_name="bench_full.json"):
         "merkle_hbm_frac": _get(full, "merkle", "hbm_frac"),
         "pedersen_hashes_per_s": _get(full, "pedersen", "hashes_per_s"),   # configs[3], warm
         "pedersen_hbm_frac": _get(full, "pedersen", "roofline", "frac"),
+        "pedersen_moved_frac_of_hbm_peak": _get(full, "pedersen", "roofline", "moved_frac_of_hbm_peak"),  # counter traffic (calibrated, profiles/r05_s6) / 8 TB/s
         "pedersen_default_table_hashes_per_s": _get(full, "pedersen", "tables", "cache_sized", "warm_hashes_per_s"),
         "pedersen_cold_first_call_ms": _get(full, "pedersen", "tables", "cache_sized", "cold_first_call_ms"),          # library default, from nothing
         "pedersen_cold_first_call_ms_hbm_table": _get(full, "pedersen", "tables", "hbm_sized", "cold_first_call_ms"),
@@ -64,6 +65,7 @@ def compact(full, full_name="bench_full.json"):
         "bh_s": _get(full, "bh_merkle", "seconds"),                        # configs[4] share: 2^23 leaves per GPU, warm
         "bh_leaves_per_s": _get(full, "bh_merkle", "leaves_per_s"),
         "bh_hbm_frac": _get(full, "bh_merkle", "roofline", "frac"),
+        "bh_moved_frac_of_hbm_peak": _get(full, "bh_merkle", "roofline", "moved_frac_of_hbm_peak"),
         "bh_default_table_s": _get(full, "bh_merkle", "tables", "cache_sized", "warm_seconds"),
         "bh_cold_first_tree_ms": _get(full, "bh_merkle", "tables", "cache_sized", "cold_first_tree_ms"),                # library default, from nothing
         "bh_cold_first_tree_ms_hbm_table": _get(full, "bh_merkle", "tables", "hbm_sized", "cold_first_tree_ms"),

@@ -80,7 +80,10 @@ def run(env):
                              "kernel_avg_ms": kavg * 1e3, "achieved": 192.0 * npd / kavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": 192.0 * npd / kavg / 1e9 / HBM_PEAK_GBS,
                              "traffic": tc["traffic"], "traffic_over_algorithmic": tc["traffic"] / (192.0 * npd),
+                             "traffic_calibration": PMC_TE["calibration"] + " (FETCH_SIZE x 2 holds for random 128-byte-line gathers: x2 = 1.045 x the distinct line bytes)",
                              "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_lds_kernel<2> + te_finalize_kernel<0>; NOT measured in this run)",
+                             "hbm_bytes_moved_per_hash": tc["traffic"] / npd, "moved_GBps": tc["traffic"] / kavg / 1e9,
+                             "moved_frac_of_hbm_peak": tc["traffic"] / kavg / 1e9 / HBM_PEAK_GBS,
                              "table_bytes_gathered_per_hash": psteps * int(lib.akp_te_entry_bytes()),
                              "gather_over_algorithmic": psteps * int(lib.akp_te_entry_bytes()) / 192.0,
                              "table": pinfo,

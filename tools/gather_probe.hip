@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 __device__ __forceinline__ uint64_t mix(uint64_t z) {
@@ -42,7 +43,46 @@ __global__ void fill_kernel(uint4* buf, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) buf[i] = make_uint4((uint32_t)i, (uint32_t)(i >> 32), 0x9e3779b9u, (uint32_t)(i * 2654435761u));
 }
 
+// streaming read of known size: 16 B per lane, coalesced (the access pattern the guide's x2 FETCH_SIZE correction was calibrated on)
+__global__ void __launch_bounds__(256) stream_kernel(const uint4* __restrict__ buf, size_t n16, uint32_t* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = buf[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+// `gather_probe calib [GB]`: launches of KNOWN traffic for a counter pass (rocprofv3 --pmc FETCH_SIZE): per window (64 MB, 1 GB,
+// max) one launch each of the whole-line gather (8 pieces), the 7-piece gather te_fetch_all issues, and a one-piece gather; then a
+// 4 GiB streaming read.  Prints one line per launch, in launch order, with the bytes of distinct 128-byte lines it touches.
+static int calibrate(size_t max_gb) {
+    uint32_t* sink;
+    CK(hipMalloc(&sink, 4));
+    void* buf;
+    CK(hipMalloc(&buf, max_gb << 30));
+    fill_kernel<<<4096, 256>>>((uint4*)buf, (max_gb << 30) / 16);
+    CK(hipDeviceSynchronize());
+    const int grid = 1024, rounds = 128;  // 4 waves per SIMD, U = 2: 2^26 lines = 8.59 GB of lines per launch
+    const double lines = (double)grid * 256 * rounds * 2;
+    for (size_t mb : {(size_t)64, (size_t)1024, max_gb << 10}) {
+        const uint64_t n_lines = (mb << 20) / 128;
+        gather_kernel<2, 8><<<grid, 256>>>((const uint4*)buf, n_lines, rounds, sink);
+        gather_kernel<2, 7><<<grid, 256>>>((const uint4*)buf, n_lines, rounds, sink);
+        gather_kernel<2, 1><<<grid, 256>>>((const uint4*)buf, n_lines, rounds, sink);
+        CK(hipDeviceSynchronize());
+        for (int pieces : {8, 7, 1})
+            printf("CALIB gather_kernel<2,%d> window_MB %zu lines %.0f line_bytes %.0f requested_bytes %.0f\n", pieces, mb, lines, lines * 128, lines * 16 * pieces);
+    }
+    const size_t n16 = ((size_t)4 << 30) / 16;
+    stream_kernel<<<4096, 256>>>((const uint4*)buf, n16, sink);
+    CK(hipDeviceSynchronize());
+    printf("CALIB stream_kernel window_MB 4096 lines %.0f line_bytes %.0f requested_bytes %.0f\n", (double)n16 / 8, (double)n16 * 16, (double)n16 * 16);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "calib")) return calibrate(argc > 2 ? (size_t)atol(argv[2]) : 64);
     const size_t max_gb = argc > 1 ? (size_t)atol(argv[1]) : 64;
     uint32_t* sink;
     CK(hipMalloc(&sink, 4));

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3 (kernel trace and --pmc passes): a few launches of every hot kernel at the
-BASELINE sizes, inputs resident in HBM.  `python tools/prof_driver.py [poseidon] [te] [tree]`"""
+BASELINE sizes, inputs resident in HBM.  `python tools/prof_driver.py [poseidon] [te] [tree]`; PROF_TABLES=hbm: the HBM-sized curve
+tables instead of the library's default (cache-sized) ones"""
 import os
 import sys
 
@@ -15,6 +16,8 @@ from crypto_primitives_amd._lib import lib, check  # noqa: E402
 what = set(sys.argv[1:]) or {"poseidon", "te", "tree"}
 dev = torch.device("cuda", 0)
 ctx = cpa.default_context(0)
+if os.environ.get("PROF_TABLES") == "hbm":  # the HBM-sized curve tables (opt-in since round 5); default: the cache-sized ones
+    ctx.set_table_budget(cpa._lib.TABLE_BUDGET_DEVICE)
 stream = torch.cuda.current_stream(dev).cuda_stream
 REPS = int(os.environ.get("PROF_REPS", "3"))
 
