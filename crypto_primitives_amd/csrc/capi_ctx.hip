@@ -94,6 +94,11 @@ extern "C" void akp_ctx_destroy(akp_ctx* c) {
         c->te_event[i] = nullptr;
     }
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->gate_flags) (void)hipFree(c->gate_flags);
+    if (c->gate_done) (void)hipHostFree(c->gate_done);
+    c->gate_flags = nullptr;
+    c->gate_done = c->gate_done_dev = nullptr;
+    c->gate_done_cap = 0;
     for (int i = 0; i < 7; ++i)
         if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -67,6 +67,14 @@ struct akp_ctx {
     // calls fail cleanly until then (handles created on akp_multi_ctx may outlive akp_multi_destroy without touching freed memory)
     int live_handles = 0;
     bool dead = false;
+    // gated (persistent) curve-hash launch of the pinned host path (capi_te.hip te_crh_gated): per-chunk arrival flags in FINE-GRAINED
+    // device memory (+ one error word), per-workgroup completion words in pinned host memory, the epoch that tags one call's values
+    u32* gate_flags = nullptr;   // [64] flags + [64] error word
+    u32* gate_done = nullptr;    // host pointer
+    u32* gate_done_dev = nullptr;  // its device alias
+    size_t gate_done_cap = 0;
+    u32 gate_epoch = 0;
+    bool gate_unavailable = false;  // an allocation / hipStreamWriteValue32 failed once: the chunked launches from then on
     // HBM one precomputed curve table may take (akp_ctx_set_table_budget); 0: 320 MiB (cache-sized tables); AKP_TABLE_BUDGET_DEVICE: a
     // quarter of the device's memory, at most half of what is free
     size_t table_budget = 0;

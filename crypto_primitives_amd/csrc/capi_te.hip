@@ -2,6 +2,7 @@
 // Product code.  Never includes, links or calls anything under oracle/; there is no CPU fallback for any compute entry
 // point (a missing device is AKP_ERR_HIP).
 #include "capi_internal.hpp"
+#include <chrono>
 #include "te_kernels.hpp"
 #include "te_shape.hpp"
 #include "ragged_sort.hpp"
@@ -613,8 +614,18 @@ int32_t te_tree_prepare(akp_te_params* leafp, akp_te_params* two, hipStream_t s)
 // stay busy when the range allows.  Measured at 2^20 Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K /
 // 256 K / 512 K lanes -> 3.57 / 3.41 / 3.39 | 3.21 / 3.24 / 3.29 / 3.46 ms for accumulate + finalize (two boxes): one wave
 // per SIMD it is (a compile-time choice since round 3).
-static int32_t te_launch_finalize(const akp_te_params* p, const F29Pad* x, F29Pad* pre, Fr* d_out, size_t cnt, hipStream_t st) {
-    constexpr size_t target = 65536;
+// `target`: lanes to keep busy: 65536 = one wave per SIMD.  A pass that runs BESIDE an accumulate kernel (the chunks of the pinned host
+// path) is bound by the LATENCY of its dependent chains, not by its instruction count: longer inversion chains on fewer lanes (8192
+// / 2048 lanes) measured slower, as did one inversion per message (131072 lanes) -- profiles/r05_s8/gated_sweep.txt.  What helps is
+// issue priority: te_finalize_kernel raises its waves' priority (s_setprio), 1.1 -> 0.25 ms per chunk beside the accumulate kernel.
+static inline size_t te_chunk_finalize_lanes() {
+#if defined(AKP_TEST_HOOKS)
+    return env_size("AKP_TE_CHUNK_FINALIZE_LANES", 65536);  // A/B (test build only): 8192 / 2048 lanes (longer inversion chains) measured SLOWER
+#else
+    return 65536;
+#endif
+}
+static int32_t te_launch_finalize(const akp_te_params* p, const F29Pad* x, F29Pad* pre, Fr* d_out, size_t cnt, hipStream_t st, size_t target = 65536) {
     const size_t chain = std::min<size_t>(64, std::max<size_t>(1, cnt / target));
     const size_t lanes = (cnt + chain - 1) / chain;
     const unsigned fgrid = (unsigned)((lanes + 255) / 256);
@@ -722,7 +733,8 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     };
     // projective -> affine for the same range (te_launch_finalize)
     auto finalize = [&](size_t first, size_t cnt, hipStream_t st) -> int32_t {
-        return te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, d_out + first * fe, cnt, st);
+        return te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, d_out + first * fe, cnt, st,
+                pipe ? te_chunk_finalize_lanes() : (size_t)65536);
     };
 #if defined(AKP_TE_SPLIT_FINALIZE)
     // A/B arm (`make splitfin`, round 3): the latency-bound finalize pass of the first half runs on a side stream under the
@@ -769,6 +781,147 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     return finalize(0, n, s);
 }
 
+// ---- the pinned host path as ONE gated launch (round 5; DESIGN.md section 1, profiles/r05_s8) --------------------------------------------
+// Until round 4 a pinned batch ran as eight chunked launches, each behind its chunk's DMA: every launch pays its ramp (0.45-0.5 ms per
+// 2^17 messages against 0.29 ms of the resident launch's share) and the call sat at that floor (4.2 ms per 2^20 Pedersen hashes
+// against 2.3-3.2 ms resident).  Here the accumulate kernel is launched ONCE over the whole batch while the messages are still
+// arriving: workgroups wait on their chunk's arrival flag (te_accumulate_lds_gated_kernel; flag = hipStreamWriteValue32 behind the
+// chunk's copy), report completion per workgroup in pinned host memory, and this thread releases each chunk's finalize pass (its own
+// stream) and copy-out (DMA, side stream) as soon as the chunk's workgroups are done.  *used = false: preconditions not met or the
+// gate failed (nothing was written to `out`): the caller runs the chunked launches.
+static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, size_t msg_len, void* h_out, bool* used) {
+    *used = false;
+    akp_ctx* c = p->ctx;
+    if (c->gate_unavailable) return AKP_OK;
+    size_t chunk = (size_t)1 << 17;
+#if defined(AKP_TEST_HOOKS)
+    if (env_u32("AKP_TE_GATED", 1, 0, 1) == 0) return AKP_OK;  // A/B against the chunked launches (test build only)
+    chunk = env_size("AKP_TE_PIPE_CHUNK", chunk);
+#endif
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    if (te_lds_block(msg_len, msg_len) != 256 || (chunk & 255) || n_chunks < 2 || n_chunks > 64) return AKP_OK;
+    const size_t n_wg = (n + 255) / 256;
+    auto give_up = [&](const char* what, hipError_t e) {  // gate resources unavailable on this stack: remember, use the chunked launches
+        (void)hipGetLastError();
+        (void)what; (void)e;
+        c->gate_unavailable = true;
+        return AKP_OK;
+    };
+    if (!c->gate_flags) {
+        hipError_t e = hipExtMallocWithFlags((void**)&c->gate_flags, 128 * sizeof(u32), hipDeviceMallocFinegrained);
+        if (e == hipSuccess) e = hipMemset(c->gate_flags, 0, 128 * sizeof(u32));
+        if (e != hipSuccess) { c->gate_flags = nullptr; return give_up("fine-grained flags", e); }
+    }
+    if (c->gate_done_cap < n_wg) {
+        if (c->gate_done) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(c->gate_done); c->gate_done = nullptr; c->gate_done_cap = 0; }
+        hipError_t e = hipHostMalloc((void**)&c->gate_done, n_wg * sizeof(u32), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->gate_done_dev, c->gate_done, 0);
+        if (e != hipSuccess) { if (c->gate_done) (void)hipHostFree(c->gate_done); c->gate_done = nullptr; return give_up("pinned completion words", e); }
+        memset(c->gate_done, 0, n_wg * sizeof(u32));
+        c->gate_done_cap = n_wg;
+    }
+    if (++c->gate_epoch == 0) ++c->gate_epoch;  // 0 is what fresh memory holds
+    const u32 epoch = c->gate_epoch;
+    hipStream_t s = c->stream;
+    if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
+    if (!c->pipe[4]) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->pipe[4], hipStreamNonBlocking, hi));
+    }
+    for (int i = 5; i <= 6; ++i)
+        if (!c->pipe[i]) {  // two finalize streams (the passes of consecutive chunks overlap), dispatched ahead of the accumulate kernel's workgroups
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&c->pipe[i], hipStreamNonBlocking, hi));
+        }
+    for (int i = 0; i < 8; ++i)
+        if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
+    hipStream_t cin = c->pipe[0], side = c->pipe[4], fins[2] = {c->pipe[5], c->pipe[6]};
+    const u32 fe = te_fe_per_digest(p);
+    const size_t dig = fe * sizeof(Fr);
+    void *dm = nullptr, *dout = nullptr, *xyz = nullptr, *prefix = nullptr;
+    if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
+    if (int32_t rc = ctx_scratch(c, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
+    HIP_TRY(hipMemsetAsync(c->gate_flags + 64, 0, sizeof(u32), s));
+    HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
+    HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));
+    HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[7], 0));
+    HIP_TRY(hipStreamWaitEvent(fins[0], c->chunk_event[7], 0));
+    HIP_TRY(hipStreamWaitEvent(fins[1], c->chunk_event[7], 0));
+    {
+        TeTable* t = p->t;
+        std::lock_guard<std::mutex> table_lock(t->mu);
+        TeResolved rs;
+        if (int32_t rc = te_resolve(p, msg_len, msg_len, s, &rs)) return rc;
+        // all copies first, each followed by its flag; nothing of this call has been launched yet if the write-value is refused
+        for (size_t k = 0; k < n_chunks; ++k) {
+            const size_t first = k * chunk, cnt = std::min(chunk, n - first);
+            HIP_TRY(hipMemcpyAsync((uint8_t*)dm + first * msg_len, h_msgs + first * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
+            const hipError_t e = hipStreamWriteValue32(cin, c->gate_flags + k, epoch, 0);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(cin);
+                return give_up("hipStreamWriteValue32", e);
+            }
+        }
+        const TeGate gate{c->gate_flags, c->gate_done_dev, c->gate_flags + 64, epoch, (u32)(chunk / 256), 1u << 15};
+        // at least 40 KB of LDS per workgroup = at most four workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks
+        // below the runtime's DMA threshold, the copies themselves are small KERNELS -- with every wave slot held by a spinning
+        // workgroup they never run and nothing arrives (measured: tools/persist_probe.hip; a 63x9 batch in 4 MB chunks timed out)
+        const size_t shm = std::max<size_t>(te_lds_image_bytes(256, msg_len, msg_len), 40960);
+        const dim3 grid((unsigned)n_wg);
+        if (t->pedersen && t->signed_subset)
+            hipLaunchKernelGGL(te_accumulate_lds_gated_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape, rs.groups,
+                    rs.steps, rs.tail, (F29Pad*)xyz, n, gate);
+        else if (t->pedersen)
+            hipLaunchKernelGGL(te_accumulate_lds_gated_kernel<0>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape, rs.groups,
+                    rs.steps, rs.tail, (F29Pad*)xyz, n, gate);
+        else
+            hipLaunchKernelGGL(te_accumulate_lds_gated_kernel<1>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape, rs.groups,
+                    rs.steps, rs.tail, (F29Pad*)xyz, n, gate);
+        HIP_TRY(hipGetLastError());
+    }
+    // release every chunk's finalize pass + copy-out when its workgroups have reported (they finish roughly in launch order)
+    const volatile u32* done = c->gate_done;
+    bool gave_up = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t k = 0; k < n_chunks && !gave_up; ++k) {
+        const size_t first = k * chunk, cnt = std::min(chunk, n - first);
+        const size_t wg0 = first / 256, wg1 = (first + cnt + 255) / 256;
+        for (size_t b = wg0; b < wg1; ++b) {
+            unsigned spins = 0;
+            while (done[b] != epoch) {
+                if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) {
+                    gave_up = true;  // the kernel's own spin limit has ended it long before: its error word says why
+                    break;
+                }
+            }
+            if (gave_up) break;
+        }
+        if (gave_up) break;
+        hipStream_t fin = fins[k & 1];
+        if (int32_t rc = te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, (Fr*)dout + first * fe, cnt, fin, te_chunk_finalize_lanes())) return rc;
+        HIP_TRY(hipEventRecord(c->chunk_event[k & 3], fin));
+        HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[k & 3], 0));
+        HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
+    }
+    HIP_TRY(hipStreamSynchronize(cin));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize(fins[0]));
+    HIP_TRY(hipStreamSynchronize(fins[1]));
+    HIP_TRY(hipStreamSynchronize(side));
+    u32 err = 0;
+    HIP_TRY(hipMemcpy(&err, c->gate_flags + 64, sizeof(u32), hipMemcpyDeviceToHost));
+    if (gave_up || err) {  // *used stays false: the caller repeats the batch with the chunked launches -- and this context stops trying
+        c->gate_unavailable = true;
+        return AKP_OK;
+    }
+    *used = true;
+    return AKP_OK;
+}
+
 extern "C" int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out, void* stream) {
     NEED_TE(p, "akp_te_crh_batch_dev");
     return te_crh_dev(p, d_msgs, n, msg_len, (Fr*)d_out, pick_stream(p->ctx, stream));
@@ -800,6 +953,9 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     // A pageable buffer on either side keeps the double-buffered loop below (its staged copies block this thread, which
     // that loop's issue order is built around).
     if (n > te_split_max && msg_len >= 4 && out_pinned && device_alias(msgs, n * msg_len)) {
+        bool gated = false;
+        if (int32_t rc = te_crh_gated(p, msgs, n, msg_len, out, &gated)) return rc;
+        if (gated) return AKP_OK;
         if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
         if (!c->pipe[4]) {  // the copy-out stream: its copy kernels should not queue behind the hash kernels' workgroups
             int lo = 0, hi = 0;

@@ -867,11 +867,39 @@ AKP_HD size_t te_lds_image_bytes(size_t block, size_t msg_len, size_t stride) {
     const size_t dwords = chunks * 4;
     return (dwords + (dwords >> 5) + 4) * 4;
 }
-template <int KIND>
-__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
-                                                           const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
-                                                           u32 n_steps, const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n) {
+// GATED (round 5, the pinned host path): the launch covers the WHOLE batch while its messages are still arriving by DMA, chunk after
+// chunk.  Workgroup b belongs to chunk b / wg_per_chunk; before it touches its messages, thread 0 polls gate_flags[chunk] -- a word in
+// FINE-GRAINED DEVICE memory that hipStreamWriteValue32 on the copy stream sets to `epoch` behind the chunk's copy -- and when its
+// sums are stored the workgroup writes `epoch` to done[b] in pinned HOST memory (a plain posted write; the host thread releases the
+// chunk's finalize pass and copy-out when all its words are there).  Measured preconditions (tools/persist_probe.hip,
+// profiles/r05_s8): the polls must stay on the device (thousands of workgroups polling host memory starve the very copies they wait
+// for) and the kernel must leave wave slots free (a copy / write-value needs one: with every slot spinning nothing arrives) --
+// this kernel holds 3 waves per SIMD.  The spin is bounded: on a timeout the workgroup reports through *gate_err and leaves, the
+// host falls back to the chunked launches.
+struct TeGate {
+    const u32* flags;   // [n_chunks], fine-grained device memory
+    u32* done;          // [grid], pinned host memory (device alias)
+    u32* err;           // device word: workgroups that gave up
+    u32 epoch, wg_per_chunk, spin_limit;
+};
+template <int KIND, bool GATED>
+__device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
+                                                       const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups, u32 n_steps,
+                                                       const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n, const TeGate& gate) {
     extern __shared__ u32 te_msg_image[];
+    if (GATED) {
+        __shared__ u32 gate_open;
+        if (threadIdx.x == 0) {
+            const u32 chunk = blockIdx.x / gate.wg_per_chunk;
+            u32 it = 0;
+            while (__hip_atomic_load(gate.flags + chunk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gate.epoch && ++it < gate.spin_limit)
+                __builtin_amdgcn_s_sleep(16);
+            gate_open = it < gate.spin_limit;
+            if (!gate_open) atomicAdd(gate.err, 1u);
+        }
+        __syncthreads();
+        if (!gate_open) return;
+    }
     const size_t first = (size_t)blockIdx.x * blockDim.x;
     const size_t cnt = n - first < blockDim.x ? n - first : blockDim.x;  // the grid covers n: cnt >= 1
     const uint8_t* g0 = msgs + first * stride;
@@ -888,13 +916,31 @@ __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_kerne
     }
     __syncthreads();
     const size_t idx = first + threadIdx.x;
-    if (idx >= n) return;
-    const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
-    Ext acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
-    if (tail) acc = te_madd(acc, load_niels(tail));
-    f29_store_pad(xyz + idx * 3, acc.X);
-    f29_store_pad(xyz + idx * 3 + 1, acc.Y);
-    f29_store_pad(xyz + idx * 3 + 2, acc.Z);
+    if (idx < n) {
+        const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
+        Ext acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
+        if (tail) acc = te_madd(acc, load_niels(tail));
+        f29_store_pad(xyz + idx * 3, acc.X);
+        f29_store_pad(xyz + idx * 3 + 1, acc.Y);
+        f29_store_pad(xyz + idx * 3 + 2, acc.Z);
+    }
+    if (GATED) {
+        __threadfence();  // the sums of this workgroup are visible device-wide (another kernel, possibly on another XCD, reads them next)
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(gate.done + blockIdx.x, gate.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+template <int KIND>
+__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
+                                                           const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
+                                                           u32 n_steps, const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n) {
+    te_accumulate_lds_body<KIND, false>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, xyz, n, TeGate{});
+}
+template <int KIND>
+__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_gated_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
+                                                           const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
+                                                           u32 n_steps, const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n, TeGate gate) {
+    te_accumulate_lds_body<KIND, true>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, xyz, n, gate);
 }
 #endif
 // sum of the single-chunk entries 1 * G[c], c in [from, to): the constant of a zero tail (one thread; once per parameter set)
@@ -964,6 +1010,12 @@ __global__ void __launch_bounds__(256) te_finalize_kernel(const F29Pad* __restri
                                                          Fr* __restrict__ out, size_t n, size_t lanes) {
     const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= lanes || l >= n) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a pass of few waves and long dependent chains: when it shares its SIMDs with an accumulate kernel (the chunks of the pinned host
+    // path) its instructions go first -- beside three accumulate waves per SIMD a chunk's pass took 1.1 ms instead of 0.2 ms and the
+    // eight serialised passes were the floor of the call (profiles/r05_s8/timeline_gated1_hbm.txt); alone it makes no difference
+    __builtin_amdgcn_s_setprio(3);
+#endif
     te_finalize_lane<KIND>(xyz, prefix, out, n, lanes, l);
 }
 
