@@ -60,18 +60,12 @@ def free_port():
     return p
 
 
-def curve_parity_status():
+def curve_parity_status(attempt=False):
     """pin status of the curve half (Pedersen / Bowe-Hopwood digests, byte formats): `tests/golden/reference_vectors.json` is written
     by shim/examples/emit_vectors.rs on a machine with a Rust toolchain; without it the oracle those legs are checked against is a
-    faithful but UNPINNED restatement"""
-    p = os.path.join(ROOT, "tests", "golden", "reference_vectors.json")
-    if not os.path.exists(p):
-        return "unpinned (emitter not run): tests/golden/reference_vectors.json is absent -- shim/examples/README.md"
-    try:
-        meta = json.load(open(p)).get("emitter", {})
-        return "pinned by tests/golden/reference_vectors.json (emitter %s, Cargo.lock %s)" % (meta.get("git_sha", "?"), meta.get("cargo_lock_sha256", "?")[:16])
-    except Exception as exc:
-        return "reference_vectors.json present but unreadable: %r" % (exc,)
+    faithful but UNPINNED restatement.  tools/bench_legs/pin.py looks for `cargo` and runs the emitter when it can."""
+    from bench_legs import pin
+    return pin.status(attempt)[0]
 
 
 def main():
@@ -280,6 +274,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    from bench_legs import pin
+    pin_status = pin.status(attempt=True)  # runs the reference-vector emitter once if this box has cargo + the crates offline
     total_perms = n * world * args.steps
     value = total_perms / elapsed
     achieved = ALGO_BYTES_PER_PERM * n / kern_avg_s / 1e9
@@ -307,7 +303,8 @@ def main():
                    "rank_devices": rank_devices},
         "parity_probe_bit_exact": parity["bit_exact"],
         "parity": parity,
-        "curve_parity": curve_parity_status(),
+        "curve_parity": pin_status[0],
+        "curve_parity_emitter": pin_status[1],
         "curve_tables": "warm curve-hash legs run with akp_ctx_set_table_budget(AKP_TABLE_BUDGET_DEVICE) (HBM-sized tables, opt-in); the library default is the "
                         "cache-sized table: pedersen.tables / bh_merkle.tables hold cold-start and warm figures of both" if not shared_gpu else "library default (cache-sized)",
         "roofline": {"bound": "hbm", "kernel": parity["probe_kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -354,13 +354,28 @@ extern "C" int32_t akp_deserialize_te_parameters(const uint8_t* in, size_t in_le
     return AKP_OK;
 }
 
+// Path / MultiPath carry TWO digest types: LeafDigest (leaf_sibling_hash) and InnerDigest (the authentication path); a Config may give them
+// different widths (a Pedersen leaf hash whose affine point feeds, through a DigestConverter, a field-element two-to-one hash).  The
+// fe_per_digest argument of the four entry points below is AKP_FE_PAIR(leaf_fe, inner_fe) = leaf_fe << 8 | inner_fe; a plain 1 or 2
+// means both (every configuration of the reference's tests).
+static int32_t split_fe(uint32_t* fe_inner, u32* fe_leaf, const char* what) {
+    const u32 v = *fe_inner, inner = v & 0xffu, leaf = (v >> 8) ? (v >> 8) : inner;
+    if (v >> 16) return fail(AKP_ERR_BAD_PARAMS, "%s: fe_per_digest %u is not 1, 2 or AKP_FE_PAIR(leaf, inner)", what, v);
+    if (int32_t rc = check_fe(inner, what)) return rc;
+    if (int32_t rc = check_fe(leaf, what)) return rc;
+    *fe_inner = inner;
+    *fe_leaf = leaf;
+    return AKP_OK;
+}
+
 // ---- Path (merkle_tree/mod.rs:139-152) --------------------------------------------------------------------------------------------
 extern "C" int32_t akp_serialize_path(const uint64_t* leaf_sibling_hash, const uint64_t* auth_path, size_t depth, uint64_t leaf_index, uint32_t fe,
         int32_t compress, uint8_t* out, size_t out_cap, size_t* out_len) {
-    if (int32_t rc = check_fe(fe, "akp_serialize_path")) return rc;
+    u32 lfe = 0;
+    if (int32_t rc = split_fe(&fe, &lfe, "akp_serialize_path")) return rc;
     if (!leaf_sibling_hash || (depth && !auth_path)) return fail(AKP_ERR_BAD_PARAMS, "akp_serialize_path: NULL buffer");
     Writer w(out, out_cap);
-    w.digest(leaf_sibling_hash, fe, compress != 0);
+    w.digest(leaf_sibling_hash, lfe, compress != 0);
     w.u64(depth);
     for (size_t j = 0; j < depth; ++j) w.digest(auth_path + j * 4 * fe, fe, compress != 0);
     w.u64(leaf_index);
@@ -368,11 +383,12 @@ extern "C" int32_t akp_serialize_path(const uint64_t* leaf_sibling_hash, const u
 }
 extern "C" int32_t akp_deserialize_path(const uint8_t* in, size_t in_len, uint32_t fe, int32_t compress, int32_t validate, uint64_t* leaf_sibling_hash,
         uint64_t* auth_path, size_t auth_cap, size_t* depth, uint64_t* leaf_index) {
-    if (int32_t rc = check_fe(fe, "akp_deserialize_path")) return rc;
+    u32 lfe = 0;
+    if (int32_t rc = split_fe(&fe, &lfe, "akp_deserialize_path")) return rc;
     if (!in) return fail(AKP_ERR_BAD_PARAMS, "akp_deserialize_path: in is NULL");
     Reader r(in, in_len, "akp_deserialize_path");
     const bool fill = leaf_sibling_hash != nullptr;
-    r.digest(leaf_sibling_hash, fe, compress != 0, fill && validate != 0, 0);
+    r.digest(leaf_sibling_hash, lfe, compress != 0, fill && validate != 0, 0);
     const size_t d = r.count(digest_bytes(fe, compress != 0));
     if (!r.rc && fill && d > auth_cap) return fail(AKP_ERR_BAD_LENGTH, "akp_deserialize_path: auth_path holds %zu digests, the buffer %zu", d, auth_cap);
     if (!r.rc && fill && d && !auth_path) return fail(AKP_ERR_BAD_PARAMS, "akp_deserialize_path: auth_path is NULL");
@@ -390,11 +406,12 @@ extern "C" int32_t akp_deserialize_path(const uint8_t* in, size_t in_len, uint32
 extern "C" int32_t akp_serialize_multipath(const uint64_t* leaf_siblings_hashes, const uint64_t* prefix_lengths, const uint64_t* suffix_lengths,
         const uint64_t* suffixes, const uint64_t* leaf_indexes, size_t m, size_t depth, uint32_t fe, int32_t compress, uint8_t* out, size_t out_cap,
         size_t* out_len) {
-    if (int32_t rc = check_fe(fe, "akp_serialize_multipath")) return rc;
+    u32 lfe = 0;
+    if (int32_t rc = split_fe(&fe, &lfe, "akp_serialize_multipath")) return rc;
     if (m && (!leaf_siblings_hashes || !prefix_lengths || !leaf_indexes)) return fail(AKP_ERR_BAD_PARAMS, "akp_serialize_multipath: NULL buffer");
     Writer w(out, out_cap);
     w.u64(m);
-    for (size_t i = 0; i < m; ++i) w.digest(leaf_siblings_hashes + i * 4 * fe, fe, compress != 0);
+    for (size_t i = 0; i < m; ++i) w.digest(leaf_siblings_hashes + i * 4 * lfe, lfe, compress != 0);
     w.u64(m);
     for (size_t i = 0; i < m; ++i) w.u64(prefix_lengths[i]);
     w.u64(m);
@@ -417,16 +434,17 @@ extern "C" int32_t akp_serialize_multipath(const uint64_t* leaf_siblings_hashes,
 extern "C" int32_t akp_deserialize_multipath(const uint8_t* in, size_t in_len, uint32_t fe, int32_t compress, int32_t validate, size_t* m_out,
         size_t* n_suffix_out, uint64_t* leaf_siblings_hashes, uint64_t* prefix_lengths, uint64_t* suffix_lengths, uint64_t* suffixes,
         uint64_t* leaf_indexes, size_t m_cap, size_t suffix_cap) {
-    if (int32_t rc = check_fe(fe, "akp_deserialize_multipath")) return rc;
+    u32 lfe = 0;
+    if (int32_t rc = split_fe(&fe, &lfe, "akp_deserialize_multipath")) return rc;
     if (!in) return fail(AKP_ERR_BAD_PARAMS, "akp_deserialize_multipath: in is NULL");
     const bool fill = leaf_siblings_hashes != nullptr;
     if (fill && (!prefix_lengths || !suffix_lengths || !leaf_indexes)) return fail(AKP_ERR_BAD_PARAMS, "akp_deserialize_multipath: NULL buffer");
     Reader r(in, in_len, "akp_deserialize_multipath");
     const size_t per = digest_bytes(fe, compress != 0);
     const bool val = fill && validate != 0;
-    const size_t m = r.count(per);
+    const size_t m = r.count(digest_bytes(lfe, compress != 0));
     if (!r.rc && fill && m > m_cap) return fail(AKP_ERR_BAD_LENGTH, "akp_deserialize_multipath: %zu paths, the buffers hold %zu", m, m_cap);
-    for (size_t i = 0; i < m && !r.rc; ++i) r.digest(fill ? leaf_siblings_hashes + i * 4 * fe : nullptr, fe, compress != 0, val, i);
+    for (size_t i = 0; i < m && !r.rc; ++i) r.digest(fill ? leaf_siblings_hashes + i * 4 * lfe : nullptr, lfe, compress != 0, val, i);
     const size_t m2 = r.count(8);
     if (!r.rc && m2 != m) return fail(AKP_ERR_BAD_PARAMS, "akp_deserialize_multipath: %zu sibling hashes but %zu prefix lengths", m, m2);
     for (size_t i = 0; i < m2 && !r.rc; ++i) {

@@ -429,7 +429,10 @@ int32_t akp_deserialize_te_parameters(const uint8_t* in, size_t in_len, int32_t 
                                       uint64_t* generators_affine, size_t cap_points, uint32_t* window_size,
                                       uint32_t* num_windows);
 /* Path { leaf_sibling_hash, auth_path (root side first), leaf_index }.  Reader: leaf_sibling_hash == NULL only reports
- * *depth and *leaf_index. */
+ * *depth and *leaf_index.  fe_per_digest (here and for MultiPath): 1 or 2 when LeafDigest and InnerDigest have the same width (every
+ * configuration of the reference's tests), AKP_FE_PAIR(leaf_fe, inner_fe) when a Config gives them different ones (leaf_sibling_hash
+ * / leaf_siblings_hashes are then leaf_fe Fr per digest, the authentication paths inner_fe). */
+#define AKP_FE_PAIR(leaf_fe, inner_fe) (((uint32_t)(leaf_fe) << 8) | (uint32_t)(inner_fe))
 int32_t akp_serialize_path(const uint64_t* leaf_sibling_hash, const uint64_t* auth_path, size_t depth, uint64_t leaf_index,
                            uint32_t fe_per_digest, int32_t compress, uint8_t* out, size_t out_cap, size_t* out_len);
 int32_t akp_deserialize_path(const uint8_t* in, size_t in_len, uint32_t fe_per_digest, int32_t compress, int32_t validate,

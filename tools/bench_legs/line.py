@@ -36,6 +36,7 @@ def compact(full, full_name="bench_full.json"):
     par = full["parity"]
     line["parity"] = {"bit_exact": par["bit_exact"], "states_checked": par["timed_buffer_states_checked"], "kernel": par["probe_kernel"]}
     line["curve_parity"] = full["curve_parity"].split(":")[0][:160]
+    line["curve_parity_emitter"] = (full.get("curve_parity_emitter") or "")[:120]
     line["roofline"] = {"bound": rf["bound"], "kernel": rf["kernel"], "achieved": _r(rf["achieved"]), "peak": rf["peak"], "unit": rf["unit"],
                         "frac": _r(rf["achieved"] / rf["peak"]), "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
                         "kernel_avg_ms": _r(rf["kernel_avg_ms"]), "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
