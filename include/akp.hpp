@@ -140,6 +140,18 @@ struct CRH {
         return out;
     }
     static Output evaluate(const Parameters& p, const std::vector<FrWire>& input) { return evaluate_batch(p, input, input.size())[0]; }
+    // inputs of DIFFERENT lengths in one launch, each hashed as evaluate() would hash it (akp_poseidon_crh_batch_ragged)
+    static std::vector<Output> evaluate_many(const Parameters& p, const std::vector<std::vector<FrWire>>& inputs) {
+        std::vector<uint64_t> offs(inputs.size() + 1, 0);
+        std::vector<FrWire> flat;
+        for (size_t i = 0; i < inputs.size(); ++i) {
+            flat.insert(flat.end(), inputs[i].begin(), inputs[i].end());
+            offs[i + 1] = flat.size();
+        }
+        std::vector<Output> out(inputs.size());
+        if (!inputs.empty()) check(akp_poseidon_crh_batch_ragged(p.get(), flat.empty() ? nullptr : flat[0].data(), offs.data(), inputs.size(), out[0].data()));
+        return out;
+    }
 };
 // poseidon::TwoToOneCRH<Fr> (crh/poseidon/mod.rs:43-80)
 struct TwoToOneCRH {
@@ -204,6 +216,15 @@ class TeParameters {  // pedersen::Parameters / bowe_hopwood::Parameters { gener
   private:
     akp_te_params* h_ = nullptr;
 };
+// byte strings of different lengths -> flat buffer + offsets (the `_ragged` entry points)
+inline void flatten_ragged(const std::vector<std::vector<uint8_t>>& msgs, std::vector<uint8_t>& flat, std::vector<uint64_t>& offs) {
+    offs.assign(msgs.size() + 1, 0);
+    flat.clear();
+    for (size_t i = 0; i < msgs.size(); ++i) {
+        flat.insert(flat.end(), msgs[i].begin(), msgs[i].end());
+        offs[i + 1] = flat.size();
+    }
+}
 namespace pedersen {
 using Parameters = TeParameters<AKP_TE_PEDERSEN>;
 struct CRH {  // crh/pedersen/mod.rs:58-130: Input = [u8], Output = affine point
@@ -215,6 +236,15 @@ struct CRH {  // crh/pedersen/mod.rs:58-130: Input = [u8], Output = affine point
         return out;
     }
     static Output evaluate(const Parameters& p, const std::vector<uint8_t>& input) { return evaluate_batch(p, input, input.size())[0]; }
+    // inputs of different lengths, each padded with zero bits to the window as evaluate() does (:82-99); one launch
+    static std::vector<Output> evaluate_many(const Parameters& p, const std::vector<std::vector<uint8_t>>& msgs) {
+        std::vector<uint8_t> flat;
+        std::vector<uint64_t> offs;
+        flatten_ragged(msgs, flat, offs);
+        std::vector<Output> out(msgs.size());
+        if (!msgs.empty()) check(akp_te_crh_batch_ragged(p.get(), flat.data(), offs.data(), msgs.size(), out[0].x.data()));
+        return out;
+    }
 };
 struct TwoToOneCRH {  // :149-198
     using Output = AffineWire;
@@ -242,6 +272,15 @@ struct CRH {  // crh/bowe_hopwood/mod.rs:75-187: Output = Fq (x coordinate)
         return out;
     }
     static Output evaluate(const Parameters& p, const std::vector<uint8_t>& input) { return evaluate_batch(p, input, input.size())[0]; }
+    // inputs of different lengths, each padded to a multiple of 3 bits only (:131-138): the digest depends on the length; one launch
+    static std::vector<Output> evaluate_many(const Parameters& p, const std::vector<std::vector<uint8_t>>& msgs) {
+        std::vector<uint8_t> flat;
+        std::vector<uint64_t> offs;
+        flatten_ragged(msgs, flat, offs);
+        std::vector<Output> out(msgs.size());
+        if (!msgs.empty()) check(akp_te_crh_batch_ragged(p.get(), flat.data(), offs.data(), msgs.size(), out[0].data()));
+        return out;
+    }
 };
 struct TwoToOneCRH {  // :189-240
     using Output = FrWire;

@@ -40,6 +40,15 @@ static int te_cases(const Context& ctx, const char* path) {
             catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_LENGTH); }  // the reference panics (:82-89)
             auto batch = pedersen::CRH::evaluate_batch(P, std::vector<uint8_t>(msg), L);
             REQUIRE(batch.size() == 1 && batch[0].x == want.x);
+            {  // inputs of different lengths in one launch == evaluate on each (round 5); tables are shared per device: same id, built once
+                const std::vector<std::vector<uint8_t>> many = {msg, {}, std::vector<uint8_t>(msg.begin(), msg.begin() + 1), msg};
+                const auto dg = pedersen::CRH::evaluate_many(P, many);
+                REQUIRE(dg.size() == 4 && dg[0].x == want.x && dg[3].y == want.y);
+                for (size_t i = 0; i < many.size(); ++i) REQUIRE(dg[i].x == pedersen::CRH::evaluate(P, many[i]).x);
+                pedersen::Parameters P2(ctx, W, N, gens);
+                REQUIRE(P2.table_info().table_id == P.table_info().table_id && P.table_info().handles_attached >= 2);
+                P2.prepare((size_t)W * N / 8);
+            }
             // the table shape is a tuning choice: an explicit digit width and a small table budget give the same digest
             pedersen::Parameters P5(ctx, W, N, gens, 5);
             REQUIRE(P5.info().digit_bits_or_group == 5 && pedersen::CRH::evaluate(P5, msg).x == want.x);
@@ -70,6 +79,13 @@ static int te_cases(const Context& ctx, const char* path) {
             bowe_hopwood::Parameters B3(ctx, W, N, gens, 3);  // groups of three chunks (+ the remainder step)
             REQUIRE(B3.info().digit_bits_or_group == 3 && bowe_hopwood::CRH::evaluate(B3, msg) == want);
             REQUIRE(fr_to_canonical({bowe_hopwood::CRH::evaluate(B, {})})[0] == (FrWire{0, 0, 0, 0}));  // empty message: x of the identity
+            {
+                const std::vector<std::vector<uint8_t>> many = {msg, {}, std::vector<uint8_t>(msg.begin(), msg.begin() + 2)};
+                const auto dg = bowe_hopwood::CRH::evaluate_many(B, many);
+                REQUIRE(dg.size() == 3 && dg[0] == want);
+                for (size_t i = 0; i < many.size(); ++i) REQUIRE(dg[i] == bowe_hopwood::CRH::evaluate(B, many[i]));
+                B.prepare_compress();
+            }
             try { bowe_hopwood::TwoToOneCRH::evaluate(B, lo, std::vector<uint8_t>(lo.size() + 1)); REQUIRE(false); }
             catch (const Error& e) { REQUIRE(e.code == AKP_ERR_BAD_LENGTH); }
         }
@@ -99,6 +115,11 @@ int main(int argc, char** argv) {
     const FrWire a = fr_from_u64(1), b = fr_from_u64(2);
     REQUIRE(poseidon::TwoToOneCRH::compress(cfg, a, b) == poseidon::CRH::evaluate(cfg, {a, b}));
     REQUIRE(poseidon::TwoToOneCRH::evaluate(cfg, a, b) == poseidon::TwoToOneCRH::compress(cfg, a, b));
+    {  // inputs of different lengths in one launch (akp_poseidon_crh_batch_ragged) == evaluate on each
+        const std::vector<std::vector<FrWire>> many = {{a}, {}, {a, b}, {a, b, fr_from_u64(3)}};
+        const auto dg = poseidon::CRH::evaluate_many(cfg, many);
+        for (size_t i = 0; i < many.size(); ++i) REQUIRE(dg[i] == poseidon::CRH::evaluate(cfg, many[i]));
+    }
     // Merkle tree of 8 one-element leaves [1]..[8]: proofs verify, wrong root / wrong leaf do not
     std::vector<FrWire> leaves;
     for (uint64_t i = 1; i <= 8; ++i) leaves.push_back(fr_from_u64(i));

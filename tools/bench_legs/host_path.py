@@ -1,5 +1,5 @@
 """`host_path`: the host-pointer entry points (what a Rust host calls), PCIe-inclusive -- never `value`.  Wall time per call,
-MEDIAN of `reps` calls (one call in ~14 of the three-stream curve-hash pipeline takes +6 ms in a runtime wait: profiles/r04_s3)."""
+MEDIAN of `reps` calls (round 4: one call in ~14 of the three-stream curve-hash pipeline took +6 ms in a runtime wait, profiles/r04_s3)."""
 import ctypes as C
 import time
 
@@ -59,8 +59,9 @@ def run(env, host_states, n):
         same = bool(np.array_equal(pinned_out, ho))
         host_path["pedersen_pinned"] = {"hashes_per_s": nph / hs2, "ms_per_batch": hs2 * 1e3, "ms_min": lo2 * 1e3, "ms_max": hi2 * 1e3, "GBps_in": 128.0 * nph / hs2 / 1e9,
                                         "GBps_out": 64.0 * nph / hs2 / 1e9, "digests_equal_the_pageable_call": same,
-                                        "mode": "pinned buffers on both sides: DMA copy-in of every 2^17-message chunk issued up front, kernels back to back, DMA copy-out "
-                                                "on a high-priority side stream (round 4; zero copy in either direction measured slower: profiles/r04_s1/README.md)"}
+                                        "mode": "pinned buffers on both sides, ONE gated launch (round 5, profiles/r05_s8): DMA copy-in of every 2^17-message chunk issued "
+                                                "up front with an arrival flag behind it, the accumulate kernel launched once over the whole batch (workgroups wait on "
+                                                "their chunk's flag), per-chunk finalize + DMA copy-out released by the host thread as workgroups report"}
         check(lib.akp_host_free(pm))
         check(lib.akp_host_free(po))
         if not same:
