@@ -800,6 +800,11 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
 #endif
     const size_t n_chunks = (n + chunk - 1) / chunk;
     if (te_lds_block(msg_len, msg_len) != 256 || (chunk & 255) || n_chunks < 2 || n_chunks > 64) return AKP_OK;
+    // ONE gated launch per device at a time: two of them (two host threads with a context each) would hold all eight wave slots of
+    // every SIMD with waiting workgroups, and the flag writes they wait for could not run.  A second caller takes the chunked launches.
+    static std::mutex gate_busy[64];
+    std::unique_lock<std::mutex> gate_turn(gate_busy[c->device & 63], std::try_to_lock);
+    if (!gate_turn.owns_lock()) return AKP_OK;
     const size_t n_wg = (n + 255) / 256;
     auto give_up = [&](const char* what, hipError_t e) {  // gate resources unavailable on this stack: remember, use the chunked launches
         (void)hipGetLastError();

@@ -65,3 +65,47 @@ def test_pinned_batches_through_the_gated_launch(cpa, kind, W, N, L):
             po.free()
         si = np.unique(np.concatenate([np.arange(40), np.arange(chunk - 20, chunk + 20), np.linspace(0, n - 1, 300).astype(np.int64), np.arange(n - 40, n)]))
         assert np.array_equal(want[si].reshape(len(si), fe, 4), ora(np.ascontiguousarray(msgs[si]), len(si)).reshape(len(si), fe, 4)), (kind, L, n)
+
+
+def test_two_threads_with_contexts_of_their_own_hash_pinned_batches_at_once(cpa):
+    """the shim's shape: every OS thread has a context; two threads push pinned batches through the same parameters at the same time.
+    Only ONE gated launch runs per device (the other caller takes the chunked launches: two gated kernels would hold every wave slot
+    with waiting workgroups); both get the oracle's digests, call after call, and the table is shared"""
+    import threading
+    from crypto_primitives_amd._lib import Context
+    from crypto_primitives_amd.crh import bowe_hopwood
+    g = gens_array(jj.bowe_hopwood_generators(0xE5E50003, 63, 9))
+    ora = cref.CurveParams(63, 9, g)
+    B = bowe_hopwood.Parameters(g)
+    ctxs = [Context(0), Context(0)]
+    n, L = (1 << 18) + 77, 64
+    errs = []
+
+    def work(i):
+        try:
+            h = B.handle(ctxs[i])
+            msgs = np.random.default_rng(50 + i).integers(0, 256, size=(n, L), dtype=np.uint8)
+            pm, po = _Pinned(cpa, msgs.nbytes), _Pinned(cpa, n * 32)
+            pm.array(np.uint8, msgs.shape)[:] = msgs
+            out = po.array(np.uint64, (n, 4))
+            si = np.unique(np.concatenate([np.arange(64), np.linspace(0, n - 1, 400).astype(np.int64), np.arange(n - 64, n)]))
+            want = ora.bh_crh_batch(np.ascontiguousarray(msgs[si]), len(si), L, threads=2)
+            first = None
+            for rep in range(6):
+                out[:] = 0
+                cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, pm.p, n, L, po.p))
+                assert np.array_equal(out[si], want), (i, rep)
+                if first is None:
+                    first = out.copy()
+                assert np.array_equal(out, first), (i, rep)
+            pm.free()
+            po.free()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert B.handle(ctxs[0]).table_info()["table_id"] == B.handle(ctxs[1]).table_info()["table_id"]
