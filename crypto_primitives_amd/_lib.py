@@ -136,6 +136,7 @@ def _load():
         "akp_merkle_tree_export": (i32, [vp, u64p, u64p]),
         "akp_merkle_tree_device_ptrs": (i32, [vp, pp, pp]),
         "akp_merkle_tree_gather_paths": (i32, [vp, u64p, sz, u64p, u64p]),
+        "akp_merkle_tree_multi_proof": (i32, [vp, u64p, sz, u64p, u64p, u64p, sz, C.POINTER(sz)]),
         "akp_merkle_tree_update_batch": (i32, [vp, u64p, vp, sz, sz]),
         "akp_merkle_tree_check_update": (i32, [vp, u64, vp, sz, u64p, C.POINTER(i32)]),
         "akp_merkle_multipath_encode": (i32, [u64p, sz, sz, u32, u64p, u64p, C.POINTER(sz)]),

@@ -543,19 +543,18 @@ class GpuMerkleTree:
         return self.generate_proofs([index])[0]
 
     def generate_multi_proof(self, indexes) -> MultiPath:
-        """:592-625: sorted, de-duplicated indexes; gather on the device, prefix_encode_path through the ABI."""
+        """:592-625: sorted, de-duplicated indexes; gather, prefix_encode_path and suffix compaction on the device (round 5)."""
         import ctypes as C
         idxs = sorted(set(int(i) for i in indexes))
         idx = np.array(idxs, dtype=np.uint64)
         m, shp, depth = len(idx), self.config.digest_shape, self._height - 2
         sibs = np.empty((m,) + shp, dtype=np.uint64)
-        auth = np.empty((m, max(depth, 0)) + shp, dtype=np.uint64)
-        check(lib.akp_merkle_tree_gather_paths(self._h, idx.ctypes.data, m, sibs.ctypes.data, auth.ctypes.data if depth > 0 else None))
         pre = np.zeros(m, dtype=np.uint64)
         suf = np.empty((m * max(depth, 0),) + shp, dtype=np.uint64)
         cnt = C.c_size_t(0)
-        check(lib.akp_merkle_multipath_encode(auth.ctypes.data if depth > 0 else None, m, max(depth, 0), self._fe, pre.ctypes.data,
-                                              suf.ctypes.data if depth > 0 else None, C.byref(cnt)))
+        # gather + prefix_encode_path + compaction on the device (akp_merkle_tree_multi_proof): only the suffixes cross PCIe
+        check(lib.akp_merkle_tree_multi_proof(self._h, idx.ctypes.data, m, sibs.ctypes.data, pre.ctypes.data, suf.ctypes.data if depth > 0 else None,
+                                              m * max(depth, 0), C.byref(cnt)))
         suffixes, o = [], 0
         for i in range(m):
             k = max(depth, 0) - int(pre[i])

@@ -368,6 +368,12 @@ int32_t akp_merkle_tree_device_ptrs(akp_merkle_tree* t, uint64_t** d_leaf_nodes,
  * (root side first) */
 int32_t akp_merkle_tree_gather_paths(akp_merkle_tree* t, const uint64_t* leaf_indices, size_t m,
                                      uint64_t* leaf_sibling_hashes, uint64_t* auth_paths);
+/* MerkleTree::generate_multi_proof (:592-625) for m SORTED, DISTINCT leaf indexes, prefix_encode_path (:795-805) done on the device: the
+ * dense paths never leave HBM, only leaf_sibling_hashes [m], prefix_lengths [m] and the concatenated suffixes come back
+ * (*n_suffix_digests of them; suffix_cap = m * (log2(n) - 1) always suffices; a smaller buffer that turns out too small is
+ * AKP_ERR_BAD_LENGTH with the needed count in *n_suffix_digests).  The same flat form as akp_merkle_multipath_encode. */
+int32_t akp_merkle_tree_multi_proof(akp_merkle_tree* t, const uint64_t* leaf_indices, size_t m, uint64_t* leaf_sibling_hashes,
+                                    uint64_t* prefix_lengths, uint64_t* suffixes, size_t suffix_cap, size_t* n_suffix_digests);
 /* MerkleTree::update (:692-702), batched: equal to update(leaf_indices[k], new_leaves[k]) for k = 0..m-1 in order (a
  * repeated index keeps its last leaf); every level is one hash launch over the distinct touched nodes.  An index out
  * of range (the reference asserts) is AKP_ERR_BAD_PARAMS and leaves the tree untouched. */

@@ -77,6 +77,7 @@ def compact(full, full_name="bench_full.json"):
         "ragged_pedersen_hashes_per_s": _get(full, "ragged", "pedersen_4x256", "hashes_per_s"),
         "ragged_poseidon_hashes_per_s": _get(full, "ragged", "poseidon_rate2", "hashes_per_s"),
         "verify_paths_hashes_per_s": _get(full, "proofs", "poseidon", "verify_all_leaves_dev", "hashes_per_s_device"),
+        "multi_proof_proofs_per_s": _get(full, "proofs", "poseidon", "generate_multi_proof", "proofs_per_s"),
         "update_2p10_leaves_per_s": _get(full, "proofs", "poseidon", "update_batch", "2^10", "leaves_per_s"),
         "host_pinned_perm_per_s": _get(full, "host_path", "pinned", "permutations_per_s"),
         "host_pageable_perm_per_s": _get(full, "host_path", "pageable", "permutations_per_s"),

@@ -8,7 +8,8 @@ C ABI with numpy / device buffers (no per-item Python):
   generate_proof        akp_merkle_tree_gather_paths, m = 2^16 random indices (host outputs), and the all-leaves form of the
                         reference's bench through akp_merkle_gather_paths_dev (paths stay in HBM)
   verify_paths          akp_merkle_verify_paths_*: leaf hash + log2(n) two-to-one levels, all m paths advancing together
-  generate_multi_proof  gather + akp_merkle_multipath_encode (prefix_encode_path :795-805) over the sorted distinct indices
+  generate_multi_proof  akp_merkle_tree_multi_proof: gather + prefix_encode_path (:795-805) + suffix compaction on the device, over the sorted
+                        distinct indices (round 5; the host-encoded form of rounds 3-4 timed beside it)
   verify_multipath      akp_merkle_verify_multipath_* (the reference's memoisation: one hash per distinct node)
   update_batch          akp_merkle_tree_update_batch, m = 2^10 and 2^16 new leaves
 Each leg reports items/s from the host wall clock (the entry points take host pointers: staging copies included), the device
@@ -225,16 +226,24 @@ def run(config, log2_leaves=20, log2_m=16, device_index=0, seed=0xA5A50006):
     suf = np.empty((mu * depth, 4), np.uint64)
     cnt = C.c_size_t(0)
 
-    def gen_multi():
+    def gen_multi_host_encode():  # rounds 3-4: dense paths over PCIe, prefix_encode_path on the host
         check(lib.akp_merkle_tree_gather_paths(tree, uidx.ctypes.data, mu, usib.ctypes.data, uauth.ctypes.data))
         check(lib.akp_merkle_multipath_encode(uauth.ctypes.data, mu, depth, 1, pre.ctypes.data, suf.ctypes.data, C.byref(cnt)))
+    wall_h, dms_h = T.run(gen_multi_host_encode)
+    pre_h, suf_h, cnt_h = pre.copy(), suf[: cnt.value].copy(), cnt.value
+
+    def gen_multi():  # round 5: gather + prefix_encode_path + suffix compaction on the device, only the suffixes cross PCIe
+        check(lib.akp_merkle_tree_multi_proof(tree, uidx.ctypes.data, mu, usib.ctypes.data, pre.ctypes.data, suf.ctypes.data, mu * depth, C.byref(cnt)))
     wall, dms = T.run(gen_multi)
-    # prefix lengths against a plain numpy restatement of prefix_encode_path (:795-805) on the gathered paths
+    # prefix lengths against a plain numpy restatement of prefix_encode_path (:795-805) on the gathered paths, suffixes against the host encoding
     eq = (uauth[1:] == uauth[:-1]).all(axis=2)
     exp_pre = np.concatenate([[0], np.where(eq.all(axis=1), depth, np.argmin(eq, axis=1))]).astype(np.uint64)
     out["generate_multi_proof"] = {"distinct_indices": int(mu), "proofs_per_s": mu / wall, "wall_ms": wall * 1e3, "device_ms": dms,
+                                   "entry_point": "akp_merkle_tree_multi_proof (encoded on the device)",
+                                   "wall_ms_host_encode": wall_h * 1e3, "device_ms_host_encode": dms_h,
                                    "suffix_digests": int(cnt.value), "dense_digests": int(mu * depth), "compression": cnt.value / float(mu * depth),
-                                   "prefix_lengths_match_restatement": bool(np.array_equal(pre, exp_pre))}
+                                   "prefix_lengths_match_restatement": bool(np.array_equal(pre, exp_pre) and np.array_equal(pre, pre_h) and cnt.value == cnt_h
+                                                                            and np.array_equal(suf[: cnt.value], suf_h))}
     ulv = np.ascontiguousarray(leaves[uidx.astype(np.int64)])
     okm = C.c_int32(0)
     wall, dms = T.run(lambda: check(verify_multi(lh.h, th.h, root.ctypes.data, ulv.ctypes.data, mu, leaf_len, uidx.ctypes.data, usib.ctypes.data, pre.ctypes.data,
