@@ -311,10 +311,10 @@ impl<P: GpuConfig> GpuMerkleTree<P> {
         let fe = 4 * P::FE_PER_DIGEST;
         let (m, depth) = (leaf_indexes.len(), self.height - 2);
         let idx: Vec<u64> = leaf_indexes.iter().map(|i| *i as u64).collect();
-        let (mut sib, mut auth) = (vec![0u64; m * fe], vec![0u64; m * depth * fe]);
-        check(unsafe { ffi::akp_merkle_tree_gather_paths(self.h, idx.as_ptr(), m, sib.as_mut_ptr(), auth.as_mut_ptr()) }, 0)?;
+        // gather + prefix_encode_path (`:795-805`) + suffix compaction on the device: only the suffixes cross PCIe (round 5)
+        let mut sib = vec![0u64; m * fe];
         let (mut pre, mut suf, mut cnt) = (vec![0u64; m], vec![0u64; m * depth * fe], 0usize);
-        check(unsafe { ffi::akp_merkle_multipath_encode(auth.as_ptr(), m, depth, P::FE_PER_DIGEST as u32, pre.as_mut_ptr(), suf.as_mut_ptr(), &mut cnt) }, 0)?;
+        check(unsafe { ffi::akp_merkle_tree_multi_proof(self.h, idx.as_ptr(), m, sib.as_mut_ptr(), pre.as_mut_ptr(), suf.as_mut_ptr(), m * depth, &mut cnt) }, 0)?;
         let mut off = 0;
         let mut auth_paths_suffixes = Vec::with_capacity(m);
         for k in 0..m {

@@ -133,6 +133,31 @@ static int te_section(akp_ctx* ctx, const char* path) {
             uint8_t ok = 0;
             OKC(akp_merkle_verify_paths_te(p, p, root.data(), nleaf.data(), 1, leaf_len, &idx, sib.data(), auth.data(), 1, &ok));
             REQUIRE(ok == 1);
+            // the shim's path for leaves of DIFFERENT lengths (round 5: te_tree_build -> akp_merkle_tree_build_te_ragged; evaluate_many ->
+            // akp_te_crh_batch_ragged): leaf digests == the per-item hashes, and the multi-proof comes encoded from the device
+            {
+                const size_t lens[4] = {leaf_len, 0, 1, leaf_len > 2 ? leaf_len - 1 : leaf_len};
+                std::vector<uint64_t> offs(5, 0);
+                for (int i = 0; i < 4; ++i) offs[i + 1] = offs[i] + lens[i];
+                std::vector<uint8_t> flat(offs[4] + 1);
+                for (auto& b : flat) b = (uint8_t)splitmix();
+                akp_merkle_tree* tr = nullptr;
+                OKC(akp_merkle_tree_build_te_ragged(p, p, flat.data(), offs.data(), 4, &tr));
+                std::vector<uint64_t> lnr(4 * fe * 4), dr(4 * fe * 4), one_d(fe * 4);
+                OKC(akp_merkle_tree_export(tr, lnr.data(), nullptr));
+                OKC(akp_te_crh_batch_ragged(p, flat.data(), offs.data(), 4, dr.data()));
+                REQUIRE(lnr == dr);
+                for (int i = 0; i < 4; ++i) {
+                    OKC(akp_te_crh_batch(p, flat.data() + offs[i], 1, lens[i], one_d.data()));
+                    REQUIRE(std::memcmp(one_d.data(), &dr[i * fe * 4], fe * 32) == 0);
+                }
+                const uint64_t both[2] = {1, 3};
+                std::vector<uint64_t> sibs(2 * fe * 4), pre(2), suf(2 * fe * 4);
+                size_t nsuf = 0;
+                OKC(akp_merkle_tree_multi_proof(tr, both, 2, sibs.data(), pre.data(), suf.data(), 2, &nsuf));
+                REQUIRE(pre[0] == 0 && nsuf == 2 - pre[1]);
+                akp_merkle_tree_destroy(tr);
+            }
             akp_merkle_tree_destroy(t);
         }
         akp_te_params_destroy(p);
