@@ -11,29 +11,32 @@ existing torchrun launch it uses the ranks it was given and asserts world size =
 own 2^20 states (weak scaling, the batch shards with no data-path collective); `value` = states permuted by all
 ranks / max-over-ranks time between barriers.
 
-Extra objects on the same JSON line (rank 0):
-  roofline      dominant kernel -- algorithmic bytes (192 B / permutation) / average launch
-                duration measured with events on the launch stream, against the 8 TB/s HBM peak; `valu` gives the
-                integer-ALU view (the real bound).  Fields copied from earlier profiling sessions say so
-                (`static_from`).
+Output (rank 0): ONE short JSON line on stdout (tools/bench_legs/line.py: < 6 KB -- the contract keys, `roofline` and `cpu_baseline` with
+scalar fields, `parity`, `curve_parity`, one scalar per side leg under `legs`, `"full": "bench_full.json"`) and the FULL record in
+bench_full.json beside this file (AKP_BENCH_FULL overrides the path).  Objects of the full record:
+  roofline      dominant kernel -- algorithmic bytes (192 B / permutation) / average launch duration measured with events
+                on the launch stream, against the 8 TB/s HBM peak; `valu` gives the integer-ALU view (the real bound); `traffic` from the
+                PMC passes of this round (`traffic_source`)
   parity        which kernel the probe exercised and how many states of the TIMED buffer were checked
-  sustained     the same launch looped for >= `--sustain-seconds` (2^20 and 2^24 states): rate, min / median / max
-                launch time, GPU clock read from sysfs before / after
-  merkle        BASELINE config 3: MerkleTree::new over 2^24 Poseidon leaves (strong scaling over ranks; leaf
-                shards + ONE all-gather of sub-roots over RCCL)
-  pedersen      BASELINE config 4: Pedersen 4x256 CRH over 2^20 x 128 B per GPU, sampled oracle parity, roofline
-  bh_merkle     BASELINE config 5: Bowe-Hopwood 63x9 tree, 2^23 x 32 B leaves per GPU (2^26 on 8 GPUs)
-  proofs        SURVEY.md 8(f) ranks 1-2 as the reference benches them (benches/merkle_tree.rs:60-191): batched generate_proof,
-                Path::verify, generate_multi_proof + MultiPath::verify and update_batch on an HBM-resident 2^20-leaf tree, Poseidon
-                and Bowe-Hopwood configurations (tools/bench_proofs.py), items/s + device ms + sampled oracle parity
-  host_path     PCIe-inclusive rates of the host-pointer entry points (pageable and pinned buffers), median wall time per call
-  sweep         permutations/s and Poseidon-tree leaves/s at 2^20 / 2^22 / 2^24 / 2^26 on one GPU, with the HBM fraction of each point
+  sustained     the same launch looped for >= `--sustain-seconds` (2^20 and 2^24 states)
+  merkle        BASELINE config 3: MerkleTree::new over 2^24 Poseidon leaves (strong scaling over ranks; leaf shards + ONE all-gather)
+  pedersen      BASELINE config 4: Pedersen 4x256 CRH over 2^20 x 128 B per GPU; `tables`: every figure from a FRESH handle, cold first
+                batch and warm rate, for the library's default (cache-sized) table and the HBM-sized one (opt-in); roofline incl. the
+                moved-bytes view (counter traffic, calibrated: profiles/r05_s6)
+  bh_merkle     BASELINE config 5: Bowe-Hopwood 63x9 tree, 2^23 x 32 B leaves per GPU (2^26 on 8 GPUs); `tables` as above + ONE 2^26-leaf
+                tree on one GPU from nothing
+  ragged        batches whose items differ in length (one launch, lanes ordered by step count): Bowe-Hopwood, Pedersen, Poseidon
+  proofs        SURVEY.md 8(f): batched generate_proof, Path::verify, generate_multi_proof (encoded on the device), MultiPath::verify,
+                update_batch on an HBM-resident 2^20-leaf tree, Poseidon and Bowe-Hopwood (tools/bench_proofs.py)
+  host_path     PCIe-inclusive rates of the host-pointer entry points (pageable and pinned buffers; the pinned curve-hash call is one
+                gated launch), median wall time per call
+  sweep         permutations/s and tree leaves/s at 2^20 .. 2^26 on one GPU (clocks settled per point)
   predicted_scaling  the 2 / 4 / 8-GPU tree build times the design implies from this run's one-GPU numbers (a model, not a measurement)
-  curve_parity  pin status of the curve half of the oracle (unpinned until the reference-vector emitter has been run)
-  cpu_baseline  oracle C restatement ("port") on this host: 1 thread and the best thread count; `cores` is the EFFECTIVE core
-                count (min of affinity, cgroup quota, hardware threads); Pedersen and Bowe-Hopwood-tree legs beside the permutation
+  curve_parity  pin status of the curve half of the oracle; `curve_parity_emitter`: what the cargo probe found on this box
+  cpu_baseline  oracle C restatement ("port") on this host: 1 thread and the best thread count; `cores` is the EFFECTIVE core count;
+                Pedersen and Bowe-Hopwood-tree legs beside the permutation (rank 0 at N = 1 only; null in the line otherwise)
 The legs live in tools/bench_legs/ (one module per object); this file keeps the launch plumbing, the headline measurement and
-the assembly of the line.  The oracle is used only as checker and as the `cpu_baseline` leg.
+the assembly of the record.  The oracle is used only as checker and as the `cpu_baseline` leg.
 """
 import argparse
 import json
