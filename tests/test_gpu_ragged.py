@@ -304,3 +304,35 @@ def test_ragged_batch_at_full_size_sampled(cpa):
     sel = np.nonzero(lens == 32)[0]
     idx = offs[sel].astype(np.int64)[:, None] + np.arange(32)[None, :]
     assert np.array_equal(out[sel], bowe_hopwood.CRH.evaluate_batch(B, np.ascontiguousarray(flat[idx])))
+
+
+def test_ragged_tree_at_2pow18_leaves_sampled(cpa):
+    """a Bowe-Hopwood tree over 2^18 leaves of 0 .. 64 bytes: sampled leaf digests against the oracle, the inner nodes equal the tree
+    built from those leaf digests (MerkleTree::new == new_with_leaf_digest of the leaf hashes, merkle_tree/mod.rs:411-422), proofs of
+    leaves of every length verify with their own leaf"""
+    from crypto_primitives_amd.crh import bowe_hopwood
+    g = gens_array(jj.bowe_hopwood_generators(0xD5D50009, 63, 9))
+    ora = cref.CurveParams(63, 9, g)
+    B = bowe_hopwood.Parameters(g)
+    n = 1 << 18
+    rng = np.random.default_rng(18)
+    lens = rng.integers(0, 65, size=n).astype(np.uint64)
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    flat = rng.integers(0, 256, size=int(offs[-1]), dtype=np.uint8)
+    h = C.c_void_p()
+    lh = B.handle()
+    cpa._lib.check(cpa.lib.akp_merkle_tree_build_te_ragged(lh.h, lh.h, flat.ctypes.data, offs.ctypes.data, n, C.byref(h)))
+    tree = cpa.GpuMerkleTree(cpa.BoweHopwoodByteConfig, B, B, h)
+    host = tree.to_host()
+    si = np.unique(np.concatenate([np.arange(48), np.linspace(0, n - 1, 700).astype(np.int64), np.arange(n - 48, n)]))
+    sub_offs = np.zeros(len(si) + 1, np.uint64)
+    sub_offs[1:] = np.cumsum(lens[si])
+    sub_flat = np.concatenate([flat[int(offs[i]):int(offs[i + 1])] for i in si])
+    assert np.array_equal(host.leaf_nodes[si], _by_length(sub_flat, sub_offs, (4,), lambda a, k, L: ora.bh_crh_batch(a, k, L, threads=16)))
+    again = cpa.GpuMerkleTree.new_with_leaf_digest(cpa.BoweHopwoodByteConfig, B, B, host.leaf_nodes)
+    assert np.array_equal(again.to_host().non_leaf_nodes, host.non_leaf_nodes) and np.array_equal(np.asarray(again.root()), np.asarray(tree.root()))
+    pick = [int(np.nonzero(lens == L)[0][0]) for L in (0, 1, 2, 3, 31, 32, 33, 63, 64)]
+    proofs = tree.generate_proofs(pick)
+    leaves = [bytes(flat[int(offs[i]):int(offs[i + 1])]) for i in pick]
+    assert all(cpa.merkle_tree.verify_paths(cpa.BoweHopwoodByteConfig, B, B, tree.root(), proofs, leaves))
