@@ -116,6 +116,8 @@ def _load():
         "akp_merkle_inner_te_dev": (i32, [vp, u64p, sz, u64p, vp]),
         "akp_merkle_build_te": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, u64p]),
         "akp_merkle_build_te_dev": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, vp]),
+        "akp_merkle_build_poseidon_ragged_dev": (i32, [vp, vp, u64p, u64p, sz, u64p, u64p, vp]),
+        "akp_merkle_build_te_ragged_dev": (i32, [vp, vp, u8p, u64p, sz, sz, u64p, u64p, vp]),
         "akp_merkle_gather_paths": (i32, [u64p, u64p, sz, u32, u64p, sz, u64p, u64p]),
         "akp_merkle_gather_paths_dev": (i32, [vp, u64p, u64p, sz, u32, u64p, sz, u64p, u64p, vp]),
         "akp_merkle_verify_paths_poseidon": (i32, [vp, vp, u64p, u64p, sz, sz, u64p, u64p, u64p, sz, u8p]),

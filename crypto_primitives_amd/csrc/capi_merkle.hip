@@ -111,6 +111,19 @@ extern "C" int32_t akp_merkle_build_poseidon(akp_poseidon* leafp, akp_poseidon* 
         [&](hipStream_t s) -> int32_t { return akp_merkle_inner_poseidon_dev(two, (const uint64_t*)dln, n, (uint64_t*)dnl, (void*)s); });
 }
 
+// the same for the Poseidon field tree (leaf i = elements [d_offsets[i], d_offsets[i+1]) of d_leaves; t = 3 leaf parameters)
+extern "C" int32_t akp_merkle_build_poseidon_ragged_dev(akp_poseidon* leafp, akp_poseidon* two, const uint64_t* d_leaves, const uint64_t* d_offsets,
+        size_t n, uint64_t* d_leaf_nodes, uint64_t* d_non_leaf, void* stream) {
+    NEED_DEV(leafp, "akp_merkle_build_poseidon_ragged_dev");
+    NEED_DEV(two, "akp_merkle_build_poseidon_ragged_dev");
+    if (leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "leaf and two-to-one parameters belong to different contexts");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    if (!d_offsets || !d_leaf_nodes || !d_non_leaf) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    hipStream_t s = pick_stream(leafp->ctx, stream);
+    if (int32_t rc = poseidon_crh_ragged_dev(leafp, (const Fr*)d_leaves, d_offsets, n, (Fr*)d_leaf_nodes, s)) return rc;
+    return akp_merkle_inner_poseidon_dev(two, d_leaf_nodes, n, d_non_leaf, (void*)s);
+}
+
 extern "C" int32_t akp_merkle_inner_te_dev(akp_te_params* two, const uint64_t* d_leaf_nodes, size_t n, uint64_t* d_non_leaf, void* stream) {
     NEED_TE(two, "akp_merkle_inner_te_dev");
     if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
@@ -151,6 +164,20 @@ extern "C" int32_t akp_merkle_build_te_dev(akp_te_params* leafp, akp_te_params* 
     hipStream_t s = pick_stream(leafp->ctx, stream);
     if (int32_t rc = te_tree_prepare(leafp, two, s)) return rc;
     if (int32_t rc = te_crh_dev(leafp, d_leaves, n, leaf_len, (Fr*)d_leaf_nodes, s)) return rc;
+    return akp_merkle_inner_te_dev(two, d_leaf_nodes, n, d_non_leaf, (void*)s);
+}
+// MerkleTree::new over leaves of DIFFERENT lengths, everything in device memory (round 5; merkle_tree/mod.rs:411-422): leaf i = bytes
+// [d_offsets[i], d_offsets[i+1]) of d_leaves; max_len bounds the longest leaf (the table is built for it).  Enqueue only.
+extern "C" int32_t akp_merkle_build_te_ragged_dev(akp_te_params* leafp, akp_te_params* two, const uint8_t* d_leaves, const uint64_t* d_offsets, size_t n,
+        size_t max_len, uint64_t* d_leaf_nodes, uint64_t* d_non_leaf, void* stream) {
+    NEED_TE(leafp, "akp_merkle_build_te_ragged_dev");
+    NEED_TE(two, "akp_merkle_build_te_ragged_dev");
+    if (leafp->kind != two->kind || leafp->ctx != two->ctx) return fail(AKP_ERR_BAD_PARAMS, "leaf / two-to-one parameters mismatch");
+    if (!pow2_gt1(n)) return fail(AKP_ERR_NOT_POW2, "leaves.len() should be power of two and greater than one (got %zu)", n);
+    if (!d_offsets || !d_leaf_nodes || !d_non_leaf) return fail(AKP_ERR_BAD_PARAMS, "NULL buffer");
+    hipStream_t s = pick_stream(leafp->ctx, stream);
+    if (int32_t rc = te_tree_prepare(leafp, two, s)) return rc;
+    if (int32_t rc = te_crh_ragged_dev(leafp, d_leaves, d_offsets, n, max_len, (Fr*)d_leaf_nodes, s)) return rc;
     return akp_merkle_inner_te_dev(two, d_leaf_nodes, n, d_non_leaf, (void*)s);
 }
 extern "C" int32_t akp_merkle_build_te(akp_te_params* leafp, akp_te_params* two, const uint8_t* leaves, size_t n, size_t leaf_len,

@@ -100,9 +100,19 @@ class GpuPoseidonBackend:
         return self.device
 
     def build_subtree_tensors(self, d_leaves):
-        """d_leaves: int64 cuda tensor [n_local, leaf_len, 4]."""
+        """d_leaves: int64 cuda tensor [n_local, leaf_len, 4]; or, for leaves of DIFFERENT lengths, a tuple (flat int64 tensor [total, 4],
+        offsets int64 tensor [n_local + 1] in elements): akp_merkle_build_poseidon_ragged_dev."""
         from ._lib import lib, check
         torch = self.torch
+        if isinstance(d_leaves, tuple):
+            flat, offs = d_leaves[0], d_leaves[1]
+            n = offs.shape[0] - 1
+            leaf_nodes = torch.empty((n, 4), dtype=torch.int64, device=self.device)
+            non_leaf = torch.empty((n - 1, 4), dtype=torch.int64, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            check(lib.akp_merkle_build_poseidon_ragged_dev(self.leaf_h.h, self.two_h.h, flat.data_ptr(), offs.data_ptr(), n,
+                                                           leaf_nodes.data_ptr(), non_leaf.data_ptr(), stream))
+            return leaf_nodes, non_leaf
         n = d_leaves.shape[0]
         leaf_nodes = torch.empty((n, 4), dtype=torch.int64, device=self.device)
         non_leaf = torch.empty((n - 1, 4), dtype=torch.int64, device=self.device)
@@ -154,8 +164,19 @@ class GpuTeBackend:
         return self.device
 
     def build_subtree_tensors(self, d_leaves):
+        """d_leaves: uint8 cuda tensor [n_local, leaf_len]; or, for leaves of DIFFERENT lengths, a tuple (flat uint8 tensor, offsets
+        int64 tensor [n_local + 1] into it, max_len): akp_merkle_build_te_ragged_dev"""
         from ._lib import lib, check
         torch = self.torch
+        if isinstance(d_leaves, tuple):
+            flat, offs, max_len = d_leaves
+            n = offs.shape[0] - 1
+            leaf_nodes = torch.empty((n, self.fe * 4), dtype=torch.int64, device=self.device)
+            non_leaf = torch.empty((n - 1, self.fe * 4), dtype=torch.int64, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            check(lib.akp_merkle_build_te_ragged_dev(self.leaf_h.h, self.two_h.h, flat.data_ptr(), offs.data_ptr(), n, int(max_len),
+                                                     leaf_nodes.data_ptr(), non_leaf.data_ptr(), stream))
+            return leaf_nodes, non_leaf
         n, L = d_leaves.shape[0], d_leaves.shape[1]
         leaf_nodes = torch.empty((n, self.fe * 4), dtype=torch.int64, device=self.device)
         non_leaf = torch.empty((n - 1, self.fe * 4), dtype=torch.int64, device=self.device)

@@ -298,6 +298,16 @@ int32_t akp_merkle_build_te_dev(akp_te_params* leaf_params, akp_te_params* two_t
                                 size_t n_leaves, size_t leaf_len, uint64_t* d_leaf_nodes, uint64_t* d_non_leaf_nodes,
                                 void* stream);
 
+/* MerkleTree::new over leaves of DIFFERENT lengths with every buffer in device memory (the resident handle's form:
+ * akp_merkle_tree_build_*_ragged below): leaf i = elements (Poseidon; t = 3 leaf parameters) / bytes (te) [d_offsets[i], d_offsets[i+1])
+ * of d_leaves; max_len bounds the longest byte leaf.  Enqueue only. */
+int32_t akp_merkle_build_poseidon_ragged_dev(akp_poseidon* leaf_params, akp_poseidon* two_to_one_params, const uint64_t* d_leaves,
+                                             const uint64_t* d_offsets, size_t n_leaves, uint64_t* d_leaf_nodes,
+                                             uint64_t* d_non_leaf_nodes, void* stream);
+int32_t akp_merkle_build_te_ragged_dev(akp_te_params* leaf_params, akp_te_params* two_to_one_params, const uint8_t* d_leaves,
+                                       const uint64_t* d_offsets, size_t n_leaves, size_t max_len, uint64_t* d_leaf_nodes,
+                                       uint64_t* d_non_leaf_nodes, void* stream);
+
 /* ---- Merkle proofs (merkle_tree/mod.rs:146-213, 536-579) -------------------------------------------- */
 /* MerkleTree::generate_proof for m leaf indices at once (get_leaf_sibling_hash :536-544 + compute_auth_path
  * :547-569): pure index arithmetic over the heap-ordered arrays.  fe_per_digest = 1 (Poseidon / Bowe-Hopwood)

@@ -30,5 +30,17 @@ res = build_sharded(tb, bl[lo:hi], n, dist)
 full = build_sharded(tb, bl, n, None)
 nl = full["non_leaf_nodes"].cpu().numpy().view(np.uint64)
 assert np.array_equal(res["root"], nl[0]) and np.array_equal(res["top_nodes"], nl[: world - 1]), "bh top mismatch"
+# leaves of DIFFERENT lengths (round 5): every rank passes its slice of the flat buffer + its own offsets (rebased to the slice)
+lens = np.random.default_rng(2).integers(0, 65, size=n).astype(np.int64)
+offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum(lens)
+flat = torch.from_numpy(np.random.default_rng(3).integers(0, 256, size=int(offs[-1]), dtype=np.uint8)).to(dev)
+d_offs = torch.from_numpy(offs).to(dev)
+mine = (flat[int(offs[lo]):int(offs[hi])], (d_offs[lo:hi + 1] - int(offs[lo])).contiguous(), 64)
+res = build_sharded(tb, mine, n, dist)
+full = build_sharded(tb, (flat, d_offs, 64), n, None)
+nl = full["non_leaf_nodes"].cpu().numpy().view(np.uint64)
+assert np.array_equal(res["root"], nl[0]) and np.array_equal(res["top_nodes"], nl[: world - 1]), "ragged bh top mismatch"
+ref = cpa.GpuMerkleTree.new(cpa.BoweHopwoodByteConfig, B, B, [bytes(flat[int(offs[i]):int(offs[i + 1])].cpu().numpy()) for i in range(n)])
+assert np.array_equal(np.asarray(ref.root()).reshape(-1), nl[0].reshape(-1)), "ragged tree (device form) differs from the resident ragged tree"
 dist.barrier(); dist.destroy_process_group()
 print("rank %d ok" % rank)
