@@ -254,7 +254,8 @@ int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, 
  * bytes [offsets[i], offsets[i+1]) of msgs (offsets: n + 1 non-decreasing byte offsets).  One launch, per-lane step counts; the
  * items are ordered by step count on the device (counting sort, longest first) so that a wave's lanes finish together.  A message
  * longer than the window is AKP_ERR_BAD_LENGTH for the whole call (the reference panics on that item).  `_dev`: max_len is the
- * caller's bound on the longest message (the table is built for it; a longer item is hashed as if truncated to the table). */
+ * caller's bound on the longest message (the table is built for it; an item that is longer all the same gets an unspecified digest --
+ * its table steps are clamped to what is built, nothing is read out of bounds). */
 int32_t akp_te_crh_batch_ragged(akp_te_params* p, const uint8_t* msgs, const uint64_t* offsets, size_t n, uint64_t* out);
 int32_t akp_te_crh_batch_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_t* d_offsets, size_t n, size_t max_len,
                                     uint64_t* d_out, void* stream);
