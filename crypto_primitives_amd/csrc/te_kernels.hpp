@@ -872,7 +872,7 @@ AKP_HD size_t te_lds_image_bytes(size_t block, size_t msg_len, size_t stride) {
 // FINE-GRAINED DEVICE memory that hipStreamWriteValue32 on the copy stream sets to `epoch` behind the chunk's copy -- and when its
 // sums are stored the workgroup writes `epoch` to done[b] in pinned HOST memory (a plain posted write; the host thread releases the
 // chunk's finalize pass and copy-out when all its words are there).  Measured preconditions (tools/persist_probe.hip,
-// profiles/r05_s8): the polls must stay on the device (thousands of workgroups polling host memory starve the very copies they wait
+// profiles/r05_s8): the polls must stay on the device (polling host memory competes over PCIe with the very copies the workgroups wait
 // for) and the kernel must leave wave slots free (a copy / write-value needs one: with every slot spinning nothing arrives) --
 // this kernel holds 3 waves per SIMD.  The spin is bounded: on a timeout the workgroup reports through *gate_err and leaves, the
 // host falls back to the chunked launches.
