@@ -798,6 +798,17 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     if (env_u32("AKP_TE_GATED", 1, 0, 1) == 0) return AKP_OK;  // A/B against the chunked launches (test build only)
     chunk = env_size("AKP_TE_PIPE_CHUNK", chunk);
 #endif
+    // fused: the workgroups finish their digests themselves (one inversion per workgroup) -- 4.43 -> 4.2 ms (default table) / 3.9 -> 3.65 ms
+    // (HBM table) per 2^20 Pedersen hashes against separate per-chunk finalize passes.  zero_copy_out: digests stored straight into the pinned
+    // buffer through an LDS staging area (whole lines per store) instead of DMA copy-outs: measured SLOWER (4.6 / 3.9 ms), kept as a
+    // test-build arm only (profiles/r05_s13)
+    bool fused = true, zero_copy_out = false;
+#if defined(AKP_TEST_HOOKS)
+    fused = env_u32("AKP_TE_GATED_FUSED", 1, 0, 1) != 0;
+    zero_copy_out = env_u32("AKP_TE_GATED_ZERO_COPY_OUT", 0, 0, 1) != 0;
+#endif
+    void* out_alias = device_alias(h_out, n * te_fe_per_digest(p) * sizeof(Fr));
+    zero_copy_out = zero_copy_out && fused && out_alias != nullptr;
     const size_t n_chunks = (n + chunk - 1) / chunk;
     if (te_lds_block(msg_len, msg_len) != 256 || (chunk & 255) || n_chunks < 2 || n_chunks > 64) return AKP_OK;
     // ONE gated launch per device at a time: two of them (two host threads with a context each) would hold all eight wave slots of
@@ -871,13 +882,25 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
                 return give_up("hipStreamWriteValue32", e);
             }
         }
-        const TeGate gate{c->gate_flags, c->gate_done_dev, c->gate_flags + 64, epoch, (u32)(chunk / 256), 1u << 15};
+        const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;  // the tree / staging area behind it: 16-byte aligned
+        const TeGate gate{c->gate_flags, c->gate_done_dev, c->gate_flags + 64, epoch, (u32)(chunk / 256), 1u << 15, zero_copy_out ? (Fr*)out_alias : (Fr*)dout, fe,
+                          (u32)(image / 4), zero_copy_out ? 1u : 0u};
         // at least 40 KB of LDS per workgroup = at most four workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks
         // below the runtime's DMA threshold, the copies themselves are small KERNELS -- with every wave slot held by a spinning
         // workgroup they never run and nothing arrives (measured: tools/persist_probe.hip; a 63x9 batch in 4 MB chunks timed out)
-        const size_t shm = std::max<size_t>(te_lds_image_bytes(256, msg_len, msg_len), 40960);
+        const size_t shm = std::max<size_t>(image + (fused ? 9 * 512 * sizeof(u32) : 0), 40960);
         const dim3 grid((unsigned)n_wg);
-        if (t->pedersen && t->signed_subset)
+        if (fused) {  // the workgroups finish their digests themselves (one inversion per workgroup through an LDS product tree): no finalize passes
+            if (t->pedersen && t->signed_subset)
+                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                        rs.groups, rs.steps, rs.tail, n, gate);
+            else if (t->pedersen)
+                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<0>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                        rs.groups, rs.steps, rs.tail, n, gate);
+            else
+                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<1>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                        rs.groups, rs.steps, rs.tail, n, gate);
+        } else if (t->pedersen && t->signed_subset)
             hipLaunchKernelGGL(te_accumulate_lds_gated_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape, rs.groups,
                     rs.steps, rs.tail, (F29Pad*)xyz, n, gate);
         else if (t->pedersen)
@@ -907,10 +930,12 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
         }
         if (gave_up) break;
         hipStream_t fin = fins[k & 1];
-        if (int32_t rc = te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, (Fr*)dout + first * fe, cnt, fin, te_chunk_finalize_lanes())) return rc;
-        HIP_TRY(hipEventRecord(c->chunk_event[k & 3], fin));
-        HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[k & 3], 0));
-        HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
+        if (!fused) {
+            if (int32_t rc = te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, (Fr*)dout + first * fe, cnt, fin, te_chunk_finalize_lanes())) return rc;
+            HIP_TRY(hipEventRecord(c->chunk_event[k & 3], fin));
+            HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[k & 3], 0));
+        }
+        if (!zero_copy_out) HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
     }
     HIP_TRY(hipStreamSynchronize(cin));
     HIP_TRY(hipStreamSynchronize(s));

@@ -881,8 +881,62 @@ struct TeGate {
     u32* done;          // [grid], pinned host memory (device alias)
     u32* err;           // device word: workgroups that gave up
     u32 epoch, wg_per_chunk, spin_limit;
+    // FUSED: the workgroup also finishes its digests (projective -> affine with ONE inversion per workgroup) and writes them to
+    // `out` (`fe` Fr per digest: x, or x and y); `tree_dwords`: offset of the 9 x 512-dword product tree behind the message image
+    Fr* out;
+    u32 fe, tree_dwords;
+    u32 stage_out;  // 1: `out` is pinned host memory (device alias): digests leave through an LDS staging area, whole lines per store
 };
-template <int KIND, bool GATED>
+// One inversion for the 256 sums of a workgroup: a product tree over the Z coordinates in LDS (up-sweep: 8 levels of pairwise products),
+// one inversion of the root by lane 0, and the down-sweep that turns every node's product into its inverse (inv_left = inv_parent *
+// prod_right and vice versa), in place -- a child's slot is read by its parent's lane only and rewritten by that lane, its own
+// children still hold their products when their turn comes.  Node n, limb i lives at tree[i * 512 + n]: consecutive lanes touch
+// consecutive banks.  Cost per workgroup: wave 0 ~ 8 + 16 products + the 16 k-instruction inversion, the other waves wait at the
+// barriers (their SIMDs run the other workgroups of the CU); +10 % on the accumulate work against +15 % for the eight separate
+// finalize passes of a pinned batch -- and no second kernel that has to fight the accumulate kernel for issue slots.
+#if defined(__HIPCC__)
+__device__ __forceinline__ FS te_tree_load(const u32* tree, u32 node) {
+    FS r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (int32_t)tree[i * 512 + node];
+    return r;
+}
+__device__ __forceinline__ void te_tree_store(u32* tree, u32 node, const FS& v) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tree[i * 512 + node] = (u32)v.l[i];
+}
+// all 256 threads of the workgroup call this; returns 1 / z of the calling lane's z (in the form f29_mul expects, as f29_inv does)
+__device__ __forceinline__ FS te_workgroup_inverse(u32* tree, const FS& z) {
+    te_tree_store(tree, 255u + threadIdx.x, z);
+    __syncthreads();
+    // the tree work (24 products and the inversion, all on the lowest lanes) rotates over the four waves with the workgroup index: with
+    // wave 0 always in charge, the SIMD that hosts the wave 0 of every workgroup did 84 k instructions per workgroup against 64 k
+    // on the others and set the pace of the CU (0.45 instead of 0.35 ms per 2^17-message chunk, profiles/r05_s13)
+    const u32 tid = (threadIdx.x + ((blockIdx.x & 3u) << 6)) & 255u;
+#pragma unroll 1
+    for (u32 count = 128; count >= 1; count >>= 1) {
+        if (tid < count) {
+            const u32 node = count - 1u + tid;
+            te_tree_store(tree, node, f29_mul(te_tree_load(tree, 2u * node + 1u), te_tree_load(tree, 2u * node + 2u)));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) te_tree_store(tree, 0u, f29_inv(te_tree_load(tree, 0u)));
+    __syncthreads();
+#pragma unroll 1
+    for (u32 count = 1; count <= 128; count <<= 1) {
+        if (tid < count) {
+            const u32 node = count - 1u + tid;
+            const FS inv = te_tree_load(tree, node), a = te_tree_load(tree, 2u * node + 1u), b = te_tree_load(tree, 2u * node + 2u);
+            te_tree_store(tree, 2u * node + 1u, f29_mul(inv, b));
+            te_tree_store(tree, 2u * node + 2u, f29_mul(inv, a));
+        }
+        __syncthreads();
+    }
+    return te_tree_load(tree, 255u + threadIdx.x);
+}
+#endif
+template <int KIND, bool GATED, bool FUSED = false>
 __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
                                                        const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups, u32 n_steps,
                                                        const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n, const TeGate& gate) {
@@ -916,7 +970,43 @@ __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict
     }
     __syncthreads();
     const size_t idx = first + threadIdx.x;
-    if (idx < n) {
+    if (FUSED) {
+        Ext acc = ext_identity();  // lanes past the end of the batch take part in the product tree with Z = 1
+        if (idx < n) {
+            const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
+            acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
+            if (tail) acc = te_madd(acc, load_niels(tail));
+        }
+        u32* tree = te_msg_image + gate.tree_dwords;
+        const FS zi = te_workgroup_inverse(tree, acc.Z);
+        if (!gate.stage_out) {
+            if (idx < n) {
+                store_fr_g(gate.out + idx * gate.fe, f29_to_wire(f29_mul(acc.X, zi)));
+                if (gate.fe == 2) store_fr_g(gate.out + idx * 2 + 1, f29_to_wire(f29_mul(acc.Y, zi)));
+            }
+        } else {
+            // `out` is PINNED HOST memory: the workgroup's digests (16 KB for 256 points) go through LDS so that every store instruction
+            // writes whole contiguous lines over PCIe -- a lane storing its own 64 bytes at a 64-byte pitch crosses PCIe at 17 GB/s
+            // (profiles/r04_s2), and the blit kernels of a DMA copy-out would share the CUs with this kernel
+            __syncthreads();  // every lane holds its inverse: the tree becomes the staging area (9 x 512 dwords >= 256 x 16)
+            if (idx < n) {
+                const Fr x = f29_to_wire(f29_mul(acc.X, zi));
+                uint4* st = reinterpret_cast<uint4*>(tree) + (size_t)threadIdx.x * gate.fe * 2;
+                st[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+                st[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+                if (gate.fe == 2) {
+                    const Fr y = f29_to_wire(f29_mul(acc.Y, zi));
+                    st[2] = make_uint4(y.l[0], y.l[1], y.l[2], y.l[3]);
+                    st[3] = make_uint4(y.l[4], y.l[5], y.l[6], y.l[7]);
+                }
+            }
+            __syncthreads();
+            const uint4* src = reinterpret_cast<const uint4*>(tree);
+            uint4* dst = reinterpret_cast<uint4*>(gate.out + first * gate.fe);
+            const u32 pieces = (u32)cnt * gate.fe * 2u;
+            for (u32 k = threadIdx.x; k < pieces; k += 256u) dst[k] = src[k];
+        }
+    } else if (idx < n) {
         const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
         Ext acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
         if (tail) acc = te_madd(acc, load_niels(tail));
@@ -941,6 +1031,13 @@ __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_gated
                                                            const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
                                                            u32 n_steps, const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n, TeGate gate) {
     te_accumulate_lds_body<KIND, true>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, xyz, n, gate);
+}
+// ... and with the digests finished inside the workgroup (TeGate::out): no xyz array, no finalize pass
+template <int KIND>
+__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_gated_fused_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
+                                                           const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
+                                                           u32 n_steps, const TeEntry* __restrict__ tail, size_t n, TeGate gate) {
+    te_accumulate_lds_body<KIND, true, true>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, nullptr, n, gate);
 }
 #endif
 // sum of the single-chunk entries 1 * G[c], c in [from, to): the constant of a zero tail (one thread; once per parameter set)
