@@ -61,7 +61,8 @@ def run(env, host_states, n):
                                         "GBps_out": 64.0 * nph / hs2 / 1e9, "digests_equal_the_pageable_call": same,
                                         "mode": "pinned buffers on both sides, ONE gated launch (round 5, profiles/r05_s8): DMA copy-in of every 2^17-message chunk issued "
                                                 "up front with an arrival flag behind it, the accumulate kernel launched once over the whole batch (workgroups wait on "
-                                                "their chunk's flag), per-chunk finalize + DMA copy-out released by the host thread as workgroups report"}
+                                                "their chunk's flag and finish their digests themselves: one inversion per workgroup), DMA copy-out of a chunk released "
+                                                "by the host thread as its workgroups report (profiles/r05_s13)"}
         check(lib.akp_host_free(pm))
         check(lib.akp_host_free(po))
         if not same:
