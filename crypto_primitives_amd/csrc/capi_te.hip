@@ -883,7 +883,11 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
             }
         }
         const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;  // the tree / staging area behind it: 16-byte aligned
-        const TeGate gate{c->gate_flags, c->gate_done_dev, c->gate_flags + 64, epoch, (u32)(chunk / 256), 1u << 15, zero_copy_out ? (Fr*)out_alias : (Fr*)dout, fe,
+        u32 spin_limit = 1u << 15;
+#if defined(AKP_TEST_HOOKS)
+        spin_limit = env_u32("AKP_TE_GATE_SPIN_LIMIT", spin_limit, 1, 1u << 24);  // 1: every workgroup that has to wait gives up -- exercises the fallback
+#endif
+        const TeGate gate{c->gate_flags, c->gate_done_dev, c->gate_flags + 64, epoch, (u32)(chunk / 256), spin_limit, zero_copy_out ? (Fr*)out_alias : (Fr*)dout, fe,
                           (u32)(image / 4), zero_copy_out ? 1u : 0u};
         // at least 40 KB of LDS per workgroup = at most four workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks
         // below the runtime's DMA threshold, the copies themselves are small KERNELS -- with every wave slot held by a spinning

@@ -109,3 +109,48 @@ def test_two_threads_with_contexts_of_their_own_hash_pinned_batches_at_once(cpa)
         t.join()
     assert not errs, errs
     assert B.handle(ctxs[0]).table_info()["table_id"] == B.handle(ctxs[1]).table_info()["table_id"]
+
+
+def test_a_gate_that_fails_falls_back_to_the_chunked_launches():
+    """the safety net of the gated launch: with a spin limit of ONE poll (test build, AKP_TE_GATE_SPIN_LIMIT=1) every workgroup whose chunk
+    has not arrived yet gives up at once; the call must notice (error word), repeat the batch with round 4's chunked launches, return the
+    right digests, and the context must stop gating (the next call goes straight to the chunked launches)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "crypto_primitives_amd", "lib", "libakp_testhooks.so")
+    assert os.path.exists(hooks)
+    code = r"""
+import ctypes as C, sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import crypto_primitives_amd as cpa
+from crypto_primitives_amd.crh import bowe_hopwood
+from oracle import jubjub as jj, cref
+from helpers import gens_array
+g = gens_array(jj.bowe_hopwood_generators(0xE5E50009, 63, 9))
+B = bowe_hopwood.Parameters(g)
+h = B.handle()
+n, L = (1 << 18) + 5, 64
+msgs = np.random.default_rng(1).integers(0, 256, size=(n, L), dtype=np.uint8)
+want = np.empty((n, 4), np.uint64)
+cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, msgs.ctypes.data, n, L, want.ctypes.data))
+pm, po = C.c_void_p(), C.c_void_p()
+cpa._lib.check(cpa.lib.akp_host_alloc(msgs.nbytes, C.byref(pm))); cpa._lib.check(cpa.lib.akp_host_alloc(want.nbytes, C.byref(po)))
+np.ctypeslib.as_array((C.c_uint8 * msgs.size).from_address(pm.value))[:] = msgs.reshape(-1)
+out = np.ctypeslib.as_array((C.c_uint64 * want.size).from_address(po.value)).reshape(want.shape)
+times = []
+for rep in range(3):
+    out[:] = 0
+    t0 = time.perf_counter()
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, pm, n, L, po))
+    times.append(time.perf_counter() - t0)
+    assert np.array_equal(out, want), rep
+si = np.linspace(0, n - 1, 200).astype(np.int64)
+assert np.array_equal(want[si], cref.CurveParams(63, 9, g).bh_crh_batch(np.ascontiguousarray(msgs[si]), len(si), L, threads=4))
+print("FALLBACK OK", ["%%.1f ms" %% (t * 1e3) for t in times])
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, AKP_LIB=hooks, AKP_TE_GATE_SPIN_LIMIT="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "FALLBACK OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
