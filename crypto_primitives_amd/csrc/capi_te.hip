@@ -859,8 +859,10 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     void *dm = nullptr, *dout = nullptr, *xyz = nullptr, *prefix = nullptr;
     if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
-    if (int32_t rc = ctx_scratch(c, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
+    if (!fused) {  // the fused kernel keeps its sums in registers and finishes them itself: no xyz / prefix arrays
+        if (int32_t rc = ctx_scratch(c, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
+        if (int32_t rc = ctx_scratch(c, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
+    }
     HIP_TRY(hipMemsetAsync(c->gate_flags + 64, 0, sizeof(u32), s));
     HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
     HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));
