@@ -564,7 +564,27 @@ class GpuMerkleTree:
         return MultiPath(self.config, [sibs[i] for i in range(m)], [int(x) for x in pre], suffixes, idxs)
 
     def update_batch(self, indices, new_leaves):
-        idx = np.ascontiguousarray(list(indices), dtype=np.uint64)
+        """update(indices[k], new_leaves[k]) for k in order (a repeated index keeps its LAST leaf), one hash launch per level.  New
+        leaves of different lengths: the repeated indexes are resolved here (last one wins), then one call per distinct length --
+        the touched paths of different calls only meet in nodes that the later call recomputes from the tree's current state."""
+        idx_list = [int(i) for i in indices]
+        if _ragged_leaves(self.config, list(new_leaves)) is not None:
+            assert len(idx_list) == len(new_leaves), "one leaf per index"
+            last = {}
+            for k, i in enumerate(idx_list):
+                last[i] = k
+            keep = sorted(last.values())
+            by_len = {}
+            for k in keep:
+                leaf = new_leaves[k]
+                L = len(leaf) if isinstance(leaf, (bytes, bytearray)) else len(np.asarray(leaf).reshape(-1, 4) if self.config is PoseidonFieldConfig else np.asarray(leaf).reshape(-1))
+                by_len.setdefault(L, []).append(k)
+            for L in sorted(by_len):
+                ks = by_len[L]
+                self.update_batch([idx_list[k] for k in ks], [new_leaves[k] for k in ks] if self.config is not PoseidonFieldConfig
+                                  else np.stack([np.asarray(new_leaves[k], dtype=np.uint64).reshape(-1, 4) for k in ks]))
+            return
+        idx = np.ascontiguousarray(idx_list, dtype=np.uint64)
         x, n, k = self._leaf_array(self.config, new_leaves)
         assert n == len(idx), "one leaf per index"
         check(lib.akp_merkle_tree_update_batch(self._h, idx.ctypes.data, x.ctypes.data if x.size else None, n, k))

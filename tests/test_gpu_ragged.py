@@ -336,3 +336,23 @@ def test_ragged_tree_at_2pow18_leaves_sampled(cpa):
     proofs = tree.generate_proofs(pick)
     leaves = [bytes(flat[int(offs[i]):int(offs[i + 1])]) for i in pick]
     assert all(cpa.merkle_tree.verify_paths(cpa.BoweHopwoodByteConfig, B, B, tree.root(), proofs, leaves))
+
+
+def test_update_batch_with_new_leaves_of_different_lengths(cpa):
+    """GpuMerkleTree.update_batch with unequal new leaves (and a repeated index): equal to the reference's sequential update() calls --
+    i.e. to a tree built over the final leaves"""
+    from crypto_primitives_amd.crh import bowe_hopwood
+    g = gens_array(jj.bowe_hopwood_generators(0xD5D5000A, 63, 9))
+    B = bowe_hopwood.Parameters(g)
+    n = 128
+    rng = np.random.default_rng(4)
+    leaves = [bytes(rng.integers(0, 256, size=int(L), dtype=np.uint8)) for L in rng.integers(0, 40, size=n)]
+    tree = cpa.GpuMerkleTree.new(cpa.BoweHopwoodByteConfig, B, B, leaves)
+    idx = [5, 77, 5, 0, 127, 64, 77]
+    new = [b"a", b"bb", b"the last write to leaf five wins", b"", b"z" * 33, b"four", b"seventy-seven, second write"]
+    tree.update_batch(idx, new)
+    for i, leaf in zip(idx, new):
+        leaves[i] = leaf
+    fresh = cpa.GpuMerkleTree.new(cpa.BoweHopwoodByteConfig, B, B, leaves)
+    assert np.array_equal(np.asarray(tree.root()), np.asarray(fresh.root()))
+    assert np.array_equal(tree.to_host().non_leaf_nodes, fresh.to_host().non_leaf_nodes) and np.array_equal(tree.to_host().leaf_nodes, fresh.to_host().leaf_nodes)
