@@ -69,8 +69,8 @@ struct akp_ctx {
     bool dead = false;
     // gated (persistent) curve-hash launch of the pinned host path (capi_te.hip te_crh_gated): per-chunk arrival flags in FINE-GRAINED
     // device memory (+ one error word), per-workgroup completion words in pinned host memory, the epoch that tags one call's values
-    u32* gate_flags = nullptr;   // [64] flags + [64] error word
-    u32* gate_done = nullptr;    // host pointer
+    u32* gate_flags = nullptr;   // [64] arrival flags (fine-grained device memory)
+    u32* gate_done = nullptr;    // host pointer: word 0 = a workgroup gave up, completion words from word 16
     u32* gate_done_dev = nullptr;  // its device alias
     size_t gate_done_cap = 0;
     u32 gate_epoch = 0;

@@ -798,25 +798,64 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     if (env_u32("AKP_TE_GATED", 1, 0, 1) == 0) return AKP_OK;  // A/B against the chunked launches (test build only)
     chunk = env_size("AKP_TE_PIPE_CHUNK", chunk);
 #endif
-    // fused: the workgroups finish their digests themselves (one inversion per workgroup) -- 4.43 -> 4.2 ms (default table) / 3.9 -> 3.65 ms
-    // (HBM table) per 2^20 Pedersen hashes against separate per-chunk finalize passes.  zero_copy_out: digests stored straight into the pinned
-    // buffer through an LDS staging area (whole lines per store) instead of DMA copy-outs: measured SLOWER (4.6 / 3.9 ms), kept as a
-    // test-build arm only (profiles/r05_s13)
-    bool fused = true, zero_copy_out = false;
+    // fused: the workgroups finish their digests themselves (one inversion per workgroup of 2 x 256 points) -- 4.43 -> 3.95 ms (default
+    // table) / 3.9 -> 3.45 ms (HBM table) per 2^20 Pedersen hashes against separate per-chunk finalize passes (profiles/r05_s13, r05_s16).
+    // Measured and dropped: the digests stored straight into the pinned buffer through an LDS staging area instead of DMA copy-outs
+    // (4.6 / 3.9 ms when the DMA form took 4.2 / 3.65: profiles/r05_s13)
+    bool fused = true;
 #if defined(AKP_TEST_HOOKS)
     fused = env_u32("AKP_TE_GATED_FUSED", 1, 0, 1) != 0;
-    zero_copy_out = env_u32("AKP_TE_GATED_ZERO_COPY_OUT", 0, 0, 1) != 0;
 #endif
-    void* out_alias = device_alias(h_out, n * te_fe_per_digest(p) * sizeof(Fr));
-    zero_copy_out = zero_copy_out && fused && out_alias != nullptr;
-    const size_t n_chunks = (n + chunk - 1) / chunk;
-    if (te_lds_block(msg_len, msg_len) != 256 || (chunk & 255) || n_chunks < 2 || n_chunks > 64) return AKP_OK;
+    // timing probes (test build): the gated kernel without the copies it normally runs beside -- the digests are then those of whatever
+    // the device buffer held (tools/gpu_r5_gate_knobs.py reads times only)
+    bool skip_in = false, skip_out = false;
+    const char* stamps_path = nullptr;
+    void* d_stamps = nullptr;
+    (void)stamps_path;
+#if defined(AKP_TEST_HOOKS)
+    stamps_path = getenv("AKP_TE_GATE_STAMPS");
+    if (stamps_path && (!*stamps_path || !fused)) stamps_path = nullptr;
+    skip_in = env_u32("AKP_TE_GATE_SKIP_COPY_IN", 0, 0, 1) != 0;
+    skip_out = env_u32("AKP_TE_GATE_SKIP_COPY_OUT", 0, 0, 1) != 0;
+#endif
+    // Chunks of one launch differ in size: a quarter chunk first (the workgroups start after 0.08 ms of copying instead of 0.31), small
+    // ones last (the copy-out behind the last workgroup is short), full ones between.  Sizes in granules of chunk / 4 messages; the kernel
+    // maps workgroup -> granule -> chunk through TeGate::chunk_of (64 granules at most: larger batches take larger granules)
+    bool ramp = true;
+#if defined(AKP_TEST_HOOKS)
+    ramp = env_u32("AKP_TE_GATE_RAMP", 1, 0, 1) != 0;
+#endif
+    if (te_lds_block(msg_len, msg_len) != 256 || (chunk & 2047) || n <= chunk) return AKP_OK;
+    size_t granule = chunk / 4;
+    while ((n + granule - 1) / granule > 64) granule *= 2;
+    const size_t n_granules = (n + granule - 1) / granule;
+    std::vector<size_t> chunk_first;  // first message of every chunk, then n
+    {
+        const size_t full = std::max<size_t>(1, chunk / granule);
+        static const size_t head[3] = {1, 1, 2}, tail[3] = {2, 1, 1};
+        std::vector<size_t> sizes;
+        size_t left = n_granules;
+        if (ramp && full == 4 && n_granules >= 12) {
+            for (size_t h : head) sizes.push_back(h);
+            left -= 8;
+            while (left) { const size_t k = std::min(left, full); sizes.push_back(k); left -= k; }
+            for (size_t t : tail) sizes.push_back(t);
+        } else {
+            while (left) { const size_t k = std::min(left, full); sizes.push_back(k); left -= k; }
+        }
+        size_t at = 0;
+        for (size_t k : sizes) { chunk_first.push_back(at * granule); at += k; }
+        chunk_first.push_back(n);
+    }
+    const size_t n_chunks = chunk_first.size() - 1;
+    if (n_chunks < 2 || n_chunks > 64) return AKP_OK;
     // ONE gated launch per device at a time: two of them (two host threads with a context each) would hold all eight wave slots of
     // every SIMD with waiting workgroups, and the flag writes they wait for could not run.  A second caller takes the chunked launches.
     static std::mutex gate_busy[64];
     std::unique_lock<std::mutex> gate_turn(gate_busy[c->device & 63], std::try_to_lock);
     if (!gate_turn.owns_lock()) return AKP_OK;
-    const size_t n_wg = (n + 255) / 256;
+    const size_t per_wg = fused ? 256 * TE_FUSED_ITEMS : 256;  // messages per workgroup
+    const size_t n_wg = (n + per_wg - 1) / per_wg;
     auto give_up = [&](const char* what, hipError_t e) {  // gate resources unavailable on this stack: remember, use the chunked launches
         (void)hipGetLastError();
         (void)what; (void)e;
@@ -830,10 +869,11 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     }
     if (c->gate_done_cap < n_wg) {
         if (c->gate_done) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(c->gate_done); c->gate_done = nullptr; c->gate_done_cap = 0; }
-        hipError_t e = hipHostMalloc((void**)&c->gate_done, n_wg * sizeof(u32), hipHostMallocMapped);
+        // word 0: set by a workgroup that gave up; the completion words start at word 16
+        hipError_t e = hipHostMalloc((void**)&c->gate_done, (n_wg + 16) * sizeof(u32), hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->gate_done_dev, c->gate_done, 0);
         if (e != hipSuccess) { if (c->gate_done) (void)hipHostFree(c->gate_done); c->gate_done = nullptr; return give_up("pinned completion words", e); }
-        memset(c->gate_done, 0, n_wg * sizeof(u32));
+        memset(c->gate_done, 0, (n_wg + 16) * sizeof(u32));
         c->gate_done_cap = n_wg;
     }
     if (++c->gate_epoch == 0) ++c->gate_epoch;  // 0 is what fresh memory holds
@@ -863,7 +903,7 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
         if (int32_t rc = ctx_scratch(c, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
         if (int32_t rc = ctx_scratch(c, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
     }
-    HIP_TRY(hipMemsetAsync(c->gate_flags + 64, 0, sizeof(u32), s));
+    __atomic_store_n(c->gate_done, 0u, __ATOMIC_RELEASE);  // nothing of this context is running a gated kernel now
     HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
     HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));
     HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[7], 0));
@@ -876,25 +916,37 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
         if (int32_t rc = te_resolve(p, msg_len, msg_len, s, &rs)) return rc;
         // all copies first, each followed by its flag; nothing of this call has been launched yet if the write-value is refused
         for (size_t k = 0; k < n_chunks; ++k) {
-            const size_t first = k * chunk, cnt = std::min(chunk, n - first);
-            HIP_TRY(hipMemcpyAsync((uint8_t*)dm + first * msg_len, h_msgs + first * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
+            const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
+            if (!skip_in) HIP_TRY(hipMemcpyAsync((uint8_t*)dm + first * msg_len, h_msgs + first * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
+            // (the flag write is a small kernel; putting it on a stream of its own behind an event, so that the copies stay back to
+            // back on the copy engine, measured the same: profiles/r05_s16)
             const hipError_t e = hipStreamWriteValue32(cin, c->gate_flags + k, epoch, 0);
             if (e != hipSuccess) {
                 (void)hipStreamSynchronize(cin);
                 return give_up("hipStreamWriteValue32", e);
             }
         }
-        const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;  // the tree / staging area behind it: 16-byte aligned
-        u32 spin_limit = 1u << 15;
+        const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;  // (the fused kernel's product tree / staging area takes its place afterwards)
+        u32 spin_limit = 1u << 15, poll_sleep = 0;
+        size_t gate_lds_floor = 36864;
 #if defined(AKP_TEST_HOOKS)
+        gate_lds_floor = env_size("AKP_TE_GATE_LDS_FLOOR", gate_lds_floor);
+        if (stamps_path) {  // per-workgroup release / end times of this launch (100 MHz constant clock), [0] of a one-lane kernel ahead of it
+            if (int32_t rc = ctx_scratch(c, SCR_F, (2 * n_wg + 2) * sizeof(uint64_t), &d_stamps, s)) return rc;
+            HIP_TRY(hipMemsetAsync(d_stamps, 0, (2 * n_wg + 2) * sizeof(uint64_t), s));
+        }
         spin_limit = env_u32("AKP_TE_GATE_SPIN_LIMIT", spin_limit, 1, 1u << 24);  // 1: every workgroup that has to wait gives up -- exercises the fallback
+        poll_sleep = env_u32("AKP_TE_GATE_POLL_SLEEP", 0, 0, 64);
+        if (poll_sleep) spin_limit = std::max(1u, spin_limit / (1u + 8u * poll_sleep));  // the same bound in time
 #endif
-        const TeGate gate{c->gate_flags, c->gate_done_dev, c->gate_flags + 64, epoch, (u32)(chunk / 256), spin_limit, zero_copy_out ? (Fr*)out_alias : (Fr*)dout, fe,
-                          (u32)(image / 4), zero_copy_out ? 1u : 0u};
+        TeGate gate{c->gate_flags, c->gate_done_dev + 16, c->gate_done_dev, epoch, (u32)(granule / per_wg), spin_limit, {}, poll_sleep, (Fr*)dout, fe,
+                    (unsigned long long*)d_stamps};
+        for (size_t k = 0; k < n_chunks; ++k)
+            for (size_t g = chunk_first[k] / granule; g * granule < chunk_first[k + 1]; ++g) gate.chunk_of[g] = (uint8_t)k;
         // at least 40 KB of LDS per workgroup = at most four workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks
         // below the runtime's DMA threshold, the copies themselves are small KERNELS -- with every wave slot held by a spinning
         // workgroup they never run and nothing arrives (measured: tools/persist_probe.hip; a 63x9 batch in 4 MB chunks timed out)
-        const size_t shm = std::max<size_t>(image + (fused ? 9 * 512 * sizeof(u32) : 0), 40960);
+        const size_t shm = std::max<size_t>(std::max<size_t>(image, fused ? 9 * 512 * sizeof(u32) : 0), gate_lds_floor);  // the product tree re-uses the image
         const dim3 grid((unsigned)n_wg);
         if (fused) {  // the workgroups finish their digests themselves (one inversion per workgroup through an LDS product tree): no finalize passes
             if (t->pedersen && t->signed_subset)
@@ -918,12 +970,12 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
         HIP_TRY(hipGetLastError());
     }
     // release every chunk's finalize pass + copy-out when its workgroups have reported (they finish roughly in launch order)
-    const volatile u32* done = c->gate_done;
+    const volatile u32* done = c->gate_done + 16;
     bool gave_up = false;
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t k = 0; k < n_chunks && !gave_up; ++k) {
-        const size_t first = k * chunk, cnt = std::min(chunk, n - first);
-        const size_t wg0 = first / 256, wg1 = (first + cnt + 255) / 256;
+        const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
+        const size_t wg0 = first / per_wg, wg1 = (first + cnt + per_wg - 1) / per_wg;
         for (size_t b = wg0; b < wg1; ++b) {
             unsigned spins = 0;
             while (done[b] != epoch) {
@@ -941,15 +993,24 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
             HIP_TRY(hipEventRecord(c->chunk_event[k & 3], fin));
             HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[k & 3], 0));
         }
-        if (!zero_copy_out) HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
+        if (!skip_out) HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
     }
     HIP_TRY(hipStreamSynchronize(cin));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipStreamSynchronize(fins[0]));
     HIP_TRY(hipStreamSynchronize(fins[1]));
     HIP_TRY(hipStreamSynchronize(side));
-    u32 err = 0;
-    HIP_TRY(hipMemcpy(&err, c->gate_flags + 64, sizeof(u32), hipMemcpyDeviceToHost));
+    const u32 err = __atomic_load_n(c->gate_done, __ATOMIC_ACQUIRE);  // the kernel has ended: its writes to host memory are there
+#if defined(AKP_TEST_HOOKS)
+    if (d_stamps) {
+        std::vector<uint64_t> st(2 * n_wg);
+        HIP_TRY(hipMemcpy(st.data(), d_stamps, st.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(stamps_path, "wb")) {
+            fwrite(st.data(), sizeof(uint64_t), st.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     if (gave_up || err) {  // *used stays false: the caller repeats the batch with the chunked launches -- and this context stops trying
         c->gate_unavailable = true;
         return AKP_OK;

@@ -868,7 +868,7 @@ AKP_HD size_t te_lds_image_bytes(size_t block, size_t msg_len, size_t stride) {
     return (dwords + (dwords >> 5) + 4) * 4;
 }
 // GATED (round 5, the pinned host path): the launch covers the WHOLE batch while its messages are still arriving by DMA, chunk after
-// chunk.  Workgroup b belongs to chunk b / wg_per_chunk; before it touches its messages, thread 0 polls gate_flags[chunk] -- a word in
+// chunk.  Workgroup b belongs to chunk chunk_of[b / wg_per_granule]; before it touches its messages, thread 0 polls gate_flags[chunk] -- a word in
 // FINE-GRAINED DEVICE memory that hipStreamWriteValue32 on the copy stream sets to `epoch` behind the chunk's copy -- and when its
 // sums are stored the workgroup writes `epoch` to done[b] in pinned HOST memory (a plain posted write; the host thread releases the
 // chunk's finalize pass and copy-out when all its words are there).  Measured preconditions (tools/persist_probe.hip,
@@ -879,13 +879,16 @@ AKP_HD size_t te_lds_image_bytes(size_t block, size_t msg_len, size_t stride) {
 struct TeGate {
     const u32* flags;   // [n_chunks], fine-grained device memory
     u32* done;          // [grid], pinned host memory (device alias)
-    u32* err;           // device word: workgroups that gave up
-    u32 epoch, wg_per_chunk, spin_limit;
+    u32* err;           // pinned host word (device alias): set by a workgroup that gave up
+    u32 epoch, wg_per_granule, spin_limit;
+    uint8_t chunk_of[64];  // chunk of every granule of wg_per_granule workgroups: the chunks of one launch differ in size (small ones first and last)
+    u32 poll_sleep;     // extra s_sleep(127) (~4 us each at 2 GHz) between two polls of a waiting workgroup
     // FUSED: the workgroup also finishes its digests (projective -> affine with ONE inversion per workgroup) and writes them to
-    // `out` (`fe` Fr per digest: x, or x and y); `tree_dwords`: offset of the 9 x 512-dword product tree behind the message image
+    // `out` (`fe` Fr per digest: x, or x and y).  The 9 x 512-dword product tree takes the place of the message image, which is dead
+    // by then: the launch needs max(image, 18 KB) of LDS
     Fr* out;
-    u32 fe, tree_dwords;
-    u32 stage_out;  // 1: `out` is pinned host memory (device alias): digests leave through an LDS staging area, whole lines per store
+    u32 fe;
+    unsigned long long* stamps;  // test build: [2 * grid] wall_clock64 at gate-open and at the end of every workgroup (nullptr: none)
 };
 // One inversion for the 256 sums of a workgroup: a product tree over the Z coordinates in LDS (up-sweep: 8 levels of pairwise products),
 // one inversion of the root by lane 0, and the down-sweep that turns every node's product into its inverse (inv_left = inv_parent *
@@ -936,6 +939,28 @@ __device__ __forceinline__ FS te_workgroup_inverse(u32* tree, const FS& z) {
     return te_tree_load(tree, 255u + threadIdx.x);
 }
 #endif
+// the image of `cnt` messages starting at `g0` (pitch `stride`), padded against bank conflicts; returns the misalignment of g0
+__device__ __forceinline__ u32 te_load_msg_image(u32* image, const uint8_t* g0, size_t cnt, size_t msg_len, size_t stride) {
+    const u32 mis = (u32)((uintptr_t)g0 & 15u);
+    const uint4* a0 = reinterpret_cast<const uint4*>(g0 - mis);
+    const u32 chunks = (u32)((mis + (cnt - 1) * stride + msg_len + 15) >> 4);
+    for (u32 k = threadIdx.x; k < chunks; k += blockDim.x) {
+        const uint4 v = a0[k];
+        u32* w = image + 4u * k + (k >> 3);  // dwords 4k .. 4k+3 share one 32-dword group: one pad offset
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+    }
+    return mis;
+}
+// FUSED (gated launches only): the workgroup hashes TE_FUSED_ITEMS x 256 messages -- lane t takes messages first + t and
+// first + 256 + t, one image after the other -- and finishes all of them with ONE inversion: the lane multiplies its Z coordinates,
+// the product tree inverts the 256 products, 1 / Z1 = inv * Z2 and 1 / Z2 = inv * Z1.  The inversion (16 k instructions on one lane) and
+// the tree (24 products) are +9 % on a workgroup of 256 points and +4.5 % on one of 512 (profiles/r05_s16).
+#ifndef TE_FUSED_ITEMS
+#define TE_FUSED_ITEMS 2  // 1: one point per lane (build-time A/B arm)
+#endif
 template <int KIND, bool GATED, bool FUSED = false>
 __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
                                                        const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups, u32 n_steps,
@@ -944,80 +969,76 @@ __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict
     if (GATED) {
         __shared__ u32 gate_open;
         if (threadIdx.x == 0) {
-            const u32 chunk = blockIdx.x / gate.wg_per_chunk;
+            const u32 chunk = gate.chunk_of[blockIdx.x / gate.wg_per_granule];
             u32 it = 0;
-            while (__hip_atomic_load(gate.flags + chunk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gate.epoch && ++it < gate.spin_limit)
+            // RELAXED polls and ONE acquire fence behind the last: an acquire load at system scope is followed by a cache invalidate
+            // (buffer_inv sc0 sc1) -- issued every half microsecond by some 700 waiting workgroups it took the table lines of the
+            // RUNNING workgroups with it (profiles/r05_s16: 3.64 -> 3.47 ms per 2^20 pinned Pedersen hashes)
+            while (__hip_atomic_load(gate.flags + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gate.epoch && ++it < gate.spin_limit) {
                 __builtin_amdgcn_s_sleep(16);
+                for (u32 q = 0; q < gate.poll_sleep; ++q) __builtin_amdgcn_s_sleep(127);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope: the chunk's bytes, written by the copy engine, are what the loads below see
             gate_open = it < gate.spin_limit;
-            if (!gate_open) atomicAdd(gate.err, 1u);
+            if (!gate_open) __hip_atomic_store(gate.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (gate.stamps) gate.stamps[2 * (size_t)blockIdx.x] = wall_clock64();
         }
         __syncthreads();
         if (!gate_open) return;
     }
-    const size_t first = (size_t)blockIdx.x * blockDim.x;
-    const size_t cnt = n - first < blockDim.x ? n - first : blockDim.x;  // the grid covers n: cnt >= 1
-    const uint8_t* g0 = msgs + first * stride;
-    const u32 mis = (u32)((uintptr_t)g0 & 15u);
-    const uint4* a0 = reinterpret_cast<const uint4*>(g0 - mis);
-    const u32 chunks = (u32)((mis + (cnt - 1) * stride + msg_len + 15) >> 4);
-    for (u32 k = threadIdx.x; k < chunks; k += blockDim.x) {
-        const uint4 v = a0[k];
-        u32* w = te_msg_image + 4u * k + (k >> 3);  // dwords 4k .. 4k+3 share one 32-dword group: one pad offset
-        w[0] = v.x;
-        w[1] = v.y;
-        w[2] = v.z;
-        w[3] = v.w;
-    }
-    __syncthreads();
-    const size_t idx = first + threadIdx.x;
     if (FUSED) {
-        Ext acc = ext_identity();  // lanes past the end of the batch take part in the product tree with Z = 1
-        if (idx < n) {
-            const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
-            acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
-            if (tail) acc = te_madd(acc, load_niels(tail));
-        }
-        u32* tree = te_msg_image + gate.tree_dwords;
-        const FS zi = te_workgroup_inverse(tree, acc.Z);
-        if (!gate.stage_out) {
-            if (idx < n) {
-                store_fr_g(gate.out + idx * gate.fe, f29_to_wire(f29_mul(acc.X, zi)));
-                if (gate.fe == 2) store_fr_g(gate.out + idx * 2 + 1, f29_to_wire(f29_mul(acc.Y, zi)));
-            }
-        } else {
-            // `out` is PINNED HOST memory: the workgroup's digests (16 KB for 256 points) go through LDS so that every store instruction
-            // writes whole contiguous lines over PCIe -- a lane storing its own 64 bytes at a 64-byte pitch crosses PCIe at 17 GB/s
-            // (profiles/r04_s2), and the blit kernels of a DMA copy-out would share the CUs with this kernel
-            __syncthreads();  // every lane holds its inverse: the tree becomes the staging area (9 x 512 dwords >= 256 x 16)
-            if (idx < n) {
-                const Fr x = f29_to_wire(f29_mul(acc.X, zi));
-                uint4* st = reinterpret_cast<uint4*>(tree) + (size_t)threadIdx.x * gate.fe * 2;
-                st[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-                st[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
-                if (gate.fe == 2) {
-                    const Fr y = f29_to_wire(f29_mul(acc.Y, zi));
-                    st[2] = make_uint4(y.l[0], y.l[1], y.l[2], y.l[3]);
-                    st[3] = make_uint4(y.l[4], y.l[5], y.l[6], y.l[7]);
+        const size_t base = (size_t)blockIdx.x * (TE_FUSED_ITEMS * 256);
+        Ext acc[TE_FUSED_ITEMS];
+#pragma unroll
+        for (int h = 0; h < TE_FUSED_ITEMS; ++h) {
+            const size_t first = base + (size_t)h * 256;
+            acc[h] = ext_identity();  // lanes past the end of the batch take part in the product tree with Z = 1
+            if (first < n) {          // uniform over the workgroup
+                if (h) __syncthreads();  // every wave has read its last byte of the previous image
+                const size_t cnt = n - first < 256 ? n - first : 256;
+                const u32 mis = te_load_msg_image(te_msg_image, msgs + first * stride, cnt, msg_len, stride);
+                __syncthreads();
+                if (first + threadIdx.x < n) {
+                    const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
+                    acc[h] = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
+                    if (tail) acc[h] = te_madd(acc[h], load_niels(tail));
                 }
             }
-            __syncthreads();
-            const uint4* src = reinterpret_cast<const uint4*>(tree);
-            uint4* dst = reinterpret_cast<uint4*>(gate.out + first * gate.fe);
-            const u32 pieces = (u32)cnt * gate.fe * 2u;
-            for (u32 k = threadIdx.x; k < pieces; k += 256u) dst[k] = src[k];
         }
-    } else if (idx < n) {
-        const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
-        Ext acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
-        if (tail) acc = te_madd(acc, load_niels(tail));
-        f29_store_pad(xyz + idx * 3, acc.X);
-        f29_store_pad(xyz + idx * 3 + 1, acc.Y);
-        f29_store_pad(xyz + idx * 3 + 2, acc.Z);
+        static_assert(TE_FUSED_ITEMS == 1 || TE_FUSED_ITEMS == 2, "the pairing below is written for two points per lane");
+        __syncthreads();  // the image is dead: it becomes the product tree
+        const FS zi = te_workgroup_inverse(te_msg_image, TE_FUSED_ITEMS == 2 ? f29_mul(acc[0].Z, acc[TE_FUSED_ITEMS - 1].Z) : acc[0].Z);
+#pragma unroll
+        for (int h = 0; h < TE_FUSED_ITEMS; ++h) {
+            const size_t idx = base + (size_t)h * 256 + threadIdx.x;
+            if (idx < n) {
+                const FS zh = TE_FUSED_ITEMS == 2 ? f29_mul(zi, acc[TE_FUSED_ITEMS - 1 - h].Z) : zi;  // 1 / Z of point h
+                store_fr_g(gate.out + idx * gate.fe, f29_to_wire(f29_mul(acc[h].X, zh)));
+                if (gate.fe == 2) store_fr_g(gate.out + idx * 2 + 1, f29_to_wire(f29_mul(acc[h].Y, zh)));
+            }
+        }
+    } else {
+        const size_t first = (size_t)blockIdx.x * blockDim.x;
+        const size_t cnt = n - first < blockDim.x ? n - first : blockDim.x;  // the grid covers n: cnt >= 1
+        const u32 mis = te_load_msg_image(te_msg_image, msgs + first * stride, cnt, msg_len, stride);
+        __syncthreads();
+        const size_t idx = first + threadIdx.x;
+        if (idx < n) {
+            const MsgLds m{te_msg_image, mis + (u32)(threadIdx.x * stride)};
+            Ext acc = te_accumulate_item<KIND>(lut, lut1, m, msg_len, D, n_groups, n_steps);
+            if (tail) acc = te_madd(acc, load_niels(tail));
+            f29_store_pad(xyz + idx * 3, acc.X);
+            f29_store_pad(xyz + idx * 3 + 1, acc.Y);
+            f29_store_pad(xyz + idx * 3 + 2, acc.Z);
+        }
     }
     if (GATED) {
-        __threadfence();  // the sums of this workgroup are visible device-wide (another kernel, possibly on another XCD, reads them next)
+        __threadfence();  // the results of this workgroup are visible device-wide (a copy engine, or another kernel on another XCD, reads them next)
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(gate.done + blockIdx.x, gate.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            if (gate.stamps) gate.stamps[2 * (size_t)blockIdx.x + 1] = wall_clock64();
+            __hip_atomic_store(gate.done + blockIdx.x, gate.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 template <int KIND>

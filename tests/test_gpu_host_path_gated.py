@@ -67,6 +67,39 @@ def test_pinned_batches_through_the_gated_launch(cpa, kind, W, N, L):
         assert np.array_equal(want[si].reshape(len(si), fe, 4), ora(np.ascontiguousarray(msgs[si]), len(si)).reshape(len(si), fe, 4)), (kind, L, n)
 
 
+@pytest.mark.parametrize("kind,W,N,L", [("pedersen", 4, 256, 128), ("bh", 63, 9, 64)])
+def test_consecutive_gated_calls_read_the_bytes_of_their_own_batch(cpa, kind, W, N, L):
+    """The workgroups of a gated launch read bytes that a copy engine wrote WHILE the kernel was running, into a device buffer that the
+    previous call's kernel read at the same addresses: a cache line of the previous batch that survived in an L2 would go unnoticed if
+    both calls hashed the same messages.  Batches A and B (same shape, different bytes) alternate through the same pinned buffer with no
+    other call between them; expected digests from the pageable path, computed beforehand."""
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    if kind == "pedersen":
+        prm, fe = pedersen.Parameters(gens_array(jj.pedersen_generators(0xE5E50001, W, N))), 2
+    else:
+        prm, fe = bowe_hopwood.Parameters(gens_array(jj.bowe_hopwood_generators(0xE5E50002, W, N))), 1
+    h = prm.handle()
+    n = (1 << 18) + 4096  # 32 MB of 128-byte messages: what the eight L2s and the memory-side cache can hold
+    batches, wants = [], []
+    for seed in (1, 2):
+        m = np.random.default_rng(seed).integers(0, 256, size=(n, L), dtype=np.uint8)
+        w = np.empty((n, 4 * fe), np.uint64)
+        cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, n, L, w.ctypes.data))
+        batches.append(m)
+        wants.append(w)
+    pm, po = _Pinned(cpa, batches[0].nbytes), _Pinned(cpa, wants[0].nbytes)
+    try:
+        out = po.array(np.uint64, wants[0].shape)
+        for turn in (0, 1, 0, 1, 1, 0):
+            pm.array(np.uint8, batches[turn].shape)[:] = batches[turn]
+            out[:] = 0
+            cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, pm.p, n, L, po.p))
+            assert np.array_equal(out, wants[turn]), (kind, turn, np.nonzero((out != wants[turn]).any(axis=1))[0][:8])
+    finally:
+        pm.free()
+        po.free()
+
+
 def test_two_threads_with_contexts_of_their_own_hash_pinned_batches_at_once(cpa):
     """the shim's shape: every OS thread has a context; two threads push pinned batches through the same parameters at the same time.
     Only ONE gated launch runs per device (the other caller takes the chunked launches: two gated kernels would hold every wave slot
