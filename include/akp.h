@@ -98,17 +98,19 @@ int32_t akp_clock_probe_dev(akp_ctx* ctx, uint32_t chain_len, uint64_t* d_out3, 
  * thread).  Memory from akp_host_alloc, or registered with akp_host_register:
  *   - the Poseidon batch kernels address it DIRECTLY (zero copy: every item is read once and written once over PCIe, both
  *     directions at the same time) when all buffers of a call are of that kind;
- *   - akp_te_crh_batch, when BOTH `msgs` and `out` are of that kind, runs as ONE gated launch (round 5): every chunk of 2^17 messages is
- *     copied in by asynchronous DMA, all copies issued up front, each followed by an arrival flag; the accumulate kernel is launched
- *     once over the whole batch, its workgroups wait for their chunk's flag and finish their digests themselves (one inversion per
- *     workgroup); the digests of a chunk leave by DMA as soon as its workgroups have reported -- never by zero copy: in-place reads make every workgroup wait for PCIe at the same
- *     moments and in-place 16-byte digest stores cross PCIe at 17 GB/s (measured, profiles/r04_s2 .. r04_s3).  Pinned on one side
- *     only behaves like pageable memory; a second caller on the same device while a gated launch is in flight, or a stack on
- *     which the gate cannot work, gets round 4's chunked launches (same digests).
- * Pinned buffers gain 20 % for the Poseidon batches (3.5e8 against 2.9e8 permutations/s) and, since round 5, 10 - 30 % for the curve
- * hashes (per 2^20 hashes, median wall time: Pedersen 4x256 3.65 - 4.2 ms pinned against 4.1 ms pageable with the HBM-sized table and
- * 5.0 ms with the default one; Bowe-Hopwood 63x9 64-byte inputs 2.3 - 2.5 ms against 3.5 ms; profiles/r05_s8, r05_s13) -- the resident
- * launch takes 2.3 - 3.3 / 1.4 - 1.9 ms, the rest is PCIe (134 MB in, 67 MB out per 2^20 Pedersen hashes) and compute that
+ *   - akp_te_crh_batch, when BOTH `msgs` and `out` are of that kind, runs as ONE gated launch (round 5): the batch is copied in by
+ *     asynchronous DMA in chunks of up to 2^17 messages (smaller ones first and last), all copies issued up front, each followed by
+ *     an arrival flag; the accumulate kernel is launched once over the whole batch, its workgroups wait for their chunk's flag and
+ *     finish their digests themselves (one inversion per workgroup of 512 points); the digests of a chunk leave by DMA as soon as
+ *     its workgroups have reported -- never by zero copy: in-place reads make every workgroup wait for PCIe at the same moments and
+ *     in-place 16-byte digest stores cross PCIe at 17 GB/s (measured, profiles/r04_s2 .. r04_s3).  Pinned on one side only behaves
+ *     like pageable memory; a second caller on the same device while a gated launch is in flight, or a stack on which the gate
+ *     cannot work, gets round 4's chunked launches (same digests).
+ * Pinned buffers gain 20 % for the Poseidon batches (3.5e8 against 2.9e8 permutations/s) and, since round 5, 15 - 35 % for the curve
+ * hashes (per 2^20 hashes, median wall time: Pedersen 4x256 3.4 ms pinned against 4.0 ms pageable with the HBM-sized table, 4.0
+ * against 5.0 ms with the default one; Bowe-Hopwood 63x9 64-byte inputs 2.0 - 2.3 ms against 2.8 - 3.5 ms; profiles/r05_s16) -- the
+ * resident launch takes 2.3 - 3.3 / 1.4 - 1.9 ms, the rest is PCIe (134 MB in, 67 MB out per 2^20 Pedersen hashes: the copy-in alone
+ * takes 2.5 ms) and, with the default table, compute that
  * shares the device with the copies.  Register a buffer as a whole: the runtime rejects copies that straddle registered and unregistered memory. */
 int32_t akp_host_alloc(size_t bytes, void** out);
 int32_t akp_host_free(void* p);
