@@ -48,7 +48,10 @@ def test_pinned_batches_through_the_gated_launch(cpa, kind, W, N, L):
         ora = lambda m, k: cref.CurveParams(W, N, g).bh_crh_batch(m, k, L, threads=8)  # noqa: E731
     h = prm.handle()
     chunk = 1 << 17
-    for rep, n in enumerate((2 * chunk, 3 * chunk + 1000, 2 * chunk + 1, 5 * chunk - 255)):
+    # 8, 13, 9 and 20 granules of 2^15 messages: uniform chunks below 12 granules, the ramped schedule (1 1 2 4 .. 2 1 1) from there;
+    # for the 32-byte Bowe-Hopwood case also 2^22 + 5 messages (granules of 2^17: 33 chunks) and 2^23 + 2^16 (granules of 2^18, 33 chunks)
+    sizes = (2 * chunk, 3 * chunk + 1000, 2 * chunk + 1, 5 * chunk - 255) + (((1 << 22) + 5, (1 << 23) + (1 << 16)) if L == 32 else ())
+    for rep, n in enumerate(sizes):
         msgs = np.random.default_rng(100 * rep + L).integers(0, 256, size=(n, L), dtype=np.uint8)
         want = np.empty((n, 4 * fe), np.uint64)
         cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, msgs.ctypes.data, n, L, want.ctypes.data))  # pageable: the chunked launches
