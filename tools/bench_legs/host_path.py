@@ -59,10 +59,11 @@ def run(env, host_states, n):
         same = bool(np.array_equal(pinned_out, ho))
         host_path["pedersen_pinned"] = {"hashes_per_s": nph / hs2, "ms_per_batch": hs2 * 1e3, "ms_min": lo2 * 1e3, "ms_max": hi2 * 1e3, "GBps_in": 128.0 * nph / hs2 / 1e9,
                                         "GBps_out": 64.0 * nph / hs2 / 1e9, "digests_equal_the_pageable_call": same,
-                                        "mode": "pinned buffers on both sides, ONE gated launch (round 5, profiles/r05_s8): DMA copy-in of every 2^17-message chunk issued "
-                                                "up front with an arrival flag behind it, the accumulate kernel launched once over the whole batch (workgroups wait on "
-                                                "their chunk's flag and finish their digests themselves: one inversion per workgroup), DMA copy-out of a chunk released "
-                                                "by the host thread as its workgroups report (profiles/r05_s13)"}
+                                        "mode": "pinned buffers on both sides, ONE gated launch (round 5, profiles/r05_s8, r05_s13, r05_s16): DMA copy-in in chunks of up to "
+                                                "2^17 messages (smaller first and last) issued up front with an arrival flag behind each, the accumulate kernel launched "
+                                                "once over the whole batch (workgroups wait on their chunk's flag with relaxed polls, hash two messages per lane and finish "
+                                                "their digests themselves: one inversion per 512 points), DMA copy-out of a chunk released by the host thread as its "
+                                                "workgroups report"}
         check(lib.akp_host_free(pm))
         check(lib.akp_host_free(po))
         if not same:
