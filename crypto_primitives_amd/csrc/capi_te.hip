@@ -781,72 +781,114 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     return finalize(0, n, s);
 }
 
-// ---- the pinned host path as ONE gated launch (round 5; DESIGN.md section 1, profiles/r05_s8) --------------------------------------------
+// ---- the pinned host path as ONE gated launch (round 5; DESIGN.md section 1, profiles/r05_s8, r05_s13, r05_s16) -----------------------
 // Until round 4 a pinned batch ran as eight chunked launches, each behind its chunk's DMA: every launch pays its ramp (0.45-0.5 ms per
 // 2^17 messages against 0.29 ms of the resident launch's share) and the call sat at that floor (4.2 ms per 2^20 Pedersen hashes
 // against 2.3-3.2 ms resident).  Here the accumulate kernel is launched ONCE over the whole batch while the messages are still
-// arriving: workgroups wait on their chunk's arrival flag (te_accumulate_lds_gated_kernel; flag = hipStreamWriteValue32 behind the
-// chunk's copy), report completion per workgroup in pinned host memory, and this thread releases each chunk's finalize pass (its own
-// stream) and copy-out (DMA, side stream) as soon as the chunk's workgroups are done.  *used = false: preconditions not met or the
-// gate failed (nothing was written to `out`): the caller runs the chunked launches.
+// arriving: workgroups wait on their chunk's arrival flag (te_accumulate_lds_gated_fused_kernel; flag = hipStreamWriteValue32 behind the
+// chunk's copy), hash two messages per lane, finish their digests themselves (one inversion per workgroup) and report completion in
+// pinned host memory; this thread releases a chunk's copy-out (DMA, side stream) as soon as the chunk's workgroups are done.
+// Measured and dropped on the way: separate per-chunk finalize passes behind an accumulate-only gated kernel (4.43 / 3.9 ms per 2^20
+// Pedersen hashes when this form took 4.2 / 3.65; they fight the accumulate kernel for issue slots), the digests stored straight
+// into the pinned buffer through an LDS staging area (4.6 / 3.9 ms), the flag writes on a stream of their own (same), four
+// workgroups per CU instead of three (same): profiles/r05_s13, r05_s16.
+
+// Chunks of one launch differ in size: a quarter chunk first (the workgroups start after 0.08 ms of copying instead of 0.31), small
+// ones last (the copy-out behind the last workgroup is short), full ones between.  Sizes in granules of chunk / 4 messages; the kernel
+// maps workgroup -> granule -> chunk through TeGate::chunk_of (64 granules at most: larger batches take larger granules).
+// Returns the first message of every chunk, then n.
+static std::vector<size_t> te_gate_schedule(size_t n, size_t chunk, bool ramp, size_t* granule_out) {
+    size_t granule = chunk / 4;
+    while ((n + granule - 1) / granule > 64) granule *= 2;
+    const size_t n_granules = (n + granule - 1) / granule, full = std::max<size_t>(1, chunk / granule);
+    std::vector<size_t> sizes;
+    size_t left = n_granules;
+    const bool ramped = ramp && full == 4 && n_granules >= 12;
+    if (ramped) {
+        sizes = {1, 1, 2};
+        left -= 8;
+    }
+    while (left) {
+        const size_t k = std::min(left, full);
+        sizes.push_back(k);
+        left -= k;
+    }
+    if (ramped) sizes.insert(sizes.end(), {2, 1, 1});
+    std::vector<size_t> first;
+    size_t at = 0;
+    for (size_t k : sizes) {
+        first.push_back(at * granule);
+        at += k;
+    }
+    first.push_back(n);
+    *granule_out = granule;
+    return first;
+}
+// the context's gate resources: 64 arrival flags in fine-grained device memory, n_wg completion words (+ the error word) in pinned host
+// memory, the copy-in and copy-out streams.  false (hipSuccess cleared): this stack cannot gate, the context stops trying
+static bool te_gate_resources(akp_ctx* c, size_t n_wg) {
+    auto ok = [](hipError_t e) {
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    };
+    if (!c->gate_flags) {
+        if (!ok(hipExtMallocWithFlags((void**)&c->gate_flags, 64 * sizeof(u32), hipDeviceMallocFinegrained))) { c->gate_flags = nullptr; return false; }
+        if (!ok(hipMemset(c->gate_flags, 0, 64 * sizeof(u32)))) return false;
+    }
+    if (c->gate_done_cap < n_wg) {
+        if (c->gate_done) {
+            if (!ok(hipDeviceSynchronize())) return false;
+            (void)hipHostFree(c->gate_done);
+            c->gate_done = c->gate_done_dev = nullptr;
+            c->gate_done_cap = 0;
+        }
+        // word 0: set by a workgroup that gave up; the completion words start at word 16
+        if (!ok(hipHostMalloc((void**)&c->gate_done, (n_wg + 16) * sizeof(u32), hipHostMallocMapped))) { c->gate_done = nullptr; return false; }
+        if (!ok(hipHostGetDevicePointer((void**)&c->gate_done_dev, c->gate_done, 0))) {
+            (void)hipHostFree(c->gate_done);
+            c->gate_done = c->gate_done_dev = nullptr;
+            return false;
+        }
+        memset(c->gate_done, 0, (n_wg + 16) * sizeof(u32));
+        c->gate_done_cap = n_wg;
+    }
+    if (!c->pipe[0] && !ok(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking))) return false;
+    if (!c->pipe[4]) {
+        int lo = 0, hi = 0;
+        if (!ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) || !ok(hipStreamCreateWithPriority(&c->pipe[4], hipStreamNonBlocking, hi))) return false;
+    }
+    if (!c->chunk_event[7] && !ok(hipEventCreateWithFlags(&c->chunk_event[7], hipEventDisableTiming))) return false;
+    return true;
+}
+// *used = false: preconditions not met or the gate failed (the caller runs the chunked launches, which write every digest again)
 static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, size_t msg_len, void* h_out, bool* used) {
     *used = false;
     akp_ctx* c = p->ctx;
     if (c->gate_unavailable) return AKP_OK;
-    size_t chunk = (size_t)1 << 17;
-#if defined(AKP_TEST_HOOKS)
-    if (env_u32("AKP_TE_GATED", 1, 0, 1) == 0) return AKP_OK;  // A/B against the chunked launches (test build only)
-    chunk = env_size("AKP_TE_PIPE_CHUNK", chunk);
-#endif
-    // fused: the workgroups finish their digests themselves (one inversion per workgroup of 2 x 256 points) -- 4.43 -> 3.95 ms (default
-    // table) / 3.9 -> 3.45 ms (HBM table) per 2^20 Pedersen hashes against separate per-chunk finalize passes (profiles/r05_s13, r05_s16).
-    // Measured and dropped: the digests stored straight into the pinned buffer through an LDS staging area instead of DMA copy-outs
-    // (4.6 / 3.9 ms when the DMA form took 4.2 / 3.65: profiles/r05_s13)
-    bool fused = true;
-#if defined(AKP_TEST_HOOKS)
-    fused = env_u32("AKP_TE_GATED_FUSED", 1, 0, 1) != 0;
-#endif
-    // timing probes (test build): the gated kernel without the copies it normally runs beside -- the digests are then those of whatever
-    // the device buffer held (tools/gpu_r5_gate_knobs.py reads times only)
-    bool skip_in = false, skip_out = false;
+    // the test build's switches (tools/gpu_r5_gated.py, gpu_r5_gate_knobs.py, the fallback test); libakp.so reads none of them
+    size_t chunk = (size_t)1 << 17, lds_floor = 36864;
+    u32 spin_limit = 1u << 15, poll_sleep = 0;
+    bool ramp = true, skip_in = false, skip_out = false;
     const char* stamps_path = nullptr;
-    void* d_stamps = nullptr;
     (void)stamps_path;
 #if defined(AKP_TEST_HOOKS)
-    stamps_path = getenv("AKP_TE_GATE_STAMPS");
-    if (stamps_path && (!*stamps_path || !fused)) stamps_path = nullptr;
+    if (env_u32("AKP_TE_GATED", 1, 0, 1) == 0) return AKP_OK;  // A/B against the chunked launches
+    chunk = env_size("AKP_TE_PIPE_CHUNK", chunk);
+    lds_floor = env_size("AKP_TE_GATE_LDS_FLOOR", lds_floor);
+    ramp = env_u32("AKP_TE_GATE_RAMP", 1, 0, 1) != 0;
+    spin_limit = env_u32("AKP_TE_GATE_SPIN_LIMIT", spin_limit, 1, 1u << 24);  // 1: every workgroup that has to wait gives up -- exercises the fallback
+    poll_sleep = env_u32("AKP_TE_GATE_POLL_SLEEP", 0, 0, 64);
+    if (poll_sleep) spin_limit = std::max(1u, spin_limit / (1u + 8u * poll_sleep));  // the same bound in time
+    // timing probes: the gated kernel without the copies it normally runs beside (the digests are then those of whatever the device
+    // buffer held: the tools read times only), and per-workgroup release / end times written to a file
     skip_in = env_u32("AKP_TE_GATE_SKIP_COPY_IN", 0, 0, 1) != 0;
     skip_out = env_u32("AKP_TE_GATE_SKIP_COPY_OUT", 0, 0, 1) != 0;
-#endif
-    // Chunks of one launch differ in size: a quarter chunk first (the workgroups start after 0.08 ms of copying instead of 0.31), small
-    // ones last (the copy-out behind the last workgroup is short), full ones between.  Sizes in granules of chunk / 4 messages; the kernel
-    // maps workgroup -> granule -> chunk through TeGate::chunk_of (64 granules at most: larger batches take larger granules)
-    bool ramp = true;
-#if defined(AKP_TEST_HOOKS)
-    ramp = env_u32("AKP_TE_GATE_RAMP", 1, 0, 1) != 0;
+    stamps_path = getenv("AKP_TE_GATE_STAMPS");
+    if (stamps_path && !*stamps_path) stamps_path = nullptr;
 #endif
     if (te_lds_block(msg_len, msg_len) != 256 || (chunk & 2047) || n <= chunk) return AKP_OK;
-    size_t granule = chunk / 4;
-    while ((n + granule - 1) / granule > 64) granule *= 2;
-    const size_t n_granules = (n + granule - 1) / granule;
-    std::vector<size_t> chunk_first;  // first message of every chunk, then n
-    {
-        const size_t full = std::max<size_t>(1, chunk / granule);
-        static const size_t head[3] = {1, 1, 2}, tail[3] = {2, 1, 1};
-        std::vector<size_t> sizes;
-        size_t left = n_granules;
-        if (ramp && full == 4 && n_granules >= 12) {
-            for (size_t h : head) sizes.push_back(h);
-            left -= 8;
-            while (left) { const size_t k = std::min(left, full); sizes.push_back(k); left -= k; }
-            for (size_t t : tail) sizes.push_back(t);
-        } else {
-            while (left) { const size_t k = std::min(left, full); sizes.push_back(k); left -= k; }
-        }
-        size_t at = 0;
-        for (size_t k : sizes) { chunk_first.push_back(at * granule); at += k; }
-        chunk_first.push_back(n);
-    }
+    size_t granule = 0;
+    const std::vector<size_t> chunk_first = te_gate_schedule(n, chunk, ramp, &granule);
     const size_t n_chunks = chunk_first.size() - 1;
     if (n_chunks < 2 || n_chunks > 64) return AKP_OK;
     // ONE gated launch per device at a time: two of them (two host threads with a context each) would hold all eight wave slots of
@@ -854,151 +896,89 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     static std::mutex gate_busy[64];
     std::unique_lock<std::mutex> gate_turn(gate_busy[c->device & 63], std::try_to_lock);
     if (!gate_turn.owns_lock()) return AKP_OK;
-    const size_t per_wg = fused ? 256 * TE_FUSED_ITEMS : 256;  // messages per workgroup
+    constexpr size_t per_wg = 256 * TE_FUSED_ITEMS;  // messages per workgroup
     const size_t n_wg = (n + per_wg - 1) / per_wg;
-    auto give_up = [&](const char* what, hipError_t e) {  // gate resources unavailable on this stack: remember, use the chunked launches
-        (void)hipGetLastError();
-        (void)what; (void)e;
+    if (!te_gate_resources(c, n_wg)) {
         c->gate_unavailable = true;
         return AKP_OK;
-    };
-    if (!c->gate_flags) {
-        hipError_t e = hipExtMallocWithFlags((void**)&c->gate_flags, 128 * sizeof(u32), hipDeviceMallocFinegrained);
-        if (e == hipSuccess) e = hipMemset(c->gate_flags, 0, 128 * sizeof(u32));
-        if (e != hipSuccess) { c->gate_flags = nullptr; return give_up("fine-grained flags", e); }
-    }
-    if (c->gate_done_cap < n_wg) {
-        if (c->gate_done) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(c->gate_done); c->gate_done = nullptr; c->gate_done_cap = 0; }
-        // word 0: set by a workgroup that gave up; the completion words start at word 16
-        hipError_t e = hipHostMalloc((void**)&c->gate_done, (n_wg + 16) * sizeof(u32), hipHostMallocMapped);
-        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->gate_done_dev, c->gate_done, 0);
-        if (e != hipSuccess) { if (c->gate_done) (void)hipHostFree(c->gate_done); c->gate_done = nullptr; return give_up("pinned completion words", e); }
-        memset(c->gate_done, 0, (n_wg + 16) * sizeof(u32));
-        c->gate_done_cap = n_wg;
     }
     if (++c->gate_epoch == 0) ++c->gate_epoch;  // 0 is what fresh memory holds
     const u32 epoch = c->gate_epoch;
-    hipStream_t s = c->stream;
-    if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
-    if (!c->pipe[4]) {
-        int lo = 0, hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&c->pipe[4], hipStreamNonBlocking, hi));
-    }
-    for (int i = 5; i <= 6; ++i)
-        if (!c->pipe[i]) {  // two finalize streams (the passes of consecutive chunks overlap), dispatched ahead of the accumulate kernel's workgroups
-            int lo = 0, hi = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_TRY(hipStreamCreateWithPriority(&c->pipe[i], hipStreamNonBlocking, hi));
-        }
-    for (int i = 0; i < 8; ++i)
-        if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
-    hipStream_t cin = c->pipe[0], side = c->pipe[4], fins[2] = {c->pipe[5], c->pipe[6]};
+    hipStream_t s = c->stream, cin = c->pipe[0], side = c->pipe[4];
     const u32 fe = te_fe_per_digest(p);
     const size_t dig = fe * sizeof(Fr);
-    void *dm = nullptr, *dout = nullptr, *xyz = nullptr, *prefix = nullptr;
+    void *dm = nullptr, *dout = nullptr, *d_stamps = nullptr;
     if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
-    if (!fused) {  // the fused kernel keeps its sums in registers and finishes them itself: no xyz / prefix arrays
-        if (int32_t rc = ctx_scratch(c, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
-        if (int32_t rc = ctx_scratch(c, SCR_F, n * sizeof(F29Pad), &prefix, s)) return rc;
+#if defined(AKP_TEST_HOOKS)
+    if (stamps_path) {
+        if (int32_t rc = ctx_scratch(c, SCR_F, 2 * n_wg * sizeof(uint64_t), &d_stamps, s)) return rc;
+        HIP_TRY(hipMemsetAsync(d_stamps, 0, 2 * n_wg * sizeof(uint64_t), s));
     }
-    __atomic_store_n(c->gate_done, 0u, __ATOMIC_RELEASE);  // nothing of this context is running a gated kernel now
+#endif
+    __atomic_store_n(c->gate_done, 0u, __ATOMIC_RELEASE);  // the error word; nothing of this context is running a gated kernel now
     HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
     HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));
     HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[7], 0));
-    HIP_TRY(hipStreamWaitEvent(fins[0], c->chunk_event[7], 0));
-    HIP_TRY(hipStreamWaitEvent(fins[1], c->chunk_event[7], 0));
     {
         TeTable* t = p->t;
         std::lock_guard<std::mutex> table_lock(t->mu);
         TeResolved rs;
         if (int32_t rc = te_resolve(p, msg_len, msg_len, s, &rs)) return rc;
-        // all copies first, each followed by its flag; nothing of this call has been launched yet if the write-value is refused
+        // all copies first, each followed by its flag (a small kernel); nothing of this call has been launched yet if the write-value
+        // is refused
         for (size_t k = 0; k < n_chunks; ++k) {
             const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
             if (!skip_in) HIP_TRY(hipMemcpyAsync((uint8_t*)dm + first * msg_len, h_msgs + first * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
-            // (the flag write is a small kernel; putting it on a stream of its own behind an event, so that the copies stay back to
-            // back on the copy engine, measured the same: profiles/r05_s16)
-            const hipError_t e = hipStreamWriteValue32(cin, c->gate_flags + k, epoch, 0);
-            if (e != hipSuccess) {
+            if (hipStreamWriteValue32(cin, c->gate_flags + k, epoch, 0) != hipSuccess) {
+                (void)hipGetLastError();
                 (void)hipStreamSynchronize(cin);
-                return give_up("hipStreamWriteValue32", e);
+                c->gate_unavailable = true;
+                return AKP_OK;
             }
         }
-        const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;  // (the fused kernel's product tree / staging area takes its place afterwards)
-        u32 spin_limit = 1u << 15, poll_sleep = 0;
-        size_t gate_lds_floor = 36864;
-#if defined(AKP_TEST_HOOKS)
-        gate_lds_floor = env_size("AKP_TE_GATE_LDS_FLOOR", gate_lds_floor);
-        if (stamps_path) {  // per-workgroup release / end times of this launch (100 MHz constant clock), [0] of a one-lane kernel ahead of it
-            if (int32_t rc = ctx_scratch(c, SCR_F, (2 * n_wg + 2) * sizeof(uint64_t), &d_stamps, s)) return rc;
-            HIP_TRY(hipMemsetAsync(d_stamps, 0, (2 * n_wg + 2) * sizeof(uint64_t), s));
-        }
-        spin_limit = env_u32("AKP_TE_GATE_SPIN_LIMIT", spin_limit, 1, 1u << 24);  // 1: every workgroup that has to wait gives up -- exercises the fallback
-        poll_sleep = env_u32("AKP_TE_GATE_POLL_SLEEP", 0, 0, 64);
-        if (poll_sleep) spin_limit = std::max(1u, spin_limit / (1u + 8u * poll_sleep));  // the same bound in time
-#endif
         TeGate gate{c->gate_flags, c->gate_done_dev + 16, c->gate_done_dev, epoch, (u32)(granule / per_wg), spin_limit, {}, poll_sleep, (Fr*)dout, fe,
                     (unsigned long long*)d_stamps};
         for (size_t k = 0; k < n_chunks; ++k)
             for (size_t g = chunk_first[k] / granule; g * granule < chunk_first[k + 1]; ++g) gate.chunk_of[g] = (uint8_t)k;
-        // at least 40 KB of LDS per workgroup = at most four workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks
-        // below the runtime's DMA threshold, the copies themselves are small KERNELS -- with every wave slot held by a spinning
-        // workgroup they never run and nothing arrives (measured: tools/persist_probe.hip; a 63x9 batch in 4 MB chunks timed out)
-        const size_t shm = std::max<size_t>(std::max<size_t>(image, fused ? 9 * 512 * sizeof(u32) : 0), gate_lds_floor);  // the product tree re-uses the image
+        // LDS: one message image (the product tree takes its place afterwards), and more than 32 KB per workgroup = at most four
+        // workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks below the runtime's DMA threshold, the copies
+        // themselves are small KERNELS -- with every wave slot held by a spinning workgroup they never run and nothing arrives
+        // (measured: tools/persist_probe.hip; a 63x9 batch in 4 MB chunks timed out)
+        const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;
+        const size_t shm = std::max(std::max<size_t>(image, 9 * 512 * sizeof(u32)), lds_floor);
         const dim3 grid((unsigned)n_wg);
-        if (fused) {  // the workgroups finish their digests themselves (one inversion per workgroup through an LDS product tree): no finalize passes
-            if (t->pedersen && t->signed_subset)
-                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
-                        rs.groups, rs.steps, rs.tail, n, gate);
-            else if (t->pedersen)
-                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<0>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
-                        rs.groups, rs.steps, rs.tail, n, gate);
-            else
-                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<1>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
-                        rs.groups, rs.steps, rs.tail, n, gate);
-        } else if (t->pedersen && t->signed_subset)
-            hipLaunchKernelGGL(te_accumulate_lds_gated_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape, rs.groups,
-                    rs.steps, rs.tail, (F29Pad*)xyz, n, gate);
+        if (t->pedersen && t->signed_subset)
+            hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                    rs.groups, rs.steps, rs.tail, n, gate);
         else if (t->pedersen)
-            hipLaunchKernelGGL(te_accumulate_lds_gated_kernel<0>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape, rs.groups,
-                    rs.steps, rs.tail, (F29Pad*)xyz, n, gate);
+            hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<0>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                    rs.groups, rs.steps, rs.tail, n, gate);
         else
-            hipLaunchKernelGGL(te_accumulate_lds_gated_kernel<1>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape, rs.groups,
-                    rs.steps, rs.tail, (F29Pad*)xyz, n, gate);
+            hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<1>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                    rs.groups, rs.steps, rs.tail, n, gate);
         HIP_TRY(hipGetLastError());
     }
-    // release every chunk's finalize pass + copy-out when its workgroups have reported (they finish roughly in launch order)
+    // release every chunk's copy-out when its workgroups have reported (they finish roughly in launch order)
     const volatile u32* done = c->gate_done + 16;
     bool gave_up = false;
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t k = 0; k < n_chunks && !gave_up; ++k) {
         const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
-        const size_t wg0 = first / per_wg, wg1 = (first + cnt + per_wg - 1) / per_wg;
-        for (size_t b = wg0; b < wg1; ++b) {
+        const size_t wg1 = (first + cnt + per_wg - 1) / per_wg;
+        for (size_t b = first / per_wg; b < wg1 && !gave_up; ++b) {
             unsigned spins = 0;
-            while (done[b] != epoch) {
+            while (done[b] != epoch)
                 if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) {
                     gave_up = true;  // the kernel's own spin limit has ended it long before: its error word says why
                     break;
                 }
-            }
-            if (gave_up) break;
         }
-        if (gave_up) break;
-        hipStream_t fin = fins[k & 1];
-        if (!fused) {
-            if (int32_t rc = te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, (Fr*)dout + first * fe, cnt, fin, te_chunk_finalize_lanes())) return rc;
-            HIP_TRY(hipEventRecord(c->chunk_event[k & 3], fin));
-            HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[k & 3], 0));
-        }
-        if (!skip_out) HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
+        if (!gave_up && !skip_out)
+            HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
     }
     HIP_TRY(hipStreamSynchronize(cin));
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipStreamSynchronize(fins[0]));
-    HIP_TRY(hipStreamSynchronize(fins[1]));
     HIP_TRY(hipStreamSynchronize(side));
     const u32 err = __atomic_load_n(c->gate_done, __ATOMIC_ACQUIRE);  // the kernel has ended: its writes to host memory are there
 #if defined(AKP_TEST_HOOKS)

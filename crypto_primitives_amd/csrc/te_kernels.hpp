@@ -870,8 +870,8 @@ AKP_HD size_t te_lds_image_bytes(size_t block, size_t msg_len, size_t stride) {
 // GATED (round 5, the pinned host path): the launch covers the WHOLE batch while its messages are still arriving by DMA, chunk after
 // chunk.  Workgroup b belongs to chunk chunk_of[b / wg_per_granule]; before it touches its messages, thread 0 polls gate_flags[chunk] -- a word in
 // FINE-GRAINED DEVICE memory that hipStreamWriteValue32 on the copy stream sets to `epoch` behind the chunk's copy -- and when its
-// sums are stored the workgroup writes `epoch` to done[b] in pinned HOST memory (a plain posted write; the host thread releases the
-// chunk's finalize pass and copy-out when all its words are there).  Measured preconditions (tools/persist_probe.hip,
+// digests are stored the workgroup writes `epoch` to done[b] in pinned HOST memory (a plain posted write; the host thread releases the
+// chunk's copy-out when all its words are there).  Measured preconditions (tools/persist_probe.hip,
 // profiles/r05_s8): the polls must stay on the device (polling host memory competes over PCIe with the very copies the workgroups wait
 // for) and the kernel must leave wave slots free (a copy / write-value needs one: with every slot spinning nothing arrives) --
 // this kernel holds 3 waves per SIMD.  The spin is bounded: on a timeout the workgroup reports through *gate_err and leaves, the
@@ -883,7 +883,7 @@ struct TeGate {
     u32 epoch, wg_per_granule, spin_limit;
     uint8_t chunk_of[64];  // chunk of every granule of wg_per_granule workgroups: the chunks of one launch differ in size (small ones first and last)
     u32 poll_sleep;     // extra s_sleep(127) (~4 us each at 2 GHz) between two polls of a waiting workgroup
-    // FUSED: the workgroup also finishes its digests (projective -> affine with ONE inversion per workgroup) and writes them to
+    // the workgroup also finishes its digests (projective -> affine with ONE inversion per workgroup) and writes them to
     // `out` (`fe` Fr per digest: x, or x and y).  The 9 x 512-dword product tree takes the place of the message image, which is dead
     // by then: the launch needs max(image, 18 KB) of LDS
     Fr* out;
@@ -961,7 +961,7 @@ __device__ __forceinline__ u32 te_load_msg_image(u32* image, const uint8_t* g0, 
 #ifndef TE_FUSED_ITEMS
 #define TE_FUSED_ITEMS 2  // 1: one point per lane (build-time A/B arm)
 #endif
-template <int KIND, bool GATED, bool FUSED = false>
+template <int KIND, bool GATED>  // GATED: the gated launch of the pinned host path, which also finishes its digests
 __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
                                                        const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups, u32 n_steps,
                                                        const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n, const TeGate& gate) {
@@ -986,7 +986,7 @@ __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict
         __syncthreads();
         if (!gate_open) return;
     }
-    if (FUSED) {
+    if (GATED) {
         const size_t base = (size_t)blockIdx.x * (TE_FUSED_ITEMS * 256);
         Ext acc[TE_FUSED_ITEMS];
 #pragma unroll
@@ -1048,17 +1048,10 @@ __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_kerne
     te_accumulate_lds_body<KIND, false>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, xyz, n, TeGate{});
 }
 template <int KIND>
-__global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_gated_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
-                                                           const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
-                                                           u32 n_steps, const TeEntry* __restrict__ tail, F29Pad* __restrict__ xyz, size_t n, TeGate gate) {
-    te_accumulate_lds_body<KIND, true>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, xyz, n, gate);
-}
-// ... and with the digests finished inside the workgroup (TeGate::out): no xyz array, no finalize pass
-template <int KIND>
 __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_lds_gated_fused_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
                                                            const uint8_t* __restrict__ msgs, size_t msg_len, size_t stride, u32 D, u32 n_groups,
                                                            u32 n_steps, const TeEntry* __restrict__ tail, size_t n, TeGate gate) {
-    te_accumulate_lds_body<KIND, true, true>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, nullptr, n, gate);
+    te_accumulate_lds_body<KIND, true>(lut, lut1, msgs, msg_len, stride, D, n_groups, n_steps, tail, nullptr, n, gate);
 }
 #endif
 // sum of the single-chunk entries 1 * G[c], c in [from, to): the constant of a zero tail (one thread; once per parameter set)
