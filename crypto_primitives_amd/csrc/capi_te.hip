@@ -1032,6 +1032,13 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     if (n > te_split_max && msg_len >= 4 && out_pinned && device_alias(msgs, n * msg_len)) {
         bool gated = false;
         if (int32_t rc = te_crh_gated(p, msgs, n, msg_len, out, &gated)) return rc;
+#if defined(AKP_TEST_HOOKS)
+        if (const char* report = getenv("AKP_TE_GATE_REPORT"))  // one line per pinned call: which form ran it (tools/gpu_r5_gated_stress.py counts them)
+            if (FILE* f = fopen(report, "a")) {
+                fprintf(f, "%zu %zu %d\n", n, msg_len, gated ? 1 : 0);
+                fclose(f);
+            }
+#endif
         if (gated) return AKP_OK;
         if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
         if (!c->pipe[4]) {  // the copy-out stream: its copy kernels should not queue behind the hash kernels' workgroups
