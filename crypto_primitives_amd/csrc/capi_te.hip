@@ -891,6 +891,9 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     const std::vector<size_t> chunk_first = te_gate_schedule(n, chunk, ramp, &granule);
     const size_t n_chunks = chunk_first.size() - 1;
     if (n_chunks < 2 || n_chunks > 64) return AKP_OK;
+    // a waiting workgroup gives up after the time its chunk would take at 1/10 of the link's rate (two polls per microsecond, 5 GB/s;
+    // at least 2^15 polls): batches above 2^23 messages come in chunks of up to 2^-6 of the batch
+    if (spin_limit == 1u << 15) spin_limit = (u32)std::min<size_t>(1u << 24, std::max<size_t>(spin_limit, 4 * granule * msg_len * 2 / 5000));
     // ONE gated launch per device at a time: two of them (two host threads with a context each) would hold all eight wave slots of
     // every SIMD with waiting workgroups, and the flag writes they wait for could not run.  A second caller takes the chunked launches.
     static std::mutex gate_busy[64];
@@ -920,62 +923,74 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
     HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));
     HIP_TRY(hipStreamWaitEvent(side, c->chunk_event[7], 0));
-    {
-        TeTable* t = p->t;
-        std::lock_guard<std::mutex> table_lock(t->mu);
-        TeResolved rs;
-        if (int32_t rc = te_resolve(p, msg_len, msg_len, s, &rs)) return rc;
-        // all copies first, each followed by its flag (a small kernel); nothing of this call has been launched yet if the write-value
-        // is refused
-        for (size_t k = 0; k < n_chunks; ++k) {
-            const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
-            if (!skip_in) HIP_TRY(hipMemcpyAsync((uint8_t*)dm + first * msg_len, h_msgs + first * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
-            if (hipStreamWriteValue32(cin, c->gate_flags + k, epoch, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipStreamSynchronize(cin);
-                c->gate_unavailable = true;
-                return AKP_OK;
-            }
-        }
-        TeGate gate{c->gate_flags, c->gate_done_dev + 16, c->gate_done_dev, epoch, (u32)(granule / per_wg), spin_limit, {}, poll_sleep, (Fr*)dout, fe,
-                    (unsigned long long*)d_stamps};
-        for (size_t k = 0; k < n_chunks; ++k)
-            for (size_t g = chunk_first[k] / granule; g * granule < chunk_first[k + 1]; ++g) gate.chunk_of[g] = (uint8_t)k;
-        // LDS: one message image (the product tree takes its place afterwards), and more than 32 KB per workgroup = at most four
-        // workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks below the runtime's DMA threshold, the copies
-        // themselves are small KERNELS -- with every wave slot held by a spinning workgroup they never run and nothing arrives
-        // (measured: tools/persist_probe.hip; a 63x9 batch in 4 MB chunks timed out)
-        const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;
-        const size_t shm = std::max(std::max<size_t>(image, 9 * 512 * sizeof(u32)), lds_floor);
-        const dim3 grid((unsigned)n_wg);
-        if (t->pedersen && t->signed_subset)
-            hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
-                    rs.groups, rs.steps, rs.tail, n, gate);
-        else if (t->pedersen)
-            hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<0>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
-                    rs.groups, rs.steps, rs.tail, n, gate);
-        else
-            hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<1>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
-                    rs.groups, rs.steps, rs.tail, n, gate);
-        HIP_TRY(hipGetLastError());
-    }
-    // release every chunk's copy-out when its workgroups have reported (they finish roughly in launch order)
-    const volatile u32* done = c->gate_done + 16;
-    bool gave_up = false;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (size_t k = 0; k < n_chunks && !gave_up; ++k) {
-        const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
-        const size_t wg1 = (first + cnt + per_wg - 1) / per_wg;
-        for (size_t b = first / per_wg; b < wg1 && !gave_up; ++b) {
-            unsigned spins = 0;
-            while (done[b] != epoch)
-                if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) {
-                    gave_up = true;  // the kernel's own spin limit has ended it long before: its error word says why
-                    break;
+    // an error from here on leaves copies of the caller's buffers (and possibly the kernel, which its spin limit ends) in flight:
+    // the streams are drained before it is returned
+    bool gave_up = false, refused = false;
+    const int32_t rc = [&]() -> int32_t {
+        {
+            TeTable* t = p->t;
+            std::lock_guard<std::mutex> table_lock(t->mu);
+            TeResolved rs;
+            if (int32_t rc = te_resolve(p, msg_len, msg_len, s, &rs)) return rc;
+            // all copies first, each followed by its flag (a small kernel); nothing of this call has been launched yet if the write-value
+            // is refused
+            for (size_t k = 0; k < n_chunks; ++k) {
+                const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
+                if (!skip_in) HIP_TRY(hipMemcpyAsync((uint8_t*)dm + first * msg_len, h_msgs + first * msg_len, cnt * msg_len, hipMemcpyHostToDevice, cin));
+                if (hipStreamWriteValue32(cin, c->gate_flags + k, epoch, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    refused = true;
+                    return AKP_OK;
                 }
+            }
+            TeGate gate{c->gate_flags, c->gate_done_dev + 16, c->gate_done_dev, epoch, (u32)(granule / per_wg), spin_limit, {}, poll_sleep, (Fr*)dout, fe,
+                        (unsigned long long*)d_stamps};
+            for (size_t k = 0; k < n_chunks; ++k)
+                for (size_t g = chunk_first[k] / granule; g * granule < chunk_first[k + 1]; ++g) gate.chunk_of[g] = (uint8_t)k;
+            // LDS: one message image (the product tree takes its place afterwards), and more than 32 KB per workgroup = at most four
+            // workgroups (four waves per SIMD) on a CU: the flag writes and, for chunks below the runtime's DMA threshold, the copies
+            // themselves are small KERNELS -- with every wave slot held by a spinning workgroup they never run and nothing arrives
+            // (measured: tools/persist_probe.hip; a 63x9 batch in 4 MB chunks timed out)
+            const size_t image = (te_lds_image_bytes(256, msg_len, msg_len) + 15) & ~(size_t)15;
+            const size_t shm = std::max(std::max<size_t>(image, 9 * 512 * sizeof(u32)), lds_floor);
+            const dim3 grid((unsigned)n_wg);
+            if (t->pedersen && t->signed_subset)
+                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<2>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                        rs.groups, rs.steps, rs.tail, n, gate);
+            else if (t->pedersen)
+                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<0>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                        rs.groups, rs.steps, rs.tail, n, gate);
+            else
+                hipLaunchKernelGGL(te_accumulate_lds_gated_fused_kernel<1>, grid, dim3(256), shm, s, rs.lut, rs.lut1, (const uint8_t*)dm, msg_len, msg_len, rs.shape,
+                        rs.groups, rs.steps, rs.tail, n, gate);
+            HIP_TRY(hipGetLastError());
         }
-        if (!gave_up && !skip_out)
-            HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
+        // release every chunk's copy-out when its workgroups have reported (they finish roughly in launch order)
+        const volatile u32* done = c->gate_done + 16;
+        auto t0 = std::chrono::steady_clock::now();  // of the last workgroup seen to report: the watchdog is about PROGRESS, batches of any size pass
+        for (size_t k = 0; k < n_chunks && !gave_up; ++k) {
+            const size_t first = chunk_first[k], cnt = chunk_first[k + 1] - first;
+            const size_t wg1 = (first + cnt + per_wg - 1) / per_wg;
+            for (size_t b = first / per_wg; b < wg1 && !gave_up; ++b) {
+                unsigned spins = 0;
+                while (done[b] != epoch)
+                    if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) {
+                        gave_up = true;  // the kernel's own spin limit has ended it long before: its error word says why
+                        break;
+                    }
+                if (spins > 0xfff) t0 = std::chrono::steady_clock::now();
+            }
+            if (!gave_up && !skip_out)
+                HIP_TRY(hipMemcpyAsync((char*)h_out + first * dig, (const char*)dout + first * dig, cnt * dig, hipMemcpyDeviceToHost, side));
+        }
+        return AKP_OK;
+    }();
+    if (rc || refused) {
+        (void)hipStreamSynchronize(cin);
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(side);
+        if (refused) c->gate_unavailable = true;  // hipStreamWriteValue32 is not available on this stack
+        return rc;
     }
     HIP_TRY(hipStreamSynchronize(cin));
     HIP_TRY(hipStreamSynchronize(s));
