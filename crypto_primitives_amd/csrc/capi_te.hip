@@ -908,6 +908,8 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     if (++c->gate_epoch == 0) ++c->gate_epoch;  // 0 is what fresh memory holds
     const u32 epoch = c->gate_epoch;
     hipStream_t s = c->stream, cin = c->pipe[0], side = c->pipe[4];
+    // (`side` has the highest stream priority: device-to-host copies are blit KERNELS on this stack whatever the stream, and at normal
+    // priority they wait until the hash kernel thins out -- the copy-outs of a large batch would pile up behind it: profiles/r05_s16)
     const u32 fe = te_fe_per_digest(p);
     const size_t dig = fe * sizeof(Fr);
     void *dm = nullptr, *dout = nullptr, *d_stamps = nullptr;
