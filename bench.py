@@ -152,18 +152,19 @@ def main():
     from bench_legs import bh_merkle as bh_leg, cpu_baseline as cpu_leg, host_path as host_leg, merkle as merkle_leg, pedersen as ped_leg, ragged as ragged_leg, scaling, sustained as sus_leg, sweep as sweep_leg
 
     ctx = cpa.default_context(local_rank)
-    # curve tables: the library's default is the cache-sized table (fast from cold); the warm legs below opt into the HBM-sized ones
-    # (AKP_TABLE_BUDGET_DEVICE), and the pedersen / bh_merkle legs report BOTH, cold and warm.  Ranks that share one GPU (test hook)
-    # keep the default: every process would build tables of its own.
-    if not shared_gpu:
-        ctx.set_table_budget(cpa._lib.TABLE_BUDGET_DEVICE)
+    # curve tables: every leg runs with the LIBRARY DEFAULT (the cache-sized table: akp_ctx_set_table_budget 0); the pedersen and
+    # bh_merkle legs measure the HBM-sized tables (AKP_TABLE_BUDGET_DEVICE, opt-in) beside it on handles of their own, cold and warm
     cfg = cpa.get_default_poseidon_parameters(2, False)
     ph = cfg.handle(ctx)
     n = 1 << args.log2_states
     t = cfg.t
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def barrier():
+    from bench_legs.runner import LegRunner
+    runner = LegRunner(torch, dist, rank, world, "cpu" if shared_gpu else dev, sync_device=lambda: torch.cuda.synchronize(dev))
+
+
+    def barrier():  # the timed region's barrier: the process group's own
         torch.cuda.synchronize(dev)
         if dist:
             dist.barrier()
@@ -180,7 +181,7 @@ def main():
     env.args, env.np, env.torch, env.cpa, env.field, env.lib, env.check = args, np, torch, cpa, field, lib, check
     env.dev, env.ctx, env.stream, env.cfg, env.ph = dev, ctx, stream, cfg, ph
     env.rank, env.world, env.local_rank, env.dist, env.shared_gpu = rank, world, local_rank, dist, shared_gpu
-    env.barrier, env.max_over_ranks = barrier, max_over_ranks
+    env.barrier, env.max_over_ranks = runner.barrier, runner.max_over_ranks  # the legs' collectives carry the abort flag (bench_legs/runner.py)
     env.GpuPoseidonBackend, env.GpuTeBackend, env.build_sharded = GpuPoseidonBackend, GpuTeBackend, build_sharded
     env.ora_threads = max(1, min(32, (os.cpu_count() or 1)))
     env.bench_path = os.path.abspath(__file__)
@@ -197,11 +198,17 @@ def main():
         check(lib.akp_poseidon_permute_batch_dev(ph.h, d_states.data_ptr(), n, stream))
 
     # ================= side legs first: from an idle device the first launches run on ramping clocks =================
-    merkle = merkle_leg.run(env)        # BASELINE configs[2]
-    pedersen = ped_leg.run(env)         # BASELINE configs[3]
-    bh_merkle = bh_leg.run(env)         # BASELINE configs[4]
-    proofs = None                       # SURVEY.md 8(f) ranks 1-2 (+ rank 4: device-resident sponges); one process only
-    if args.proofs_log2 and world == 1 and rank == 0:
+    # every leg through runner.run: whatever a leg raises becomes `leg_errors[name]` and the run goes on to the headline (bench_legs/runner.py)
+    import gc
+
+    def leg_cleanup():
+        ctx.set_table_budget(0)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def proofs_leg():  # SURVEY.md 8(f) ranks 1-2 (+ rank 4: device-resident sponges); one process only
+        if not (args.proofs_log2 and world == 1 and rank == 0):
+            return None
         import bench_proofs
         proofs = {}
         for name in ("poseidon", "bh"):
@@ -212,19 +219,34 @@ def main():
         if not proofs["sponge"]["sampled_parity_bit_exact"]:
             raise SystemExit("sponge leg: sampled squeezes differ from the oracle")
         proofs["profiles"] = "profiles/r04_s4/proofs_poseidon_kernel_stats_walk*.csv, profiles/r03_s6/proofs_* (rocprofv3 --kernel-trace --stats of `python tools/bench_proofs.py`)"
-    ragged = ragged_leg.run(env)        # per-item lengths (the reference's per-leaf evaluate): one launch, lanes ordered by step count
-    sweep = sweep_leg.run(env, tuple(lg for lg in (20, 22, 24, 26) if lg <= max(20, args.sweep_max_log2))) if world == 1 else None
+        return proofs
+    merkle = runner.run("merkle", merkle_leg.run, env, cleanup=leg_cleanup)        # BASELINE configs[2]
+    pedersen = runner.run("pedersen", ped_leg.run, env, cleanup=leg_cleanup)       # BASELINE configs[3]
+    bh_merkle = runner.run("bh_merkle", bh_leg.run, env, cleanup=leg_cleanup)      # BASELINE configs[4]
+    proofs = runner.run("proofs", proofs_leg, cleanup=leg_cleanup)
+    ragged = runner.run("ragged", ragged_leg.run, env, cleanup=leg_cleanup)        # per-item lengths (the reference's per-leaf evaluate)
+    sweep = runner.run("sweep", lambda: sweep_leg.run(env, tuple(lg for lg in (20, 22, 24, 26) if lg <= max(20, args.sweep_max_log2))) if world == 1 else None,
+                       cleanup=leg_cleanup)
 
     # ================= the headline: W warm-up + K timed steps of the 2^20-state permutation ==========================
     parity = {"probe_kernel": lib.akp_poseidon_kernel_for(ph.h, n, 0).decode(), "timed_buffer_states_checked": 0, "bit_exact": None}
-    step()  # one pass outside W: its output is checked against the oracle on a strided sample of the TIMED buffer
-    torch.cuda.synchronize(dev)
+    step()  # one pass outside W (and outside K): its output is checked against the oracle -- the WHOLE timed buffer when this host has >= 8
+    torch.cuda.synchronize(dev)  # cores (2^20 permutations take the C oracle ~1-3 s there), a strided sample of it otherwise
     if rank == 0:
-        si = np.unique(np.concatenate([np.arange(128), np.linspace(0, n - 1, 385).astype(np.int64), np.arange(n - 128, n)]))
-        got = d_states[torch.from_numpy(si).to(dev)].cpu().numpy().view(np.uint64).reshape(len(si), t, 4)
-        exp = env.ora.permute_batch(np.ascontiguousarray(host_states[si]), threads=env.ora_threads).reshape(len(si), t, 4)
-        parity["timed_buffer_states_checked"] = int(len(si))
+        full_probe = (os.cpu_count() or 1) >= 8 and os.environ.get("AKP_BENCH_PROBE") != "sample"
+        if full_probe:
+            got = d_states.cpu().numpy().view(np.uint64).reshape(n, t, 4)
+            exp = env.ora.permute_batch(host_states, threads=env.ora_threads).reshape(n, t, 4)
+            checked = n
+        else:
+            si = np.unique(np.concatenate([np.arange(128), np.linspace(0, n - 1, 385).astype(np.int64), np.arange(n - 128, n)]))
+            got = d_states[torch.from_numpy(si).to(dev)].cpu().numpy().view(np.uint64).reshape(len(si), t, 4)
+            exp = env.ora.permute_batch(np.ascontiguousarray(host_states[si]), threads=env.ora_threads).reshape(len(si), t, 4)
+            checked = len(si)
+        parity["timed_buffer_states_checked"] = int(checked)
+        parity["of_states"] = int(n)
         parity["bit_exact"] = bool(np.array_equal(got, exp))
+        del got, exp
         if not parity["bit_exact"]:
             raise SystemExit("parity probe FAILED: the timed kernel's output differs from the oracle")
     # the oracle check above left the GPU idle for ~0.1 s and the clocks drop within milliseconds: settle them with untimed
@@ -268,8 +290,8 @@ def main():
     around = pre + post
     eff_mhz = sum(p["mhz"] for p in around) / len(around) if around else None
 
-    sustained = sus_leg.run(env, d_states, n, kern_avg_s)
-    host_path = host_leg.run(env, host_states, n)
+    sustained = runner.run("sustained", sus_leg.run, env, d_states, n, kern_avg_s, cleanup=leg_cleanup)
+    host_path = runner.run("host_path", host_leg.run, env, host_states, n, cleanup=leg_cleanup)
 
     if rank != 0:
         if dist:
@@ -278,7 +300,9 @@ def main():
         return
 
     from bench_legs import pin
-    pin_status = pin.status(attempt=True)  # runs the reference-vector emitter once if this box has cargo + the crates offline
+    # AKP_RUN_EMITTER=1: run the reference-vector emitter (`cargo run`, writes tests/golden/reference_vectors.json) if this box has cargo + the
+    # crates offline; without the switch only the presence of cargo and of the vectors is reported
+    pin_status = pin.status(attempt=os.environ.get("AKP_RUN_EMITTER") == "1")
     total_perms = n * world * args.steps
     value = total_perms / elapsed
     achieved = ALGO_BYTES_PER_PERM * n / kern_avg_s / 1e9
@@ -308,11 +332,11 @@ def main():
         "parity": parity,
         "curve_parity": pin_status[0],
         "curve_parity_emitter": pin_status[1],
-        "curve_tables": "warm curve-hash legs run with akp_ctx_set_table_budget(AKP_TABLE_BUDGET_DEVICE) (HBM-sized tables, opt-in); the library default is the "
-                        "cache-sized table: pedersen.tables / bh_merkle.tables hold cold-start and warm figures of both" if not shared_gpu else "library default (cache-sized)",
+        "curve_tables": "every leg runs with the library default (the cache-sized table, akp_ctx_set_table_budget 0); pedersen.tables / bh_merkle.tables hold "
+                        "cold-start and warm figures of the HBM-sized tables (AKP_TABLE_BUDGET_DEVICE, opt-in) beside it",
         "roofline": {"bound": "hbm", "kernel": parity["probe_kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_PERM * n,
-                     "traffic_source": PMC_TRAFFIC_SOURCE,
+                     "traffic_measured_in_this_run": False, "traffic_source": PMC_TRAFFIC_SOURCE,
                      "traffic_static_from": PMC_TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                             "correction; NOT measured in this run)",
                      "peak_measured_copy": hbm_copy_gbs, "frac_of_measured_copy": achieved / hbm_copy_gbs if hbm_copy_gbs else None,
@@ -337,25 +361,37 @@ def main():
                               "frac_of_mad_issue_peak": mad_rate / (valu_peak_wave_instr(eff_mhz or NOMINAL_SCLK_MHZ) * 64),
                               "frac_of_mad_issue_peak_at_nominal_2400mhz": mad_rate / (valu_peak_wave_instr() * 64),
                               "valu_instructions_per_permutation": 1224736768 // 16384, "valu_busy_percent": 97.8,
+                              "valu_counters_measured_in_this_run": False,
                               "valu_counters_static_from": "profiles/r05_s7/pmc_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy 97.8-97.9 on that box; 93.6-96.1 in rounds 3-4; NOT measured in this run)"}},
     }
     for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("proofs", proofs), ("host_path", host_path),
                      ("ragged", ragged), ("sweep", sweep)):
         if leg:
             out[key] = leg
-    if world == 1:
-        out["predicted_scaling"] = scaling.predict(merkle, bh_merkle)
-    elif args.merkle_log2 == 24 and args.bh_merkle_log2 == 23:
-        # N > 1: the model calibrated on the committed one-GPU line (profiles/r04_s14/bench.json), so that THIS run's measured tree times
-        # stand next to what the design implied for them
-        ref = scaling.predict({"leaves": 1 << 24, "seconds": 0.0656}, {"leaves_per_gpu": 1 << 23, "seconds": 0.0170})
-        key = "%d_gpus" % world
-        out["predicted_scaling"] = {"calibrated_on": "profiles/r04_s14/bench.json (one GPU: Poseidon 2^24 leaves 0.0656 s, Bowe-Hopwood 2^23 leaves 0.0170 s)",
-                                    "model": ref["model"],
-                                    "merkle_strong": {"predicted": ref["merkle_strong"].get(key), "measured_seconds": merkle["seconds"] if merkle else None},
-                                    "bh_merkle_weak": {"predicted": ref["bh_merkle_weak"].get(key), "measured_seconds": bh_merkle["seconds"] if bh_merkle else None}}
+
+    def predicted():
+        if world == 1:
+            return scaling.predict(merkle, bh_merkle)
+        if args.merkle_log2 == 24 and args.bh_merkle_log2 == 23:
+            # N > 1: the model calibrated on the committed one-GPU line (profiles/r04_s14/bench.json), so that THIS run's measured tree times
+            # stand next to what the design implied for them
+            ref = scaling.predict({"leaves": 1 << 24, "seconds": 0.0656}, {"leaves_per_gpu": 1 << 23, "seconds": 0.0170})
+            key = "%d_gpus" % world
+            return {"calibrated_on": "profiles/r04_s14/bench.json (one GPU: Poseidon 2^24 leaves 0.0656 s, Bowe-Hopwood 2^23 leaves 0.0170 s)",
+                    "model": ref["model"],
+                    "merkle_strong": {"predicted": ref["merkle_strong"].get(key), "measured_seconds": merkle["seconds"] if merkle else None},
+                    "bh_merkle_weak": {"predicted": ref["bh_merkle_weak"].get(key), "measured_seconds": bh_merkle["seconds"] if bh_merkle else None}}
+        return None
+    # rank 0 only from here on (the other ranks wait in the closing barrier): no collectives, so a failure cannot desynchronise anything
+    solo = LegRunner(torch, None, 0, 1, "cpu")
+    ps = solo.run("predicted_scaling", predicted)
+    if ps:
+        out["predicted_scaling"] = ps
     if not args.no_cpu_baseline and world == 1:
-        cpu_leg.run(env, out, host_states, n, value, pedersen, bh_merkle)
+        solo.run("cpu_baseline", cpu_leg.run, env, out, host_states, n, value, pedersen, bh_merkle)
+    errors = dict(runner.errors, **solo.errors)
+    out["legs_failed"] = sorted(errors)
+    out["leg_errors"] = errors
     # the full record goes to a file; stdout gets ONE short line (tools/bench_legs/line.py: < 6 KB, the driver parses its last line)
     full_path = os.environ.get("AKP_BENCH_FULL", os.path.join(ROOT, "bench_full.json"))
     with open(full_path, "w") as fh:

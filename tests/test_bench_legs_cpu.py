@@ -81,3 +81,108 @@ def test_compact_line_of_committed_full_records_is_short_and_complete():
     full.pop("cpu_baseline"), full.pop("gpu_over_cpu")
     full["n_gpus"] = 8
     assert line_mod.compact(full)["cpu_baseline"] is None
+
+
+# ---- a failing side leg must not void the headline: tools/bench_legs/runner.py ----------------------------------
+def test_leg_runner_single_process_catches_everything_a_leg_raises():
+    import torch
+    from bench_legs.runner import LegRunner
+    r = LegRunner(torch, None, 0, 1, "cpu")
+    assert r.run("fine", lambda x: {"v": x}, 3) == {"v": 3} and not r.errors
+
+    def exits():
+        raise SystemExit("parity check of this leg failed")
+
+    def oom():
+        raise MemoryError("hipErrorOutOfMemory")
+    cleaned = []
+    assert r.run("exits", exits, cleanup=lambda: cleaned.append(1)) is None
+    assert r.run("oom", oom) is None
+    assert r.run("after", lambda: 7) == 7  # the run goes on
+    assert sorted(r.errors) == ["exits", "oom"] and "SystemExit" in r.errors["exits"] and "MemoryError" in r.errors["oom"] and cleaned == [1]
+    os.environ["AKP_BENCH_FAIL_LEG"] = "pedersen"
+    try:
+        r2 = LegRunner(torch, None, 0, 1, "cpu")
+        assert r2.run("merkle", lambda: 1) == 1 and r2.run("pedersen", lambda: 2) is None and "injected" in r2.errors["pedersen"]
+    finally:
+        del os.environ["AKP_BENCH_FAIL_LEG"]
+
+
+RUNNER_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.path.join(%(root)r, "tools"))
+import torch, torch.distributed as dist
+from datetime import timedelta
+from bench_legs.runner import LegRunner
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+r = LegRunner(torch, dist, rank, world, "cpu")
+where, bad = os.environ["AKP_T_WHERE"], int(os.environ["AKP_T_RANK"])
+
+def leg(tag):  # the shape of a real leg: barrier, work, barrier, max over ranks, rank-0-only check at the end
+    r.barrier()
+    if tag == "B" and where == "mid" and rank == bad:
+        raise RuntimeError("rank %%d fell over between two barriers" %% rank)
+    r.barrier()
+    m = r.max_over_ranks(float(rank))
+    assert m == world - 1
+    if tag == "B" and where == "late" and rank == bad:
+        raise SystemExit("rank-local parity check after the last collective")
+    return {"leg": tag, "max": m}
+a = r.run("A", leg, "A")
+b = r.run("B", leg, "B")
+c = r.run("C", leg, "C")   # every rank must arrive here in step, whichever rank failed where in B
+assert a == {"leg": "A", "max": world - 1} and c == {"leg": "C", "max": world - 1}, (a, c)
+assert sorted(r.errors) == ["B"], r.errors
+if where == "mid":
+    assert b is None
+else:  # the failure came after the leg's last collective: the other ranks keep their result, and still name the leg as failed
+    assert (b is None) == (rank == bad)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok", json.dumps(r.errors))
+'''
+
+
+def _run_runner_world(world, where, bad):
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rk in range(world):
+        env = dict(os.environ, RANK=str(rk), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AKP_T_WHERE=where, AKP_T_RANK=str(bad))
+        procs.append(subprocess.Popen([sys.executable, "-c", RUNNER_WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for rk, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % rk) in o, "rank %d:\n%s" % (rk, o)
+
+
+def test_leg_runner_world2_gloo_one_rank_fails_between_barriers():
+    _run_runner_world(2, "mid", 1)
+
+
+def test_leg_runner_world4_gloo_rank0_fails_between_barriers():
+    _run_runner_world(4, "mid", 0)
+
+
+def test_leg_runner_world4_gloo_one_rank_fails_after_the_last_collective():
+    _run_runner_world(4, "late", 2)
+
+
+def test_compact_line_names_failed_legs_and_static_counters():
+    from bench_legs import line as line_mod
+    import glob
+    full = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_s*", "bench_full.json"))) + sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_s14", "bench.json"))):
+        try:
+            full = json.load(open(p))
+        except ValueError:
+            continue
+        if isinstance(full, dict) and "roofline" in full and "timed_buffer_states_checked" in full.get("parity", {}):
+            break
+    assert full
+    full.pop("pedersen", None)  # what a failed leg leaves behind: no object, an entry in leg_errors
+    full["leg_errors"] = {"pedersen": "RuntimeError: hipErrorOutOfMemory " + "x" * 500}
+    ln = line_mod.compact(full)
+    assert ln["legs_failed"] == ["pedersen"] and len(ln["leg_errors"]["pedersen"]) <= 160 and "pedersen_hashes_per_s" not in ln["legs"]
+    assert ln["roofline"]["traffic_measured_in_this_run"] is False
+    assert ln["value"] == full["value"] and len(json.dumps(ln)) < line_mod.LIMIT

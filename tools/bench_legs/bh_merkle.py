@@ -2,7 +2,7 @@
 scaling: 2^26 on 8 GPUs), ByteDigestConverter"""
 import time
 
-from .common import HBM_PEAK_GBS, MADS_PER_PRODUCT, PMC_TE, VALU_PEAK_WAVE_INSTR, te_counters
+from .common import HBM_PEAK_GBS, MADS_PER_PRODUCT, VALU_PEAK_WAVE_INSTR, te_counters, te_pmc
 
 
 def run(env):
@@ -52,19 +52,27 @@ def run(env):
                 "rec": {"group": hh.info()["digit_bits_or_group"], "table_bytes": hh.info(32)["table_bytes"], "steps_leaf": hh.info(32)["steps"],
                         "steps_inner": hh.info(64)["steps"], "cold_first_tree_ms": cold_ms, "warm_seconds": bsec, "warm_leaves_per_s": total / bsec}}
     cache = one_table(0)
-    hbm = one_table(TABLE_BUDGET_DEVICE) if not env.shared_gpu else None
-    main = hbm or cache
+    hbm = hbm_error = None
+    if not env.shared_gpu:
+        try:  # the opt-in tables are figures BESIDE the leg's own: if they cannot be built here (memory), the leg stands without them
+            hbm = one_table(TABLE_BUDGET_DEVICE)
+        except Exception as exc:  # noqa: BLE001
+            hbm_error = repr(exc)[:300]
+    main = cache  # `seconds`, `leaves_per_s` and `roofline` of this leg are the LIBRARY DEFAULT's; the HBM-sized tables stand beside them
     B, res, bsec, dev_ms = main["B"], main["res"], main["bsec"], main["dev_ms"]
     tables = {"cache_sized": cache["rec"], "library_default": "cache_sized (akp_ctx_set_table_budget 0 = 320 MiB)",
               "cold_first_tree_ms_means": "fresh handles: tables for the leaf and inner-node lengths + scratch allocation + one tree of %d leaves "
                                           "per GPU, host wall clock, max over ranks; the cache-sized handle is measured first and also pays the "
-                                          "context's first scratch allocation (and, at N > 1, the first collective)" % per,
-              "headline_table": "hbm_sized (opt-in: AKP_TABLE_BUDGET_DEVICE)" if hbm else "cache_sized"}
+                                          "context's first scratch allocation (and, at N > 1, the first collective).  With the HBM-sized budget the "
+                                          "first trees run on the cache-sized tables while the wide ones are built in the background" % per,
+              "headline_table": "cache_sized (the library default)"}
+    if hbm_error:
+        tables["hbm_sized_error"] = hbm_error
     if hbm:
         tables["hbm_sized"] = hbm["rec"]
         d_cold = (hbm["rec"]["cold_first_tree_ms"] - cache["rec"]["cold_first_tree_ms"]) / 1e3
         d_tree = cache["rec"]["warm_seconds"] - hbm["rec"]["warm_seconds"]
-        tables["break_even_trees"] = 1 + d_cold / d_tree if d_tree > 0 and d_cold > 0 else None
+        tables["break_even_trees"] = 1 + max(d_cold, 0.0) / d_tree if d_tree > 0 else None
     # configs[4] as ONE tree of 2^26 leaves on one GPU, from nothing, for both tables (generators of their own: nothing is built yet)
     if env.world == 1 and not env.shared_gpu and not args.no_sweep and args.sweep_max_log2 >= 26 and args.bh_merkle_log2 >= 20:
         big = 1 << 26
@@ -88,19 +96,21 @@ def run(env):
         del d_big
         torch.cuda.empty_cache()
     h = B.handle(env.ctx)
+    pmc = te_pmc(h.info(64)["table_bytes"])
     grp = h.info()["digit_bits_or_group"]
     # additions per inner node: the table steps of the 64 data bytes; the constant of the zero-padded tail (a zero chunk adds +g) is
     # folded into the remainder step when the 171 data chunks leave one (groups of 8: 21 + 1), else it is one more addition
     inner_adds = h.info(64)["steps"] + (0 if grp > 1 and 171 % grp else 1)
     bh_merkle = {"config": "BASELINE configs[4]: MerkleTree::new, Bowe-Hopwood 63x9 over Jubjub, 32-byte leaves, ByteDigestConverter",
                  "leaves": total, "leaves_per_gpu": per, "tables": tables, "seconds": bsec, "leaves_per_s": total / bsec, "scaling": "weak",
+                 "hbm_table_seconds": hbm["rec"]["warm_seconds"] if hbm else None,
                  "roofline": {"bound": "hbm", "kernels": "te_accumulate_lds_kernel<1> + te_finalize_kernel<1> + te_serialize_pairs_kernel per level",
                               "algorithmic_bytes_per_leaf": 160, "device_ms_per_build": dev_ms, "achieved": 160.0 * per / (dev_ms / 1e3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * per / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                               "table": h.info(32),
-                              "traffic": te_counters("bh_32B", per, h.info(32)["steps"])["traffic"] + te_counters("bh_70B", per - 1, inner_adds)["traffic"],
-                              "traffic_calibration": PMC_TE["calibration"] + " (FETCH_SIZE x 2 holds for random 128-byte-line gathers: x2 = 1.045 x the distinct line bytes)",
-                             "traffic_static_from": PMC_TE["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_lds_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
+                              "traffic": te_counters("bh_32B", per, h.info(32)["steps"], pmc)["traffic"] + te_counters("bh_70B", per - 1, inner_adds, pmc)["traffic"],
+                              "traffic_measured_in_this_run": False, "traffic_calibration": pmc["calibration"] + " (FETCH_SIZE x 2 holds for random 128-byte-line gathers: x2 = 1.045 x the distinct line bytes)",
+                             "traffic_static_from": pmc["source"] + " (FETCH_SIZE x 2 + WRITE_SIZE of te_accumulate_lds_kernel<1> + te_finalize_kernel<1> at 2^20 x 32 B "
                                                      "for the leaf level and 2^20 x 70 B scaled to the inner nodes' table steps; levels of <= 2^14 nodes run the split kernel; "
                                                      "NOT measured in this run)",
                               "valu": {"table_steps_per_leaf_hash": h.info(32)["steps"],

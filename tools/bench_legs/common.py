@@ -43,10 +43,25 @@ MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) 
 # last one dot2 + one product; no conversion products.
 
 
-def te_counters(key, hashes, steps=None):
-    """bytes / instructions for `hashes` hashes from the per-2^20 PMC figures; the gather-proportional parts are scaled to `steps`
-    table steps per hash when the run's table shape differs from the profiled one"""
-    c = PMC_TE[key]
+# the same kernels with the library's DEFAULT tables (cache-sized: 16-bit Pedersen digits, 64 steps; Bowe-Hopwood groups of 5: 18 steps per
+# 32-byte leaf, 36 per inner node) -- profiles/r05_s7/pmc_te.txt.  FETCH_SIZE counts the Infinity Cache's hits as well: for these tables
+# `traffic` is what crosses the fabric into the L2, most of it served by the 256 MiB cache, not by HBM.
+PMC_TE_DEFAULT = {"source": "profiles/r05_s7/pmc_te.txt", "calibration": PMC_TE["calibration"],
+                  "pedersen_128B": {"fetch_kb": 3777575 + 164640, "write_kb": 147490 + 114832, "valu_instr": 1545830000 + 48292900, "steps": 64},
+                  "bh_32B": {"fetch_kb": 883960 + 163455, "write_kb": 147576 + 81920, "valu_instr": 426050000 + 39591900, "steps": 18},
+                  "bh_70B": {"fetch_kb": 1937305 + 164866, "write_kb": 147525 + 81920, "valu_instr": 921133000 + 39591900, "steps": 36}}
+
+
+def te_pmc(table_bytes):
+    """the PMC record that belongs to a handle's table: the HBM-sized one above 1 GiB, else the cache-sized default"""
+    return PMC_TE if table_bytes and table_bytes > (1 << 30) else PMC_TE_DEFAULT
+
+
+def te_counters(key, hashes, steps=None, pmc=None):
+    """bytes / instructions for `hashes` hashes from the per-2^20 PMC figures of `pmc` (PMC_TE: HBM-sized tables, the default here for the
+    callers of round 5; PMC_TE_DEFAULT: cache-sized); the gather-proportional parts are scaled to `steps` table steps per hash when the
+    run's table shape differs from the profiled one"""
+    c = (pmc or PMC_TE)[key]
     steps_scale = 1.0 if steps is None else steps / float(c["steps"])
     per = hashes / float(1 << 20)
     return {"traffic": (2.0 * c["fetch_kb"] * steps_scale + c["write_kb"]) * 1024.0 * per, "valu_instr": c["valu_instr"] * steps_scale * per}

@@ -34,11 +34,12 @@ def compact(full, full_name="bench_full.json"):
     line["data"] = full["data"]
     line["config"] = {k: full["config"][k] for k in ("workload", "states_per_gpu", "parallelism")}
     par = full["parity"]
-    line["parity"] = {"bit_exact": par["bit_exact"], "states_checked": par["timed_buffer_states_checked"], "kernel": par["probe_kernel"]}
+    line["parity"] = {"bit_exact": par["bit_exact"], "states_checked": par["timed_buffer_states_checked"], "of_states": par.get("of_states"), "kernel": par["probe_kernel"]}
     line["curve_parity"] = full["curve_parity"].split(":")[0][:160]
     line["curve_parity_emitter"] = (full.get("curve_parity_emitter") or "")[:120]
     line["roofline"] = {"bound": rf["bound"], "kernel": rf["kernel"], "achieved": _r(rf["achieved"]), "peak": rf["peak"], "unit": rf["unit"],
-                        "frac": _r(rf["achieved"] / rf["peak"]), "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
+                        "frac": _r(rf["achieved"] / rf["peak"]), "traffic": rf.get("traffic"), "traffic_measured_in_this_run": bool(rf.get("traffic_measured_in_this_run", False)),
+                        "traffic_source": rf.get("traffic_source"),
                         "kernel_avg_ms": _r(rf["kernel_avg_ms"]), "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
                         "effective_sclk_mhz": _r(rf.get("effective_sclk_mhz")), "frac_of_mad_issue_peak": _r(valu.get("frac_of_mad_issue_peak"))}
     cb = full.get("cpu_baseline")
@@ -55,22 +56,24 @@ def compact(full, full_name="bench_full.json"):
         "merkle_s": _get(full, "merkle", "seconds"),                       # configs[2]: 2^24 Poseidon leaves, all ranks
         "merkle_leaves_per_s": _get(full, "merkle", "leaves_per_s"),
         "merkle_hbm_frac": _get(full, "merkle", "hbm_frac"),
-        "pedersen_hashes_per_s": _get(full, "pedersen", "hashes_per_s"),   # configs[3], warm
+        "pedersen_hashes_per_s": _get(full, "pedersen", "hashes_per_s"),   # configs[3], warm, the library's default (cache-sized) table
+        "pedersen_hbm_table_hashes_per_s": _get(full, "pedersen", "tables", "hbm_sized", "warm_hashes_per_s"),   # opt-in: AKP_TABLE_BUDGET_DEVICE
         "pedersen_hbm_frac": _get(full, "pedersen", "roofline", "frac"),
         "pedersen_moved_frac_of_hbm_peak": _get(full, "pedersen", "roofline", "moved_frac_of_hbm_peak"),  # counter traffic (calibrated, profiles/r05_s6) / 8 TB/s
-        "pedersen_default_table_hashes_per_s": _get(full, "pedersen", "tables", "cache_sized", "warm_hashes_per_s"),
         "pedersen_cold_first_call_ms": _get(full, "pedersen", "tables", "cache_sized", "cold_first_call_ms"),          # library default, from nothing
         "pedersen_cold_first_call_ms_hbm_table": _get(full, "pedersen", "tables", "hbm_sized", "cold_first_call_ms"),
+        "pedersen_hbm_table_ready_after_ms": _get(full, "pedersen", "tables", "hbm_sized", "upgrade_ready_after_ms"),
         "pedersen_break_even_hashes": _get(full, "pedersen", "tables", "break_even_hashes"),
         "bh_leaves": _get(full, "bh_merkle", "leaves"),
-        "bh_s": _get(full, "bh_merkle", "seconds"),                        # configs[4] share: 2^23 leaves per GPU, warm
+        "bh_s": _get(full, "bh_merkle", "seconds"),                        # configs[4] share: 2^23 leaves per GPU, warm, the library's default tables
+        "bh_hbm_table_s": _get(full, "bh_merkle", "tables", "hbm_sized", "warm_seconds"),                               # opt-in
         "bh_leaves_per_s": _get(full, "bh_merkle", "leaves_per_s"),
         "bh_hbm_frac": _get(full, "bh_merkle", "roofline", "frac"),
         "bh_moved_frac_of_hbm_peak": _get(full, "bh_merkle", "roofline", "moved_frac_of_hbm_peak"),
-        "bh_default_table_s": _get(full, "bh_merkle", "tables", "cache_sized", "warm_seconds"),
         "bh_cold_first_tree_ms": _get(full, "bh_merkle", "tables", "cache_sized", "cold_first_tree_ms"),                # library default, from nothing
         "bh_cold_first_tree_ms_hbm_table": _get(full, "bh_merkle", "tables", "hbm_sized", "cold_first_tree_ms"),
-        "bh_2p26_s": _get(full, "sweep", "points", "2^26", "bh_tree_ms"),                                               # ONE GPU, warm, hbm table
+        "bh_hbm_table_ready_after_ms": _get(full, "bh_merkle", "tables", "hbm_sized", "upgrade_ready_after_ms"),
+        "bh_2p26_s": _get(full, "sweep", "points", "2^26", "bh_tree_ms"),                                               # ONE GPU, warm, default tables
         "bh_2p26_cold_s": _get(full, "bh_merkle", "tables", "single_tree_2p26_one_gpu", "cache_sized", "cold_first_tree_s"),
         "bh_2p26_cold_s_hbm_table": _get(full, "bh_merkle", "tables", "single_tree_2p26_one_gpu", "hbm_sized", "cold_first_tree_s"),
         "ragged_bh_hashes_per_s": _get(full, "ragged", "bowe_hopwood_63x9", "hashes_per_s"),          # 2^20 items of 0 .. 64 bytes, one launch
@@ -93,6 +96,10 @@ def compact(full, full_name="bench_full.json"):
     if scal["bh_2p26_s"] is not None:
         scal["bh_2p26_s"] /= 1e3
     line["legs"] = {k: _r(v) for k, v in scal.items() if v is not None}
+    errs = full.get("leg_errors") or {}
+    line["legs_failed"] = sorted(errs)  # a failed side leg does not void the headline: it is named here, its scalars are absent above
+    if errs:
+        line["leg_errors"] = {k: str(v)[:160] for k, v in sorted(errs.items())[:8]}
     line["launch"] = {"ranks": _get(full, "launch", "ranks"), "backend": _get(full, "launch", "backend")}
     line["full"] = full_name
     s = json.dumps(line)
