@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AKP_LIB", os.path.join(_HERE, "lib", "libakp.so"))
 
 AKP_OK, AKP_ERR_BAD_LENGTH, AKP_ERR_BAD_PARAMS, AKP_ERR_HIP, AKP_ERR_RCCL, AKP_ERR_NOT_POW2 = 0, 1, 2, 3, 4, 5
-AKP_ABI_VERSION = 4
+AKP_ABI_VERSION = 5
 TE_PEDERSEN, TE_BOWE_HOPWOOD, TE_PEDERSEN_X = 0, 1, 2
 
 
@@ -21,6 +21,20 @@ class AkpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"akp error {code}: {msg}")
         self.code = code
+
+
+class TeBuildReport(C.Structure):
+    """akp_te_build_report (include/akp.h): phases of the last build / extension of a handle's wide curve table"""
+    _fields_ = [("table_bytes", C.c_uint64), ("shape", C.c_uint32), ("units_from", C.c_uint32), ("units_to", C.c_uint32), ("units_total", C.c_uint32),
+                ("in_background", C.c_uint32), ("upgrade_state", C.c_uint32), ("alloc_ms", C.c_double), ("parts_ms", C.c_double), ("combine_ms", C.c_double),
+                ("constants_ms", C.c_double), ("total_ms", C.c_double), ("note", C.c_char * 96)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["note"] = self.note.decode(errors="replace")
+        d["upgrade"] = {0: "single table", 1: "wide table pending (hashing on the cache-sized one)", 2: "hashing on the wide table",
+                        3: "wide table could not be built (staying on the cache-sized one)"}.get(self.upgrade_state, "?")
+        return d
 
 
 class IncorrectInputLength(AkpError):
@@ -94,7 +108,7 @@ def _load():
         "akp_te_params_info": (i32, [vp, vp, vp, vp, sz, vp]),
         "akp_te_params_prepare": (i32, [vp, sz]),
         "akp_te_params_prepare_compress": (i32, [vp]),
-        "akp_te_params_table_info": (i32, [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64)]),
+        "akp_te_params_table_info": (i32, [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64), C.POINTER(TeBuildReport)]),
         "akp_te_entry_bytes": (u32, []),
         "akp_te_crh_batch": (i32, [vp, u8p, sz, sz, u64p]),
         "akp_te_crh_batch_dev": (i32, [vp, u8p, sz, sz, u64p, vp]),

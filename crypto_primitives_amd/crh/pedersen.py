@@ -83,10 +83,29 @@ class _TeHandle:
 
     def table_info(self):
         """the shared table behind this handle (akp_te_params_table_info): id (equal for handles that share), handles attached,
-        wide-table builds so far"""
-        tid, refs, builds = C.c_uint64(), C.c_uint32(), C.c_uint64()
-        check(lib.akp_te_params_table_info(self.h, C.byref(tid), C.byref(refs), C.byref(builds)))
-        return {"table_id": tid.value, "handles_attached": refs.value, "wide_builds": builds.value}
+        wide-table builds so far, and the phases of the last build (`last_build`: allocation / part tables / combine kernel /
+        constants in ms, whether it ran in the background, `upgrade_state`)"""
+        from .._lib import TeBuildReport
+        tid, refs, builds, rep = C.c_uint64(), C.c_uint32(), C.c_uint64(), TeBuildReport()
+        check(lib.akp_te_params_table_info(self.h, C.byref(tid), C.byref(refs), C.byref(builds), C.byref(rep)))
+        return {"table_id": tid.value, "handles_attached": refs.value, "wide_builds": builds.value, "last_build": rep.as_dict()}
+
+    def wait_for_wide_table(self, msg_len=None, compress=False, timeout_s=30.0):
+        """a handle created under a table budget above the default starts on the cache-sized table while the wide one is built in
+        the background: poll (without blocking the builder) until calls for this length use the wide table; returns seconds waited,
+        or None if the handle has a single table / the wide one could not be built"""
+        import time
+        t0 = time.perf_counter()
+        while True:
+            st = self.table_info()["last_build"]["upgrade_state"]
+            if st in (0, 3):
+                return None
+            if st == 2:
+                self.prepare(msg_len, compress)  # (complete for another length, perhaps: this makes it so for the one asked for)
+                return time.perf_counter() - t0
+            if time.perf_counter() - t0 > timeout_s:
+                raise TimeoutError("the wide table was not ready after %.0f s" % timeout_s)
+            time.sleep(0.002)
 
     def __del__(self):
         try:

@@ -28,18 +28,7 @@ AKP_HD void store_fr_global(Fr* p, const Fr& v) {
 struct alignas(128) NielsPad {
     u32 w[32];
 };
-// Packed alternative (round 3 A/B, `make packed96`): the three values as CANONICAL 256-bit integers (8 dwords each, no
-// padding) = 96 bytes.  The 16-bit signed Pedersen table shrinks from 268 MB to 201 MB -- inside the 256 MB Infinity Cache --
-// and an entry is six 16-byte loads instead of seven, at the price of re-limbing 3 x 256 bits into 3 x 9 limbs of 29 bits in
-// registers (~50 VALU instructions per step) and of entries that straddle two 128-byte lines.  Canonical values are
-// non-negative with limbs < 2^29: they satisfy every operand bound the 128-byte form does.
-struct alignas(32) Niels96 {
-    u32 w[24];
-};
-#if defined(AKP_TE_PACKED96)
-typedef Niels96 TeEntry;
-#else
+// (a packed 96-byte entry was measured in round 3 and lost: profiles/HISTORY.md)
 typedef NielsPad TeEntry;
-#endif
 
 }  // namespace akp

@@ -89,10 +89,6 @@ extern "C" void akp_ctx_destroy(akp_ctx* c) {
     }
     for (int i = 0; i < 8; ++i)
         if (c->chunk_event[i]) (void)hipEventDestroy(c->chunk_event[i]);
-    for (int i = 0; i < 2; ++i) {
-        if (c->te_event[i]) (void)hipEventDestroy(c->te_event[i]);
-        c->te_event[i] = nullptr;
-    }
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->gate_flags) (void)hipFree(c->gate_flags);
     if (c->gate_done) (void)hipHostFree(c->gate_done);

@@ -10,12 +10,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #pragma GCC visibility push(default)
@@ -56,7 +58,6 @@ struct akp_ctx {
     // more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
     hipStream_t pipe[7] = {};
     hipEvent_t chunk_event[8] = {};  // copy-stream -> compute-stream hand-over of leaf chunks (host_tree_build)
-    hipEvent_t te_event[2] = {};     // AKP_TE_SPLIT_FINALIZE build arm: hand-over to / from the side stream of the finalize pass
     // where the last host-pointer tree build left its inner nodes (heap order, `last_tree_nodes` digests): what the
     // multi-device build reads for the all-gather of the sub-roots and the per-device copy-outs -- an explicit hand-over
     // instead of a convention about scratch slots
@@ -74,7 +75,10 @@ struct akp_ctx {
     u32* gate_done_dev = nullptr;  // its device alias
     size_t gate_done_cap = 0;
     u32 gate_epoch = 0;
-    bool gate_unavailable = false;  // an allocation / hipStreamWriteValue32 failed once: the chunked launches from then on
+    bool gate_unavailable = false;  // STRUCTURAL: an allocation / hipStreamWriteValue32 failed -- this stack cannot gate: the chunked launches from then on
+    // a gated launch that TIMED OUT (another context's long kernel held the device, say) is not structural: the batch is repeated through
+    // the chunked launches, the next `gate_skip` pinned calls take them too, then the gate is tried again (8, 16, ... 1024 calls)
+    u32 gate_skip = 0, gate_timeouts = 0;
     // HBM one precomputed curve table may take (akp_ctx_set_table_budget); 0: 320 MiB (cache-sized tables); AKP_TABLE_BUDGET_DEVICE: a
     // quarter of the device's memory, at most half of what is free
     size_t table_budget = 0;
@@ -245,9 +249,10 @@ int32_t launch_verify_paths_t3(akp_poseidon* leafp, akp_poseidon* two, const Fr*
 // rayon worker borrows the same one (crh/mod.rs:22, merkle_tree/mod.rs:417,458,494); here every worker thread has a context of its
 // own, so the tables -- up to 46 / 75 GB -- cannot belong to a handle: handles created with the same generators, window and table
 // shape on contexts of the same device ATTACH to one TeTable (process-wide store in capi_te.hip, reference-counted; the last handle
-// frees it).  `mu` serialises everything that reads or changes the table's pointers with the kernel launches that use them: a
-// launch is enqueued under the lock, an extension (free + rebuild) drains the device under the lock -- every launch that could
-// still read the old table was enqueued before the drain, whichever context or stream it came from.
+// frees it).  `mu` serialises everything that reads or changes the table's pointers with the kernel launches that use them.
+// Round 6: NOTHING a launch may have been given is freed while a handle is attached -- an extended table and superseded constants
+// are retired, not freed -- so a graph captured after akp_te_params_prepare stays valid whatever other handles of the same table hash
+// later, and no extension drains the device.
 struct TeTable {
     std::mutex mu;
     int device = 0;
@@ -291,13 +296,30 @@ struct TeTable {
     u32 key_shape = 0;               // the shape it was created with (a narrowed table leaves the store: its shape no longer says what was asked)
     std::vector<uint64_t> gens;      // host copy of the generators (key comparison; 64 KB for a 4x256 window)
     uint64_t builds = 0;             // wide-table builds so far (akp_te_params_table_info: a test can see that eight handles built once)
+    // creation (te_store_attach): the table enters the store as a placeholder and is initialised under ITS lock, not the store's
+    bool initialised = false;
+    int32_t init_rc = 0;
+    std::string init_err;
+    std::vector<void*> retired;                // device blocks superseded while handles were attached (an extended table, constants of a narrowed
+                                               // shape): a launch -- or a captured graph -- may still read them; freed with the table
+    // builds of this table run on streams of its own (never behind a caller's work): `build_stream` for a build some caller waits for,
+    // `bg_stream` (lowest priority) for the background upgrade; `active_stream`: the one the current holder of `mu` builds on
+    hipStream_t build_stream = nullptr, bg_stream = nullptr, active_stream = nullptr;
+    // background build of an HBM-sized table (te_upgrade_kick): the thread that is building or built last, whether one is running, what went wrong
+    std::thread builder;
+    std::atomic<bool> building{false};
+    std::atomic<bool> upgrade_failed{false};
+    std::string upgrade_error;
+    akp_te_build_report last_build{};          // phases of the last build / extension of the wide table (akp_te_params_table_info)
 };
 struct akp_te_params {
     akp_ctx* ctx = nullptr;
     int kind = 0;
     u32 W = 0, N = 0;
     u32 n_gen = 0;             // W * N flat generators
-    TeTable* t = nullptr;      // shared with every handle of the same parameters on this device
+    TeTable* t = nullptr;      // shared with every handle of the same parameters on this device: the table this handle was created with
+                               // -- or, when the context's table budget admits a wider one, the CACHE-SIZED table it starts hashing on
+    TeTable* wide = nullptr;   // ... and the HBM-sized table that takes over once it is built (in the background, or by akp_te_params_prepare)
     int pins = 0;              // as akp_poseidon::pins
     bool destroy_pending = false;
 };

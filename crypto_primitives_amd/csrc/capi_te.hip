@@ -16,20 +16,39 @@
 // 49 -> 57 us per 2^20 hashes, and there are fewer of them --
 //   Pedersen 4x256, 2^20 x 128 B:  D = 16 / 20 / 22 / 24:  3.16 / 2.84 / 2.62 / 2.43 ms  (268 MB / 3.5 / 12.6 / 46 GB)
 //   Bowe-Hopwood 63x9, 2^20 x 64 B: G = 5 / 6 / 7 / 8:     1.81 / 1.73 / 1.57 / 1.44 ms  (237 MB / 1.6 / 10.9 / 75 GB)
-// The width is therefore the widest the context's TABLE BUDGET admits (akp_ctx_set_table_budget; default: a quarter of the
-// device's memory, at most half of what is free -- 72 GiB on an idle MI355X), or the explicit shape of
-// akp_te_params_create_shaped.  Digits up to 24 bits / groups up to 8 chunks: 25-bit digits (the 32-bit message window of a step
-// would admit them: 41 steps, 88 GB) were measured SLOWER, 2.65 against 2.41 ms -- a digit's region of the table is then 2 GB
-// and the gather leaves the TLB reach (64.6 against 55.9 us per step; profiles/r04_s10/digit25_rejected.txt, gather_probe.txt).
-static size_t te_table_budget(const akp_ctx* ctx) {
-    if (ctx->table_budget && ctx->table_budget != AKP_TABLE_BUDGET_DEVICE) return ctx->table_budget;
-    if (!ctx->table_budget) return (size_t)320 << 20;  // the default: tables that stay inside the 256 MiB Infinity Cache and build in milliseconds
+// The width is the widest the context's TABLE BUDGET admits (akp_ctx_set_table_budget; default 320 MiB = the cache-sized tables), or the
+// explicit shape of akp_te_params_create_shaped.  Digits up to 24 bits / groups up to 8 chunks: 25-bit digits (the 32-bit message
+// window of a step would admit them: 41 steps, 88 GB) were measured SLOWER, 2.65 against 2.41 ms -- a digit's region of the table is
+// then 2 GB and the gather leaves the TLB reach (64.6 against 55.9 us per step; profiles/r04_s10/digit25_rejected.txt, gather_probe.txt).
+//
+// Round 6 -- who pays for a wide table, and when (profiles/r06_s1 .. r06_s7).  The kernels of a 46 GB build take 62 ms, but the ALLOCATION is
+// not ours to bound: the first 46 GB taken from VRAM nobody had used since the box came up cost 1.2 s (the driver's BENCH_r05 and
+// profiles/r06_s1; 0.3 ms on every later lease of the same machine), and a hipMalloc that follows a large hipFree waits for the kernel
+// driver's wipe of the released memory (4 s after freeing 128 GB, ~35 GB/s: tools/vram_probe.hip) -- while launches of OTHER threads go on
+// undisturbed (worst 0.8 ms during a 4 s stall).  Hence:
+//   * a handle whose BUDGET admits a table wider than the default starts on the cache-sized table (built in ~1 ms on the caller's thread,
+//     as always) and a thread of the library allocates and builds the wide one on a stream of its own; calls switch when it is complete
+//     (te_pick).  akp_te_params_prepare is the blocking form.  Explicit shapes (akp_te_params_create_shaped) are built by the caller, as
+//     before: that caller asked for exactly this table.
+//   * nothing a launch may have been given is freed while a handle is attached: an extension allocates the new table, builds it and RETIRES
+//     the old one (as superseded constants are), to be freed with the table object.  A graph captured after `prepare` stays valid
+//     (ADVICE r05), and the free-then-allocate of round 5's extension -- exactly the pattern that stalls -- is gone.
+static size_t te_device_quarter() {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
         (void)hipGetLastError();
         return (size_t)320 << 20;
     }
-    return std::max<size_t>(std::min(total_b / 4, free_b / 2), (size_t)64 << 20);
+    return std::max<size_t>(total_b / 4, (size_t)64 << 20);
+}
+constexpr size_t TE_DEFAULT_BUDGET = (size_t)320 << 20;  // tables that stay inside the 256 MiB Infinity Cache and build in milliseconds
+// the budget a handle's SHAPE is derived from: a function of the setting and the device, not of the memory that happens to be free at
+// this moment (two workers creating the same parameters must file them under the same shape; whether the table fits is decided when it
+// is built -- te_ensure_table narrows it or gives the upgrade up)
+static size_t te_table_budget(const akp_ctx* ctx) {
+    if (!ctx->table_budget) return TE_DEFAULT_BUDGET;
+    if (ctx->table_budget != AKP_TABLE_BUDGET_DEVICE) return ctx->table_budget;
+    return te_device_quarter();
 }
 extern "C" int32_t akp_ctx_set_table_budget(akp_ctx* ctx, size_t bytes) {
     if (!ctx) return fail(AKP_ERR_BAD_PARAMS, "NULL context");
@@ -44,44 +63,93 @@ extern "C" size_t akp_ctx_table_budget(const akp_ctx* ctx) {
 constexpr u32 TE_MAX_DIGIT = te_shape::MAX_DIGIT, TE_MAX_GROUP = te_shape::MAX_GROUP;
 static inline size_t te_pedersen_entries(size_t n_gen, u32 D) { return te_shape::pedersen_entries(n_gen, D); }
 static inline size_t te_bh_entries(size_t n_gen, u32 G) { return te_shape::bh_entries(n_gen, G); }
-// two-part construction of a wide table (te_kernels.hpp): part tables entry by entry, then one addition per wide entry.
-// KIND 2: Pedersen signed-subset table of `units` W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of
-// `units` groups of W chunks, generators `src`.
+static inline double te_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- storage of the wide table -------------------------------------------------------------------------------------------------
+// A hipMalloc of the current coverage; an extension allocates the new coverage, builds ALL of it and RETIRES the old block (launches
+// already enqueued -- or captured into a graph -- may still read it: it is freed with the table, when no handle is left).  To bound what
+// retiring costs, a table is extended at most once: the first build covers what the first messages need, the second covers everything
+// (te_ensure_table).
+// (Measured and not used, profiles/r06_s2, r06_s8: the virtual-memory API -- one reserved range, physical memory mapped as the table
+// grows, so that an extension would build only the new units in place.  Gathers from a mapped range run at the hipMalloc rate (8.65 G
+// lines/s) and 46 GB tables built fine, but hipMemSetAccess on the second piece of a range failed with "invalid argument" for some
+// range sizes on this stack (tools/vmm2_probe.hip) and one probe run ended in a GPU memory fault: not something to put under every
+// hash of a library.)
+static hipError_t te_storage_grow(TeTable* t, size_t bytes) {
+    TeEntry* fresh = nullptr;
+    const hipError_t e = hipMalloc(&fresh, bytes);
+    if (e != hipSuccess) return e;
+    if (t->d_lut) t->retired.push_back(t->d_lut);
+    t->d_lut = fresh;
+    return hipSuccess;
+}
+// the block just allocated could not be filled: back to the previous one (units_built still describes it)
+static void te_storage_undo(TeTable* t) {
+    if (t->d_lut) (void)hipFree(t->d_lut);
+    t->d_lut = nullptr;
+    if (!t->retired.empty()) {
+        t->d_lut = (TeEntry*)t->retired.back();
+        t->retired.pop_back();
+    }
+}
+// a narrowed shape gives its table up (te_narrow): kept until the table object goes, like everything a launch may have been given
+static void te_storage_retire(TeTable* t) {
+    if (t->d_lut) t->retired.push_back(t->d_lut);
+    t->d_lut = nullptr;
+    t->units_built = 0;
+}
+
+// two-part construction of a wide table (te_kernels.hpp): part tables entry by entry (for ALL units up to `units`: kilobytes to
+// megabytes, < 0.5 ms), then one addition per wide entry of the units [from, units).
+// KIND 2: Pedersen signed-subset table of W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of groups of W chunks.
 template <int KIND>
-static hipError_t te_build_wide(akp_ctx* ctx, const void* src, u32 n_gen, u32 W, u32 units, TeEntry* lut, size_t entries) {
+static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u32 from, u32 units, akp_te_build_report* rep) {
+    hipStream_t bs = t->active_stream;
     const u32 k_lo = KIND == 2 ? (W - 1) / 2 : W / 2;
+    const u32 unit_shift = KIND == 2 ? W - 1 : 3 * W - 1;
     const size_t n_lo = KIND == 2 ? (size_t)units << k_lo : (size_t)units << (3 * k_lo - 1);
     const size_t n_hi = KIND == 2 ? (size_t)units << (W - 1 - k_lo) : (size_t)units << (3 * (W - k_lo));
+    const size_t first = (size_t)from << unit_shift, entries = (size_t)units << unit_shift;
     TeEntry *lo = nullptr, *hi = nullptr;
+    double t0 = te_now_ms();
     hipError_t e = hipMalloc(&lo, n_lo * sizeof(TeEntry));
     if (e == hipSuccess) e = hipMalloc(&hi, n_hi * sizeof(TeEntry));
+    rep->alloc_ms += te_now_ms() - t0;
     if (e == hipSuccess) {
+        t0 = te_now_ms();
         const unsigned pgrid = (unsigned)((n_lo + n_hi + 63) / 64);
         if (KIND == 2)
-            hipLaunchKernelGGL(te_build_pedersen_sparts, dim3(pgrid), dim3(64), 0, ctx->stream, (const NielsPad*)src, n_gen, W, units, k_lo, lo, hi);
+            hipLaunchKernelGGL(te_build_pedersen_sparts, dim3(pgrid), dim3(64), 0, bs, (const NielsPad*)src, n_gen, W, units, k_lo, lo, hi);
         else
-            hipLaunchKernelGGL(te_build_bh_parts, dim3(pgrid), dim3(64), 0, ctx->stream, (const Fr*)src, W, k_lo, units, lo, hi);
-        const unsigned cgrid = (unsigned)((entries + 256 * AKP_TE_BUILD_RUN - 1) / (256 * AKP_TE_BUILD_RUN));
-        hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), 0, ctx->stream, lo, hi, W, k_lo, entries, lut);
+            hipLaunchKernelGGL(te_build_bh_parts, dim3(pgrid), dim3(64), 0, bs, (const Fr*)src, W, k_lo, units, lo, hi);
         e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(bs);
+        rep->parts_ms += te_now_ms() - t0;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) {
+        t0 = te_now_ms();
+        const unsigned cgrid = (unsigned)((entries - first + 256 * AKP_TE_BUILD_RUN - 1) / (256 * AKP_TE_BUILD_RUN));
+        hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), 0, bs, lo, hi, W, k_lo, first, entries, t->d_lut);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(bs);
+        rep->combine_ms += te_now_ms() - t0;
+    }
 #if defined(AKP_TEST_HOOKS)
-    // AKP_TE_TABLE_CHECK=k: every k-th entry of the table against the per-entry definition
+    // AKP_TE_TABLE_CHECK=k: every k-th entry of the table (ALL units, also those an extension left in place) against the per-entry definition
     const size_t step = env_size("AKP_TE_TABLE_CHECK", 0);
     if (e == hipSuccess && step) {
         u32* d_bad = nullptr;
         u32 bad = 0;
         e = hipMalloc(&d_bad, sizeof(u32));
-        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), bs);
         if (e == hipSuccess) {
             const size_t cnt = (entries + step - 1) / step;
-            hipLaunchKernelGGL(te_check_table_kernel<KIND>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, src, n_gen, W, entries, (size_t)0, step,
-                    lut, d_bad);
+            hipLaunchKernelGGL(te_check_table_kernel<KIND>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, bs, src, n_gen, W, entries, (size_t)0, step,
+                    t->d_lut, d_bad);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, bs);
+        if (e == hipSuccess) e = hipStreamSynchronize(bs);
         if (d_bad) (void)hipFree(d_bad);
         if (e == hipSuccess && bad) {
             fprintf(stderr, "akp: AKP_TE_TABLE_CHECK: %u of the sampled table entries differ from the per-entry definition\n", bad);
@@ -89,17 +157,34 @@ static hipError_t te_build_wide(akp_ctx* ctx, const void* src, u32 n_gen, u32 W,
         }
     }
 #endif
-    if (lo) (void)hipFree(lo);
+    if (lo) (void)hipFree(lo);  // (never handed to a launch outside this function: the stream is drained)
     if (hi) (void)hipFree(hi);
     return e;
 }
 // ---- the process-wide table store (TeTable, capi_internal.hpp) ---------------------------------------------------------------
 static std::mutex g_store_mu;
 static std::vector<TeTable*> g_store;
+static std::vector<TeTable*> g_all_tables;  // every live table (also those that left the store): the exit hook joins their builders
+static void te_join_builders_at_exit() {
+    // a build thread that is still allocating when the process exits would meet a runtime that is being torn down: wait for it
+    std::vector<TeTable*> all;
+    {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        all = g_all_tables;
+    }
+    for (TeTable* t : all)
+        if (t->builder.joinable()) t->builder.join();
+}
 static void te_table_free(TeTable* t) {  // refs == 0: no handle, no launch can name it any more
+    if (t->builder.joinable()) t->builder.join();
+    {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        g_all_tables.erase(std::remove(g_all_tables.begin(), g_all_tables.end(), t), g_all_tables.end());
+    }
     (void)hipSetDevice(t->device);
     (void)hipDeviceSynchronize();
     if (t->d_lut) (void)hipFree(t->d_lut);
+    for (void* p : t->retired) (void)hipFree(p);
     if (t->d_lut1) (void)hipFree(t->d_lut1);
     if (t->d_gens) (void)hipFree(t->d_gens);
     if (t->d_half) (void)hipFree(t->d_half);
@@ -107,6 +192,8 @@ static void te_table_free(TeTable* t) {  // refs == 0: no handle, no launch can 
         if (t->tails[i].d) (void)hipFree(t->tails[i].d);
     for (int i = 0; i < t->n_rem; ++i)
         if (t->rem[i].d) (void)hipFree(t->rem[i].d);
+    if (t->build_stream) (void)hipStreamDestroy(t->build_stream);
+    if (t->bg_stream) (void)hipStreamDestroy(t->bg_stream);
     delete t;
 }
 static void te_table_release(TeTable* t) {
@@ -119,13 +206,22 @@ static void te_table_release(TeTable* t) {
     te_table_free(t);
 }
 // everything a fresh table needs before its first hash: kilobytes and a few small kernels (the wide table itself is built by
-// te_ensure_table for the message lengths that arrive or that akp_te_params_prepare names)
-static hipError_t te_table_init(akp_ctx* ctx, TeTable* t, const uint64_t* gens, u32 shape, size_t budget) {
+// te_ensure_table for the message lengths that arrive or that akp_te_params_prepare names).  Caller holds t->mu.
+static hipError_t te_table_init(TeTable* t, const uint64_t* gens, u32 shape, size_t budget) {
     const size_t n_gen = t->n_gen;
     constexpr size_t max_entries = (size_t)1 << 32;  // entry indices are 32-bit in the kernels
     Fr* d_g = nullptr;
-    hipError_t e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
+    // builds a CALLER waits for run on `build_stream` (default priority); the background upgrade uses `bg_stream` (lowest priority: it
+    // yields the compute units to the hashing it runs beside) -- `active_stream` is whichever the thread that holds t->mu builds on
+    hipError_t e = hipStreamCreateWithFlags(&t->build_stream, hipStreamNonBlocking);
+    t->active_stream = t->build_stream;
+    hipStream_t bs = t->build_stream;
+    if (e == hipSuccess) e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (d_g) (void)hipFree(d_g);
+        return e;
+    }
     if (t->pedersen) {
         // Signed-subset table (te_kernels.hpp): needs every generator in the prime-order subgroup (checked on the device: 2 (G/2) == G),
         // stores 2^(D-1) entries per digit.  The plain table stays as the fallback for generators outside the subgroup; as an A/B
@@ -141,14 +237,13 @@ static hipError_t te_table_init(akp_ctx* ctx, TeTable* t, const uint64_t* gens, 
         if (!force_plain) {
             if (e == hipSuccess) e = hipMalloc(&d_half, n_gen * sizeof(NielsPad));
             if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(u32));
-            if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), bs);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(te_halve_generators, dim3((unsigned)((n_gen + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
-                        d_half, d_bad);
+                hipLaunchKernelGGL(te_halve_generators, dim3((unsigned)((n_gen + 63) / 64)), dim3(64), 0, bs, d_g, (u32)n_gen, d_half, d_bad);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, bs);
+            if (e == hipSuccess) e = hipStreamSynchronize(bs);
         }
         if (e == hipSuccess && bad == 0) {
             const u32 D = shape;
@@ -159,11 +254,11 @@ static hipError_t te_table_init(akp_ctx* ctx, TeTable* t, const uint64_t* gens, 
             t->units_total = (u32)n_digits;
             if (e == hipSuccess) e = hipMalloc(&t->d_lut1, (n_digits + 1) * sizeof(TeEntry));
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_half,
-                        (u32)n_gen, D, (u32)n_digits, t->d_lut1);
+                hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, bs, d_half, (u32)n_gen, D,
+                        (u32)n_digits, t->d_lut1);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(bs);
             t->d_half = d_half;
             d_half = nullptr;
         } else if (e == hipSuccess) {
@@ -175,8 +270,7 @@ static hipError_t te_table_init(akp_ctx* ctx, TeTable* t, const uint64_t* gens, 
             const size_t entries = ((n_gen + D - 1) / D) << D;
             e = hipMalloc(&t->d_lut, entries * sizeof(TeEntry));
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
-                        D, (u32)entries, t->d_lut);
+                hipLaunchKernelGGL(te_build_pedersen_lut, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, bs, d_g, (u32)n_gen, D, (u32)entries, t->d_lut);
                 e = hipGetLastError();
             }
         }
@@ -187,8 +281,7 @@ static hipError_t te_table_init(akp_ctx* ctx, TeTable* t, const uint64_t* gens, 
         if (G > 1 && te_bh_entries(n_gen, G) >= max_entries) e = hipErrorInvalidValue;
         if (e == hipSuccess) e = hipMalloc(&t->d_lut1, n_gen * 4 * sizeof(TeEntry));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, ctx->stream, d_g, (u32)n_gen,
-                    t->d_lut1);
+            hipLaunchKernelGGL(te_build_bh_lut, dim3((unsigned)((n_gen * 4 + 63) / 64)), dim3(64), 0, bs, d_g, (u32)n_gen, t->d_lut1);
             e = hipGetLastError();
         }
         if (G > 1) t->units_total = (u32)(n_gen / G);
@@ -196,9 +289,71 @@ static hipError_t te_table_init(akp_ctx* ctx, TeTable* t, const uint64_t* gens, 
         t->d_gens = d_g;  // kept: the group table and the remainder tables of later message lengths are built from them
         d_g = nullptr;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(bs);
     if (d_g) (void)hipFree(d_g);
     return e;
+}
+// The table of (device, kind, window, generators, shape): found in the store or entered as a PLACEHOLDER and initialised under its own
+// lock -- the store's lock is held for the lookup only, so creating handles of unrelated parameters (or on other devices) never waits
+// for device work, and two threads asking for the same parameters at the same moment still end up with ONE table (the second waits on
+// the table's lock until the first has initialised it).
+static int32_t te_store_attach(akp_ctx* ctx, bool ped, u32 W, u32 N, const uint64_t* gens, u32 key_shape, bool shape_auto, size_t budget, TeTable** out) {
+    const size_t n_gen = (size_t)W * N, words = n_gen * 8;
+    TeTable* t = nullptr;
+    bool mine = false;
+    std::unique_lock<std::mutex> init_lock;
+    {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        for (TeTable* c : g_store)
+            if (c->device == ctx->device && c->pedersen == ped && c->W == W && c->N == N && c->key_shape == key_shape && c->shape_auto == shape_auto &&
+                c->gens.size() == words && memcmp(c->gens.data(), gens, words * sizeof(uint64_t)) == 0) {
+                t = c;
+                break;
+            }
+        if (!t) {
+            t = new TeTable();
+            t->device = ctx->device; t->pedersen = ped; t->W = W; t->N = N; t->n_gen = (u32)n_gen;
+            t->shape_auto = shape_auto; t->key_shape = key_shape;
+            t->gens.assign(gens, gens + words);
+            t->in_store = true;
+            g_store.push_back(t);
+            static bool exit_hook = false;
+            if (!exit_hook) {
+                exit_hook = true;
+                std::atexit(te_join_builders_at_exit);
+            }
+            g_all_tables.push_back(t);
+            mine = true;
+            init_lock = std::unique_lock<std::mutex>(t->mu);  // taken before the store lock goes: nobody sees the placeholder unlocked
+        }
+        ++t->refs;
+    }
+    if (mine) {
+        const hipError_t e = te_table_init(t, gens, key_shape, budget);
+        t->initialised = true;
+        if (e != hipSuccess) {
+            t->init_rc = AKP_ERR_HIP;
+            t->init_err = hipGetErrorString(e);
+            (void)hipGetLastError();
+        }
+        init_lock.unlock();
+    } else {
+        std::lock_guard<std::mutex> wait_init(t->mu);
+    }
+    if (t->init_rc) {
+        const std::string why = t->init_err;
+        {
+            std::lock_guard<std::mutex> lk(g_store_mu);  // a table that failed to initialise is not offered again
+            if (t->in_store) {
+                g_store.erase(std::remove(g_store.begin(), g_store.end(), t), g_store.end());
+                t->in_store = false;
+            }
+        }
+        te_table_release(t);
+        return fail(AKP_ERR_HIP, "akp_te_params_create: %s", why.c_str());
+    }
+    *out = t;
+    return AKP_OK;
 }
 extern "C" void akp_te_params_destroy(akp_te_params* p);
 extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t W, uint32_t N, const uint64_t* gens, uint32_t shape,
@@ -225,41 +380,28 @@ extern "C" int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint3
     const bool ped = kind != AKP_TE_BOWE_HOPWOOD;
     const bool shape_auto = shape == 0;
     const size_t budget = te_table_budget(ctx);
-    // the shape the table is filed under: what was asked for, or what the budget admits at this moment
-    u32 key_shape = ped ? (shape ? std::max(shape, 2u) : te_shape::pick_digit(n_gen, budget, sizeof(TeEntry)))
-                        : (shape ? shape : te_shape::pick_group(n_gen, budget, sizeof(TeEntry)));
+    auto shape_for = [&](size_t b) {
+        u32 k = ped ? te_shape::pick_digit(n_gen, b, sizeof(TeEntry)) : te_shape::pick_group(n_gen, b, sizeof(TeEntry));
+        if (!ped && n_gen < k) k = (u32)n_gen;
+        return k;
+    };
+    // the shape the table is filed under: what was asked for, or what the budget admits
+    u32 key_shape = shape ? (ped ? std::max(shape, 2u) : shape) : shape_for(budget);
     if (!ped && n_gen < key_shape) key_shape = (u32)n_gen;
+    // a budget above the default: the handle starts on the cache-sized table and moves to the wide one when that is complete
+    const u32 start_shape = shape_auto ? shape_for(std::min(budget, TE_DEFAULT_BUDGET)) : key_shape;
     akp_te_params* p = new akp_te_params();
     p->ctx = ctx; p->kind = kind; p->W = W; p->N = N; p->n_gen = (u32)n_gen;
-    const size_t words = n_gen * 8;
-    {
-        // creation is serialised process-wide: two threads that ask for the same parameters at the same moment must end up with ONE
-        // table, and a fresh table costs kilobytes and microseconds (the wide table is built later, under the table's own lock)
-        std::lock_guard<std::mutex> lk(g_store_mu);
-        for (TeTable* t : g_store)
-            if (t->device == ctx->device && t->pedersen == ped && t->W == W && t->N == N && t->key_shape == key_shape && t->shape_auto == shape_auto &&
-                t->gens.size() == words && memcmp(t->gens.data(), gens, words * sizeof(uint64_t)) == 0) {
-                ++t->refs;
-                p->t = t;
-                break;
-            }
-        if (!p->t) {
-            TeTable* t = new TeTable();
-            t->device = ctx->device; t->pedersen = ped; t->W = W; t->N = N; t->n_gen = (u32)n_gen;
-            t->shape_auto = shape_auto; t->key_shape = key_shape;
-            t->gens.assign(gens, gens + words);
-            const hipError_t e = te_table_init(ctx, t, gens, key_shape, budget);
-            if (e != hipSuccess) {
-                const std::string why = hipGetErrorString(e);
-                (void)hipGetLastError();
-                te_table_free(t);
-                delete p;
-                return fail(AKP_ERR_HIP, "akp_te_params_create: %s", why.c_str());
-            }
-            t->refs = 1;
-            t->in_store = true;
-            g_store.push_back(t);
-            p->t = t;
+    if (int32_t rc = te_store_attach(ctx, ped, W, N, gens, start_shape, shape_auto, std::min(budget, TE_DEFAULT_BUDGET), &p->t)) {
+        delete p;
+        return rc;
+    }
+    // (a Pedersen table over generators outside the prime-order subgroup is the plain one: nothing wider exists for it)
+    if (shape_auto && key_shape > start_shape && !(ped && !p->t->signed_subset)) {
+        if (int32_t rc = te_store_attach(ctx, ped, W, N, gens, key_shape, shape_auto, budget, &p->wide)) {
+            te_table_release(p->t);
+            delete p;
+            return rc;
         }
     }
     ++ctx->live_handles;
@@ -279,7 +421,8 @@ extern "C" void akp_te_params_destroy(akp_te_params* p) {
         p->destroy_pending = true;
         return;
     }
-    te_table_release(p->t);  // the tables go with the LAST handle attached to them (device drained first)
+    te_table_release(p->wide);  // the tables go with the LAST handle attached to them (a running build is waited for, the device drained)
+    te_table_release(p->t);
     ctx_handle_released(p->ctx);
     delete p;
 }
@@ -307,45 +450,6 @@ static size_t te_table_bytes(const TeTable* t) {
     }
     return entries * sizeof(TeEntry);
 }
-extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset, size_t* table_bytes,
-        size_t msg_len,
-                                      uint32_t* steps) {
-    if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_info: params is NULL");
-    TeTable* t = p->t;
-    std::lock_guard<std::mutex> lk(t->mu);
-    const bool ped = t->pedersen;
-    if (digit_bits_or_group) *digit_bits_or_group = ped ? t->digit_bits : t->group;
-    if (signed_subset) *signed_subset = ped && t->signed_subset ? 1 : 0;
-    if (table_bytes) *table_bytes = te_table_bytes(t);
-    if (steps) {
-        u32 g = 0, st = 0;
-        te_steps(t, msg_len, &g, &st);
-        if (!ped && t->group > 1 && st > g) st = g + 1;  // the chunks after the last full group are one step (te_bh_remainder)
-        *steps = st;
-    }
-    return AKP_OK;
-}
-extern "C" int32_t akp_te_params_table_info(const akp_te_params* p, uint64_t* table_id, uint32_t* handles_attached, uint64_t* wide_builds) {
-    if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_table_info: params is NULL");
-    TeTable* t = p->t;
-    if (table_id) *table_id = (uint64_t)(uintptr_t)t;
-    if (handles_attached) {
-        std::lock_guard<std::mutex> lk(g_store_mu);
-        *handles_attached = (uint32_t)t->refs;
-    }
-    if (wide_builds) {
-        std::lock_guard<std::mutex> lk(t->mu);
-        *wide_builds = t->builds;
-    }
-    return AKP_OK;
-}
-// accumulate + finalize on device buffers.  scratch: SCR_E (xyz), SCR_F (prefix)
-// `data_len` <= msg_len: the bytes [data_len, msg_len) of every message are known to be zero (the padding of a two-to-one
-// buffer, crh/bowe_hopwood/mod.rs:219-224) and are not read.  Pedersen: zero bits select nothing, the sum simply stops
-// earlier.  Bowe-Hopwood: a zero chunk still adds +g (:167), so the chunks that lie wholly in the padding contribute the
-// CONSTANT sum of their generators: one table entry (computed once per shape, te_bh_tail_kernel) added at the end instead
-// of one table step per five chunks -- a 63 x 9 inner node (64 bytes of digests in a 70-byte buffer) takes 35 + 1 steps
-// instead of 39.
 // workgroup size of te_accumulate_lds_kernel for messages of data_len bytes at a pitch of `stride`: the largest whose LDS image
 // fits 40 KB (128-byte pitch: 256 messages = 33.8 KB, four workgroups per CU); 0 = pitch above 640 bytes or an empty / padded
 // message: the per-lane global loads of te_accumulate_kernel.  A/B of the two kernels on resident messages
@@ -377,24 +481,31 @@ struct TePipe {
     hipStream_t cin, side;
     hipEvent_t ev_in, ev_acc;
 };
-// Table work on the slow path (build / extend / remainder / tail constant) allocates, drains the device and waits: legal from any
-// entry point EXCEPT while the caller's stream is being captured into a graph -- there the caller must have prepared the table
-// (akp_te_params_prepare) before capture began.
-static int32_t te_slow_path_allowed(hipStream_t s, const char* what) {
+// Table work (build / extend / remainder / tail constant) allocates and waits: legal from any entry point EXCEPT while the caller's
+// stream is being captured into a graph -- there the caller must have prepared the table (akp_te_params_prepare) before capture began.
+static bool te_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) {
         (void)hipGetLastError();
-        return AKP_OK;
+        return false;
     }
-    if (st == hipStreamCaptureStatusActive)
+    return st == hipStreamCaptureStatusActive;
+}
+// how a call may treat a table that lacks something: build it (and wait), or report TE_NOT_READY (the caller falls back to the
+// cache-sized table of the handle)
+enum TeBuild { TE_LOOK = 0, TE_BUILD = 1 };
+constexpr int32_t TE_NOT_READY = -1;  // internal: never returned through the C ABI
+static int32_t te_missing(TeBuild mode, hipStream_t s, const char* what) {
+    if (mode == TE_LOOK) return TE_NOT_READY;
+    if (te_capturing(s))
         return fail(AKP_ERR_BAD_PARAMS, "%s needs a table that is not built and the stream is being captured: call akp_te_params_prepare before the capture", what);
     return AKP_OK;
 }
-// A table whose shape came from the table budget narrows it when the device cannot hold the table after all (other tables
-// were created or built in the meantime): one bit / one chunk less, everything that depends on the shape rebuilt.  The narrowed
-// table leaves the store (its shape no longer says what a new handle with this budget would get); the handles attached keep it.
-// Caller holds t->mu and has drained the device.
-static hipError_t te_narrow(akp_ctx* c, TeTable* t) {
+// A table whose shape came from the table budget narrows it when the device cannot hold the table after all: one bit / one chunk
+// less, everything that depends on the shape rebuilt (the old constants and the old range are RETIRED: a launch may hold them).  The
+// narrowed table leaves the store (its shape no longer says what a new handle with this budget would get); the handles attached keep it.
+// Caller holds t->mu.
+static hipError_t te_narrow(TeTable* t) {
     {
         std::lock_guard<std::mutex> lk(g_store_mu);
         if (t->in_store) {
@@ -402,51 +513,49 @@ static hipError_t te_narrow(akp_ctx* c, TeTable* t) {
             t->in_store = false;
         }
     }
+    te_storage_retire(t);
     if (t->pedersen) {
         const u32 D = --t->digit_bits;
         const size_t n_digits = ((size_t)t->n_gen + D - 1) / D;
         t->units_total = (u32)n_digits;
-        if (t->d_lut1) (void)hipFree(t->d_lut1);
+        if (t->d_lut1) t->retired.push_back(t->d_lut1);
         t->d_lut1 = nullptr;
         hipError_t e = hipMalloc(&t->d_lut1, (n_digits + 1) * sizeof(TeEntry));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, c->stream, t->d_half, t->n_gen, D,
+        hipLaunchKernelGGL(te_build_pedersen_cprefix, dim3((unsigned)((n_digits + 1 + 63) / 64)), dim3(64), 0, t->active_stream, t->d_half, t->n_gen, D,
                 (u32)n_digits, t->d_lut1);
         e = hipGetLastError();
-        return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+        return e == hipSuccess ? hipStreamSynchronize(t->active_stream) : e;
     }
     --t->group;
     t->units_total = t->n_gen / t->group;
     for (int i = 0; i < t->n_rem; ++i)
-        if (t->rem[i].d) (void)hipFree(t->rem[i].d);  // their first chunk follows the group size
+        if (t->rem[i].d) t->retired.push_back(t->rem[i].d);  // their first chunk follows the group size
     t->n_rem = 0;
     return hipSuccess;
 }
-// The wide table covers the digits / chunk groups [0, units_built); a message that needs more extends it: the old table is
-// released (after the device has drained: launches already enqueued on any stream of any context may still read it -- they were
-// all enqueued under t->mu, which the caller holds) and a new one is built for max(needed, twice the old coverage) units -- 0.1 s
-// for the 46 GB of a whole 4x256 table, milliseconds for the cache-sized default or the prefix a tree's 32- and 64-byte nodes use.
-// Happens once or twice in the life of a table; every other call only enqueues.  Returns the table steps of a data_len-byte
-// message (te_steps) for the shape the table ends up with.  `c`: the calling handle's context (its stream runs the build).
-static int32_t te_ensure_table(akp_ctx* c, TeTable* t, size_t data_len, u32* groups, u32* steps, hipStream_t s) {
+// The wide table covers the digits / chunk groups [0, units_built); a message that needs more extends it IN PLACE: the units
+// [units_built, target) are mapped behind the existing ones and built (target = max(needed, twice the old coverage): messages of slowly
+// growing length extend O(log) times); nothing is moved, freed or drained.  62 ms of kernel time for the 46 GB of a whole 4x256 table,
+// milliseconds for the cache-sized default or the prefix a tree's 32- and 64-byte nodes use -- plus whatever the allocation costs on this
+// box at this moment (the comment at the top).  Returns the table steps of a data_len-byte message (te_steps) for the shape the table ends
+// up with.  Caller holds t->mu; the build runs on the table's own stream and is complete when this returns.
+static int32_t te_ensure_table(TeTable* t, size_t data_len, u32* groups, u32* steps, hipStream_t s, TeBuild mode, bool background = false) {
     const bool ped = t->pedersen;
     for (;;) {
         te_steps(t, data_len, groups, steps);
         const u32 needed = ped ? *steps : *groups;
         if (needed <= t->units_built || (ped ? !t->signed_subset : t->group <= 1)) return AKP_OK;  // (plain table / single chunks: complete)
-        if (int32_t rc = te_slow_path_allowed(s, "the curve hash")) return rc;
+        if (int32_t rc = te_missing(mode, s, "the curve hash")) return rc;
         const u32 shape = ped ? t->digit_bits : t->group;
         const bool can_narrow = t->shape_auto && shape > (ped ? 8u : 2u);
         auto bytes_of = [&](u32 units) { return ((size_t)units << (ped ? shape - 1 : 3 * shape - 1)) * sizeof(TeEntry); };
-        u32 target = te_shape::grow_target(needed, t->units_built, t->units_total);
-        if (t->d_lut) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(t->d_lut));
-            t->d_lut = nullptr;
-            t->units_built = 0;
-        }
+        // the first build covers what this message needs, an extension everything (the old block is retired, not freed: at most once)
+        u32 target = t->builds ? t->units_total : te_shape::grow_target(needed, t->units_built, t->units_total);
+        akp_te_build_report rep{};
+        const double t_begin = te_now_ms();
         hipError_t e = hipSuccess;
-        if (t->shape_auto) {  // the rule of creation, applied to what is about to be built: at most half of what is free now
+        if (t->shape_auto) {  // at most half of what is free now
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 if (bytes_of(target) > free_b / 2) target = needed;
@@ -455,24 +564,33 @@ static int32_t te_ensure_table(akp_ctx* c, TeTable* t, size_t data_len, u32* gro
                 (void)hipGetLastError();
             }
         }
-        if (e == hipSuccess) e = hipMalloc(&t->d_lut, bytes_of(target));
+        double t0 = te_now_ms();
+        if (e == hipSuccess) e = te_storage_grow(t, bytes_of(target));
+        const bool grown = e == hipSuccess;
+        rep.alloc_ms = te_now_ms() - t0;
         if (e == hipErrorOutOfMemory && can_narrow) {
             (void)hipGetLastError();
-            t->d_lut = nullptr;
-            HIP_TRY(hipDeviceSynchronize());  // the constants / remainder tables of the old shape may be in use
-            e = te_narrow(c, t);
+            e = te_narrow(t);
             if (e == hipSuccess) continue;
         }
         if (e == hipSuccess)
-            e = ped ? te_build_wide<2>(c, t->d_half, t->n_gen, t->digit_bits, target, t->d_lut, bytes_of(target) / sizeof(TeEntry))
-                    : te_build_wide<1>(c, t->d_gens, t->n_gen, t->group, target, t->d_lut, bytes_of(target) / sizeof(TeEntry));
+            e = ped ? te_build_wide<2>(t, t->d_half, t->n_gen, t->digit_bits, 0, target, &rep)
+                    : te_build_wide<1>(t, t->d_gens, t->n_gen, t->group, 0, target, &rep);
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            if (t->d_lut) (void)hipFree(t->d_lut);
-            t->d_lut = nullptr;
+            if (grown) te_storage_undo(t);
             return fail(AKP_ERR_HIP, "curve table of %zu MB (%u of %u %s): %s -- lower akp_ctx_set_table_budget and create the handle again",
                     bytes_of(target) >> 20, target, t->units_total, ped ? "digits" : "chunk groups", hipGetErrorString(e));
         }
+        const u32 from = 0;
+        rep.table_bytes = bytes_of(target);
+        rep.shape = shape;
+        rep.units_from = from;
+        rep.units_to = target;
+        rep.units_total = t->units_total;
+        rep.in_background = background ? 1u : 0u;
+        rep.total_ms = te_now_ms() - t_begin;
+        t->last_build = rep;
         t->units_built = target;
         ++t->builds;
         return AKP_OK;
@@ -484,7 +602,7 @@ static int32_t te_ensure_table(akp_ctx* c, TeTable* t, size_t data_len, u32* gro
 // milliseconds).  *out stays NULL when the table's slots are taken or memory is short: the chunks are then single steps
 // from the one-chunk table and the tail its own addition, as before round 4.  A 63x9 tree node of 64 data bytes is 21 + 1
 // additions instead of 21 + 3 + 1 with groups of eight, a 32-byte leaf 10 + 1 instead of 10 + 6.  Caller holds t->mu.
-static int32_t te_bh_remainder(akp_ctx* c, TeTable* t, u32 first, u32 r, u32 tail_from, u32 tail_to, const TeEntry** out, hipStream_t s) {
+static int32_t te_bh_remainder(TeTable* t, u32 first, u32 r, u32 tail_from, u32 tail_to, const TeEntry** out, hipStream_t s, TeBuild mode) {
     *out = nullptr;
     if (tail_from >= tail_to) tail_from = tail_to = 0;
     for (int i = 0; i < t->n_rem; ++i)
@@ -493,22 +611,24 @@ static int32_t te_bh_remainder(akp_ctx* c, TeTable* t, u32 first, u32 r, u32 tai
             return AKP_OK;
         }
     if (t->n_rem == TeTable::MAX_REMAINDERS || !t->d_gens) return AKP_OK;
-    if (int32_t rc = te_slow_path_allowed(s, "the Bowe-Hopwood hash of a new message shape")) return rc;
+    if (int32_t rc = te_missing(mode, s, "the Bowe-Hopwood hash of a new message shape")) return rc;
+    const double t0 = te_now_ms();
+    hipStream_t bs = t->active_stream;
     const size_t entries = (size_t)1 << (3 * r);
     TeEntry *d = nullptr, *d_t = nullptr;
     hipError_t e = hipMalloc(&d, entries * sizeof(TeEntry));
     if (e == hipSuccess && tail_from < tail_to) {
         e = hipMalloc(&d_t, sizeof(TeEntry));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, c->stream, t->d_lut1, tail_from, tail_to, d_t);
+            hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, bs, t->d_lut1, tail_from, tail_to, d_t);
             e = hipGetLastError();
         }
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(te_build_bh_remainder, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, c->stream, t->d_gens, first, r, d_t, (u32)entries, d);
+        hipLaunchKernelGGL(te_build_bh_remainder, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, bs, t->d_gens, first, r, d_t, (u32)entries, d);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(bs);
     if (d_t) (void)hipFree(d_t);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -517,28 +637,28 @@ static int32_t te_bh_remainder(akp_ctx* c, TeTable* t, u32 first, u32 r, u32 tai
         return fail(AKP_ERR_HIP, "Bowe-Hopwood remainder table: %s", hipGetErrorString(e));
     }
     t->rem[t->n_rem++] = TeTable::Remainder{first, r, tail_from, tail_to, d};
+    t->last_build.constants_ms += te_now_ms() - t0;
     *out = d;
     return AKP_OK;
 }
 // Bowe-Hopwood: the constant of the zero-padded tail chunks [from, to) as ONE entry (shapes without a remainder table); one entry per
 // shape, computed once and never rewritten.  Caller holds t->mu.
-static int32_t te_bh_tail(akp_ctx* c, TeTable* t, u32 from, u32 to, const TeEntry** out, hipStream_t s) {
+static int32_t te_bh_tail(TeTable* t, u32 from, u32 to, const TeEntry** out, hipStream_t s, TeBuild mode) {
     for (int i = 0; i < t->n_tails; ++i)
         if (t->tails[i].from == from && t->tails[i].to == to) {
             *out = t->tails[i].d;
             return AKP_OK;
         }
-    if (int32_t rc = te_slow_path_allowed(s, "the Bowe-Hopwood hash of a new two-to-one shape")) return rc;
-    if (t->n_tails == TeTable::MAX_TAILS) {  // more shapes than slots (no real parameter set does this): start over once the device has drained
-        HIP_TRY(hipDeviceSynchronize());
-        for (int i = 0; i < t->n_tails; ++i) (void)hipFree(t->tails[i].d);
+    if (int32_t rc = te_missing(mode, s, "the Bowe-Hopwood hash of a new two-to-one shape")) return rc;
+    if (t->n_tails == TeTable::MAX_TAILS) {  // more shapes than slots (no real parameter set does this): the old entries are retired (128 bytes each)
+        for (int i = 0; i < t->n_tails; ++i) t->retired.push_back(t->tails[i].d);
         t->n_tails = 0;
     }
     TeEntry* d = nullptr;
     HIP_TRY(hipMalloc(&d, sizeof(TeEntry)));
-    hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, c->stream, t->d_lut1, from, to, d);
+    hipLaunchKernelGGL(te_bh_tail_kernel, dim3(1), dim3(64), 0, t->active_stream, t->d_lut1, from, to, d);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->active_stream);
     if (e != hipSuccess) {
         (void)hipFree(d);
         return fail(AKP_ERR_HIP, "Bowe-Hopwood tail constant: %s", hipGetErrorString(e));
@@ -548,20 +668,23 @@ static int32_t te_bh_tail(akp_ctx* c, TeTable* t, u32 from, u32 to, const TeEntr
     return AKP_OK;
 }
 // What one launch needs from the table for messages of msg_len bytes of which the first data_len carry data: built on demand
-// (slow path) or looked up.  Caller holds t->mu and keeps it until the kernels that use these pointers are enqueued.
+// (TE_BUILD) or looked up (TE_LOOK: TE_NOT_READY when something is missing).  Caller holds t->mu and keeps it until the kernels that
+// use these pointers are enqueued.  `want_rem` false: the ragged kernels take left-over chunks as single steps (no remainder table,
+// no tail: every item has its own length).
 struct TeResolved {
+    TeTable* t = nullptr;
     u32 shape = 0, groups = 0, steps = 0;
     const TeEntry *lut = nullptr, *lut1 = nullptr, *tail = nullptr;
 };
-static int32_t te_resolve(akp_te_params* p, size_t msg_len, size_t data_len, hipStream_t s, TeResolved* r) {
-    TeTable* t = p->t;
-    akp_ctx* c = p->ctx;
-    if (int32_t rc = te_ensure_table(c, t, data_len, &r->groups, &r->steps, s)) return rc;
+static int32_t te_resolve(TeTable* t, size_t msg_len, size_t data_len, hipStream_t s, TeResolved* r, TeBuild mode, bool want_rem = true, bool background = false) {
+    if (int32_t rc = te_ensure_table(t, data_len, &r->groups, &r->steps, s, mode, background)) return rc;
     // what the kernels call D: the digit width, or the chunks per group with the size of the remainder step above it (te_bh_rem)
+    r->t = t;
     r->shape = t->pedersen ? t->digit_bits : t->group;
     r->lut = t->d_lut;
     r->lut1 = t->d_lut1;
     r->tail = nullptr;
+    if (!want_rem) return AKP_OK;
     u32 tail_from = 0, tail_to = 0;
     if (!t->pedersen && data_len < msg_len) {
         tail_from = (u32)std::min<size_t>((data_len * 8 + 2) / 3, t->n_gen);
@@ -570,7 +693,7 @@ static int32_t te_resolve(akp_te_params* p, size_t msg_len, size_t data_len, hip
     bool tail_folded = false;
     if (!t->pedersen && t->group > 1 && r->steps > r->groups) {  // chunks after the last full group: one step, tail included
         const TeEntry* rem = nullptr;
-        if (int32_t rc = te_bh_remainder(c, t, t->group * r->groups, r->steps - r->groups, tail_from, tail_to, &rem, s)) return rc;
+        if (int32_t rc = te_bh_remainder(t, t->group * r->groups, r->steps - r->groups, tail_from, tail_to, &rem, s, mode)) return rc;
         if (rem) {
             r->shape |= (r->steps - r->groups) << 8;
             r->lut1 = rem;
@@ -579,26 +702,93 @@ static int32_t te_resolve(akp_te_params* p, size_t msg_len, size_t data_len, hip
         }
     }
     if (tail_from < tail_to && !tail_folded)
-        if (int32_t rc = te_bh_tail(c, t, tail_from, tail_to, &r->tail, s)) return rc;
+        if (int32_t rc = te_bh_tail(t, tail_from, tail_to, &r->tail, s, mode)) return rc;
     return AKP_OK;
 }
-// akp_te_params_prepare: build now what hashing msg_len-byte messages will need, at a time of the host's choosing
+// ---- the background upgrade ----------------------------------------------------------------------------------------------------
+// One build at a time per table: whoever finds the wide table lacking what its call needs starts the thread (if none is running) and
+// hashes on the cache-sized table meanwhile; a request that arrives while a build runs is dropped -- the next call of that shape asks
+// again.  The thread holds the table's lock for the whole build: callers TRY the lock (te_pick) and take the cache-sized table when it
+// is held.  A failed build (memory) marks the table: no further attempts, the handles stay where they are.
+static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool want_rem) {
+    if (w->upgrade_failed.load()) return;
+    bool idle = false;
+    if (!w->building.compare_exchange_strong(idle, true)) return;
+    if (w->builder.joinable()) w->builder.join();  // the previous build has ended (`building` was false): only its thread object is left
+    w->builder = std::thread([w, msg_len, data_len, want_rem] {
+        (void)hipSetDevice(w->device);
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            if (!w->bg_stream) {
+                int lo_prio = 0, hi_prio = 0;
+                if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
+                    hipStreamCreateWithPriority(&w->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
+                    (void)hipGetLastError();
+                    w->bg_stream = nullptr;
+                }
+            }
+            if (w->bg_stream) w->active_stream = w->bg_stream;
+            TeResolved r;
+            if (te_resolve(w, msg_len, data_len, w->active_stream, &r, TE_BUILD, want_rem, true) != AKP_OK) {
+                w->upgrade_error = akp_last_error();  // (this thread's: nobody else would see it)
+                w->upgrade_failed.store(true);
+            }
+            w->active_stream = w->build_stream;
+        }
+        w->building.store(false);
+    });
+}
+// The table this call hashes on, resolved, its lock held in `lk` (until the kernels that use the pointers are enqueued): the wide
+// table of the handle when it has everything the call needs, else the table the handle started on -- built on demand as ever -- with
+// a request to the builder on the way.
+static int32_t te_pick(akp_te_params* p, size_t msg_len, size_t data_len, hipStream_t s, std::unique_lock<std::mutex>& lk, TeResolved* r, bool want_rem = true) {
+    if (TeTable* w = p->wide) {
+        lk = std::unique_lock<std::mutex>(w->mu, std::try_to_lock);
+        if (lk.owns_lock()) {
+            const int32_t rc = te_resolve(w, msg_len, data_len, s, r, TE_LOOK, want_rem);
+            if (rc == AKP_OK) return AKP_OK;
+            lk.unlock();
+            if (rc != TE_NOT_READY) return rc;
+            if (!te_capturing(s)) te_upgrade_kick(w, msg_len, data_len, want_rem);  // (an allocation on another thread would break a global-mode capture)
+        }
+    }
+    lk = std::unique_lock<std::mutex>(p->t->mu);
+    return te_resolve(p->t, msg_len, data_len, s, r, TE_BUILD, want_rem);
+}
+// blocking form (akp_te_params_prepare): the wide table if the handle has one -- a running background build is waited for, what is
+// still missing is built on this thread -- else the handle's only table
+static int32_t te_prepare(akp_te_params* p, size_t msg_len, size_t data_len, hipStream_t s) {
+    TeResolved r;
+    if (TeTable* w = p->wide) {
+        std::lock_guard<std::mutex> lk(w->mu);
+        const int32_t rc = te_resolve(w, msg_len, data_len, s, &r, TE_BUILD);
+        if (rc == AKP_OK) {
+            w->upgrade_failed.store(false);
+            return AKP_OK;
+        }
+        w->upgrade_error = akp_last_error();
+        w->upgrade_failed.store(true);
+        return rc;
+    }
+    std::lock_guard<std::mutex> lk(p->t->mu);
+    return te_resolve(p->t, msg_len, data_len, s, &r, TE_BUILD);
+}
 extern "C" int32_t akp_te_params_prepare(akp_te_params* p, size_t msg_len) {
     NEED_TE(p, "akp_te_params_prepare");
     if (msg_len * 8 > te_input_bits(p))
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", msg_len, p->W, p->N);
-    std::lock_guard<std::mutex> lk(p->t->mu);
-    TeResolved r;
-    return te_resolve(p, msg_len, msg_len, p->ctx->stream, &r);
+    return te_prepare(p, msg_len, msg_len, p->ctx->stream);
 }
 // ... and what TwoToOneCRH::compress / the inner levels of a tree will need: two serialised digests in the (W*N)/8-byte buffer
-// `s`: the stream the caller is about to enqueue on (only asked whether it is being captured; the build runs on the context stream)
+static void te_compress_shape(const akp_te_params* p, size_t* buflen, size_t* used) {
+    *buflen = ((size_t)p->W * p->N) / 8;
+    *used = te_zero_tail_on() ? std::min<size_t>(*buflen, (size_t)2 * te_fe_per_digest(p) * 32) : *buflen;
+}
+// `s`: the stream the caller is about to enqueue on (only asked whether it is being captured; builds run on the table's stream)
 int32_t te_prepare_compress(akp_te_params* p, hipStream_t s) {
-    const size_t buflen = ((size_t)p->W * p->N) / 8;
-    const size_t used = std::min<size_t>(buflen, (size_t)2 * te_fe_per_digest(p) * 32);
-    std::lock_guard<std::mutex> lk(p->t->mu);
-    TeResolved r;
-    return te_resolve(p, buflen, te_zero_tail_on() ? used : buflen, s, &r);
+    size_t buflen, used;
+    te_compress_shape(p, &buflen, &used);
+    return te_prepare(p, buflen, used, s);
 }
 extern "C" int32_t akp_te_params_prepare_compress(akp_te_params* p) {
     NEED_TE(p, "akp_te_params_prepare_compress");
@@ -606,9 +796,76 @@ extern "C" int32_t akp_te_params_prepare_compress(akp_te_params* p) {
 }
 // A tree hashes its leaves first and its (usually longer) two-to-one buffers second: when both hashes share a table, building it
 // for the inner nodes FIRST means one build instead of a build and an extension (the cold first tree: profiles/r05_s2 -> r05_s4).
+// The table the handle STARTS on is built here (milliseconds); a budget-chosen wide table gets the same request in the background.
 int32_t te_tree_prepare(akp_te_params* leafp, akp_te_params* two, hipStream_t s) {
+    size_t buflen, used;
+    te_compress_shape(two, &buflen, &used);
+    if (two->wide && !te_capturing(s)) {
+        bool ready = false;
+        {
+            std::unique_lock<std::mutex> lk(two->wide->mu, std::try_to_lock);
+            TeResolved r;
+            ready = lk.owns_lock() && te_resolve(two->wide, buflen, used, s, &r, TE_LOOK) == AKP_OK;
+        }
+        if (!ready) te_upgrade_kick(two->wide, buflen, used, true);
+    }
     if (leafp->t != two->t) return AKP_OK;
-    return te_prepare_compress(two, s);
+    std::lock_guard<std::mutex> lk(two->t->mu);
+    TeResolved r;
+    return te_resolve(two->t, buflen, used, s, &r, TE_BUILD);
+}
+extern "C" int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset, size_t* table_bytes,
+        size_t msg_len,
+                                      uint32_t* steps) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_info: params is NULL");
+    // the table a call with msg_len-byte messages would use now: the wide one if it covers that length (and no build holds it)
+    TeTable* t = p->t;
+    std::unique_lock<std::mutex> lk;
+    if (p->wide) {
+        lk = std::unique_lock<std::mutex>(p->wide->mu, std::try_to_lock);
+        u32 g = 0, st = 0;
+        if (lk.owns_lock()) {
+            te_steps(p->wide, msg_len, &g, &st);
+            if (p->wide->units_built && (p->wide->pedersen ? st : g) <= p->wide->units_built) t = p->wide;
+            else lk.unlock();
+        }
+    }
+    if (t == p->t) lk = std::unique_lock<std::mutex>(t->mu);
+    const bool ped = t->pedersen;
+    if (digit_bits_or_group) *digit_bits_or_group = ped ? t->digit_bits : t->group;
+    if (signed_subset) *signed_subset = ped && t->signed_subset ? 1 : 0;
+    if (table_bytes) *table_bytes = te_table_bytes(t);
+    if (steps) {
+        u32 g = 0, st = 0;
+        te_steps(t, msg_len, &g, &st);
+        if (!ped && t->group > 1 && st > g) st = g + 1;  // the chunks after the last full group are one step (te_bh_remainder)
+        *steps = st;
+    }
+    return AKP_OK;
+}
+extern "C" int32_t akp_te_params_table_info(const akp_te_params* p, uint64_t* table_id, uint32_t* handles_attached, uint64_t* wide_builds,
+        akp_te_build_report* last_build) {
+    if (!p) return fail(AKP_ERR_BAD_PARAMS, "akp_te_params_table_info: params is NULL");
+    TeTable* t = p->wide ? p->wide : p->t;
+    if (table_id) *table_id = (uint64_t)(uintptr_t)t;
+    if (handles_attached) {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        *handles_attached = (uint32_t)t->refs;
+    }
+    if (wide_builds || last_build) {
+        // (a running background build holds the lock for its whole length: report "pending" without waiting for it)
+        std::unique_lock<std::mutex> lk(t->mu, std::try_to_lock);
+        if (!lk.owns_lock() && !p->wide) lk.lock();
+        if (wide_builds) *wide_builds = lk.owns_lock() ? t->builds : 0;
+        if (last_build) {
+            if (lk.owns_lock()) *last_build = t->last_build;
+            else memset(last_build, 0, sizeof *last_build);
+            last_build->upgrade_state = !p->wide ? 0u : t->upgrade_failed.load() ? 3u : (lk.owns_lock() && t->units_built && !t->building.load()) ? 2u : 1u;
+            memset(last_build->note, 0, sizeof last_build->note);
+            if (last_build->upgrade_state == 3 && lk.owns_lock()) snprintf(last_build->note, sizeof last_build->note, "%s", t->upgrade_error.c_str());
+        }
+    }
+    return AKP_OK;
 }
 // projective -> affine for `cnt` sums.  One inversion is shared among up to 64 messages per lane, but `target` lanes
 // stay busy when the range allows.  Measured at 2^20 Pedersen hashes (profiles/r02_s27): 16 K / 32 K / 64 K / 128 K /
@@ -651,12 +908,13 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     if (n > ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32", n);
     const bool tail_on = te_zero_tail_on();
     if (data_len > msg_len || !tail_on) data_len = msg_len;
-    TeTable* t = p->t;
     // the table's pointers are read and the kernels that use them enqueued under its lock (TeTable, capi_internal.hpp): handles of
-    // other contexts share the table, and one of them may be extending it right now
-    std::lock_guard<std::mutex> table_lock(t->mu);
+    // other contexts share the table, and one of them may be extending it right now.  te_pick: the wide table of the handle once it
+    // is complete, the cache-sized one until then.
+    std::unique_lock<std::mutex> table_lock;
     TeResolved rs;
-    if (int32_t rc = te_resolve(p, msg_len, data_len, s, &rs)) return rc;
+    if (int32_t rc = te_pick(p, msg_len, data_len, s, table_lock, &rs)) return rc;
+    TeTable* t = rs.t;
     const u32 shape = rs.shape, groups = rs.groups, steps = rs.steps;
     const TeEntry *lut = rs.lut, *lut1 = rs.lut1, *tail = rs.tail;
     const bool signed_subset = t->signed_subset;
@@ -736,26 +994,6 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
         return te_launch_finalize(p, (const F29Pad*)xyz + first * 3, (F29Pad*)prefix + first, d_out + first * fe, cnt, st,
                 pipe ? te_chunk_finalize_lanes() : (size_t)65536);
     };
-#if defined(AKP_TE_SPLIT_FINALIZE)
-    // A/B arm (`make splitfin`, round 3): the latency-bound finalize pass of the first half runs on a side stream under the
-    // accumulate kernel of the second half.  Measured: see profiles/r03_s8 -- not the default.
-    if (n >= ((size_t)1 << 19)) {
-        akp_ctx* c = p->ctx;
-        if (!c->pipe[3]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[3], hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i)
-            if (!c->te_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->te_event[i], hipEventDisableTiming));
-        const size_t half = (n / 2 + 255) & ~(size_t)255;
-        if (int32_t rc = accumulate(0, half, s)) return rc;
-        HIP_TRY(hipEventRecord(c->te_event[0], s));
-        HIP_TRY(hipStreamWaitEvent(c->pipe[3], c->te_event[0], 0));
-        if (int32_t rc = finalize(0, half, c->pipe[3])) return rc;
-        HIP_TRY(hipEventRecord(c->te_event[1], c->pipe[3]));
-        if (int32_t rc = accumulate(half, n - half, s)) return rc;
-        if (int32_t rc = finalize(half, n - half, s)) return rc;
-        HIP_TRY(hipStreamWaitEvent(s, c->te_event[1], 0));
-        return AKP_OK;
-    }
-#endif
     if (pipe) {
         const size_t dig = fe * sizeof(Fr);
         for (size_t first = 0; first < n; first += pipe->chunk) {
@@ -865,6 +1103,10 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     *used = false;
     akp_ctx* c = p->ctx;
     if (c->gate_unavailable) return AKP_OK;
+    if (c->gate_skip) {  // backing off after a timeout
+        --c->gate_skip;
+        return AKP_OK;
+    }
     // the test build's switches (tools/gpu_r5_gated.py, gpu_r5_gate_knobs.py, the fallback test); libakp.so reads none of them
     size_t chunk = (size_t)1 << 17, lds_floor = 36864;
     u32 spin_limit = 1u << 15, poll_sleep = 0;
@@ -930,10 +1172,10 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     bool gave_up = false, refused = false;
     const int32_t rc = [&]() -> int32_t {
         {
-            TeTable* t = p->t;
-            std::lock_guard<std::mutex> table_lock(t->mu);
+            std::unique_lock<std::mutex> table_lock;
             TeResolved rs;
-            if (int32_t rc = te_resolve(p, msg_len, msg_len, s, &rs)) return rc;
+            if (int32_t rc = te_pick(p, msg_len, msg_len, s, table_lock, &rs)) return rc;
+            TeTable* t = rs.t;
             // all copies first, each followed by its flag (a small kernel); nothing of this call has been launched yet if the write-value
             // is refused
             for (size_t k = 0; k < n_chunks; ++k) {
@@ -1008,10 +1250,16 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
         }
     }
 #endif
-    if (gave_up || err) {  // *used stays false: the caller repeats the batch with the chunked launches -- and this context stops trying
-        c->gate_unavailable = true;
+    if (gave_up || err) {
+        // *used stays false: the caller repeats the batch with the chunked launches.  A timeout is a moment, not a property of the stack
+        // (ADVICE r05): back off for 8, 16, ... 1024 pinned calls, then try again; akp_last_error() carries a note after the (successful) call
+        ++c->gate_timeouts;
+        c->gate_skip = 8u << std::min<u32>(c->gate_timeouts - 1, 7);
+        (void)fail(AKP_OK, "note: the gated launch of a pinned curve-hash batch timed out (%u time(s) on this context): this call and the next %u pinned calls use the chunked launches",
+                c->gate_timeouts, c->gate_skip);
         return AKP_OK;
     }
+    c->gate_timeouts = 0;
     *used = true;
     return AKP_OK;
 }
@@ -1145,11 +1393,11 @@ int32_t te_crh_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_
         return fail(AKP_ERR_BAD_LENGTH, "incorrect input length %zu for window params %ux%u (the reference panics)", max_len, p->W, p->N);
     if (n == 0) return AKP_OK;
     if (n >= ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32 - 1", n);
-    TeTable* t = p->t;
     akp_ctx* c = p->ctx;
-    std::lock_guard<std::mutex> table_lock(t->mu);
-    u32 groups = 0, steps = 0;
-    if (int32_t rc = te_ensure_table(c, t, max_len, &groups, &steps, s)) return rc;
+    std::unique_lock<std::mutex> table_lock;
+    TeResolved rs;
+    if (int32_t rc = te_pick(p, max_len, max_len, s, table_lock, &rs, false)) return rc;
+    TeTable* t = rs.t;
     const u32 D = t->pedersen ? t->digit_bits : t->group;  // Bowe-Hopwood: no remainder table (R = 0): left-over chunks are single steps
     void *xyz = nullptr, *prefix = nullptr, *work = nullptr;
     if (int32_t rc = ctx_scratch(c, SCR_E, n * 3 * sizeof(F29Pad), &xyz, s)) return rc;
@@ -1166,13 +1414,13 @@ int32_t te_crh_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_
     const u32 built = t->pedersen && !t->signed_subset ? 0xffffffffu : (t->pedersen || t->group > 1 ? t->units_built : 0u);
     if (t->pedersen && t->signed_subset)
         hipLaunchKernelGGL(te_accumulate_ragged_kernel<2>, dim3(grid), dim3(256), 0, s, t->d_lut, t->d_lut1, d_msgs, d_offsets, order, D, t->n_gen, built,
-                (F29Pad*)xyz, n);
+                (u32)max_len, (F29Pad*)xyz, n);
     else if (t->pedersen)
         hipLaunchKernelGGL(te_accumulate_ragged_kernel<0>, dim3(grid), dim3(256), 0, s, t->d_lut, t->d_lut1, d_msgs, d_offsets, order, D, t->n_gen, built,
-                (F29Pad*)xyz, n);
+                (u32)max_len, (F29Pad*)xyz, n);
     else
         hipLaunchKernelGGL(te_accumulate_ragged_kernel<1>, dim3(grid), dim3(256), 0, s, t->d_lut, t->d_lut1, d_msgs, d_offsets, order, D, t->n_gen, built,
-                (F29Pad*)xyz, n);
+                (u32)max_len, (F29Pad*)xyz, n);
     HIP_TRY(hipGetLastError());
     return te_launch_finalize(p, (const F29Pad*)xyz, (F29Pad*)prefix, d_out, n, s);
 }

@@ -158,7 +158,7 @@ AKP_HD Fr fr_mul_portable(const Fr& a, const Fr& b) {
     return fr_cond_sub_p(t, (u32)acc);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(AKP_FR_PORTABLE)
+#if defined(__HIP_DEVICE_COMPILE__)
 // ---------------------------------------------------------------------------------------
 // gfx950 form: the same FIPS schedule, but each partial product is exactly
 //   v_mad_u64_u32 acc, vcc, x, y, acc ; v_addc_co_u32 c2, vcc, 0, c2, vcc

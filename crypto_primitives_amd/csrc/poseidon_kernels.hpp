@@ -288,8 +288,9 @@ __global__ void __launch_bounds__(256) poseidon_crh_ragged_t3_kernel(PoseidonDim
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const size_t idx = order ? order[slot] : slot;
-    const uint64_t off = offsets[idx];
-    store_fr_global(out + idx, poseidon_crh_item_t3<FULLFORM>(D, C, in + off, nullptr, (size_t)(offsets[idx + 1] - off), 0));
+    const uint64_t off = offsets[idx], end = offsets[idx + 1];
+    // (a pair of device-resident offsets that DECREASES is the empty input, not a length of ~2^64: the lane would never end)
+    store_fr_global(out + idx, poseidon_crh_item_t3<FULLFORM>(D, C, in + off, nullptr, end > off ? (size_t)(end - off) : 0, 0));
 }
 
 // Path::verify (merkle_tree/mod.rs:172-212) with each lane walking its OWN path: leaf hash, then depth + 1 two-to-one hashes

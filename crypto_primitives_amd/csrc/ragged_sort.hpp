@@ -24,6 +24,7 @@ struct RaggedKey {
     u32 unit, cap;
 };
 AKP_HD u32 ragged_key_of(const RaggedKey& k, uint64_t len) {
+    if (len > 0xffffffffu) len = 0;  // offsets that decrease (the item hashes as the empty one): `len * 8` below must not wrap
     u32 v;
     if (k.mode == 0) {
         const uint64_t used = len * 8 < k.cap ? len * 8 : k.cap;

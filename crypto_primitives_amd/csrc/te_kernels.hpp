@@ -117,30 +117,6 @@ AKP_HD void store_niels(NielsPad* p, const Niels& n) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-AKP_HD Niels niels_of_words24(const u32* w) {
-    Niels r;
-    r.ypx = f29_unpack<true>(Fr{{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]}});
-    r.ymx = f29_unpack<true>(Fr{{w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]}});
-    r.dxy = f29_unpack<true>(Fr{{w[16], w[17], w[18], w[19], w[20], w[21], w[22], w[23]}});
-    return r;
-}
-AKP_HD Niels load_niels(const Niels96* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5];
-    const u32 w[24] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w,
-                       v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w, v5.x, v5.y, v5.z, v5.w};
-    return niels_of_words24(w);
-}
-AKP_HD void store_niels(Niels96* p, const Niels& n) {
-    const Fr a = f29_canonical_pack(n.ypx), b = f29_canonical_pack(n.ymx), c = f29_canonical_pack(n.dxy);
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
-    q[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
-    q[2] = make_uint4(b.l[0], b.l[1], b.l[2], b.l[3]);
-    q[3] = make_uint4(b.l[4], b.l[5], b.l[6], b.l[7]);
-    q[4] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
-    q[5] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
-}
 AKP_HD Niels niels_of_ext(const Ext& acc) {  // affine point of acc, as a table entry
     const FS zi = f29_inv(acc.Z);
     return niels_from_affine(f29_mul(acc.X, zi), f29_mul(acc.Y, zi));
@@ -410,10 +386,11 @@ AKP_HD void te_build_combine_lane(const TeEntry* __restrict__ lo, const TeEntry*
         store_niels(lut + e, niels_from_affine(f29_mul(xyz.ypx, zi), f29_mul(xyz.ymx, zi)));
     }
 }
+// entries [first, n_entries): an extension of the table builds only the units it adds (round 6), the part tables cover all units
 template <int KIND>
 __global__ void __launch_bounds__(256) te_build_combine_kernel(const TeEntry* __restrict__ lo, const TeEntry* __restrict__ hi, u32 W, u32 k_lo,
-                                                              size_t n_entries, TeEntry* __restrict__ lut) {
-    te_build_combine_lane<KIND>(lo, hi, W, k_lo, n_entries, lut, (size_t)blockIdx.x * (256u * AKP_TE_BUILD_RUN) + threadIdx.x, 256u);
+                                                              size_t first, size_t n_entries, TeEntry* __restrict__ lut) {
+    te_build_combine_lane<KIND>(lo, hi, W, k_lo, n_entries, lut, first + (size_t)blockIdx.x * (256u * AKP_TE_BUILD_RUN) + threadIdx.x, 256u);
 }
 // test build: the wide table against the per-entry definition (canonical values), mismatches counted
 template <int KIND>
@@ -607,7 +584,7 @@ AKP_HD Ext te_madd_signed(const Ext& p, const Niels& q, u32 neg) {
     return r;
 }
 // A table entry on its way in: address, sign of the step, and the seven 16-byte pieces of the 128-byte line.
-constexpr int AKP_TE_ENTRY_VEC = sizeof(TeEntry) == 128 ? 7 : 6;  // 16-byte pieces that carry data
+constexpr int AKP_TE_ENTRY_VEC = 7;  // 16-byte pieces of a 128-byte entry that carry data
 struct NielsFetch {
     const TeEntry* base;  // lut or lut1 (kept as it is: a pointer that went through an asm statement would lose its
     u32 idx;              // address space and turn the loads into flat loads), entry index
@@ -619,13 +596,6 @@ AKP_HD void te_fetch_all(NielsFetch& f) {
 #pragma unroll
     for (int k = 0; k < AKP_TE_ENTRY_VEC; ++k) f.v[k] = q[k];
 }
-#if defined(AKP_TE_PACKED96)
-AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
-    const u32 w[24] = {f.v[0].x, f.v[0].y, f.v[0].z, f.v[0].w, f.v[1].x, f.v[1].y, f.v[1].z, f.v[1].w, f.v[2].x, f.v[2].y, f.v[2].z, f.v[2].w,
-                       f.v[3].x, f.v[3].y, f.v[3].z, f.v[3].w, f.v[4].x, f.v[4].y, f.v[4].z, f.v[4].w, f.v[5].x, f.v[5].y, f.v[5].z, f.v[5].w};
-    return niels_of_words24(w);
-}
-#else
 AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
     const u32 w[28] = {f.v[0].x, f.v[0].y, f.v[0].z, f.v[0].w, f.v[1].x, f.v[1].y, f.v[1].z, f.v[1].w, f.v[2].x, f.v[2].y,
                        f.v[2].z, f.v[2].w, f.v[3].x, f.v[3].y, f.v[3].z, f.v[3].w, f.v[4].x, f.v[4].y, f.v[4].z, f.v[4].w,
@@ -639,7 +609,6 @@ AKP_HD Niels niels_of_fetch(const NielsFetch& f) {
     }
     return r;
 }
-#endif
 template <int KIND, class M = const uint8_t*>
 AKP_HD MsgRaw te_step_bits(const M& msg, size_t msg_len, u32 D, u32 n_groups, u32 u) {
     u32 w;
@@ -839,12 +808,14 @@ template <int KIND>
 __global__ void __launch_bounds__(256, AKP_TE_MIN_WAVES) te_accumulate_ragged_kernel(const TeEntry* __restrict__ lut, const TeEntry* __restrict__ lut1,
                                                            const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offsets,
                                                            const u32* __restrict__ order, u32 D, u32 n_gen, u32 units_built,
-                                                           F29Pad* __restrict__ xyz, size_t n) {
+                                                           u32 max_len, F29Pad* __restrict__ xyz, size_t n) {
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const size_t idx = order ? order[slot] : slot;
-    const uint64_t off = offsets[idx];
-    const size_t len = (size_t)(offsets[idx + 1] - off);
+    const uint64_t off = offsets[idx], end = offsets[idx + 1];
+    // device-resident offsets are the caller's: a pair that DECREASES is the empty message (not a length of ~2^64), an item longer than
+    // the caller's own bound is cut at that bound -- the bytes read are [off, off + min(len, max_len)) and nothing else
+    const size_t len = end <= off ? 0 : (end - off < max_len ? (size_t)(end - off) : (size_t)max_len);
     u32 groups, steps;
     te_item_steps<KIND>(n_gen, D, len, units_built, &groups, &steps);
     const MsgAny m{msgs + off};

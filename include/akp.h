@@ -51,7 +51,7 @@ extern "C" {
 #define AKP_ERR_RCCL 4 /* RCCL could not be loaded / a collective of the multi-device entry points failed */
 #define AKP_ERR_NOT_POW2 5
 
-#define AKP_ABI_VERSION 4
+#define AKP_ABI_VERSION 5
 
 typedef struct akp_ctx akp_ctx;
 typedef struct akp_poseidon akp_poseidon; /* PoseidonConfig<Fr>, sponge/poseidon/mod.rs:27-45 */
@@ -72,12 +72,16 @@ void akp_ctx_destroy(akp_ctx* ctx);
 int32_t akp_ctx_synchronize(akp_ctx* ctx);
 /* HBM that ONE precomputed curve table (akp_te_params_create) may occupy on this context's device, bytes.
  *   0 (the default)           320 MiB: the tables stay inside the 256 MiB Infinity Cache (4x256 Pedersen: 16-bit digits, 268 MB;
- *                             63x9 Bowe-Hopwood: groups of 5 chunks, 237 MB) and are built in milliseconds -- the faster choice
- *                             for a host that hashes ONE batch or builds ONE tree (cold figures: profiles/r05_*);
- *   AKP_TABLE_BUDGET_DEVICE   a quarter of the device's memory, but at most half of what is free when the handle is created
- *                             (72 GiB on an idle 288 GB MI355X: 24-bit digits = 46 GB, groups of 8 chunks = 75 GB): -23 % time per
- *                             hash once the table exists, ~0.1 s to build it -- for a host that keeps hashing with one parameter set;
+ *                             63x9 Bowe-Hopwood: groups of 5 chunks, 237 MB) and are built in milliseconds;
+ *   AKP_TABLE_BUDGET_DEVICE   a quarter of the device's memory (72 GiB on a 288 GB MI355X: 24-bit digits = 46 GB, groups of 8 chunks
+ *                             = 75 GB): -23 % time per hash once the table exists -- for a host that keeps hashing with one parameter set;
  *   any other value           that many bytes.
+ * A budget above the default costs NOTHING at the start (round 6): the handle begins to hash on the cache-sized table, the wide one
+ * is allocated and built by a thread of the library on a stream of its own (62 ms of kernel time for the 46 GB table; but the FIRST
+ * 46 GB allocation on a box whose VRAM nobody has used yet took 1.2 s, and an allocation that follows a large hipFree waits for the
+ * driver's wipe of the released memory, ~35 GB/s: profiles/r06_s1 .. r06_s7 -- which is why none of it happens on the caller's thread), and
+ * calls switch to it when it is complete.  akp_te_params_prepare waits for it.  If the device cannot hold it the handle stays on the
+ * cache-sized table (akp_te_params_table_info says so).
  * Handles that exist keep their tables.  akp_ctx_table_budget returns the value the next handle would be created with. */
 #define AKP_TABLE_BUDGET_DEVICE ((size_t)-1)
 int32_t akp_ctx_set_table_budget(akp_ctx* ctx, size_t bytes);
@@ -214,30 +218,52 @@ int32_t akp_te_params_create(akp_ctx* ctx, int32_t kind, uint32_t window_size, u
  * not depend on the shape.
  * The table is BUILT FOR THE MESSAGE LENGTHS THAT ARRIVE: creation allocates kilobytes, the first hash of a length builds the
  * digits / groups that length touches (a 63x9 handle that only hashes a tree's 32- and 64-byte nodes holds 22.5 of the 75 GB),
- * a longer message later extends the table (the device is drained once, the old table released, the new one built: ~0.1 s
- * for the widest complete table).  akp_te_params_info reports what the handle holds at the moment. */
+ * a longer message later extends the table: ONCE, to the complete table (a new allocation is built; the old table is kept until the
+ * last handle of these generators is destroyed, the device is not drained).  Nothing a launch was given is freed while a handle
+ * of the table is alive: a HIP graph captured after akp_te_params_prepare stays valid whatever other handles of the same
+ * generators hash later.  An explicit shape is built by the call that first needs it (or by akp_te_params_prepare); only shapes
+ * chosen by the budget start on the cache-sized table.  akp_te_params_info reports what a call would use at the moment. */
 int32_t akp_te_params_create_shaped(akp_ctx* ctx, int32_t kind, uint32_t window_size, uint32_t num_windows,
                                     const uint64_t* generators_affine, uint32_t digit_bits_or_group, akp_te_params** out);
 void akp_te_params_destroy(akp_te_params* p);
 /* Build NOW what hashing messages of msg_len bytes needs (the wide table up to that length; for Bowe-Hopwood also the remainder
- * table of that length), on the context's stream, and wait for it: the host chooses the moment of the 0.1 s an HBM-sized table
- * takes (milliseconds for the default budget) instead of meeting it inside its first hash.  akp_te_params_prepare_compress does
- * the same for TwoToOneCRH::compress / the inner levels of a tree (two serialised digests in the (W*N)/8-byte buffer).
- * Without it the table work happens lazily inside the first call that needs it -- also a `_dev`
- * call, which then allocates, drains the device and waits ONCE (never while its stream is being captured into a graph: that
- * call fails with AKP_ERR_BAD_PARAMS and names this function). */
+ * table of that length) and wait for it: the host chooses the moment instead of meeting the build inside its first hash (explicit
+ * shapes) or hashing on the cache-sized table until the background build has finished (budget-chosen shapes).
+ * akp_te_params_prepare_compress does the same for TwoToOneCRH::compress / the inner levels of a tree (two serialised digests in
+ * the (W*N)/8-byte buffer).  Without it the table work of an explicit shape happens lazily inside the first call that needs it --
+ * also a `_dev` call, which then allocates and waits ONCE (never while its stream is being captured into a graph: that call fails
+ * with AKP_ERR_BAD_PARAMS and names this function). */
 int32_t akp_te_params_prepare(akp_te_params* p, size_t msg_len);
 int32_t akp_te_params_prepare_compress(akp_te_params* p);
+/* phases of the last build / extension of a handle's wide table, host wall clock (milliseconds) */
+typedef struct akp_te_build_report {
+    uint64_t table_bytes;   /* bytes of the wide table after that build */
+    uint32_t shape;         /* digit bits (Pedersen) / chunks per group (Bowe-Hopwood) */
+    uint32_t units_from, units_to, units_total; /* digits / groups it added: [units_from, units_to) of units_total */
+    uint32_t in_background; /* 1: built by the library's thread while the handle hashed on the cache-sized table */
+    /* 0: the handle has ONE table (default budget or explicit shape); 1: a wide table is wanted and not complete yet (the handle
+     * hashes on the cache-sized one); 2: calls use the wide table; 3: the wide table could not be built, the handle stays on the
+     * cache-sized one (akp_last_error of the akp_te_params_prepare that failed, or `note`) */
+    uint32_t upgrade_state;
+    double alloc_ms;        /* hipMalloc of the table and of its part tables */
+    double parts_ms;        /* part-table kernels */
+    double combine_ms;      /* te_build_combine_kernel: one curve addition per entry, the first writes to the new memory */
+    double constants_ms;    /* Bowe-Hopwood remainder table / tail constant of the message shape */
+    double total_ms;
+    char note[96];          /* why upgrade_state is 3, else empty */
+} akp_te_build_report;
 /* the shared table behind a handle (any pointer may be NULL): an identifier that is equal for two handles iff they use the same
- * tables, the number of handles attached to it, and how often its wide table has been built or extended so far */
-int32_t akp_te_params_table_info(const akp_te_params* p, uint64_t* table_id, uint32_t* handles_attached, uint64_t* wide_builds);
+ * tables, the number of handles attached to it, how often its wide table has been built or extended so far, and the phases of the
+ * last of those builds.  For a handle with a budget-chosen wide table all four describe THAT table. */
+int32_t akp_te_params_table_info(const akp_te_params* p, uint64_t* table_id, uint32_t* handles_attached, uint64_t* wide_builds,
+                                 akp_te_build_report* last_build);
 /* Tuning facts of a handle (any pointer may be NULL): digit width of the Pedersen table / chunks per table step of the
  * Bowe-Hopwood table, whether the Pedersen table is the signed-subset one, bytes of precomputed tables in HBM, and the
- * number of table steps (curve additions + 1) an input of msg_len bytes takes. */
+ * number of table steps (curve additions + 1) an input of msg_len bytes takes -- of the table a call with msg_len-byte messages
+ * would use NOW (the cache-sized one while a budget-chosen wide table is not complete for that length). */
 int32_t akp_te_params_info(const akp_te_params* p, uint32_t* digit_bits_or_group, int32_t* signed_subset,
                            size_t* table_bytes, size_t msg_len, uint32_t* steps);
-/* bytes one table entry occupies in HBM = what one lane gathers per table step (128: one cache line per entry, the default
- * build; 96: the packed A/B build, `make packed96`) */
+/* bytes one table entry occupies in HBM = what one lane gathers per table step (128: one cache line per entry) */
 uint32_t akp_te_entry_bytes(void);
 /* pedersen::CRH::evaluate (crh/pedersen/mod.rs:76-129) / bowe_hopwood::CRH::evaluate
  * (crh/bowe_hopwood/mod.rs:114-186): n messages of msg_len bytes each ->
@@ -256,8 +282,9 @@ int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, 
  * bytes [offsets[i], offsets[i+1]) of msgs (offsets: n + 1 non-decreasing byte offsets).  One launch, per-lane step counts; the
  * items are ordered by step count on the device (counting sort, longest first) so that a wave's lanes finish together.  A message
  * longer than the window is AKP_ERR_BAD_LENGTH for the whole call (the reference panics on that item).  `_dev`: max_len is the
- * caller's bound on the longest message (the table is built for it; an item that is longer all the same gets an unspecified digest --
- * its table steps are clamped to what is built, nothing is read out of bounds). */
+ * caller's bound on the longest message (the table is built for it).  The device-resident offsets are the caller's: item i reads the
+ * bytes [offsets[i], offsets[i] + min(len_i, max_len)) of d_msgs and nothing else -- an item longer than max_len is cut there (its
+ * digest is that of the cut message), a pair of offsets that decreases is the empty message; table reads are clamped to what is built. */
 int32_t akp_te_crh_batch_ragged(akp_te_params* p, const uint8_t* msgs, const uint64_t* offsets, size_t n, uint64_t* out);
 int32_t akp_te_crh_batch_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_t* d_offsets, size_t n, size_t max_len,
                                     uint64_t* d_out, void* stream);

@@ -205,10 +205,11 @@ class TeParameters {  // pedersen::Parameters / bowe_hopwood::Parameters { gener
         uint64_t table_id = 0;
         uint32_t handles_attached = 0;
         uint64_t wide_builds = 0;
+        akp_te_build_report last_build{};  // phases of the last build of the wide table; upgrade_state (akp.h)
     };
     TableInfo table_info() const {
         TableInfo t;
-        check(akp_te_params_table_info(h_, &t.table_id, &t.handles_attached, &t.wide_builds));
+        check(akp_te_params_table_info(h_, &t.table_id, &t.handles_attached, &t.wide_builds, &t.last_build));
         return t;
     }
     uint32_t window_size, num_windows;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} declared in include/akp.h but not exported"
     # and the python binding declares prototypes for exactly that set
     assert sorted(cpa._lib.DECLARED_SYMBOLS) == syms
-    assert cpa.lib.akp_abi_version() == cpa._lib.AKP_ABI_VERSION == 4
+    assert cpa.lib.akp_abi_version() == cpa._lib.AKP_ABI_VERSION == 5
 
 
 def test_library_exports_nothing_but_the_header():

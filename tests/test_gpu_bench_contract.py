@@ -29,7 +29,7 @@ def _check(out, full_path):
     ln = json.loads(line)
     assert REQUIRED <= set(ln), REQUIRED - set(ln)
     assert ln["parity"]["bit_exact"] is True and ln["value"] > 1e6
-    assert ln["parity"]["states_checked"] >= 256  # the probe reads the buffer the timed kernel wrote
+    assert ln["parity"]["states_checked"] >= 256 and ln["roofline"]["traffic_measured_in_this_run"] is False  # the probe reads the buffer the timed kernel wrote
     r = ln["roofline"]
     assert ROOFLINE_KEYS <= set(r), ROOFLINE_KEYS - set(r)
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
@@ -164,3 +164,40 @@ def test_bench_self_launches_ranks_from_plain_python(tmp_path):
     if torch.cuda.device_count() < 2:
         p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + args, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
         assert p.returncode != 0 and "only 1 HIP device" in (p.stderr + p.stdout)
+
+
+def test_bench_line_survives_a_failing_side_leg_world1(tmp_path):
+    """a side leg that raises (an out-of-memory on a wide table, an RCCL error, a leg's own parity SystemExit) must not
+    void the headline: the line is printed, rc 0, the leg is named under legs_failed / leg_errors, its scalars are absent, every other leg
+    is there.  (AKP_BENCH_FAIL_LEG is the test hook of tools/bench_legs/runner.py.)"""
+    env = dict(os.environ, AKP_BENCH_FAIL_LEG="pedersen")
+    p, full = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5"] + SMALL, tmp_path, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _check(p.stdout, full)
+    ln = d["_line"]
+    assert ln["legs_failed"] == ["pedersen"] and "injected" in ln["leg_errors"]["pedersen"] and "pedersen" not in d
+    assert "pedersen_hashes_per_s" not in ln["legs"] and ln["legs"]["merkle_s"] > 0 and ln["legs"]["bh_s"] > 0 and ln["legs"]["ragged_bh_hashes_per_s"] > 0
+    assert ln["cpu_baseline"]["value"] > 0 and "pedersen" not in d["cpu_baseline"]  # the CPU leg skips the part whose GPU leg is missing
+    # ... and a leg that fails AFTER it has run (its own parity check, say)
+    env = dict(os.environ, AKP_BENCH_FAIL_LEG="sweep:end")
+    p, full = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"] + SMALL, tmp_path, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert _check(p.stdout, full)["_line"]["legs_failed"] == ["sweep"]
+
+
+@pytest.mark.parametrize("where", ["bh_merkle@3", "merkle@0:end"])
+def test_bench_line_survives_a_leg_failing_on_one_rank_world8(where, tmp_path):
+    """the same at world 8 (ranks sharing GPU 0, gloo): ONE rank's leg raises -- before the leg's first collective, or after its last -- and
+    the other seven must neither hang in a barrier nor lose step with it: every rank leaves the leg after the same number of
+    all-reduces (runner.py), the line is printed by rank 0 with the leg named"""
+    world = 8
+    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"] + SMALL
+    args[args.index("--log2-states") + 1] = "14"
+    env = dict(os.environ, AKP_BENCH_SHARED_GPU="1", AKP_BENCH_FAIL_LEG=where)
+    p, full = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                    "127.0.0.1", "--master-port", str(29570 + len(where)), "bench.py", "--gpus", str(world)] + args, tmp_path, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    d = _check(p.stdout, full)
+    leg = where.split("@")[0]
+    other = "merkle_s" if leg == "bh_merkle" else "bh_s"
+    assert d["_line"]["legs_failed"] == [leg] and d["n_gpus"] == world and d["_line"]["legs"][other] > 0

@@ -216,12 +216,19 @@ def test_table_budget_picks_the_shape(cpa):
             ctx.set_table_budget(budget)
             assert ctx.table_budget() == budget
             P, B = pedersen.Parameters(gens), bowe_hopwood.Parameters(bgens)
-            ip, ib = P.handle(ctx).info(128), B.handle(ctx).info(64)
+            if want_d > 16:  # round 6: a budget above the default starts on the cache-sized table; the wide one is built in the background --
+                st = P.handle(ctx).table_info()["last_build"]["upgrade_state"]
+                assert st in (1, 2) and B.handle(ctx).table_info()["last_build"]["upgrade_state"] in (1, 2), st
+                assert P.handle(ctx).info(128)["digit_bits_or_group"] == 16 and B.handle(ctx).info(64)["digit_bits_or_group"] == 5  # what a call would use NOW
+            P.handle(ctx).prepare(128)  # -- or, as here, by the call that waits for it
+            ip = P.handle(ctx).info(128)
+            B.handle(ctx).prepare(64)
+            ib = B.handle(ctx).info(64)
             assert ip["digit_bits_or_group"] == want_d and ip["table_bytes"] <= budget + (1 << 20), ip
             assert ib["digit_bits_or_group"] == want_g and ib["table_bytes"] <= budget + (1 << 20), ib
             assert ip["steps"] == -(-1024 // want_d) and ib["steps"] == 171 // want_g + 1
             out[budget] = (pedersen.CRH.evaluate_batch(P, m), bowe_hopwood.CRH.evaluate_batch(B, mb))
-            assert B.handle(ctx).info(64)["table_bytes"] > ib["table_bytes"] or 171 % want_g < 2  # the remainder table of 64-byte messages
+            assert B.handle(ctx).info(64) == ib and P.handle(ctx).info(128) == ip  # hashing found everything built
             del P, B
     finally:
         ctx.set_table_budget(0)
@@ -229,7 +236,7 @@ def test_table_budget_picks_the_shape(cpa):
     from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
     ctx.set_table_budget(TABLE_BUDGET_DEVICE)
     try:
-        assert ctx.table_budget() >= 64 << 20 and ctx.table_budget() != TABLE_BUDGET_DEVICE  # a quarter of the device, at most half of what is free
+        assert ctx.table_budget() >= 64 << 20 and ctx.table_budget() != TABLE_BUDGET_DEVICE  # a quarter of the device's memory
     finally:
         ctx.set_table_budget(0)
     # shapes outside 2..24 bits / 1..8 chunks are the caller's error
@@ -367,12 +374,15 @@ def test_table_info_of_the_baseline_windows(cpa):
     finally:
         ctx.set_table_budget(0)
     if wide:
-        pedersen.CRH.evaluate_batch(P, longest_p)
+        pedersen.CRH.evaluate_batch(P, longest_p)  # (starts on the cache-sized table, asks for the wide one)
+        assert hp.wait_for_wide_table(128) is not None
         assert hp.info(128) == {"digit_bits_or_group": 24, "signed_subset": True, "table_bytes": ((43 << 23) + 44) * 128, "steps": 43}
         assert hp.info(32)["steps"] == 11
         bowe_hopwood.CRH.evaluate_batch(B, _msgs(1, 64, 3))  # a tree node: 21 of the 70 groups + the 3-chunk remainder
+        assert hb.wait_for_wide_table(64) is not None
         assert hb.info(32) == {"digit_bits_or_group": 8, "signed_subset": False, "table_bytes": (567 * 4 + (21 << 23) + 512) * 128, "steps": 11}
-        assert hb.info(64)["steps"] == 22 and hb.info(70)["steps"] == 24  # 171 = 21 * 8 + 3 chunks, 187 = 23 * 8 + 3
+        assert hb.info(64)["steps"] == 22  # 171 = 21 * 8 + 3 chunks
+        assert hb.info(70)["digit_bits_or_group"] == 5  # 187 chunks = 23 groups: not covered yet -- such a call would run on the cache-sized table
 
 
 def test_tables_grow_with_the_message_lengths(cpa):
@@ -535,13 +545,15 @@ def test_budget_chosen_shape_narrows_when_memory_is_taken_after_creation(cpa):
     want_p = pedersen.CRH.evaluate_batch(pedersen.Parameters(pg, table_shape=12), m)
     want_b = bowe_hopwood.CRH.evaluate_batch(bowe_hopwood.Parameters(bg, table_shape=3), mb)
     assert hp.table_info()["table_id"] != hx.table_info()["table_id"]  # budget-chosen and explicit shapes are filed apart (only the former may narrow)
-    assert hp.info()["digit_bits_or_group"] == 24 and hb.info()["digit_bits_or_group"] == 8
+    assert hp.table_info()["last_build"]["upgrade_state"] == 1 and hb.table_info()["last_build"]["upgrade_state"] == 1  # wide tables wanted, nothing built
     free, _ = torch.cuda.mem_get_info(0)
     hog = torch.empty(free - (40 << 30), dtype=torch.uint8, device="cuda:0")  # leaves ~40 GB: half of it is below 46 GB and below 22.5 GB
     try:
+        hp.prepare(128)  # the wide table on this thread (a hash would run on the cache-sized table and leave the same work to the builder)
         assert np.array_equal(pedersen.CRH.evaluate_batch(P, m), want_p)
         d = hp.info(128)
         assert d["digit_bits_or_group"] < 24 and d["steps"] == -(-1024 // d["digit_bits_or_group"]) and d["table_bytes"] < 24 << 30, d
+        hb.prepare(64)
         assert np.array_equal(bowe_hopwood.CRH.evaluate_batch(B, mb), want_b)
         g = hb.info(64)
         assert g["digit_bits_or_group"] < 8 and g["table_bytes"] < 12 << 30, g

@@ -205,7 +205,7 @@ def test_c_abi_serializer_size_queries_and_small_buffers():
     m, ns = C.c_size_t(), C.c_size_t()
     raw = (C.c_uint8 * len(ragged)).from_buffer_copy(ragged)
     assert lib.akp_deserialize_multipath(raw, len(ragged), 1, 0, 1, C.byref(m), C.byref(ns), None, None, None, None, None, 0, 0) == AKP_ERR_BAD_PARAMS
-    assert cpa.lib.akp_abi_version() == 4
+    assert cpa.lib.akp_abi_version() == 5
 
 
 @pytest.mark.parametrize("compress", [False, True])

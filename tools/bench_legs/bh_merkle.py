@@ -37,6 +37,17 @@ def run(env):
         env.build_sharded(tb, d_leaves, total, env.dist)
         torch.cuda.synchronize(env.dev)
         cold_ms = env.max_over_ranks(time.perf_counter() - c0) * 1e3
+        # a budget above the default: that first tree ran (wholly or partly) on the cache-sized tables while a thread of the library builds
+        # the wide ones; keep building trees until calls use them, and note when that was
+        hh0 = Bp.handle(env.ctx)
+        ready_ms, trees_before = None, 0
+        if budget:
+            while hh0.table_info()["last_build"]["upgrade_state"] == 1 and time.perf_counter() - c0 < 60.0:
+                env.build_sharded(tb, d_leaves, per, None)  # (this rank's shard as a tree of its own: no collective inside the wait)
+                torch.cuda.synchronize(env.dev)
+                trees_before += 1
+            ready_ms = (time.perf_counter() - c0) * 1e3
+            hh0.prepare(32, compress=True)
         env.barrier()
         reps = 3
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -50,7 +61,8 @@ def run(env):
         hh = Bp.handle(env.ctx)
         return {"B": Bp, "tb": tb, "res": res, "bsec": bsec, "dev_ms": sum(a.elapsed_time(b) for a, b in evs) / reps,
                 "rec": {"group": hh.info()["digit_bits_or_group"], "table_bytes": hh.info(32)["table_bytes"], "steps_leaf": hh.info(32)["steps"],
-                        "steps_inner": hh.info(64)["steps"], "cold_first_tree_ms": cold_ms, "warm_seconds": bsec, "warm_leaves_per_s": total / bsec}}
+                        "steps_inner": hh.info(64)["steps"], "cold_first_tree_ms": cold_ms, "warm_seconds": bsec, "warm_leaves_per_s": total / bsec,
+                        "upgrade_ready_after_ms": ready_ms, "trees_built_meanwhile": trees_before + 1 if budget else None, "last_build": hh.table_info()["last_build"]}}
     cache = one_table(0)
     hbm = hbm_error = None
     if not env.shared_gpu:
@@ -86,6 +98,8 @@ def run(env):
             r2 = env.build_sharded(tb2, d_big, big, None)
             torch.cuda.synchronize(env.dev)
             cold = time.perf_counter() - c0
+            if budget:
+                Bp.handle(env.ctx).prepare(32, compress=True)  # (the background build of the wide tables, waited for: the warm tree uses them)
             c0 = time.perf_counter()
             r2 = env.build_sharded(tb2, d_big, big, None)
             torch.cuda.synchronize(env.dev)

@@ -64,6 +64,20 @@ def run(env, host_states, n):
                                                 "once over the whole batch (workgroups wait on their chunk's flag with relaxed polls, hash two messages per lane and finish "
                                                 "their digests themselves: one inversion per 512 points), DMA copy-out of a chunk released by the host thread as its "
                                                 "workgroups report"}
+        if not env.shared_gpu:  # the same pinned call with the HBM-sized table (opt-in budget; prepared first, not built in the background beside the calls)
+            from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
+            env.ctx.set_table_budget(TABLE_BUDGET_DEVICE)
+            try:
+                Pw = cped2.Parameters(cparams2.pedersen_generators(0xA5A50004, 4, 256))
+                hw = Pw.handle(env.ctx)
+            finally:
+                env.ctx.set_table_budget(0)
+            hw.prepare(128)
+            hs3, lo3, hi3 = _median_call(lambda: check(lib.akp_te_crh_batch(hw.h, pm, nph, 128, po)), 9)
+            host_path["pedersen_pinned_hbm_table"] = {"hashes_per_s": nph / hs3, "ms_per_batch": hs3 * 1e3, "ms_min": lo3 * 1e3, "ms_max": hi3 * 1e3,
+                                                      "digests_equal_the_pageable_call": bool(np.array_equal(pinned_out, ho)), "table": hw.info(128)}
+            same = same and host_path["pedersen_pinned_hbm_table"]["digests_equal_the_pageable_call"]
+            del hw, Pw
         check(lib.akp_host_free(pm))
         check(lib.akp_host_free(po))
         if not same:

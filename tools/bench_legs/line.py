@@ -84,7 +84,8 @@ def compact(full, full_name="bench_full.json"):
         "update_2p10_leaves_per_s": _get(full, "proofs", "poseidon", "update_batch", "2^10", "leaves_per_s"),
         "host_pinned_perm_per_s": _get(full, "host_path", "pinned", "permutations_per_s"),
         "host_pageable_perm_per_s": _get(full, "host_path", "pageable", "permutations_per_s"),
-        "pedersen_pinned_hashes_per_s": _get(full, "host_path", "pedersen_pinned", "hashes_per_s"),
+        "pedersen_pinned_hashes_per_s": _get(full, "host_path", "pedersen_pinned", "hashes_per_s"),                  # default table
+        "pedersen_pinned_hbm_table_hashes_per_s": _get(full, "host_path", "pedersen_pinned_hbm_table", "hashes_per_s"),
         "sustained_perm_per_s": _get(full, "sustained", "2^%d" % (full["config"]["states_per_gpu"].bit_length() - 1), "permutations_per_s"),
         "cpu_pedersen_hashes_per_s": _get(full, "cpu_baseline", "pedersen", "value"),
         "cpu_bh_leaves_per_s": _get(full, "cpu_baseline", "bh_merkle", "value"),

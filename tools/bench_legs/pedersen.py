@@ -37,6 +37,16 @@ def run(env):
         ped_step()
         torch.cuda.synchronize(env.dev)
         cold_ms = (time.perf_counter() - c0) * 1e3
+        # a budget above the default: that first batch ran on the cache-sized table while a thread of the library builds the wide one;
+        # keep hashing until calls use it (what a host does), and note when that was
+        ready_ms, calls_before = None, 0
+        if budget:
+            while h.table_info()["last_build"]["upgrade_state"] == 1 and time.perf_counter() - c0 < 60.0:
+                ped_step()
+                torch.cuda.synchronize(env.dev)
+                calls_before += 1
+            ready_ms = (time.perf_counter() - c0) * 1e3
+            h.prepare(128)
         for _ in range(3):
             ped_step()
         env.barrier()
@@ -53,7 +63,9 @@ def run(env):
         info = h.info(128)
         return {"P": P, "h": h, "reps": reps, "psec": psec, "kavg": sum(kms) / len(kms) / 1e3,
                 "rec": {"digit_bits": info["digit_bits_or_group"], "table_bytes": info["table_bytes"], "steps": info["steps"],
-                        "cold_first_call_ms": cold_ms, "warm_ms_per_batch": psec / reps * 1e3, "warm_hashes_per_s": npd * env.world * reps / psec}}
+                        "cold_first_call_ms": cold_ms, "warm_ms_per_batch": psec / reps * 1e3, "warm_hashes_per_s": npd * env.world * reps / psec,
+                        "upgrade_ready_after_ms": ready_ms, "batches_hashed_on_the_cache_sized_table_meanwhile": calls_before + 1 if budget else None,
+                        "last_build": h.table_info()["last_build"]}}
     # the library's default first (cache-sized table), then the HBM-sized table a host opts into -- both from nothing
     cache = one_table(0)
     hbm = runner_hbm = None

@@ -47,6 +47,7 @@ while time.time() < t_end:
             bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9))
         fe = 2 if kind == "pedersen" else 1
         h = prm.handle(ctx)
+        h.prepare(128 if kind == "pedersen" else 189)  # round 6: the wide table (built in the background otherwise) before the measured calls
         for _ in range(12):
             if time.time() >= t_end:
                 break

@@ -3,6 +3,7 @@
 #   fresh   `python bench.py` as the FIRST GPU process of the lease (what the driver does), then a second run on the same lease
 #   vram    tools/vram_probe: hipMalloc / first write / second write per 16 GB slice, two rounds; background hipMalloc beside launches;
 #           the virtual-memory API (reserve + create + map per slice)
+#   single  tools/vram_probe in `single` mode, two processes: ONE 46 GB hipMalloc (+ one of 23 GB), twice per process
 #   test    pytest -m gpu        smoke   __graft_entry__.smoke()        bench   one more bench.py (line + full record)
 #   stats   rocprofv3 --kernel-trace --stats of the bench command (side loops off)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r06_sX}; mkdir -p $OUT
@@ -14,6 +15,7 @@ for P in $PARTS; do case $P in
          timeout 900 python bench.py > $OUT/bench_line_second_process.json 2> $OUT/bench_stderr_second.txt; echo "bench(second) rc=$?"; cp bench_full.json $OUT/bench_full_second_process.json
          cat $OUT/bench_line_first_process.json; cat $OUT/bench_line_second_process.json ;;
   vram)  for M in malloc bg vmm; do timeout 300 tools/vram_probe ${VRAM_GB:-16} ${VRAM_SLICES:-8} 2 $M > $OUT/vram_probe_$M.txt 2>&1; echo "vram $M rc=$?"; cat $OUT/vram_probe_$M.txt; done ;;
+  single) for I in 1 2; do timeout 300 tools/vram_probe 46 1 2 single > $OUT/vram_probe_single_process$I.txt 2>&1; echo "single $I rc=$?"; cat $OUT/vram_probe_single_process$I.txt; done ;;
   test)  timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_gpu.txt ;;
   smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.txt ;;
   bench) timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt; echo "bench rc=$?"; cp bench_full.json $OUT/; wc -c $OUT/bench_line.json; cat $OUT/bench_line.json ;;

@@ -53,6 +53,9 @@ if "te" in what:
     P = pedersen.Parameters(cparams.pedersen_generators(0xA5A50004, 4, 256))
     B = bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9))
     hp, hb = P.handle(ctx), B.handle(ctx)
+    hp.prepare(128)  # (PROF_TABLES=hbm: the wide tables built before the profiled launches, not in the background beside them)
+    hb.prepare(70)
+    hb.prepare(32)
     rng = np.random.default_rng(4)
     m128 = torch.from_numpy(rng.integers(0, 256, size=(n, 128), dtype=np.uint8)).to(dev)
     m32 = torch.from_numpy(rng.integers(0, 256, size=(n, 32), dtype=np.uint8)).to(dev)

@@ -88,6 +88,22 @@ int main(int argc, char** argv) {
         if (time_fill(w, 1 << 20, &ms)) return 1;
         CK(hipFree(w));
     }
+    // "single": ONE hipMalloc of `gb` GB (the shape of a curve table: 46 GB Pedersen, 22 / 75 GB Bowe-Hopwood), then a second of half the size;
+    // alloc / first write / second write / free, `rounds` times in this process
+    for (int r = 0; on("single") && r < rounds; ++r) {
+        for (size_t sz : {bytes, bytes / 2}) {
+            void* p = nullptr;
+            double t0 = now();
+            CK(hipMalloc(&p, sz));
+            const double t_alloc = (now() - t0) * 1e3;
+            double w1 = 0, w2 = 0;
+            if (time_fill(p, sz, &w1) || time_fill(p, sz, &w2)) return 1;
+            t0 = now();
+            CK(hipFree(p));
+            printf("round %d: ONE hipMalloc of %5.1f GB: %8.2f ms   first write pass %8.2f ms   second %7.2f ms   hipFree %7.2f ms\n", r + 1, sz / 1073741824.0, t_alloc, w1, w2,
+                   (now() - t0) * 1e3);
+        }
+    }
     for (int r = 0; on("malloc") && r < rounds; ++r) {
         std::vector<void*> ptrs;
         printf("round %d: hipMalloc of %d x %zu GB\n", r + 1, slices, gb);
@@ -132,6 +148,52 @@ int main(int argc, char** argv) {
         printf("background hipMalloc of %zu GB: %.2f ms; %d foreground launches (64 MB fill + sync) meanwhile: mean %.3f ms, worst %.3f ms\n", slices * gb / 2, alloc_ms, cnt,
                sum / cnt, worst);
         if (big) CK(hipFree(big));
+        CK(hipFree(w));
+    }
+    // "stall": the same question when the background hipMalloc really STALLS: free `slices` x `gb` GB (the driver wipes released VRAM by
+    // DMA, ~35 GB/s; an allocation made while wipes are queued waits for them -- seen above as one multi-second hipMalloc), then allocate
+    // them again on a second thread while this thread keeps launching
+    if (on("stall")) {
+        std::vector<void*> ptrs;
+        for (int i = 0; i < slices; ++i) {
+            void* p = nullptr;
+            double ms;
+            CK(hipMalloc(&p, bytes));
+            if (time_fill(p, bytes, &ms)) return 1;
+            ptrs.push_back(p);
+        }
+        void* w = nullptr;
+        CK(hipMalloc(&w, (size_t)1 << 30));
+        for (void* p : ptrs) CK(hipFree(p));
+        volatile int done = 0;
+        std::vector<double> alloc_ms(slices, 0.0);
+        std::thread th([&] {
+            (void)hipSetDevice(0);
+            std::vector<void*> q;
+            for (int i = 0; i < slices; ++i) {
+                void* p = nullptr;
+                const double t0 = now();
+                if (hipMalloc(&p, bytes) != hipSuccess) break;
+                alloc_ms[i] = (now() - t0) * 1e3;
+                q.push_back(p);
+            }
+            for (void* p : q) (void)hipFree(p);
+            done = 1;
+        });
+        double worst = 0, sum = 0, t_worst = 0;
+        int cnt = 0;
+        const double t_begin = now();
+        while (!done) {
+            double ms;
+            if (time_fill(w, (size_t)1 << 26, &ms)) return 1;
+            if (ms > worst) { worst = ms; t_worst = now() - t_begin; }
+            sum += ms;
+            ++cnt;
+        }
+        th.join();
+        printf("stall: background hipMalloc x %d of %zu GB right after freeing them:", slices, gb);
+        for (double a : alloc_ms) printf(" %.1f", a);
+        printf(" ms\n       %d foreground launches (64 MB fill + sync) meanwhile, %.2f s: mean %.3f ms, worst %.3f ms (at %.2f s)\n", cnt, now() - t_begin, sum / cnt, worst, t_worst);
         CK(hipFree(w));
     }
     if (!on("vmm")) return 0;
