@@ -105,6 +105,8 @@ static void te_storage_retire(TeTable* t) {
 template <int KIND>
 static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u32 from, u32 units, akp_te_build_report* rep) {
     hipStream_t bs = t->active_stream;
+    // (a background build runs on a stream confined to a few compute units: te_upgrade_kick)
+    const size_t polite_lds = 0;
     const u32 k_lo = KIND == 2 ? (W - 1) / 2 : W / 2;
     const u32 unit_shift = KIND == 2 ? W - 1 : 3 * W - 1;
     const size_t n_lo = KIND == 2 ? (size_t)units << k_lo : (size_t)units << (3 * k_lo - 1);
@@ -129,7 +131,7 @@ static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u
     if (e == hipSuccess) {
         t0 = te_now_ms();
         const unsigned cgrid = (unsigned)((entries - first + 256 * AKP_TE_BUILD_RUN - 1) / (256 * AKP_TE_BUILD_RUN));
-        hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), 0, bs, lo, hi, W, k_lo, first, entries, t->d_lut);
+        hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), polite_lds, bs, lo, hi, W, k_lo, first, entries, t->d_lut);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(bs);
         rep->combine_ms += te_now_ms() - t0;
@@ -553,6 +555,7 @@ static int32_t te_ensure_table(TeTable* t, size_t data_len, u32* groups, u32* st
         // the first build covers what this message needs, an extension everything (the old block is retired, not freed: at most once)
         u32 target = t->builds ? t->units_total : te_shape::grow_target(needed, t->units_built, t->units_total);
         akp_te_build_report rep{};
+        rep.in_background = background ? 1u : 0u;
         const double t_begin = te_now_ms();
         hipError_t e = hipSuccess;
         if (t->shape_auto) {  // at most half of what is free now
@@ -710,6 +713,7 @@ static int32_t te_resolve(TeTable* t, size_t msg_len, size_t data_len, hipStream
 // hashes on the cache-sized table meanwhile; a request that arrives while a build runs is dropped -- the next call of that shape asks
 // again.  The thread holds the table's lock for the whole build: callers TRY the lock (te_pick) and take the cache-sized table when it
 // is held.  A failed build (memory) marks the table: no further attempts, the handles stay where they are.
+static const u32 TE_BG_CUS = env_u32("AKP_TE_BG_CUS", 32, 1, 256);
 static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool want_rem) {
     if (w->upgrade_failed.load()) return;
     bool idle = false;
@@ -720,11 +724,23 @@ static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool wa
         {
             std::lock_guard<std::mutex> lk(w->mu);
             if (!w->bg_stream) {
-                int lo_prio = 0, hi_prio = 0;
-                if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
-                    hipStreamCreateWithPriority(&w->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
+                // A build that runs BESIDE hashing must not take the machine from it.  Stream priority alone does not do it (waves that
+                // are resident keep their slots: the first 2^23-leaf tree beside the build took 53 ms instead of 27, profiles/r06_s10), and
+                // capping the build's occupancy through unused LDS still costs every compute unit a share (2^26-leaf tree 234 against
+                // 179 ms, r06_s11).  So the build gets compute units of its OWN: a stream whose CU mask names TE_BG_CUS of the 256 (the
+                // mask's bits go round the XCDs), the rest of the machine never sees it.  It takes ~256 / TE_BG_CUS times as long; nobody
+                // waits for it.  Without the extension: lowest priority.
+                u32 mask[8] = {};
+                for (u32 i = 0; i < TE_BG_CUS; ++i) mask[i / 32] |= 1u << (i % 32);
+                if (hipExtStreamCreateWithCUMask(&w->bg_stream, 8, mask) != hipSuccess) {
                     (void)hipGetLastError();
                     w->bg_stream = nullptr;
+                    int lo_prio = 0, hi_prio = 0;
+                    if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
+                        hipStreamCreateWithPriority(&w->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
+                        (void)hipGetLastError();
+                        w->bg_stream = nullptr;
+                    }
                 }
             }
             if (w->bg_stream) w->active_stream = w->bg_stream;

@@ -244,3 +244,73 @@ def test_prepare_builds_at_a_time_of_the_hosts_choosing_and_dev_calls_then_only_
     with pytest.raises(cpa.IncorrectInputLength):
         h.prepare(213)
     assert cpa.lib.akp_te_params_prepare(None, 8) == AKP_ERR_BAD_PARAMS and cpa.lib.akp_te_params_prepare_compress(None) == AKP_ERR_BAD_PARAMS
+
+
+def test_budget_chosen_wide_table_is_built_in_the_background(cpa):
+    """round 6: a handle created under AKP_TABLE_BUDGET_DEVICE starts hashing on the cache-sized table at once -- the first
+    batch costs what it costs with the default budget -- while a thread of the library allocates and builds the 46 GB table; calls switch
+    to it when it is complete; every digest along the way is the oracle's.  A second handle attaches to both tables; `prepare` from
+    another thread while the build runs simply waits for it; destroying the only handle of a table that is still being built waits too."""
+    import time
+    from crypto_primitives_amd._lib import Context, TABLE_BUDGET_DEVICE
+    from crypto_primitives_amd.crh import pedersen
+    g = gens_array(jj.pedersen_generators(0xC5C50021, 4, 256))
+    ora = cref.CurveParams(4, 256, g)
+    c1, c2 = Context(0), Context(0)
+    c1.set_table_budget(TABLE_BUDGET_DEVICE)
+    c2.set_table_budget(TABLE_BUDGET_DEVICE)
+    if c1.table_budget() < 71 << 30:
+        pytest.skip("needs an idle 288 GB device")
+    n = 30000
+    m = _msgs(n, 128, 31)
+    want = ora.pedersen_crh_batch(m, n, 128, threads=8)
+    # (a default-budget handle of the same generators first: the wide handle below then finds the cache-sized table built -- its first call
+    # is a plain hash -- and this call has paid the context's scratch allocation)
+    base = pedersen.Parameters(g)
+    out = np.empty((n, 2, 4), dtype=np.uint64)
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(base.handle(c1).h, m.ctypes.data, n, 128, out.ctypes.data))
+    t0 = time.perf_counter()
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(base.handle(c1).h, m.ctypes.data, n, 128, out.ctypes.data))
+    plain_ms = (time.perf_counter() - t0) * 1e3
+    P = pedersen.Parameters(g)
+    c1_handles_before = base.handle(c1).table_info()["handles_attached"]
+    h = P.handle(c1)
+    assert base.handle(c1).table_info()["handles_attached"] == c1_handles_before + 1  # attached to the cache-sized table as well
+    ti = h.table_info()
+    assert ti["last_build"]["upgrade_state"] == 1 and ti["wide_builds"] == 0 and h.info(128)["digit_bits_or_group"] == 16
+    t0 = time.perf_counter()
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, n, 128, out.ctypes.data))
+    first_ms = (time.perf_counter() - t0) * 1e3
+    assert np.array_equal(out, want)
+    assert first_ms < plain_ms + 25.0, (first_ms, plain_ms)  # NOT the 65 ms (1.3 s on a machine's first use) of building 46 GB on this thread
+    # a second context's handle while the build runs: same tables; its `prepare` waits for the builder instead of building a second time
+    h2 = P.handle(c2)
+    assert h2.table_info()["table_id"] == h.table_info()["table_id"]
+    seen = set()
+    deadline = time.perf_counter() + 60
+    while time.perf_counter() < deadline:
+        out[:] = 0
+        cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, n, 128, out.ctypes.data))
+        assert np.array_equal(out, want)
+        st = h.table_info()["last_build"]["upgrade_state"]
+        seen.add((st, h.info(128)["digit_bits_or_group"]))
+        if st == 2:
+            break
+    assert (2, 24) in seen and all(s in ((1, 16), (2, 24)) for s in seen), seen
+    h2.prepare(128)
+    ti = h2.table_info()
+    assert ti["wide_builds"] == 1 and ti["last_build"]["in_background"] == 1 and ti["last_build"]["units_to"] == 43 and ti["last_build"]["combine_ms"] > 0, ti
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(h2.h, m.ctypes.data, n, 128, out.ctypes.data))
+    assert np.array_equal(out, want) and h2.info(128)["digit_bits_or_group"] == 24
+    # a table whose only handle goes while the builder is still at work: the release waits for the thread (no use after free, no leak)
+    g2 = gens_array(jj.pedersen_generators(0xC5C50022, 4, 256))
+    Q = pedersen.Parameters(g2)
+    hq = Q.handle(c1)
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(hq.h, m.ctypes.data, 2000, 128, out.ctypes.data))  # starts the build
+    assert np.array_equal(out[:2000], cref.CurveParams(4, 256, g2).pedersen_crh_batch(m[:2000], 2000, 128, threads=4))
+    free_before = _free_bytes()
+    Q._handles.clear()
+    del hq, Q
+    assert _free_bytes() >= free_before - (1 << 30)  # whatever the builder had allocated came back with the handle
+    c1.set_table_budget(0)
+    c2.set_table_budget(0)

@@ -63,7 +63,6 @@ def compact(full, full_name="bench_full.json"):
         "pedersen_cold_first_call_ms": _get(full, "pedersen", "tables", "cache_sized", "cold_first_call_ms"),          # library default, from nothing
         "pedersen_cold_first_call_ms_hbm_table": _get(full, "pedersen", "tables", "hbm_sized", "cold_first_call_ms"),
         "pedersen_hbm_table_ready_after_ms": _get(full, "pedersen", "tables", "hbm_sized", "upgrade_ready_after_ms"),
-        "pedersen_break_even_hashes": _get(full, "pedersen", "tables", "break_even_hashes"),
         "bh_leaves": _get(full, "bh_merkle", "leaves"),
         "bh_s": _get(full, "bh_merkle", "seconds"),                        # configs[4] share: 2^23 leaves per GPU, warm, the library's default tables
         "bh_hbm_table_s": _get(full, "bh_merkle", "tables", "hbm_sized", "warm_seconds"),                               # opt-in

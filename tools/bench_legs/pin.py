@@ -32,7 +32,8 @@ def try_emit(timeout_s=600):
 
 def status(attempt=True):
     """(short status string, note).  short status starts with 'pinned' or 'unpinned'"""
-    note = try_emit() if attempt else ("present" if os.path.exists(VECTORS) else "not attempted")
+    note = try_emit() if attempt else ("present" if os.path.exists(VECTORS) else
+                                       "not attempted (AKP_RUN_EMITTER=1 runs shim/examples/emit_vectors.rs; cargo %s on this box)" % ("present" if shutil.which("cargo") else "absent"))
     if not os.path.exists(VECTORS):
         return "unpinned (emitter not run): tests/golden/reference_vectors.json is absent -- shim/examples/README.md", note
     try:
