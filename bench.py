@@ -183,6 +183,9 @@ def main():
     env.rank, env.world, env.local_rank, env.dist, env.shared_gpu = rank, world, local_rank, dist, shared_gpu
     env.barrier, env.max_over_ranks = runner.barrier, runner.max_over_ranks  # the legs' collectives carry the abort flag (bench_legs/runner.py)
     env.GpuPoseidonBackend, env.GpuTeBackend, env.build_sharded = GpuPoseidonBackend, GpuTeBackend, build_sharded
+    # handles with HBM-sized tables stay alive until the run ends: freeing tens of GB in the middle of it would leave the driver wiping the
+    # released memory (~35 GB/s) while the next leg allocates -- and an allocation made then waits for the wipe (profiles/r06_s2, r06_s20)
+    env.keepalive = []
     env.ora_threads = max(1, min(32, (os.cpu_count() or 1)))
     env.bench_path = os.path.abspath(__file__)
     env.ora = None

@@ -51,14 +51,22 @@ int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out, hipStream_t 
     c->slot_used[slot] = true;
     c->slot_stream[slot] = s;
     if (c->scratch_bytes[slot] < bytes) {
-        if (c->scratch[slot]) {
-            HIP_TRY(hipDeviceSynchronize());  // work enqueued on other streams may still read it
-            HIP_TRY(hipFree(c->scratch[slot]));
-            c->scratch[slot] = nullptr;
-            c->scratch_bytes[slot] = 0;
+        // grow: a NEW block of at least 1.5 x the old size; the old one is RETIRED (freed with the context) -- work enqueued on other
+        // streams may still read it, and draining the device here (round 5) would also wait for whatever else runs on it: the
+        // background build of a curve table, other contexts' kernels.  Retired blocks add up to less than twice the largest.
+        void* fresh = nullptr;
+        const size_t want = std::max(bytes, c->scratch_bytes[slot] + c->scratch_bytes[slot] / 2);
+        hipError_t e = hipMalloc(&fresh, want);
+        size_t got = want;
+        if (e != hipSuccess && want > bytes) {
+            (void)hipGetLastError();
+            e = hipMalloc(&fresh, bytes);
+            got = bytes;
         }
-        HIP_TRY(hipMalloc(&c->scratch[slot], bytes));
-        c->scratch_bytes[slot] = bytes;
+        if (e != hipSuccess) return fail(AKP_ERR_HIP, "scratch of %zu MB: %s", bytes >> 20, hipGetErrorString(e));
+        if (c->scratch[slot]) c->scratch_retired.push_back(c->scratch[slot]);
+        c->scratch[slot] = fresh;
+        c->scratch_bytes[slot] = got;
     }
     *out = c->scratch[slot];
     return AKP_OK;
@@ -83,6 +91,8 @@ extern "C" void akp_ctx_destroy(akp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    for (void* r : c->scratch_retired) (void)hipFree(r);
+    c->scratch_retired.clear();
     for (int i = 0; i < SCR_COUNT; ++i) {
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
         if (c->slot_event[i]) (void)hipEventDestroy(c->slot_event[i]);

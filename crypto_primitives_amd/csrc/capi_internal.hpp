@@ -46,6 +46,7 @@ struct akp_ctx {
     hipStream_t stream = nullptr;
     void* scratch[SCR_COUNT] = {};
     size_t scratch_bytes[SCR_COUNT] = {};
+    std::vector<void*> scratch_retired;  // blocks a slot outgrew (ctx_scratch): freed with the context, never under running work
     // stream that last used each slot + an event to order the next use on ANOTHER stream behind it: `_dev` entry points
     // run on the caller's stream while the host-pointer entry points run on `stream` (non-blocking, so no implicit order
     // with the legacy default stream); without this two calls on different streams would race on the shared scratch

@@ -99,14 +99,13 @@ static void te_storage_retire(TeTable* t) {
     t->units_built = 0;
 }
 
+static const unsigned TE_BG_WGS = env_u32("AKP_TE_BG_WGS", 128, 1, 1u << 20);  // workgroups of a background build's combine kernel
 // two-part construction of a wide table (te_kernels.hpp): part tables entry by entry (for ALL units up to `units`: kilobytes to
 // megabytes, < 0.5 ms), then one addition per wide entry of the units [from, units).
 // KIND 2: Pedersen signed-subset table of W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of groups of W chunks.
 template <int KIND>
 static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u32 from, u32 units, akp_te_build_report* rep) {
     hipStream_t bs = t->active_stream;
-    // (a background build runs on a stream confined to a few compute units: te_upgrade_kick)
-    const size_t polite_lds = 0;
     const u32 k_lo = KIND == 2 ? (W - 1) / 2 : W / 2;
     const u32 unit_shift = KIND == 2 ? W - 1 : 3 * W - 1;
     const size_t n_lo = KIND == 2 ? (size_t)units << k_lo : (size_t)units << (3 * k_lo - 1);
@@ -130,8 +129,15 @@ static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u
     }
     if (e == hipSuccess) {
         t0 = te_now_ms();
-        const unsigned cgrid = (unsigned)((entries - first + 256 * AKP_TE_BUILD_RUN - 1) / (256 * AKP_TE_BUILD_RUN));
-        hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), polite_lds, bs, lo, hi, W, k_lo, first, entries, t->d_lut);
+        unsigned cgrid = (unsigned)((entries - first + 256 * AKP_TE_BUILD_RUN - 1) / (256 * AKP_TE_BUILD_RUN));
+        // A build that runs BESIDE hashing (the background upgrade) must not take the machine from it.  Stream priority alone does not do
+        // it (waves that are resident keep their slots: the first 2^23-leaf tree beside the build took 53 ms instead of 27, profiles/r06_s10);
+        // capping the build's occupancy through unused LDS costs every compute unit a share (2^26-leaf tree 234 against 179 ms, r06_s11); a
+        // stream with a CU mask did it (r06_s13) -- until the first out-of-memory hipMalloc of the process, which then hung or crashed inside
+        // the runtime (r06_s14 .. s16).  So the build simply launches FEW workgroups, each walking many tiles: TE_BG_WGS of them hold that
+        // many x 4 of the device's 8192 wave slots.  It takes ~8 times as long; nobody waits for it.
+        if (rep->in_background) cgrid = std::min(cgrid, TE_BG_WGS);
+        hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), 0, bs, lo, hi, W, k_lo, first, entries, t->d_lut);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(bs);
         rep->combine_ms += te_now_ms() - t0;
@@ -217,6 +223,16 @@ static hipError_t te_table_init(TeTable* t, const uint64_t* gens, u32 shape, siz
     // yields the compute units to the hashing it runs beside) -- `active_stream` is whichever the thread that holds t->mu builds on
     hipError_t e = hipStreamCreateWithFlags(&t->build_stream, hipStreamNonBlocking);
     t->active_stream = t->build_stream;
+    if (t->shape_auto && budget > TE_DEFAULT_BUDGET) {
+        // the background stream of a wide table is created HERE, by the thread that creates the handle, not by the builder beside the
+        // handle's first call: the process's first lowest-priority stream brings a hardware queue into being
+        int lo_prio = 0, hi_prio = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
+            hipStreamCreateWithPriority(&t->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
+            (void)hipGetLastError();
+            t->bg_stream = nullptr;
+        }
+    }
     hipStream_t bs = t->build_stream;
     if (e == hipSuccess) e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
@@ -713,7 +729,6 @@ static int32_t te_resolve(TeTable* t, size_t msg_len, size_t data_len, hipStream
 // hashes on the cache-sized table meanwhile; a request that arrives while a build runs is dropped -- the next call of that shape asks
 // again.  The thread holds the table's lock for the whole build: callers TRY the lock (te_pick) and take the cache-sized table when it
 // is held.  A failed build (memory) marks the table: no further attempts, the handles stay where they are.
-static const u32 TE_BG_CUS = env_u32("AKP_TE_BG_CUS", 32, 1, 256);
 static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool want_rem) {
     if (w->upgrade_failed.load()) return;
     bool idle = false;
@@ -724,23 +739,11 @@ static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool wa
         {
             std::lock_guard<std::mutex> lk(w->mu);
             if (!w->bg_stream) {
-                // A build that runs BESIDE hashing must not take the machine from it.  Stream priority alone does not do it (waves that
-                // are resident keep their slots: the first 2^23-leaf tree beside the build took 53 ms instead of 27, profiles/r06_s10), and
-                // capping the build's occupancy through unused LDS still costs every compute unit a share (2^26-leaf tree 234 against
-                // 179 ms, r06_s11).  So the build gets compute units of its OWN: a stream whose CU mask names TE_BG_CUS of the 256 (the
-                // mask's bits go round the XCDs), the rest of the machine never sees it.  It takes ~256 / TE_BG_CUS times as long; nobody
-                // waits for it.  Without the extension: lowest priority.
-                u32 mask[8] = {};
-                for (u32 i = 0; i < TE_BG_CUS; ++i) mask[i / 32] |= 1u << (i % 32);
-                if (hipExtStreamCreateWithCUMask(&w->bg_stream, 8, mask) != hipSuccess) {
+                int lo_prio = 0, hi_prio = 0;  // lowest priority + few workgroups (te_build_wide)
+                if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
+                    hipStreamCreateWithPriority(&w->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
                     (void)hipGetLastError();
                     w->bg_stream = nullptr;
-                    int lo_prio = 0, hi_prio = 0;
-                    if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
-                        hipStreamCreateWithPriority(&w->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
-                        (void)hipGetLastError();
-                        w->bg_stream = nullptr;
-                    }
                 }
             }
             if (w->bg_stream) w->active_stream = w->bg_stream;

@@ -386,11 +386,15 @@ AKP_HD void te_build_combine_lane(const TeEntry* __restrict__ lo, const TeEntry*
         store_niels(lut + e, niels_from_affine(f29_mul(xyz.ypx, zi), f29_mul(xyz.ymx, zi)));
     }
 }
-// entries [first, n_entries): an extension of the table builds only the units it adds (round 6), the part tables cover all units
+// entries [first, n_entries) in tiles of 256 x AKP_TE_BUILD_RUN; workgroup b takes the tiles b, b + gridDim.x, ...: a grid of one
+// workgroup per tile is the fast build, a grid of a few workgroups the POLITE one (round 6: a table built in the background beside
+// hashing occupies that many wave slots and no more -- capi_te.hip te_build_wide)
 template <int KIND>
 __global__ void __launch_bounds__(256) te_build_combine_kernel(const TeEntry* __restrict__ lo, const TeEntry* __restrict__ hi, u32 W, u32 k_lo,
                                                               size_t first, size_t n_entries, TeEntry* __restrict__ lut) {
-    te_build_combine_lane<KIND>(lo, hi, W, k_lo, n_entries, lut, first + (size_t)blockIdx.x * (256u * AKP_TE_BUILD_RUN) + threadIdx.x, 256u);
+    constexpr size_t tile = 256u * AKP_TE_BUILD_RUN;
+    for (size_t at = first + (size_t)blockIdx.x * tile; at < n_entries; at += (size_t)gridDim.x * tile)
+        te_build_combine_lane<KIND>(lo, hi, W, k_lo, n_entries, lut, at + threadIdx.x, 256u);
 }
 // test build: the wide table against the per-entry definition (canonical values), mismatches counted
 template <int KIND>

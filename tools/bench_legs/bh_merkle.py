@@ -27,15 +27,24 @@ def run(env):
         finally:
             env.ctx.set_table_budget(budget_before)
 
+    def warm_allocator(leaves_):
+        """the node arrays of one tree, allocated and handed back to torch's caching allocator: the timed builds below then reuse those
+        blocks.  A hipMalloc issued while the driver is still mapping a 22 GB table allocated a moment ago (the background build) takes
+        tens of ms instead of 0.1 (profiles/r06_s21: first tree 59 instead of 25 ms when its node arrays are fresh allocations) -- the
+        cold figures are about the library's start, not about the allocator's"""
+        tmp = [torch.empty((leaves_, 4), dtype=torch.int64, device=env.dev), torch.empty((leaves_ - 1, 4), dtype=torch.int64, device=env.dev)]
+        del tmp
+
     def one_table(budget):
         """a FRESH handle under `budget`: the first tree from nothing (tables for 32- and 64-byte nodes + scratch + RCCL warm-up + the
         tree), then the warm build time"""
         Bp, tb = fresh(budget, gens)
         assert Bp.handle(env.ctx).table_info()["wide_builds"] == 0
+        warm_allocator(per)
         env.barrier()
         c0 = time.perf_counter()
         env.build_sharded(tb, d_leaves, total, env.dist)
-        torch.cuda.synchronize(env.dev)
+        torch.cuda.current_stream(env.dev).synchronize()  # the launch stream: a device-wide synchronize would also wait for the background build
         cold_ms = env.max_over_ranks(time.perf_counter() - c0) * 1e3
         # a budget above the default: that first tree ran (wholly or partly) on the cache-sized tables while a thread of the library builds
         # the wide ones; keep building trees until calls use them, and note when that was
@@ -44,7 +53,7 @@ def run(env):
         if budget:
             while hh0.table_info()["last_build"]["upgrade_state"] == 1 and time.perf_counter() - c0 < 60.0:
                 env.build_sharded(tb, d_leaves, per, None)  # (this rank's shard as a tree of its own: no collective inside the wait)
-                torch.cuda.synchronize(env.dev)
+                torch.cuda.current_stream(env.dev).synchronize()
                 trees_before += 1
             ready_ms = (time.perf_counter() - c0) * 1e3
             hh0.prepare(32, compress=True)
@@ -70,6 +79,7 @@ def run(env):
             hbm = one_table(TABLE_BUDGET_DEVICE)
         except Exception as exc:  # noqa: BLE001
             hbm_error = repr(exc)[:300]
+    env.keepalive.append((cache, hbm))
     main = cache  # `seconds`, `leaves_per_s` and `roofline` of this leg are the LIBRARY DEFAULT's; the HBM-sized tables stand beside them
     B, res, bsec, dev_ms = main["B"], main["res"], main["bsec"], main["dev_ms"]
     tables = {"cache_sized": cache["rec"], "library_default": "cache_sized (akp_ctx_set_table_budget 0 = 320 MiB)",
@@ -90,13 +100,15 @@ def run(env):
         big = 1 << 26
         d_big = d_leaves.repeat(big // per, 1) if big > per else d_leaves[:big]
         g2 = cparams.bowe_hopwood_generators(0xA5A50105, 63, 9)
-        single = {}
+        single, alive = {}, []  # (`alive`: nothing of this block is freed before both variants are measured -- a hipMalloc that follows a
+        # large hipFree waits for the driver's wipe of the released memory, seconds for tens of GB: profiles/r06_s2, r06_s20)
         for name, budget in (("cache_sized", 0), ("hbm_sized", TABLE_BUDGET_DEVICE)):
             Bp, tb2 = fresh(budget, g2)
+            warm_allocator(big)
             torch.cuda.synchronize(env.dev)
             c0 = time.perf_counter()
             r2 = env.build_sharded(tb2, d_big, big, None)
-            torch.cuda.synchronize(env.dev)
+            torch.cuda.current_stream(env.dev).synchronize()
             cold = time.perf_counter() - c0
             if budget:
                 Bp.handle(env.ctx).prepare(32, compress=True)  # (the background build of the wide tables, waited for: the warm tree uses them)
@@ -104,11 +116,11 @@ def run(env):
             r2 = env.build_sharded(tb2, d_big, big, None)
             torch.cuda.synchronize(env.dev)
             single[name] = {"cold_first_tree_s": cold, "warm_tree_s": time.perf_counter() - c0, "table_bytes": Bp.handle(env.ctx).info(32)["table_bytes"]}
-            del r2, tb2, Bp
-            torch.cuda.empty_cache()
+            alive.append((tb2, Bp))
+            del r2
         tables["single_tree_2p26_one_gpu"] = single
+        env.keepalive.append(alive)
         del d_big
-        torch.cuda.empty_cache()
     h = B.handle(env.ctx)
     pmc = te_pmc(h.info(64)["table_bytes"])
     grp = h.info()["digit_bits_or_group"]

@@ -77,7 +77,7 @@ def run(env, host_states, n):
             host_path["pedersen_pinned_hbm_table"] = {"hashes_per_s": nph / hs3, "ms_per_batch": hs3 * 1e3, "ms_min": lo3 * 1e3, "ms_max": hi3 * 1e3,
                                                       "digests_equal_the_pageable_call": bool(np.array_equal(pinned_out, ho)), "table": hw.info(128)}
             same = same and host_path["pedersen_pinned_hbm_table"]["digests_equal_the_pageable_call"]
-            del hw, Pw
+            env.keepalive.append((hw, Pw))
         check(lib.akp_host_free(pm))
         check(lib.akp_host_free(po))
         if not same:

@@ -35,7 +35,7 @@ def run(env):
         torch.cuda.synchronize(env.dev)
         c0 = time.perf_counter()
         ped_step()
-        torch.cuda.synchronize(env.dev)
+        torch.cuda.current_stream(env.dev).synchronize()  # the launch stream: a device-wide synchronize would also wait for the background build
         cold_ms = (time.perf_counter() - c0) * 1e3
         # a budget above the default: that first batch ran on the cache-sized table while a thread of the library builds the wide one;
         # keep hashing until calls use it (what a host does), and note when that was
@@ -43,7 +43,7 @@ def run(env):
         if budget:
             while h.table_info()["last_build"]["upgrade_state"] == 1 and time.perf_counter() - c0 < 60.0:
                 ped_step()
-                torch.cuda.synchronize(env.dev)
+                torch.cuda.current_stream(env.dev).synchronize()
                 calls_before += 1
             ready_ms = (time.perf_counter() - c0) * 1e3
             h.prepare(128)
@@ -74,6 +74,7 @@ def run(env):
             hbm = one_table(TABLE_BUDGET_DEVICE)
         except Exception as exc:  # noqa: BLE001
             runner_hbm = repr(exc)[:300]
+    env.keepalive.append((cache, hbm))
     main = cache  # the leg's `hashes_per_s`, `roofline` and `sustained` are the LIBRARY DEFAULT's (the opt-in is not the headline)
     hP, reps, psec, kavg = main["h"], main["reps"], main["psec"], main["kavg"]
     state["h"] = hP

@@ -45,6 +45,17 @@ __global__ void gather_kernel(const uint4* p, size_t lines, int steps, uint32_t*
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// a long kernel of few workgroups: `wgs` workgroups spin for `cycles` of the constant 100 MHz clock
+__global__ void spin_kernel(unsigned long long ticks, uint32_t* sink) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    unsigned long long now_ = t0;
+    uint32_t acc = threadIdx.x;
+    while (now_ - t0 < ticks) {
+        for (int i = 0; i < 256; ++i) acc = acc * 1664525u + 1013904223u;
+        now_ = __builtin_readcyclecounter();
+    }
+    if (acc == 0x12345u) sink[0] = acc;
+}
 static int time_fill(void* p, size_t bytes, double* ms) {
     const double t0 = now();
     hipLaunchKernelGGL(fill_kernel, dim3(256 * 16), dim3(256), 0, 0, (uint4*)p, bytes / 16, 7u);
@@ -194,6 +205,55 @@ int main(int argc, char** argv) {
         printf("stall: background hipMalloc x %d of %zu GB right after freeing them:", slices, gb);
         for (double a : alloc_ms) printf(" %.1f", a);
         printf(" ms\n       %d foreground launches (64 MB fill + sync) meanwhile, %.2f s: mean %.3f ms, worst %.3f ms (at %.2f s)\n", cnt, now() - t_begin, sum / cnt, worst, t_worst);
+        CK(hipFree(w));
+    }
+    // "beside": does ONE long kernel of few workgroups on another stream hold up short launches of this thread?  (the background table
+    // build as 128 workgroups walking the table.)  Stream kinds: lowest priority, default priority (non-blocking), CU mask of 32.
+    if (on("beside")) {
+        void* w = nullptr;
+        uint32_t* sink = nullptr;
+        CK(hipMalloc(&w, (size_t)1 << 30));
+        CK(hipMalloc(&sink, 4));
+        int lo_p = 0, hi_p = 0;
+        CK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        for (int kind = 0; kind < 3; ++kind) {
+            hipStream_t bs = nullptr;
+            if (kind == 0) CK(hipStreamCreateWithPriority(&bs, hipStreamNonBlocking, lo_p));
+            if (kind == 1) CK(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
+            if (kind == 2) {
+                uint32_t mask[8] = {0xffffffffu, 0, 0, 0, 0, 0, 0, 0};
+                CK(hipExtStreamCreateWithCUMask(&bs, 8, mask));
+            }
+            for (int fg = 0; fg < 2; ++fg) {  // foreground on the NULL stream / on a non-blocking stream of its own
+                hipStream_t fs = nullptr;
+                if (fg) CK(hipStreamCreateWithFlags(&fs, hipStreamNonBlocking));
+                double ms;
+                for (int i = 0; i < 50; ++i) {
+                    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, fs, (uint4*)w, ((size_t)1 << 26) / 16, 7u);
+                    CK(hipStreamSynchronize(fs));
+                }
+                hipLaunchKernelGGL(spin_kernel, dim3(128), dim3(256), 0, bs, 30000000ull /* 0.3 s at 100 MHz */, sink);
+                CK(hipGetLastError());
+                const double t_begin = now();
+                double worst = 0, sum = 0;
+                int cnt = 0;
+                while (hipStreamQuery(bs) == hipErrorNotReady) {
+                    const double t0 = now();
+                    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, fs, (uint4*)w, ((size_t)1 << 26) / 16, 7u);
+                    CK(hipStreamSynchronize(fs));
+                    ms = (now() - t0) * 1e3;
+                    worst = ms > worst ? ms : worst;
+                    sum += ms;
+                    ++cnt;
+                }
+                (void)hipGetLastError();
+                printf("beside: long kernel (128 workgroups, %.0f ms) on a %s stream, short launches on %s: %d launches, mean %.3f ms, worst %.3f ms\n", (now() - t_begin) * 1e3,
+                       kind == 0 ? "lowest-priority" : kind == 1 ? "default-priority" : "CU-mask(32)", fg ? "a non-blocking stream" : "the NULL stream", cnt, cnt ? sum / cnt : 0.0, worst);
+                if (fs) CK(hipStreamDestroy(fs));
+            }
+            CK(hipStreamDestroy(bs));
+        }
+        CK(hipFree(sink));
         CK(hipFree(w));
     }
     if (!on("vmm")) return 0;
