@@ -314,3 +314,56 @@ def test_budget_chosen_wide_table_is_built_in_the_background(cpa):
     assert _free_bytes() >= free_before - (1 << 30)  # whatever the builder had allocated came back with the handle
     c1.set_table_budget(0)
     c2.set_table_budget(0)
+
+
+def test_background_upgrade_under_concurrent_mixed_lengths(cpa):
+    """threads with contexts of their own hash messages of DIFFERENT lengths through handles under AKP_TABLE_BUDGET_DEVICE while the
+    library's thread builds the shared wide Bowe-Hopwood table underneath them: the first request builds a prefix, a longer message
+    asks again and the table is extended (once, to the complete 75 GB table; the prefix is retired, not freed -- launches that were
+    given it may still be running), remainder tables are added per length.  Whichever table a call lands on, every digest is the
+    oracle's; in the end every length runs on the wide table and the table was built at most twice."""
+    import time
+    from crypto_primitives_amd._lib import Context, TABLE_BUDGET_DEVICE
+    from crypto_primitives_amd.crh import bowe_hopwood
+    g = gens_array(jj.bowe_hopwood_generators(0xC5C50031, 63, 9))
+    ora = cref.CurveParams(63, 9, g)
+    lens = [8, 32, 64, 100, 150, 212, 20, 70]
+    ctxs = [Context(0) for _ in lens]
+    for c in ctxs:
+        c.set_table_budget(TABLE_BUDGET_DEVICE)
+    if ctxs[0].table_budget() < 71 << 30:
+        pytest.skip("needs an idle 288 GB device")
+    B = bowe_hopwood.Parameters(g)
+    handles = [B.handle(c) for c in ctxs]
+    for c in ctxs:
+        c.set_table_budget(0)
+    start = threading.Barrier(len(lens))
+
+    def work(i):
+        h, L = handles[i], lens[i]
+        start.wait()
+        shapes = set()
+        t_end = time.perf_counter() + 6.0
+        rep = 0
+        while rep < 6 or (time.perf_counter() < t_end and 8 not in shapes):
+            n = 20000 + 50 * (rep % 7) if i % 2 else 700 + 50 * (rep % 7)  # odd threads: the accumulate + finalize kernels; even: the split kernel
+            m = _msgs(n, L, 2000 + 10 * i + rep)
+            out = np.empty((n, 4), dtype=np.uint64)
+            cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, n, L, out.ctypes.data))
+            assert np.array_equal(out, ora.bh_crh_batch(m, n, L, threads=1)), "length %d, repetition %d" % (L, rep)
+            shapes.add(h.info(L)["digit_bits_or_group"])
+            rep += 1
+        return shapes
+    res = _run_threads(len(lens), work)
+    assert all(s <= {5, 8} for s in res), res
+    for h, L in zip(handles, lens):
+        h.prepare(L)  # (whatever the builder had not got round to)
+        assert h.info(L)["digit_bits_or_group"] == 8
+    ti = handles[0].table_info()
+    assert len({h.table_info()["table_id"] for h in handles}) == 1 and ti["handles_attached"] == len(lens)
+    assert 1 <= ti["wide_builds"] <= 2 and ti["last_build"]["upgrade_state"] == 2, ti
+    for i, (h, L) in enumerate(zip(handles, lens)):  # and once more, now all on the wide table
+        m = _msgs(900, L, 5000 + i)
+        out = np.empty((900, 4), dtype=np.uint64)
+        cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, 900, L, out.ctypes.data))
+        assert np.array_equal(out, ora.bh_crh_batch(m, 900, L, threads=2)), L

@@ -16,7 +16,7 @@ for P in $PARTS; do case $P in
          cat $OUT/bench_line_first_process.json; cat $OUT/bench_line_second_process.json ;;
   vram)  for M in malloc bg vmm; do timeout 300 tools/vram_probe ${VRAM_GB:-16} ${VRAM_SLICES:-8} 2 $M > $OUT/vram_probe_$M.txt 2>&1; echo "vram $M rc=$?"; cat $OUT/vram_probe_$M.txt; done ;;
   single) for I in 1 2; do timeout 300 tools/vram_probe 46 1 2 single > $OUT/vram_probe_single_process$I.txt 2>&1; echo "single $I rc=$?"; cat $OUT/vram_probe_single_process$I.txt; done ;;
-  test)  timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_gpu.txt ;;
+  test)  timeout 1500 python -m pytest tests -m gpu -q --timeout=600 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_gpu.txt ;;
   smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.txt ;;
   bench) timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt; echo "bench rc=$?"; cp bench_full.json $OUT/; wc -c $OUT/bench_line.json; cat $OUT/bench_line.json ;;
   stats) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-path --sustain-seconds 0 --no-sweep --proofs-log2 0 --ragged-log2 0 > $OUT/bench_under_rocprof.txt 2>&1)
