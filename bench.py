@@ -365,7 +365,7 @@ def main():
                               "frac_of_mad_issue_peak_at_nominal_2400mhz": mad_rate / (valu_peak_wave_instr() * 64),
                               "valu_instructions_per_permutation": 1224736768 // 16384, "valu_busy_percent": 97.8,
                               "valu_counters_measured_in_this_run": False,
-                              "valu_counters_static_from": "profiles/r05_s7/pmc_poseidon.txt (SQ_INSTS_VALU / 16384 waves, VALUBusy 97.8-97.9 on that box; 93.6-96.1 in rounds 3-4; NOT measured in this run)"}},
+                              "valu_counters_static_from": "profiles/r06_s25/pmc_poseidon.txt (SQ_INSTS_VALU / 16384 waves; VALUBusy 95.8-95.9 on that box, 97.8-97.9 in profiles/r05_s7, 93.6-96.1 in rounds 3-4; NOT measured in this run)"}},
     }
     for key, leg in (("sustained", sustained), ("merkle", merkle), ("pedersen", pedersen), ("bh_merkle", bh_merkle), ("proofs", proofs), ("host_path", host_path),
                      ("ragged", ragged), ("sweep", sweep)):

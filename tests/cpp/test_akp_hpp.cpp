@@ -48,6 +48,8 @@ static int te_cases(const Context& ctx, const char* path) {
                 pedersen::Parameters P2(ctx, W, N, gens);
                 REQUIRE(P2.table_info().table_id == P.table_info().table_id && P.table_info().handles_attached >= 2);
                 P2.prepare((size_t)W * N / 8);
+                const auto ti = P2.table_info();  // round 6: the phases of the last build and the upgrade state (0: ONE table, the default budget)
+                REQUIRE(ti.last_build.upgrade_state == 0 && ti.wide_builds >= 1 && ti.last_build.total_ms >= 0.0 && ti.last_build.units_to >= 1);
             }
             // the table shape is a tuning choice: an explicit digit width and a small table budget give the same digest
             pedersen::Parameters P5(ctx, W, N, gens, 5);

@@ -7,11 +7,11 @@ import subprocess
 ALGO_BYTES_PER_PERM = 192        # 96 B read + 96 B write (t = 3)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODMUL_PER_PERM_REF = 626        # reference-shaped count
-# HBM bytes per permutation from PMC passes of an earlier session of THIS round (NOT measured in this run; see `static_from`):
+# HBM bytes per permutation from PMC passes of an earlier session of THIS round (profiles/r06_s25 = r05_s7 to four digits; NOT measured in this run):
 # (2 * 49 585.3 KB + 98 304 KB) * 1024 per 2^20 permutations = 192.8 B  (algorithmic: 192 B); FETCH_SIZE 49 582.8 / 49 587.8 KB,
 # WRITE_SIZE 98 304 KB, SQ_INSTS_VALU 1 224 736 768, VALUBusy 93.6-93.9 % (tools/gpu_pmc_r4.sh; round 3: the same to four digits)
 PMC_TRAFFIC_BYTES_PER_PERM = (2 * 49584.7 + 98304.0) * 1024 / (1 << 20)
-PMC_TRAFFIC_SOURCE = "profiles/r05_s7/pmc_poseidon.txt"
+PMC_TRAFFIC_SOURCE = "profiles/r06_s25/pmc_poseidon.txt"
 NOMINAL_SCLK_MHZ = 2400.0
 CYCLES_PER_WAVE_MAD = 4.0        # one v_mad (wave64) per ~4 cycles per SIMD (profiles/r01_s1_microbench*)
 SIMDS = 256 * 4
@@ -23,13 +23,13 @@ def valu_peak_wave_instr(sclk_mhz=NOMINAL_SCLK_MHZ):
 
 
 VALU_PEAK_WAVE_INSTR = valu_peak_wave_instr()
-# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r05_s7/pmc_te_hbm.txt: rocprofv3 --pmc, one counter per pass, the
+# curve-hash kernels, per 2^20-hash launch, KB / instructions (profiles/r06_s25/pmc_te_hbm.txt = r05_s7: rocprofv3 --pmc, one counter per pass, the
 # kernels with the HBM-sized tables -- 24-bit Pedersen digits, 8-chunk Bowe-Hopwood groups + remainder step; NOT measured
 # in this run).  `steps` is the table-step count of that launch: a run whose handles got another shape (smaller table budget)
 # scales the gather-proportional parts by its own step count.  FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950 (128-byte
 # requests tallied at 64 B): with it the accumulate kernels fetch ~1.0 x the table bytes they gather -- every table line comes
 # from HBM, the L2 only serves the second half of a line.  (The 268 MB / 237 MB tables of rounds 1-3: profiles/r04_s8/pmc_te.txt.)
-PMC_TE = {"source": "profiles/r05_s7/pmc_te_hbm.txt",
+PMC_TE = {"source": "profiles/r06_s25/pmc_te_hbm.txt",
           # FETCH_SIZE x 2 for RANDOM 128-byte-line gathers: calibrated in profiles/r05_s6 (x2 = 1.045 x the distinct line bytes; every
           # fabric request is a whole line tallied at 64 B, as for streaming reads)
           "calibration": "profiles/r05_s6/README.md",
@@ -44,9 +44,9 @@ MADS_PER_PERM = 55 * (4 * 117 + 153) + (20 * 234 + 4 * 315) + (30 * (315 + 153) 
 
 
 # the same kernels with the library's DEFAULT tables (cache-sized: 16-bit Pedersen digits, 64 steps; Bowe-Hopwood groups of 5: 18 steps per
-# 32-byte leaf, 36 per inner node) -- profiles/r05_s7/pmc_te.txt.  FETCH_SIZE counts the Infinity Cache's hits as well: for these tables
+# 32-byte leaf, 36 per inner node) -- profiles/r06_s25/pmc_te.txt (= r05_s7).  FETCH_SIZE counts the Infinity Cache's hits as well: for these tables
 # `traffic` is what crosses the fabric into the L2, most of it served by the 256 MiB cache, not by HBM.
-PMC_TE_DEFAULT = {"source": "profiles/r05_s7/pmc_te.txt", "calibration": PMC_TE["calibration"],
+PMC_TE_DEFAULT = {"source": "profiles/r06_s25/pmc_te.txt", "calibration": PMC_TE["calibration"],
                   "pedersen_128B": {"fetch_kb": 3777575 + 164640, "write_kb": 147490 + 114832, "valu_instr": 1545830000 + 48292900, "steps": 64},
                   "bh_32B": {"fetch_kb": 883960 + 163455, "write_kb": 147576 + 81920, "valu_instr": 426050000 + 39591900, "steps": 18},
                   "bh_70B": {"fetch_kb": 1937305 + 164866, "write_kb": 147525 + 81920, "valu_instr": 921133000 + 39591900, "steps": 36}}
