@@ -367,3 +367,44 @@ def test_background_upgrade_under_concurrent_mixed_lengths(cpa):
         out = np.empty((900, 4), dtype=np.uint64)
         cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, 900, L, out.ctypes.data))
         assert np.array_equal(out, ora.bh_crh_batch(m, 900, L, threads=2)), L
+
+
+def test_wide_handles_created_and_dropped_at_every_stage_of_the_upgrade(cpa):
+    """handles under AKP_TABLE_BUDGET_DEVICE created, used for a few batches and destroyed at different stages of the background build
+    (before the first call, right after it, mid-build, after the switch), fresh generators each time so that every round builds anew:
+    the release of a table waits for its builder, the digests are the oracle's throughout, and the device's memory comes back."""
+    import time
+    from crypto_primitives_amd._lib import Context, TABLE_BUDGET_DEVICE
+    from crypto_primitives_amd.crh import bowe_hopwood
+    ctx = Context(0)
+    ctx.set_table_budget(TABLE_BUDGET_DEVICE)
+    if ctx.table_budget() < 71 << 30:
+        pytest.skip("needs an idle 288 GB device")
+    n = 20000
+    m = _msgs(n, 64, 77)
+    warm = bowe_hopwood.Parameters(gens_array(jj.bowe_hopwood_generators(0xC5C50040, 63, 9)), table_shape=5)
+    out = np.empty((n, 4), dtype=np.uint64)
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(warm.handle(ctx).h, m.ctypes.data, n, 64, out.ctypes.data))  # the context's scratch
+    free0 = _free_bytes()
+    stages = ["no call", "one call", "mid build", "after switch", "one call", "mid build", "no call", "after switch"]
+    for k, stage in enumerate(stages):
+        g = gens_array(jj.bowe_hopwood_generators(0xC5C50041 + k, 63, 9))
+        want = cref.CurveParams(63, 9, g).bh_crh_batch(m, n, 64, threads=8)
+        B = bowe_hopwood.Parameters(g)
+        h = B.handle(ctx)
+        calls = {"no call": 0, "one call": 1, "mid build": 4, "after switch": 10 ** 6}[stage]
+        t_end = time.perf_counter() + 30
+        done = 0
+        while done < calls and time.perf_counter() < t_end:
+            out[:] = 0
+            cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, n, 64, out.ctypes.data))
+            assert np.array_equal(out, want), (stage, done)
+            done += 1
+            if stage == "after switch" and h.table_info()["last_build"]["upgrade_state"] == 2:
+                cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, m.ctypes.data, n, 64, out.ctypes.data))
+                assert np.array_equal(out, want) and h.info(64)["digit_bits_or_group"] == 8
+                break
+        B._handles.clear()
+        del h, B  # the table goes with its only handle: a build that is still running is waited for
+    assert free0 - _free_bytes() < 1 << 30, "tables of dropped handles were not released"
+    ctx.set_table_budget(0)
