@@ -29,8 +29,10 @@ for name, cls, gens, ln in (("pedersen 4x256", pedersen, cparams.pedersen_genera
         h.prepare(ln)
         t2 = time.perf_counter()
         msgs = np.random.default_rng(1).integers(0, 256, size=(1 << 16, ln), dtype=np.uint8)
-        cls.CRH.evaluate_batch(P, msgs)
+        dg = cls.CRH.evaluate_batch(P, msgs)
         t3 = time.perf_counter()
+        import hashlib
+        chk = hashlib.sha256(np.ascontiguousarray(dg).tobytes()).hexdigest()[:16]
         print("%s, budget %s: create %.2f ms, prepare(%d) %.2f ms, first 2^16 hashes %.2f ms; %s" % (name, "DEVICE" if budget else "default", (t1 - t0) * 1e3, ln, (t2 - t1) * 1e3,
-                                                                                                  (t3 - t2) * 1e3, h.info(ln)), flush=True)
+                                                                                                  (t3 - t2) * 1e3, h.info(ln)), "digests sha256", chk, "build", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in h.table_info()["last_build"].items() if k.endswith("_ms")}, flush=True)
         ctx.set_table_budget(0)
