@@ -145,7 +145,9 @@ impl ThreadRuntime {
         // rayon workers, crh/mod.rs:22): this thread's handle attaches to them.  Their size follows the context's table budget --
         // by default 320 MiB (cache-sized tables, built in milliseconds); AKP_TABLE_BUDGET_MB here (or `set_table_budget` before
         // the first curve hash) raises it, `AKP_TABLE_BUDGET_MB=device` asks for the HBM-sized tables (46 GB for a 4x256 Pedersen
-        // window: ~0.1 s to build, -23 % per hash afterwards).
+        // window: -23 % per hash).  Since ABI version 5 a budget above the default costs nothing at the start: the handle hashes on the
+        // cache-sized table while a thread of libakp builds the wide one in the background (`akp_te_params_table_info` reports the state;
+        // `akp_te_params_prepare` waits for it).
         if let Ok(v) = std::env::var("AKP_TABLE_BUDGET_MB") {
             let bytes = if v == "device" { Some(usize::MAX) } else { v.parse::<usize>().ok().map(|mb| mb << 20) };
             if let Some(b) = bytes {
