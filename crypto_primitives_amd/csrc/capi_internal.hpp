@@ -310,6 +310,9 @@ struct TeTable {
     std::thread builder;
     std::atomic<bool> building{false};
     std::atomic<bool> upgrade_failed{false};
+    // a tree's inner-node shape, announced before its leaf level asks for the table (te_tree_prepare): the builder takes it first
+    std::atomic<bool> hint_set{false};
+    size_t hint_msg_len = 0, hint_data_len = 0;
     std::string upgrade_error;
     akp_te_build_report last_build{};          // phases of the last build / extension of the wide table (akp_te_params_table_info)
 };

@@ -158,15 +158,17 @@ static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u
         }
         if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, bs);
         if (e == hipSuccess) e = hipStreamSynchronize(bs);
-        if (d_bad) (void)hipFree(d_bad);
+        if (d_bad) t->retired.push_back(d_bad);
         if (e == hipSuccess && bad) {
             fprintf(stderr, "akp: AKP_TE_TABLE_CHECK: %u of the sampled table entries differ from the per-entry definition\n", bad);
             e = hipErrorAssert;
         }
     }
 #endif
-    if (lo) (void)hipFree(lo);  // (never handed to a launch outside this function: the stream is drained)
-    if (hi) (void)hipFree(hi);
+    // the part tables (megabytes) are RETIRED, not freed: hipFree waits for the whole device -- a caller building its cache-sized table here
+    // would wait for the background build of the wide one (first call 112 ms instead of 5: profiles/r06_s31)
+    if (lo) t->retired.push_back(lo);
+    if (hi) t->retired.push_back(hi);
     return e;
 }
 // ---- the process-wide table store (TeTable, capi_internal.hpp) ---------------------------------------------------------------
@@ -292,8 +294,8 @@ static hipError_t te_table_init(TeTable* t, const uint64_t* gens, u32 shape, siz
                 e = hipGetLastError();
             }
         }
-        if (d_half) (void)hipFree(d_half);
-        if (d_bad) (void)hipFree(d_bad);
+        if (d_half) t->retired.push_back(d_half);  // (hipFree would wait for the whole device: another table's background build, say)
+        if (d_bad) t->retired.push_back(d_bad);
     } else {
         const u32 G = shape;
         if (G > 1 && te_bh_entries(n_gen, G) >= max_entries) e = hipErrorInvalidValue;
@@ -308,7 +310,7 @@ static hipError_t te_table_init(TeTable* t, const uint64_t* gens, u32 shape, siz
         d_g = nullptr;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(bs);
-    if (d_g) (void)hipFree(d_g);
+    if (d_g) t->retired.push_back(d_g);
     return e;
 }
 // The table of (device, kind, window, generators, shape): found in the store or entered as a PLACEHOLDER and initialised under its own
@@ -648,10 +650,10 @@ static int32_t te_bh_remainder(TeTable* t, u32 first, u32 r, u32 tail_from, u32 
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(bs);
-    if (d_t) (void)hipFree(d_t);
+    if (d_t) t->retired.push_back(d_t);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        if (d) (void)hipFree(d);
+        if (d) t->retired.push_back(d);
         if (e == hipErrorOutOfMemory) return AKP_OK;
         return fail(AKP_ERR_HIP, "Bowe-Hopwood remainder table: %s", hipGetErrorString(e));
     }
@@ -748,7 +750,12 @@ static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool wa
             }
             if (w->bg_stream) w->active_stream = w->bg_stream;
             TeResolved r;
-            if (te_resolve(w, msg_len, data_len, w->active_stream, &r, TE_BUILD, want_rem, true) != AKP_OK) {
+            int32_t rc = AKP_OK;
+            // a tree announced its inner-node shape (te_tree_prepare): that one FIRST, so that the leaf level's request -- which arrives
+            // first and needs fewer units -- does not cause a build and then an extension
+            if (w->hint_set.exchange(false)) rc = te_resolve(w, w->hint_msg_len, w->hint_data_len, w->active_stream, &r, TE_BUILD, true, true);
+            if (rc == AKP_OK) rc = te_resolve(w, msg_len, data_len, w->active_stream, &r, TE_BUILD, want_rem, true);
+            if (rc != AKP_OK) {
                 w->upgrade_error = akp_last_error();  // (this thread's: nobody else would see it)
                 w->upgrade_failed.store(true);
             }
@@ -760,7 +767,20 @@ static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool wa
 // The table this call hashes on, resolved, its lock held in `lk` (until the kernels that use the pointers are enqueued): the wide
 // table of the handle when it has everything the call needs, else the table the handle started on -- built on demand as ever -- with
 // a request to the builder on the way.
-static int32_t te_pick(akp_te_params* p, size_t msg_len, size_t data_len, hipStream_t s, std::unique_lock<std::mutex>& lk, TeResolved* r, bool want_rem = true) {
+// The request to the builder goes out when the call that found the wide table lacking is DONE with its own allocations and launches
+// (the destructor of this object, declared before the table lock in every caller): allocations of two threads stall together when the
+// driver is busy wiping or mapping memory, and the call's own -- the cache-sized table on its first use, scratch -- must not queue up
+// behind the 46 GB the builder is about to ask for (first call 1.1-1.8 s instead of 5 ms: profiles/r06_s31).
+struct TeKickLater {
+    TeTable* w = nullptr;
+    size_t msg_len = 0, data_len = 0;
+    bool want_rem = true;
+    ~TeKickLater() {
+        if (w) te_upgrade_kick(w, msg_len, data_len, want_rem);
+    }
+};
+static int32_t te_pick(akp_te_params* p, size_t msg_len, size_t data_len, hipStream_t s, TeKickLater& later, std::unique_lock<std::mutex>& lk, TeResolved* r,
+        bool want_rem = true) {
     if (TeTable* w = p->wide) {
         lk = std::unique_lock<std::mutex>(w->mu, std::try_to_lock);
         if (lk.owns_lock()) {
@@ -768,7 +788,12 @@ static int32_t te_pick(akp_te_params* p, size_t msg_len, size_t data_len, hipStr
             if (rc == AKP_OK) return AKP_OK;
             lk.unlock();
             if (rc != TE_NOT_READY) return rc;
-            if (!te_capturing(s)) te_upgrade_kick(w, msg_len, data_len, want_rem);  // (an allocation on another thread would break a global-mode capture)
+            if (!te_capturing(s)) {  // (an allocation on another thread would break a global-mode capture)
+                later.w = w;
+                later.msg_len = msg_len;
+                later.data_len = data_len;
+                later.want_rem = want_rem;
+            }
         }
     }
     lk = std::unique_lock<std::mutex>(p->t->mu);
@@ -820,13 +845,11 @@ int32_t te_tree_prepare(akp_te_params* leafp, akp_te_params* two, hipStream_t s)
     size_t buflen, used;
     te_compress_shape(two, &buflen, &used);
     if (two->wide && !te_capturing(s)) {
-        bool ready = false;
-        {
-            std::unique_lock<std::mutex> lk(two->wide->mu, std::try_to_lock);
-            TeResolved r;
-            ready = lk.owns_lock() && te_resolve(two->wide, buflen, used, s, &r, TE_LOOK) == AKP_OK;
-        }
-        if (!ready) te_upgrade_kick(two->wide, buflen, used, true);
+        // the wide table is asked for by the tree's first hash call, when that call has issued its own work (TeKickLater); what the
+        // builder should build FIRST is announced here
+        two->wide->hint_msg_len = buflen;
+        two->wide->hint_data_len = used;
+        two->wide->hint_set.store(true);
     }
     if (leafp->t != two->t) return AKP_OK;
     std::lock_guard<std::mutex> lk(two->t->mu);
@@ -930,9 +953,10 @@ static int32_t te_crh_run(akp_te_params* p, const uint8_t* d_msgs, size_t n, siz
     // the table's pointers are read and the kernels that use them enqueued under its lock (TeTable, capi_internal.hpp): handles of
     // other contexts share the table, and one of them may be extending it right now.  te_pick: the wide table of the handle once it
     // is complete, the cache-sized one until then.
+    TeKickLater kick;  // (before the lock: destroyed after it)
     std::unique_lock<std::mutex> table_lock;
     TeResolved rs;
-    if (int32_t rc = te_pick(p, msg_len, data_len, s, table_lock, &rs)) return rc;
+    if (int32_t rc = te_pick(p, msg_len, data_len, s, kick, table_lock, &rs)) return rc;
     TeTable* t = rs.t;
     const u32 shape = rs.shape, groups = rs.groups, steps = rs.steps;
     const TeEntry *lut = rs.lut, *lut1 = rs.lut1, *tail = rs.tail;
@@ -1191,9 +1215,10 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     bool gave_up = false, refused = false;
     const int32_t rc = [&]() -> int32_t {
         {
+            TeKickLater kick;
             std::unique_lock<std::mutex> table_lock;
             TeResolved rs;
-            if (int32_t rc = te_pick(p, msg_len, msg_len, s, table_lock, &rs)) return rc;
+            if (int32_t rc = te_pick(p, msg_len, msg_len, s, kick, table_lock, &rs)) return rc;
             TeTable* t = rs.t;
             // all copies first, each followed by its flag (a small kernel); nothing of this call has been launched yet if the write-value
             // is refused
@@ -1413,9 +1438,10 @@ int32_t te_crh_ragged_dev(akp_te_params* p, const uint8_t* d_msgs, const uint64_
     if (n == 0) return AKP_OK;
     if (n >= ((size_t)1 << 32)) return fail(AKP_ERR_BAD_PARAMS, "batch of %zu messages exceeds the supported 2^32 - 1", n);
     akp_ctx* c = p->ctx;
+    TeKickLater kick;
     std::unique_lock<std::mutex> table_lock;
     TeResolved rs;
-    if (int32_t rc = te_pick(p, max_len, max_len, s, table_lock, &rs, false)) return rc;
+    if (int32_t rc = te_pick(p, max_len, max_len, s, kick, table_lock, &rs, false)) return rc;
     TeTable* t = rs.t;
     const u32 D = t->pedersen ? t->digit_bits : t->group;  // Bowe-Hopwood: no remainder table (R = 0): left-over chunks are single steps
     void *xyz = nullptr, *prefix = nullptr, *work = nullptr;

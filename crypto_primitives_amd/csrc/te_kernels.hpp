@@ -254,8 +254,8 @@ __global__ void te_build_pedersen_cprefix(const NielsPad* __restrict__ half, u32
 // table of 24-bit digits.  A wide entry is the sum of two NARROW ones -- the digit's low bits and its high bits select
 // independent subsets of the same generators -- so the wide table is built from two small part tables per digit / group
 // (a few thousand entries each, built entry by entry as before) with ONE mixed addition per entry, and the conversion to
-// affine shares one inversion among the AKP_TE_BUILD_RUN entries of a lane (Montgomery's trick; the addition is computed twice
-// rather than parked in memory, round 6): ~24 products + 1/16 inversion per entry.
+// affine shares one inversion among the AKP_TE_BUILD_RUN entries of a lane (Montgomery's trick; the extended point waits
+// in the entry's own 128-byte slot meanwhile): ~17 products + 1/16 inversion per entry.
 //   Pedersen, signed-subset table of D-bit digits: entry index v' has D - 1 bits (the top bit of the digit is set);
 //     lo part: bits [0, k_lo) of the digit, 2^k_lo entries;   hi part: bits [k_lo, D), 2^(D-1-k_lo) entries.
 //   Bowe-Hopwood, groups of G chunks: lo part: chunks [0, G_lo) (magnitudes k_0.. and relative signs r_1..: 2^(3 G_lo - 1)
@@ -370,6 +370,7 @@ AKP_HD void te_build_combine_lane(const TeEntry* __restrict__ lo, const TeEntry*
         u32 li, hi_i;
         te_build_split<KIND>(W, k_lo, (u32)e, &li, &hi_i);
         const Ext s = te_madd(ext_from_niels(load_niels(hi + hi_i)), load_niels(lo + li));
+        store_niels(lut + e, Niels{s.X, s.Y, s.Z});  // parked in its own slot until the shared inversion is known
         pre[j] = run;
         run = f29_mul(run, s.Z);
         cnt = j + 1u;
@@ -379,13 +380,10 @@ AKP_HD void te_build_combine_lane(const TeEntry* __restrict__ lo, const TeEntry*
 #pragma unroll 1
     for (u32 j = cnt; j-- > 0;) {
         const size_t e = base + (size_t)j * stride;
-        // the sum is computed a SECOND time from the (cache-resident) part tables instead of being parked in its slot of the wide table
-        // and re-read (rounds 4-5): one write per entry instead of two writes and a read, seven products more -- 64.4 -> 58.3 ms for the
-        // 46 GB table, 33.1 -> 30.1 ms for 22.5 GB (profiles/r06_s26), and a third of the traffic beside whatever else runs
-        u32 li, hi_i;
-        te_build_split<KIND>(W, k_lo, (u32)e, &li, &hi_i);
-        const Ext s2 = te_madd(ext_from_niels(load_niels(hi + hi_i)), load_niels(lo + li));
-        const Niels xyz{s2.X, s2.Y, s2.Z};
+        // (computing the sum a second time instead of parking it -- one write per entry instead of two writes and a read -- builds an idle
+        // device's 46 GB table in 58.3 instead of 64.4 ms, but a build that runs BESIDE hashing then competes for the vector ALUs the
+        // hashing is bound by: batches beside it took 17 instead of 7-9 ms and the first one 120 ms: profiles/r06_s26, r06_s30)
+        const Niels xyz = load_niels(lut + e);
         const FS zi = f29_mul(inv, pre[j]);
         inv = f29_mul(inv, xyz.dxy);
         store_niels(lut + e, niels_from_affine(f29_mul(xyz.ypx, zi), f29_mul(xyz.ymx, zi)));

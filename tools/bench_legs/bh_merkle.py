@@ -100,6 +100,12 @@ def run(env):
         big = 1 << 26
         d_big = d_leaves.repeat(big // per, 1) if big > per else d_leaves[:big]
         g2 = cparams.bowe_hopwood_generators(0xA5A50105, 63, 9)
+        # the context's scratch and torch's allocator at the size of a 2^26-leaf tree BEFORE the cold figures (a tree on the tables the leg
+        # has already built): `cold` below is about the tables -- a multi-GB hipMalloc inside the timed tree costs whatever the driver is
+        # busy with at that moment (0.17 -> 0.41 s for the cache-sized variant right after the 22 GB tables above were allocated, r06_s32)
+        r0 = env.build_sharded(cache["tb"], d_big, big, None)
+        torch.cuda.current_stream(env.dev).synchronize()
+        del r0
         single, alive = {}, []  # (`alive`: nothing of this block is freed before both variants are measured -- a hipMalloc that follows a
         # large hipFree waits for the driver's wipe of the released memory, seconds for tens of GB: profiles/r06_s2, r06_s20)
         for name, budget in (("cache_sized", 0), ("hbm_sized", TABLE_BUDGET_DEVICE)):
