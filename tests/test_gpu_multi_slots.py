@@ -218,6 +218,41 @@ def test_sharded_resident_tree_byte_digests(cpa, G, monkeypatch):
 
 
 @needs_hooks
+def test_background_built_wide_tables_equal_the_per_entry_definition(cpa, monkeypatch):
+    """round 6: a budget-chosen wide table is built by the library's thread with FEW workgroups that walk the tiles (grid-stride form of
+    te_build_combine_kernel), and a longer message later extends it to the complete table: AKP_TE_TABLE_CHECK (test build) recomputes
+    a sample of the entries of each build by the per-entry definition -- a build that differs fails, the upgrade is marked failed and
+    the handle would stay on the cache-sized table (state 3)"""
+    from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
+    from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+    ctx = cpa.default_context(0)
+    ctx.set_table_budget(TABLE_BUDGET_DEVICE)
+    try:
+        if ctx.table_budget() < 71 << 30:
+            pytest.skip("needs an idle 288 GB device")
+        monkeypatch.setenv("AKP_TE_TABLE_CHECK", "4099")
+        P = pedersen.Parameters(gens_array(jj.pedersen_generators(0x5252, 4, 256)))
+        B = bowe_hopwood.Parameters(gens_array(jj.bowe_hopwood_generators(0x5353, 63, 9)))
+        hp, hb = P.handle(ctx), B.handle(ctx)
+    finally:
+        ctx.set_table_budget(0)
+    m = np.frombuffer(ofr.SplitMix64(11).bytes(300 * 128), dtype=np.uint8).reshape(300, 128).copy()
+    d0 = pedersen.CRH.evaluate_batch(P, m)              # on the cache-sized table; asks for the wide one
+    assert hp.wait_for_wide_table(128) is not None
+    ti = hp.table_info()
+    assert ti["last_build"]["upgrade_state"] == 2 and ti["last_build"]["in_background"] == 1 and ti["last_build"]["note"] == "", ti
+    assert np.array_equal(pedersen.CRH.evaluate_batch(P, m), d0) and hp.info(128)["digit_bits_or_group"] == 24
+    b0 = bowe_hopwood.CRH.evaluate_batch(B, m[:, :32])  # a prefix of the group table in the background ...
+    assert hb.wait_for_wide_table(32) is not None
+    assert hb.table_info()["last_build"]["upgrade_state"] == 2 and np.array_equal(bowe_hopwood.CRH.evaluate_batch(B, m[:, :32]), b0)
+    b1 = bowe_hopwood.CRH.evaluate_batch(B, m[:, :100])  # ... then a longer message: on the cache-sized table while the wide one is extended
+    assert hb.wait_for_wide_table(100) is not None
+    ti = hb.table_info()
+    assert ti["wide_builds"] == 2 and ti["last_build"]["units_to"] == ti["last_build"]["units_total"] == 70 and ti["last_build"]["upgrade_state"] == 2, ti
+    assert np.array_equal(bowe_hopwood.CRH.evaluate_batch(B, m[:, :100]), b1) and hb.info(100)["digit_bits_or_group"] == 8
+
+
+@needs_hooks
 def test_build_arms_plain_pedersen_table_and_walked_zero_tail(cpa, monkeypatch):
     """the two arms kept for A/B in the test build agree bit for bit with the shipped paths (and the plain table reproduces the
     upstream Jubjub known answer, as the signed-subset table does in tests/test_gpu_curves.py)"""
