@@ -99,7 +99,12 @@ static void te_storage_retire(TeTable* t) {
     t->units_built = 0;
 }
 
-static const unsigned TE_BG_WGS = env_u32("AKP_TE_BG_WGS", 128, 1, 1u << 20);  // workgroups of a background build's combine kernel
+// workgroups of a background build's combine kernel.  Sweep (profiles/r06_s34; first 2^20-hash Pedersen batch / first 2^23-leaf
+// Bowe-Hopwood tree beside the build, default budget 4.6 / 26.1 ms): 32 -> 4.9 / 32.9 ms (wide table in use after 0.57 / 0.28 s),
+// 64 -> 3.7 / 34.9 ms, 128 -> 9.7 / 37.4 ms (0.35 / 0.11 s), 256 -> 8.7 / 44.5 ms.  What the build takes in all does not depend on the
+// width: a 2^26-leaf tree that saturates the device for 0.17 s beside it takes ~0.03 s longer at every width -- the 22.5 GB table's
+// 30 ms of machine time have to come from somewhere (non-temporal stores for the table: no difference, r06_s35).
+static const unsigned TE_BG_WGS = env_u32("AKP_TE_BG_WGS", 64, 1, 1u << 20);
 // two-part construction of a wide table (te_kernels.hpp): part tables entry by entry (for ALL units up to `units`: kilobytes to
 // megabytes, < 0.5 ms), then one addition per wide entry of the units [from, units).
 // KIND 2: Pedersen signed-subset table of W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of groups of W chunks.
@@ -135,7 +140,7 @@ static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u
         // capping the build's occupancy through unused LDS costs every compute unit a share (2^26-leaf tree 234 against 179 ms, r06_s11); a
         // stream with a CU mask did it (r06_s13) -- until the first out-of-memory hipMalloc of the process, which then hung or crashed inside
         // the runtime (r06_s14 .. s16).  So the build simply launches FEW workgroups, each walking many tiles: TE_BG_WGS of them hold that
-        // many x 4 of the device's 8192 wave slots.  It takes ~8 times as long; nobody waits for it.
+        // many x 4 of the device's 8192 wave slots.  It takes several times as long; nobody waits for it.
         if (rep->in_background) cgrid = std::min(cgrid, TE_BG_WGS);
         hipLaunchKernelGGL(te_build_combine_kernel<KIND>, dim3(cgrid), dim3(256), 0, bs, lo, hi, W, k_lo, first, entries, t->d_lut);
         e = hipGetLastError();

@@ -81,7 +81,7 @@ int32_t akp_ctx_synchronize(akp_ctx* ctx);
  * 46 GB allocation on a box whose VRAM nobody has used yet took 1.2 s, and an allocation that follows a large hipFree waits for the
  * driver's wipe of the released memory, ~35 GB/s: profiles/r06_s1 .. r06_s7 -- which is why none of it happens on the caller's thread), and
  * calls switch to it when it is complete.  akp_te_params_prepare waits for it.  If the device cannot hold it the handle stays on the
- * cache-sized table (akp_te_params_table_info says so).  The build is polite -- a few workgroups on a lowest-priority stream: ~0.3 s for
+ * cache-sized table (akp_te_params_table_info says so).  The build is polite -- a few workgroups on a lowest-priority stream: ~0.5 s for
  * the 46 GB table instead of 0.06 s, and the hashing beside it keeps its rate -- but a DEVICE-wide wait of the host (hipDeviceSynchronize)
  * waits for it like for any other work on the device: synchronise streams or events.
  * Handles that exist keep their tables.  akp_ctx_table_budget returns the value the next handle would be created with. */
