@@ -741,6 +741,7 @@ static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool wa
     bool idle = false;
     if (!w->building.compare_exchange_strong(idle, true)) return;
     if (w->builder.joinable()) w->builder.join();  // the previous build has ended (`building` was false): only its thread object is left
+    try {
     w->builder = std::thread([w, msg_len, data_len, want_rem] {
         (void)hipSetDevice(w->device);
         {
@@ -768,6 +769,9 @@ static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool wa
         }
         w->building.store(false);
     });
+    } catch (...) {  // no thread to be had: the handle stays on the cache-sized table, a later call asks again
+        w->building.store(false);
+    }
 }
 // The table this call hashes on, resolved, its lock held in `lk` (until the kernels that use the pointers are enqueued): the wide
 // table of the handle when it has everything the call needs, else the table the handle started on -- built on demand as ever -- with
