@@ -1,0 +1,33 @@
+import ctypes as C, os, sys, time, json
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+import crypto_primitives_amd as cpa
+from crypto_primitives_amd import params as cparams
+from crypto_primitives_amd.crh import pedersen, bowe_hopwood
+lib, check = cpa.lib, cpa._lib.check
+ctx = cpa.default_context(0)
+res = {}
+for name, cls, gens, L, fe in (("pedersen", pedersen, cparams.pedersen_generators(0xA5A50904, 4, 256), 128, 2), ("bh", bowe_hopwood, cparams.bowe_hopwood_generators(0xA5A50905, 63, 9), 64, 1)):
+    n = 1 << 20
+    msgs = np.random.default_rng(9).integers(0, 256, size=(n, L), dtype=np.uint8)
+    ref_h = cls.Parameters(gens, table_shape=(12 if cls is pedersen else 3)).handle(ctx)
+    ref = np.empty((n, 4 * fe), np.uint64)
+    check(lib.akp_te_crh_batch(ref_h.h, msgs.ctypes.data, n, L, ref.ctypes.data))
+    pm, po = C.c_void_p(), C.c_void_p()
+    check(lib.akp_host_alloc(msgs.nbytes, C.byref(pm))); check(lib.akp_host_alloc(ref.nbytes, C.byref(po)))
+    np.ctypeslib.as_array((C.c_uint8 * msgs.size).from_address(pm.value))[:] = msgs.reshape(-1)
+    out = np.ctypeslib.as_array((C.c_uint64 * ref.size).from_address(po.value)).reshape(ref.shape)
+    ctx.set_table_budget(cpa._lib.TABLE_BUDGET_DEVICE)
+    h = cls.Parameters(gens).handle(ctx)
+    ctx.set_table_budget(0)
+    rows, bad = [], 0
+    for i in range(120):
+        out[:] = 0
+        t0 = time.perf_counter()
+        check(lib.akp_te_crh_batch(h.h, pm, n, L, po))
+        ms = (time.perf_counter() - t0) * 1e3
+        bad += 0 if np.array_equal(out, ref) else 1
+        rows.append((round(ms, 2), h.table_info()["last_build"]["upgrade_state"], h.info(L)["digit_bits_or_group"]))
+    res[name] = {"wrong_batches": bad, "first": rows[:6], "last": rows[-3:], "switch_at_call": next((i for i, r in enumerate(rows) if r[1] == 2), None)}
+    check(lib.akp_host_free(pm)); check(lib.akp_host_free(po))
+print(json.dumps(res))
