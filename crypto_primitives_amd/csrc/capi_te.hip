@@ -106,7 +106,7 @@ static void te_storage_retire(TeTable* t) {
 // 30 ms of machine time have to come from somewhere (non-temporal stores for the table: no difference, r06_s35).
 static const unsigned TE_BG_WGS = env_u32("AKP_TE_BG_WGS", 64, 1, 1u << 20);
 // two-part construction of a wide table (te_kernels.hpp): part tables entry by entry (for ALL units up to `units`: kilobytes to
-// megabytes, < 0.5 ms), then one addition per wide entry of the units [from, units).
+// megabytes, < 0.5 ms), then one addition per wide entry of the units [from, units) (`from` is 0 today: every build fills a fresh block).
 // KIND 2: Pedersen signed-subset table of W-bit digits over the halved generators `src`; KIND 1: Bowe-Hopwood table of groups of W chunks.
 template <int KIND>
 static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u32 from, u32 units, akp_te_build_report* rep) {
@@ -148,7 +148,7 @@ static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u
         rep->combine_ms += te_now_ms() - t0;
     }
 #if defined(AKP_TEST_HOOKS)
-    // AKP_TE_TABLE_CHECK=k: every k-th entry of the table (ALL units, also those an extension left in place) against the per-entry definition
+    // AKP_TE_TABLE_CHECK=k: every k-th entry of the table against the per-entry definition
     const size_t step = env_size("AKP_TE_TABLE_CHECK", 0);
     if (e == hipSuccess && step) {
         u32* d_bad = nullptr;
@@ -559,12 +559,12 @@ static hipError_t te_narrow(TeTable* t) {
     t->n_rem = 0;
     return hipSuccess;
 }
-// The wide table covers the digits / chunk groups [0, units_built); a message that needs more extends it IN PLACE: the units
-// [units_built, target) are mapped behind the existing ones and built (target = max(needed, twice the old coverage): messages of slowly
-// growing length extend O(log) times); nothing is moved, freed or drained.  62 ms of kernel time for the 46 GB of a whole 4x256 table,
-// milliseconds for the cache-sized default or the prefix a tree's 32- and 64-byte nodes use -- plus whatever the allocation costs on this
-// box at this moment (the comment at the top).  Returns the table steps of a data_len-byte message (te_steps) for the shape the table ends
-// up with.  Caller holds t->mu; the build runs on the table's own stream and is complete when this returns.
+// The wide table covers the digits / chunk groups [0, units_built); a message that needs more extends it: a NEW allocation is built
+// (te_storage_grow) and the old block retired -- nothing a launch was given is freed, nothing is drained.  The first build covers what the
+// first messages need, an extension the complete table: at most one block is ever retired.  62 ms of kernel time for the 46 GB of a whole
+// 4x256 table, milliseconds for the cache-sized default or the prefix a tree's 32- and 64-byte nodes use -- plus whatever the
+// allocation costs on this box at this moment (the comment at the top).  Returns the table steps of a data_len-byte message (te_steps)
+// for the shape the table ends up with.  Caller holds t->mu; the build runs on the table's own stream and is complete when this returns.
 static int32_t te_ensure_table(TeTable* t, size_t data_len, u32* groups, u32* steps, hipStream_t s, TeBuild mode, bool background = false) {
     const bool ped = t->pedersen;
     for (;;) {
