@@ -10,6 +10,25 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AKP_LIB", os.path.join(_HERE, "lib", "libakp.so"))
 
+
+def _keep_large_buffers_out_of_the_heap():
+    """glibc raises its mmap threshold (128 KB at start) up to 32 MB once a large block has been freed: from then on multi-megabyte numpy /
+    torch CPU buffers live in the brk heap, back to back with each other and with small objects.  The host-pointer entry points hand
+    PAGEABLE buffers to the HIP runtime, which pins their pages for the duration of a copy (sources read-only); with heap-resident
+    buffers the full GPU test-suite of round 6 -- whose early tests free 100 MB arrays -- ended twice in twelve runs with "Memory access
+    fault ... Write access to a read-only page" at a heap address, in a device-to-host copy of a LATER test (profiles/r06_s38); with every
+    large buffer in a mapping of its own (the situation of rounds 1-5) it never has.  Fixing the threshold restores that.  A host that
+    wants no part of this sets AKP_KEEP_MALLOC=1 -- or passes pinned / registered buffers, which never go through the runtime's pinning."""
+    if os.environ.get("AKP_KEEP_MALLOC") == "1":
+        return
+    try:
+        C.CDLL("libc.so.6").mallopt(-3, 128 * 1024)  # M_MMAP_THRESHOLD: a fixed value also switches the dynamic adjustment off
+    except Exception:
+        pass
+
+
+_keep_large_buffers_out_of_the_heap()
+
 AKP_OK, AKP_ERR_BAD_LENGTH, AKP_ERR_BAD_PARAMS, AKP_ERR_HIP, AKP_ERR_RCCL, AKP_ERR_NOT_POW2 = 0, 1, 2, 3, 4, 5
 AKP_ABI_VERSION = 5
 TE_PEDERSEN, TE_BOWE_HOPWOOD, TE_PEDERSEN_X = 0, 1, 2

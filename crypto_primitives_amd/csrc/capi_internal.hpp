@@ -303,8 +303,9 @@ struct TeTable {
     std::string init_err;
     std::vector<void*> retired;                // device blocks superseded while handles were attached (an extended table, constants of a narrowed
                                                // shape): a launch -- or a captured graph -- may still read them; freed with the table
-    // builds of this table run on streams of its own (never behind a caller's work): `build_stream` for a build some caller waits for,
-    // `bg_stream` (lowest priority) for the background upgrade; `active_stream`: the one the current holder of `mu` builds on
+    // builds run on the DEVICE's two build streams (capi_te.hip te_dev_streams: never behind a caller's work, never destroyed): `build_stream`
+    // for a build some caller waits for, `bg_stream` (lowest priority) for the background upgrade; `active_stream`: the one the current
+    // holder of `mu` builds on
     hipStream_t build_stream = nullptr, bg_stream = nullptr, active_stream = nullptr;
     // background build of an HBM-sized table (te_upgrade_kick): the thread that is building or built last, whether one is running, what went wrong
     std::thread builder;

@@ -179,6 +179,34 @@ static hipError_t te_build_wide(TeTable* t, const void* src, u32 n_gen, u32 W, u
 // ---- the process-wide table store (TeTable, capi_internal.hpp) ---------------------------------------------------------------
 static std::mutex g_store_mu;
 static std::vector<TeTable*> g_store;
+// The streams table builds run on: ONE pair per device for the life of the process -- `build` (default priority) for a build some caller
+// waits for, `bg` (lowest priority) for the background upgrade.  Round 6 first gave every table streams of its own; a test-suite creates
+// and drops hundreds of tables, and the stream churn (each new lowest-priority stream can bring a hardware queue into being: a 28 ms
+// hiccup beside a first call) bought nothing: builds of different tables are rare enough to share a queue.
+struct TeDevStreams {
+    hipStream_t build = nullptr, bg = nullptr;
+};
+static TeDevStreams g_dev_streams[64];
+static std::mutex g_dev_streams_mu;
+static hipError_t te_dev_streams(int device, bool want_bg, hipStream_t* build, hipStream_t* bg) {  // the device is current
+    std::lock_guard<std::mutex> lk(g_dev_streams_mu);
+    TeDevStreams& d = g_dev_streams[device & 63];
+    if (!d.build) {
+        const hipError_t e = hipStreamCreateWithFlags(&d.build, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    if (want_bg && !d.bg) {
+        int lo_prio = 0, hi_prio = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
+            hipStreamCreateWithPriority(&d.bg, hipStreamNonBlocking, lo_prio) != hipSuccess) {
+            (void)hipGetLastError();
+            d.bg = nullptr;  // the builder falls back to the build stream
+        }
+    }
+    *build = d.build;
+    *bg = d.bg;
+    return hipSuccess;
+}
 static std::vector<TeTable*> g_all_tables;  // every live table (also those that left the store): the exit hook joins their builders
 static void te_join_builders_at_exit() {
     // a build thread that is still allocating when the process exits would meet a runtime that is being torn down: wait for it
@@ -207,8 +235,6 @@ static void te_table_free(TeTable* t) {  // refs == 0: no handle, no launch can 
         if (t->tails[i].d) (void)hipFree(t->tails[i].d);
     for (int i = 0; i < t->n_rem; ++i)
         if (t->rem[i].d) (void)hipFree(t->rem[i].d);
-    if (t->build_stream) (void)hipStreamDestroy(t->build_stream);
-    if (t->bg_stream) (void)hipStreamDestroy(t->bg_stream);
     delete t;
 }
 static void te_table_release(TeTable* t) {
@@ -228,18 +254,10 @@ static hipError_t te_table_init(TeTable* t, const uint64_t* gens, u32 shape, siz
     Fr* d_g = nullptr;
     // builds a CALLER waits for run on `build_stream` (default priority); the background upgrade uses `bg_stream` (lowest priority: it
     // yields the compute units to the hashing it runs beside) -- `active_stream` is whichever the thread that holds t->mu builds on
-    hipError_t e = hipStreamCreateWithFlags(&t->build_stream, hipStreamNonBlocking);
+    // (the background stream of a wide table is looked up HERE, by the thread that creates the handle, not by the builder beside the
+    // handle's first call: the process's first lowest-priority stream brings a hardware queue into being)
+    hipError_t e = te_dev_streams(t->device, t->shape_auto && budget > TE_DEFAULT_BUDGET, &t->build_stream, &t->bg_stream);
     t->active_stream = t->build_stream;
-    if (t->shape_auto && budget > TE_DEFAULT_BUDGET) {
-        // the background stream of a wide table is created HERE, by the thread that creates the handle, not by the builder beside the
-        // handle's first call: the process's first lowest-priority stream brings a hardware queue into being
-        int lo_prio = 0, hi_prio = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
-            hipStreamCreateWithPriority(&t->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
-            (void)hipGetLastError();
-            t->bg_stream = nullptr;
-        }
-    }
     hipStream_t bs = t->build_stream;
     if (e == hipSuccess) e = hipMalloc(&d_g, n_gen * 2 * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpy(d_g, gens, n_gen * 2 * sizeof(Fr), hipMemcpyHostToDevice);
@@ -746,14 +764,7 @@ static void te_upgrade_kick(TeTable* w, size_t msg_len, size_t data_len, bool wa
         (void)hipSetDevice(w->device);
         {
             std::lock_guard<std::mutex> lk(w->mu);
-            if (!w->bg_stream) {
-                int lo_prio = 0, hi_prio = 0;  // lowest priority + few workgroups (te_build_wide)
-                if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess ||
-                    hipStreamCreateWithPriority(&w->bg_stream, hipStreamNonBlocking, lo_prio) != hipSuccess) {
-                    (void)hipGetLastError();
-                    w->bg_stream = nullptr;
-                }
-            }
+            // lowest priority + few workgroups (te_build_wide); without a low-priority stream: the build stream
             if (w->bg_stream) w->active_stream = w->bg_stream;
             TeResolved r;
             int32_t rc = AKP_OK;
