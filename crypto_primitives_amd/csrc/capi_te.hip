@@ -75,22 +75,19 @@ static inline double te_now_ms() { return std::chrono::duration<double, std::mil
 // lines/s) and 46 GB tables built fine, but hipMemSetAccess on the second piece of a range failed with "invalid argument" for some
 // range sizes on this stack (tools/vmm2_probe.hip) and one probe run ended in a GPU memory fault: not something to put under every
 // hash of a library.)
-static hipError_t te_storage_grow(TeTable* t, size_t bytes) {
+static hipError_t te_storage_grow(TeTable* t, size_t bytes, TeEntry** previous) {
     TeEntry* fresh = nullptr;
     const hipError_t e = hipMalloc(&fresh, bytes);
     if (e != hipSuccess) return e;
-    if (t->d_lut) t->retired.push_back(t->d_lut);
+    *previous = t->d_lut;  // retired by the caller once the new block is filled
     t->d_lut = fresh;
     return hipSuccess;
 }
-// the block just allocated could not be filled: back to the previous one (units_built still describes it)
-static void te_storage_undo(TeTable* t) {
-    if (t->d_lut) (void)hipFree(t->d_lut);
-    t->d_lut = nullptr;
-    if (!t->retired.empty()) {
-        t->d_lut = (TeEntry*)t->retired.back();
-        t->retired.pop_back();
-    }
+// the block just allocated could not be filled: back to the previous one (units_built still describes it); the unfilled block is retired
+// (hipFree would wait for the whole device)
+static void te_storage_undo(TeTable* t, TeEntry* previous) {
+    if (t->d_lut) t->retired.push_back(t->d_lut);
+    t->d_lut = previous;
 }
 // a narrowed shape gives its table up (te_narrow): kept until the table object goes, like everything a launch may have been given
 static void te_storage_retire(TeTable* t) {
@@ -609,8 +606,10 @@ static int32_t te_ensure_table(TeTable* t, size_t data_len, u32* groups, u32* st
             }
         }
         double t0 = te_now_ms();
-        if (e == hipSuccess) e = te_storage_grow(t, bytes_of(target));
-        const bool grown = e == hipSuccess;
+        TeEntry* previous = nullptr;
+        const bool try_grow = e == hipSuccess;
+        if (try_grow) e = te_storage_grow(t, bytes_of(target), &previous);
+        const bool grown = try_grow && e == hipSuccess;
         rep.alloc_ms = te_now_ms() - t0;
         if (e == hipErrorOutOfMemory && can_narrow) {
             (void)hipGetLastError();
@@ -622,10 +621,11 @@ static int32_t te_ensure_table(TeTable* t, size_t data_len, u32* groups, u32* st
                     : te_build_wide<1>(t, t->d_gens, t->n_gen, t->group, 0, target, &rep);
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            if (grown) te_storage_undo(t);
+            if (grown) te_storage_undo(t, previous);
             return fail(AKP_ERR_HIP, "curve table of %zu MB (%u of %u %s): %s -- lower akp_ctx_set_table_budget and create the handle again",
                     bytes_of(target) >> 20, target, t->units_total, ped ? "digits" : "chunk groups", hipGetErrorString(e));
         }
+        if (previous) t->retired.push_back(previous);  // launches already enqueued (or captured) may still read it: it goes with the table
         const u32 from = 0;
         rep.table_bytes = bytes_of(target);
         rep.shape = shape;
