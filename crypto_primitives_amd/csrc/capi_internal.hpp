@@ -56,7 +56,8 @@ struct akp_ctx {
     // pinned staging for small host<->device transfers of the tree / proof entry points
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
-    // more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap)
+    // more streams for the chunked host-pointer batches (copy-in / kernel / copy-out of consecutive chunks overlap); [4] (copy-out of the
+    // pinned curve-hash path) and [5] (copy-in of its gated launch) are high-priority streams
     hipStream_t pipe[7] = {};
     hipEvent_t chunk_event[8] = {};  // copy-stream -> compute-stream hand-over of leaf chunks (host_tree_build)
     // where the last host-pointer tree build left its inner nodes (heap order, `last_tree_nodes` digests): what the
@@ -72,6 +73,12 @@ struct akp_ctx {
     // gated (persistent) curve-hash launch of the pinned host path (capi_te.hip te_crh_gated): per-chunk arrival flags in FINE-GRAINED
     // device memory (+ one error word), per-workgroup completion words in pinned host memory, the epoch that tags one call's values
     u32* gate_flags = nullptr;   // [64] arrival flags (fine-grained device memory)
+    // which form serves this context's pinned curve-hash batches -- the gated launch or the chunked launches -- is MEASURED (capi_te.hip
+    // te_gate_choice): ns per message of either form ([0] chunked, [1] gated), how often each was seen, the shape the figures belong to
+    double gate_ema[2] = {0.0, 0.0};
+    u32 gate_obs[2] = {0, 0};
+    u32 gate_calls = 0;
+    uint64_t gate_tune_key = 0;
     u32* gate_done = nullptr;    // host pointer: word 0 = a workgroup gave up, completion words from word 16
     u32* gate_done_dev = nullptr;  // its device alias
     size_t gate_done_cap = 0;

@@ -1153,11 +1153,20 @@ static bool te_gate_resources(akp_ctx* c, size_t n_wg) {
         memset(c->gate_done, 0, (n_wg + 16) * sizeof(u32));
         c->gate_done_cap = n_wg;
     }
-    if (!c->pipe[0] && !ok(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking))) return false;
-    if (!c->pipe[4]) {
-        int lo = 0, hi = 0;
-        if (!ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) || !ok(hipStreamCreateWithPriority(&c->pipe[4], hipStreamNonBlocking, hi))) return false;
-    }
+    // The copy-in stream of the gated launch is a HIGH-priority stream of its own (pipe[5]), like the copy-out stream (pipe[4]).  Its flag
+    // writes (and copies below the DMA threshold) are kernels of another hardware queue than the hash kernel's, and where the runtime
+    // puts a stream is not ours to choose: at normal priority the two streams sometimes shared ONE queue (the kernel then started behind
+    // the last copy: 6.5 instead of 3.9 ms per 2^20 pinned Pedersen hashes) and sometimes two queues on one PIPE of the command
+    // processor -- a grid with workgroups still to be placed keeps its pipe, every flag write waited for the pipe's time slice (~0.43 ms)
+    // and the copy behind it for the flag: 14 ms, in every call of the process (profiles/r06_s39 ... s41: bench.py's pinned Pedersen
+    // leg).  High-priority queues come from a pool of their own and are served first: 4.06 / 3.41 ms in exactly those two placements
+    // (profiles/r06_s45).  A grid the device holds at once (workgroups taking tile after tile) also frees the pipe, but costs 12 %
+    // where nothing collided (s42 ... s45, patch in profiles/r06_s45).
+    for (int i = 4; i <= 5; ++i)
+        if (!c->pipe[i]) {
+            int lo = 0, hi = 0;
+            if (!ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) || !ok(hipStreamCreateWithPriority(&c->pipe[i], hipStreamNonBlocking, hi))) return false;
+        }
     if (!c->chunk_event[7] && !ok(hipEventCreateWithFlags(&c->chunk_event[7], hipEventDisableTiming))) return false;
     return true;
 }
@@ -1212,7 +1221,7 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     }
     if (++c->gate_epoch == 0) ++c->gate_epoch;  // 0 is what fresh memory holds
     const u32 epoch = c->gate_epoch;
-    hipStream_t s = c->stream, cin = c->pipe[0], side = c->pipe[4];
+    hipStream_t s = c->stream, cin = c->pipe[5], side = c->pipe[4];
     // (`side` has the highest stream priority: device-to-host copies are blit KERNELS on this stack whatever the stream, and at normal
     // priority they wait until the hash kernel thins out -- the copy-outs of a large batch would pile up behind it: profiles/r05_s16)
     const u32 fe = te_fe_per_digest(p);
@@ -1328,6 +1337,40 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
     return AKP_OK;
 }
 
+// Gated or chunked?  Measured per context, not assumed.  Where the runtime puts a stream (which hardware queue, which pipe of the command
+// processor) decides how well the gated launch's copies, flag writes and copy-outs get past its kernel, and that is not the library's to
+// choose: round 6 met placements where the gated call took 5 / 6.5 / 14 ms against 3.4 / 4.9 / 4.9 ms for the chunked launches, and others where it
+// takes 3.4 / 3.9 against 3.8 / 4.9 (profiles/r06_s41 ... s47).  So: four calls of either form, in turns (the first of each pays for streams, flags,
+// scratch and is not counted; the best of the other three counts), then the faster one by a running mean of its ns per message, with
+// every 32nd call given to the other form so that the picture can change (a background table upgrade, another tenant on the device).  A new message length or parameter
+// set starts over.  Wall time of the whole call: these entry points return when the digests are in the caller's buffer.
+constexpr u32 TE_TUNE_FIRST = 4;  // calls of either form before the choice: the first is not counted, the best of the other three is its figure
+static bool te_gate_choice(akp_ctx* c, uint64_t key) {
+    if (key != c->gate_tune_key) {
+        c->gate_tune_key = key;
+        c->gate_obs[0] = c->gate_obs[1] = c->gate_calls = 0;
+        c->gate_ema[0] = c->gate_ema[1] = 0.0;
+    }
+    // AKP_TE_PINNED_FORM=gated | chunked pins the form (include/akp.h; the tests of the gated launch and the tools' A/B arms use it)
+    if (const char* form = getenv("AKP_TE_PINNED_FORM")) {
+        if (!strcmp(form, "gated")) return true;
+        if (!strcmp(form, "chunked")) return false;
+    }
+    if (c->gate_obs[1] < TE_TUNE_FIRST && c->gate_obs[1] <= c->gate_obs[0]) return true;  // in turns: both forms see the same moments of the process
+    if (c->gate_obs[0] < TE_TUNE_FIRST) return false;
+    if (c->gate_obs[1] < TE_TUNE_FIRST) return true;
+    const bool gated_faster = c->gate_ema[1] <= c->gate_ema[0];
+    return (++c->gate_calls & 31u) == 0 ? !gated_faster : gated_faster;
+}
+static void te_gate_observe(akp_ctx* c, bool gated, double ns_per_msg) {
+    const int i = gated ? 1 : 0;
+    if (c->gate_obs[i] == 1) c->gate_ema[i] = ns_per_msg;
+    else if (c->gate_obs[i] > 1 && c->gate_obs[i] < TE_TUNE_FIRST) c->gate_ema[i] = std::min(c->gate_ema[i], ns_per_msg);  // what disturbs a call only ever adds
+    else if (c->gate_obs[i] >= TE_TUNE_FIRST)  // later: down at once (one probe after a disturbed start is enough to change over), up slowly
+        c->gate_ema[i] = ns_per_msg < c->gate_ema[i] ? ns_per_msg : 0.75 * c->gate_ema[i] + 0.25 * ns_per_msg;
+    if (c->gate_obs[i] < (1u << 30)) ++c->gate_obs[i];
+}
+
 extern "C" int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out, void* stream) {
     NEED_TE(p, "akp_te_crh_batch_dev");
     return te_crh_dev(p, d_msgs, n, msg_len, (Fr*)d_out, pick_stream(p->ctx, stream));
@@ -1360,7 +1403,14 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     // that loop's issue order is built around).
     if (n > te_split_max && msg_len >= 4 && out_pinned && device_alias(msgs, n * msg_len)) {
         bool gated = false;
-        if (int32_t rc = te_crh_gated(p, msgs, n, msg_len, out, &gated)) return rc;
+        const uint64_t tune_key = ((uint64_t)(uintptr_t)p->t << 16) ^ (uint64_t)msg_len;
+        const auto call_t0 = std::chrono::steady_clock::now();
+        const auto observe = [&](bool was_gated) {
+            te_gate_observe(c, was_gated, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - call_t0).count() / (double)n);
+        };
+        const bool try_gate = te_gate_choice(c, tune_key);
+        if (try_gate)
+            if (int32_t rc = te_crh_gated(p, msgs, n, msg_len, out, &gated)) return rc;
 #if defined(AKP_TEST_HOOKS)
         if (const char* report = getenv("AKP_TE_GATE_REPORT"))  // one line per pinned call: which form ran it (tools/gpu_r5_gated_stress.py counts them)
             if (FILE* f = fopen(report, "a")) {
@@ -1368,7 +1418,10 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
                 fclose(f);
             }
 #endif
-        if (gated) return AKP_OK;
+        if (gated) {
+            observe(true);
+            return AKP_OK;
+        }
         if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
         if (!c->pipe[4]) {  // the copy-out stream: its copy kernels should not queue behind the hash kernels' workgroups
             int lo = 0, hi = 0;
@@ -1391,6 +1444,7 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
         HIP_TRY(hipStreamSynchronize(pipe.cin));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipStreamSynchronize(pipe.side));
+        if (rc == AKP_OK && !try_gate) observe(false);  // (not the calls that asked for the gate and did not get it: one of them may have waited for a time-out)
         return rc;
     }
     if (n <= chunk || msg_len == 0) {

@@ -970,6 +970,11 @@ __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict
 #pragma unroll
         for (int h = 0; h < TE_FUSED_ITEMS; ++h) {
             const size_t first = base + (size_t)h * 256;
+            // wave priority follows the progress of the workgroup (waiting 0 < first image 1 < second image 2 < the inversion 3): the
+            // workgroup closest to its completion word goes first on its SIMD, the chunks' copy-outs leave earlier (1-4 % of a pinned
+            // call, profiles/r06_s45)
+            if (h == 0) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
             acc[h] = ext_identity();  // lanes past the end of the batch take part in the product tree with Z = 1
             if (first < n) {          // uniform over the workgroup
                 if (h) __syncthreads();  // every wave has read its last byte of the previous image
@@ -985,6 +990,7 @@ __device__ __forceinline__ void te_accumulate_lds_body(const TeEntry* __restrict
         }
         static_assert(TE_FUSED_ITEMS == 1 || TE_FUSED_ITEMS == 2, "the pairing below is written for two points per lane");
         __syncthreads();  // the image is dead: it becomes the product tree
+        __builtin_amdgcn_s_setprio(3);
         const FS zi = te_workgroup_inverse(te_msg_image, TE_FUSED_ITEMS == 2 ? f29_mul(acc[0].Z, acc[TE_FUSED_ITEMS - 1].Z) : acc[0].Z);
 #pragma unroll
         for (int h = 0; h < TE_FUSED_ITEMS; ++h) {

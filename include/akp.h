@@ -111,7 +111,11 @@ int32_t akp_clock_probe_dev(akp_ctx* ctx, uint32_t chain_len, uint64_t* d_out3, 
  *     its workgroups have reported -- never by zero copy: in-place reads make every workgroup wait for PCIe at the same moments and
  *     in-place 16-byte digest stores cross PCIe at 17 GB/s (measured, profiles/r04_s2 .. r04_s3).  Pinned on one side only behaves
  *     like pageable memory; a second caller on the same device while a gated launch is in flight, or a stack on which the gate
- *     cannot work, gets round 4's chunked launches (same digests).
+ *     cannot work, gets round 4's chunked launches (same digests).  Round 6: which of the two forms is faster depends on where the
+ *     runtime happens to put the call's streams (hardware queue, pipe of the command processor: gated 3.4 - 5.1 ms against chunked
+ *     3.4 - 5.0 ms per 2^20 Pedersen hashes over the placements measured, profiles/r06_s41 ... s46), so a context MEASURES: four calls
+ *     of either form, in turns, per (parameter set, message length), then the faster one, every 32nd call given to the other.  The environment
+ *     variable AKP_TE_PINNED_FORM=gated | chunked pins the form (read at every call; anything else: measure).
  * Pinned buffers gain 20 % for the Poseidon batches (3.5e8 against 2.9e8 permutations/s) and, since round 5, 15 - 35 % for the curve
  * hashes (per 2^20 hashes, median wall time: Pedersen 4x256 3.4 ms pinned against 4.0 ms pageable with the HBM-sized table, 4.0
  * against 5.0 ms with the default one; Bowe-Hopwood 63x9 64-byte inputs 2.0 - 2.3 ms against 2.8 - 3.5 ms; profiles/r05_s16) -- the

@@ -13,6 +13,13 @@ from oracle import jubjub as jj, cref  # noqa: E402
 from helpers import gens_array  # noqa: E402
 
 
+@pytest.fixture(autouse=True)
+def _pinned_calls_take_the_gated_launch(monkeypatch):
+    """round 6: the library measures which form serves a context's pinned batches faster (last test of this file); the tests of the gated
+    launch itself pin the form"""
+    monkeypatch.setenv("AKP_TE_PINNED_FORM", "gated")
+
+
 @pytest.fixture(scope="module")
 def cpa():
     import crypto_primitives_amd as m
@@ -197,3 +204,64 @@ print("FALLBACK OK", ["%%.1f ms" %% (t * 1e3) for t in times])
     env = dict(os.environ, AKP_LIB=hooks, AKP_TE_GATE_SPIN_LIMIT="1")
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "FALLBACK OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def test_the_form_of_a_pinned_call_is_measured_not_assumed():
+    """round 6 (profiles/r06_s41 ... s46): where the runtime puts the copy streams decides whether the gated launch or the chunked launches
+    serve a pinned batch faster, so the context measures: four calls of either form in turns, then the faster form with every 32nd call
+    given to the other; a new message length starts over; with the gate switched off (test build) every call takes the chunked launches.
+    The test build reports which form ran each call (AKP_TE_GATE_REPORT); digests are checked on every call."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "crypto_primitives_amd", "lib", "libakp_testhooks.so")
+    assert os.path.exists(hooks)
+    code = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import crypto_primitives_amd as cpa
+from crypto_primitives_amd.crh import bowe_hopwood
+from oracle import jubjub as jj
+from helpers import gens_array
+B = bowe_hopwood.Parameters(gens_array(jj.bowe_hopwood_generators(0xE5E5000A, 63, 9)))
+h = B.handle()
+n = (1 << 18) + 5
+report = os.environ["AKP_TE_GATE_REPORT"]
+def forms():
+    return [int(l.split()[2]) for l in open(report)] if os.path.exists(report) else []
+for L, calls in ((64, 70), (32, 6)):
+    msgs = np.random.default_rng(L).integers(0, 256, size=(n, L), dtype=np.uint8)
+    want = np.empty((n, 4), np.uint64)
+    cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, msgs.ctypes.data, n, L, want.ctypes.data))  # pageable: not a pinned call, not reported
+    pm, po = C.c_void_p(), C.c_void_p()
+    cpa._lib.check(cpa.lib.akp_host_alloc(msgs.nbytes, C.byref(pm))); cpa._lib.check(cpa.lib.akp_host_alloc(want.nbytes, C.byref(po)))
+    np.ctypeslib.as_array((C.c_uint8 * msgs.size).from_address(pm.value))[:] = msgs.reshape(-1)
+    out = np.ctypeslib.as_array((C.c_uint64 * want.size).from_address(po.value)).reshape(want.shape)
+    before = len(forms())
+    for rep in range(calls):
+        out[:] = 0
+        cpa._lib.check(cpa.lib.akp_te_crh_batch(h.h, pm, n, L, po))
+        assert np.array_equal(out, want), (L, rep)
+    f = forms()[before:]
+    assert len(f) == calls, f
+    if os.environ.get("AKP_TE_GATED") == "0":
+        assert not any(f), f
+    else:
+        assert f[:8] == [1, 0, 1, 0, 1, 0, 1, 0][:calls], f   # four of either form first, in turns -- also for the second message length
+        if calls > 40:
+            steady = f[8:]
+            major = 1 if sum(steady) * 2 > len(steady) else 0
+            other = [i for i, x in enumerate(steady) if x != major]
+            assert 1 <= len(other) <= 3, f          # 62 calls: the other form is looked at again on every 32nd
+    cpa._lib.check(cpa.lib.akp_host_free(pm)); cpa._lib.check(cpa.lib.akp_host_free(po))
+print("TUNE OK", forms())
+""" % (root, os.path.join(root, "tests"))
+    for gate in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            env = dict(os.environ, AKP_LIB=hooks, AKP_TE_GATE_REPORT=os.path.join(d, "forms.txt"), AKP_TE_GATED=gate)
+            env.pop("AKP_TE_PINNED_FORM", None)
+            p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0 and "TUNE OK" in p.stdout, (gate, p.stdout[-1500:], p.stderr[-3000:])

@@ -7,6 +7,7 @@ import json
 import os
 import sys
 import time
+os.environ.setdefault("AKP_TE_PINNED_FORM", "gated")  # these arms choose the form themselves (round 6: the library otherwise measures and picks)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

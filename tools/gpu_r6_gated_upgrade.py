@@ -1,4 +1,5 @@
 import ctypes as C, os, sys, time, json
+os.environ.setdefault("AKP_TE_PINNED_FORM", "gated")  # these arms choose the form themselves (round 6: the library otherwise measures and picks)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import crypto_primitives_amd as cpa
