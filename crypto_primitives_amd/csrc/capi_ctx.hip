@@ -39,6 +39,24 @@ u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
 void ctx_handle_released(akp_ctx* c) {
     if (c && --c->live_handles == 0 && c->dead) delete c;
 }
+// Copy streams are high-priority streams (round 6).  The runtime's staged copies, small copies, flag writes and device-to-host copies are
+// KERNELS on the copy stream's hardware queue; where a stream's queue lands is the runtime's choice, and a queue that shares a pipe of
+// the command processor with a hash kernel's queue is served only at the pipe's time slice (~0.43 ms) while that kernel's grid has
+// workgroups left to place -- two normal-priority streams can even share one queue.  High-priority queues come from a pool of their own
+// and are served first (profiles/r04_s3, r06_s41 ... s52).
+hipError_t ctx_copy_streams(akp_ctx* c) {
+    for (int i = 4; i <= 5; ++i)
+        if (!c->pipe[i]) {
+            int lo = 0, hi = 0;
+            hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->pipe[i], hipStreamNonBlocking, hi);
+            if (e != hipSuccess) {
+                c->pipe[i] = nullptr;
+                return e;
+            }
+        }
+    return hipSuccess;
+}
 // scratch slot `slot` with at least `bytes`, to be used on stream `s`: if the previous use was enqueued on a different
 // stream, `s` first waits for it (event record + stream wait; nothing blocks on the host)
 int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out, hipStream_t s) {

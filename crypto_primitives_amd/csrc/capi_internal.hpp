@@ -94,6 +94,8 @@ struct akp_ctx {
 void ctx_handle_released(akp_ctx* c);
 // scratch slot `slot` with at least `bytes`, to be used on stream `s` (ordered behind the slot's last use on another stream)
 int32_t ctx_scratch(akp_ctx* c, int slot, size_t bytes, void** out, hipStream_t s);
+// the context's two HIGH-priority copy streams, created on first use: pipe[5] copy-in, pipe[4] copy-out (capi_ctx.hip)
+hipError_t ctx_copy_streams(akp_ctx* c);
 // `_dev` entry points use the caller's stream verbatim (NULL = HIP's legacy default stream, which is what
 // torch's default stream is), so event timing and ordering follow the caller's stream semantics.
 static inline hipStream_t pick_stream(akp_ctx*, void* s) { return (hipStream_t)s; }

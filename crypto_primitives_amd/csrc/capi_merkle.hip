@@ -17,10 +17,13 @@ static int32_t host_tree_build(akp_ctx* c, const void* leaves, size_t n, size_t 
         void* d_nl,
                                void* h_ln, void* h_nl, void* h_root, HashLeaves hash_leaves, Inner inner) {
     constexpr size_t chunk_items = (size_t)1 << 20;  // leaves per copy-in chunk (round 2: 2^18 .. 2^22 measured alike; no knob)
-    if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
+    // the copy stream is a high-priority stream (pipe[5], round 6): the staged copies of pageable leaves are small kernels on a queue of
+    // their own, and a queue that shares a pipe of the command processor with the hash kernels' queue is served late while a grid
+    // has workgroups left to place (profiles/r06_s41); neutral where the queues do not meet (profiles/r06_s52)
+    HIP_TRY(ctx_copy_streams(c));
     for (int i = 0; i < 8; ++i)
         if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
-    hipStream_t comp = c->stream, copy = c->pipe[0];
+    hipStream_t comp = c->stream, copy = c->pipe[5];
     // the scratch regions were acquired for the context stream: let the copy stream start behind whatever used them last
     HIP_TRY(hipEventRecord(c->chunk_event[7], comp));
     HIP_TRY(hipStreamWaitEvent(copy, c->chunk_event[7], 0));

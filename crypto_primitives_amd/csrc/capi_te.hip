@@ -1162,11 +1162,7 @@ static bool te_gate_resources(akp_ctx* c, size_t n_wg) {
     // leg).  High-priority queues come from a pool of their own and are served first: 4.06 / 3.41 ms in exactly those two placements
     // (profiles/r06_s45).  A grid the device holds at once (workgroups taking tile after tile) also frees the pipe, but costs 12 %
     // where nothing collided (s42 ... s45, patch in profiles/r06_s45).
-    for (int i = 4; i <= 5; ++i)
-        if (!c->pipe[i]) {
-            int lo = 0, hi = 0;
-            if (!ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) || !ok(hipStreamCreateWithPriority(&c->pipe[i], hipStreamNonBlocking, hi))) return false;
-        }
+    if (!ok(ctx_copy_streams(c))) return false;
     if (!c->chunk_event[7] && !ok(hipEventCreateWithFlags(&c->chunk_event[7], hipEventDisableTiming))) return false;
     return true;
 }
@@ -1422,19 +1418,19 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
             observe(true);
             return AKP_OK;
         }
-        if (!c->pipe[0]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking));
-        if (!c->pipe[4]) {  // the copy-out stream: its copy kernels should not queue behind the hash kernels' workgroups
-            int lo = 0, hi = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_TRY(hipStreamCreateWithPriority(&c->pipe[4], hipStreamNonBlocking, hi));  // median 4.41 -> 4.24 ms per 2^20 hashes (profiles/r04_s3)
-        }
+        // the copy streams of the chunked launches are high-priority streams: [4] the copy-out stream -- its copy kernels should not queue
+        // behind the hash kernels' workgroups (median 4.41 -> 4.24 ms per 2^20 hashes, profiles/r04_s3) -- and, since round 6, [5] the copy-in
+        // stream, shared with the gated launch (te_gate_resources): in the placement where the normal-priority copy-in stream met the hash
+        // kernels' queue on one pipe 3.9 -> 3.3 ms (Pedersen, HBM-sized table) and 2.4 -> 1.9 ms (Bowe-Hopwood), no difference elsewhere
+        // (profiles/r06_s50, r06_s51)
+        HIP_TRY(ctx_copy_streams(c));
         for (int i = 0; i < 8; ++i)
             if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
         size_t pchunk = chunk;
 #if defined(AKP_TEST_HOOKS)
         pchunk = env_size("AKP_TE_PIPE_CHUNK", chunk);
 #endif
-        const TePipe pipe{pchunk /* 2^16 / 2^18 / 2^19 measured slower, profiles/r04_s3 */, msgs, out, c->pipe[0], c->pipe[4], c->chunk_event[0], c->chunk_event[1]};
+        const TePipe pipe{pchunk /* 2^16 / 2^18 / 2^19 measured slower, profiles/r04_s3 */, msgs, out, c->pipe[5], c->pipe[4], c->chunk_event[0], c->chunk_event[1]};
         if (int32_t rc = ctx_scratch(c, SCR_A, n * msg_len, &dm, s)) return rc;
         if (int32_t rc = ctx_scratch(c, SCR_B, n * dig, &dout, s)) return rc;
         HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the side streams start behind whatever used the scratch last
@@ -1458,11 +1454,12 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     }
     if (int32_t rc = ctx_scratch(c, SCR_A, 2 * chunk * msg_len, &dm, s)) return rc;
     if (int32_t rc = ctx_scratch(c, SCR_B, 2 * chunk * dig, &dout, s)) return rc;
-    for (int i = 0; i < 2; ++i)
-        if (!c->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking));
+    // copy-in and copy-out on the context's two high-priority streams (round 6; the staged copies are kernels on queues of their own: served
+    // first, they do not wait for the hash kernels' grids to be placed: 4.57 -> 4.33 ms per 2^20 Pedersen hashes, profiles/r06_s52)
+    HIP_TRY(ctx_copy_streams(c));
     for (int i = 0; i < 8; ++i)
         if (!c->chunk_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_event[i], hipEventDisableTiming));
-    hipStream_t cin = c->pipe[0], cout = c->pipe[1];
+    hipStream_t cin = c->pipe[5], cout = c->pipe[4];
     hipEvent_t *in_done = c->chunk_event, *comp_done = c->chunk_event + 2, *out_done = c->chunk_event + 4;
     HIP_TRY(hipEventRecord(c->chunk_event[7], s));  // the copy streams start behind whatever used the scratch last
     HIP_TRY(hipStreamWaitEvent(cin, c->chunk_event[7], 0));

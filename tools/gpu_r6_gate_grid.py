@@ -47,6 +47,8 @@ def calls(fn, reps=11):
 # were switches of the test build while they were compared: profiles/r06_s45/resident_grid_arms.patch; what is left is the library's gated
 # launch against the chunked launches)
 ARMS = (("library", {}), ("gated", {"AKP_TE_PINNED_FORM": "gated"}), ("chunked", {"AKP_TE_PINNED_FORM": "chunked"}))
+if os.environ.get("GATE_GRID_REVERSE") == "1":  # the same arms last-first: is a slow arm slow, or was it early?
+    ARMS = ARMS[::-1]
 cases = (("pedersen_4x256_128B", pedersen.Parameters(cparams.pedersen_generators(0xA5A50004, 4, 256)), 128, 2),
          ("bowe_hopwood_63x9_64B", bowe_hopwood.Parameters(cparams.bowe_hopwood_generators(0xA5A50005, 63, 9)), 64, 1))
 for name, prm, L, fe in cases:
