@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: the chunked launches' copy-in stream at high priority (test build: AKP_TE_PIPE_CIN_HIGH), and the arms of gpu_r6_gate_grid.py
+# round 6: the arms of gpu_r6_gate_grid.py
 # last-first in processes that follow a process with HBM-sized tables (is the gated arm slow there, or only early?)
 O=gpurun_out/r06_s51; mkdir -p $O
 export AKP_LIB=$PWD/crypto_primitives_amd/lib/libakp_testhooks.so
