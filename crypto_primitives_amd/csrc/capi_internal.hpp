@@ -79,6 +79,7 @@ struct akp_ctx {
     u32 gate_obs[2] = {0, 0};
     u32 gate_calls = 0;
     uint64_t gate_tune_key = 0;
+    int gate_form_noted = -1;    // the form the last note in akp_last_error() named (1 gated, 0 chunked, -1 none yet)
     u32* gate_done = nullptr;    // host pointer: word 0 = a workgroup gave up, completion words from word 16
     u32* gate_done_dev = nullptr;  // its device alias
     size_t gate_done_cap = 0;

@@ -1346,6 +1346,7 @@ static bool te_gate_choice(akp_ctx* c, uint64_t key) {
         c->gate_tune_key = key;
         c->gate_obs[0] = c->gate_obs[1] = c->gate_calls = 0;
         c->gate_ema[0] = c->gate_ema[1] = 0.0;
+        c->gate_form_noted = -1;
     }
     // AKP_TE_PINNED_FORM=gated | chunked pins the form (include/akp.h; the tests of the gated launch and the tools' A/B arms use it)
     if (const char* form = getenv("AKP_TE_PINNED_FORM")) {
@@ -1356,6 +1357,11 @@ static bool te_gate_choice(akp_ctx* c, uint64_t key) {
     if (c->gate_obs[0] < TE_TUNE_FIRST) return false;
     if (c->gate_obs[1] < TE_TUNE_FIRST) return true;
     const bool gated_faster = c->gate_ema[1] <= c->gate_ema[0];
+    if ((int)gated_faster != c->gate_form_noted) {  // the choice, and every change of it, is visible: a note behind the (successful) call
+        c->gate_form_noted = (int)gated_faster;
+        (void)fail(AKP_OK, "note: the pinned curve-hash batches of this context take %s (measured: %.2f ns per message gated, %.2f chunked)",
+                gated_faster ? "the gated launch" : "the chunked launches", c->gate_ema[1], c->gate_ema[0]);
+    }
     return (++c->gate_calls & 31u) == 0 ? !gated_faster : gated_faster;
 }
 static void te_gate_observe(akp_ctx* c, bool gated, double ns_per_msg) {
