@@ -1405,7 +1405,8 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
     // that loop's issue order is built around).
     if (n > te_split_max && msg_len >= 4 && out_pinned && device_alias(msgs, n * msg_len)) {
         bool gated = false;
-        const uint64_t tune_key = ((uint64_t)(uintptr_t)p->t << 16) ^ (uint64_t)msg_len;
+        // (the handle's tables and the message length: a handle with an HBM-sized table has figures of its own)
+        const uint64_t tune_key = ((uint64_t)(uintptr_t)p->t << 16) ^ ((uint64_t)(uintptr_t)p->wide << 20) ^ (uint64_t)msg_len;
         const auto call_t0 = std::chrono::steady_clock::now();
         const auto observe = [&](bool was_gated) {
             te_gate_observe(c, was_gated, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - call_t0).count() / (double)n);

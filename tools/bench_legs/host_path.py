@@ -15,6 +15,12 @@ def _median_call(fn, reps):
     return ts[len(ts) // 2], ts[0], ts[-1]
 
 
+def _form_note(lib):
+    """which form the context settled on for the pinned batches just timed: the library announces its choice in akp_last_error() (round 6)"""
+    note = (lib.akp_last_error() or b"").decode(errors="replace")
+    return note if note.startswith("note: the pinned") else "no note (AKP_TE_PINNED_FORM pins the form, or the gate is unavailable)"
+
+
 def run(env, host_states, n):
     args, np, lib, check = env.args, env.np, env.lib, env.check
     if args.no_host_path or env.rank != 0:
@@ -64,6 +70,7 @@ def run(env, host_states, n):
                                                 "arrival flag behind each, the accumulate kernel launched once over the whole batch, workgroups wait on their chunk's flag, "
                                                 "finish their digests themselves, copy-out of a chunk released by the host thread as its workgroups report) or round 4's "
                                                 "chunked launches -- and keeps it: of the 20 calls of this leg four go to either form (in turns), twelve to the faster one"}
+        host_path["pedersen_pinned"]["form"] = _form_note(lib)
         if not env.shared_gpu:  # the same pinned call with the HBM-sized table (opt-in budget; prepared first, not built in the background beside the calls)
             from crypto_primitives_amd._lib import TABLE_BUDGET_DEVICE
             env.ctx.set_table_budget(TABLE_BUDGET_DEVICE)
@@ -76,6 +83,7 @@ def run(env, host_states, n):
             hs3, lo3, hi3 = _median_call(lambda: check(lib.akp_te_crh_batch(hw.h, pm, nph, 128, po)), 19)
             host_path["pedersen_pinned_hbm_table"] = {"hashes_per_s": nph / hs3, "ms_per_batch": hs3 * 1e3, "ms_min": lo3 * 1e3, "ms_max": hi3 * 1e3,
                                                       "digests_equal_the_pageable_call": bool(np.array_equal(pinned_out, ho)), "table": hw.info(128)}
+            host_path["pedersen_pinned_hbm_table"]["form"] = _form_note(lib)
             same = same and host_path["pedersen_pinned_hbm_table"]["digests_equal_the_pageable_call"]
             env.keepalive.append((hw, Pw))
         check(lib.akp_host_free(pm))
