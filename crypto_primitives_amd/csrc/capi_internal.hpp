@@ -74,12 +74,18 @@ struct akp_ctx {
     // device memory (+ one error word), per-workgroup completion words in pinned host memory, the epoch that tags one call's values
     u32* gate_flags = nullptr;   // [64] arrival flags (fine-grained device memory)
     // which form serves this context's pinned curve-hash batches -- the gated launch or the chunked launches -- is MEASURED (capi_te.hip
-    // te_gate_choice): ns per message of either form ([0] chunked, [1] gated), how often each was seen, the shape the figures belong to
-    double gate_ema[2] = {0.0, 0.0};
-    u32 gate_obs[2] = {0, 0};
-    u32 gate_calls = 0;
-    uint64_t gate_tune_key = 0;
-    int gate_form_noted = -1;    // the form the last note in akp_last_error() named (1 gated, 0 chunked, -1 none yet)
+    // te_gate_choice), per shape (the handle's tables, the message length): ns per message of either form ([0] chunked, [1] gated), how
+    // often each was seen, the form the last note in akp_last_error() named (1 gated, 0 chunked, -1 none yet).  Four shapes are
+    // remembered (a host that alternates between a few shapes keeps their figures), the least recently used one makes room.
+    struct GateTune {
+        uint64_t key = 0;
+        double ema[2] = {0.0, 0.0};
+        u32 obs[2] = {0, 0};
+        u32 calls = 0, last_used = 0;
+        int form_noted = -1;
+    };
+    GateTune gate_tune[4];
+    u32 gate_tune_clock = 0;
     u32* gate_done = nullptr;    // host pointer: word 0 = a workgroup gave up, completion words from word 16
     u32* gate_done_dev = nullptr;  // its device alias
     size_t gate_done_cap = 0;

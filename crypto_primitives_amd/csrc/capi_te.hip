@@ -1338,39 +1338,48 @@ static int32_t te_crh_gated(akp_te_params* p, const uint8_t* h_msgs, size_t n, s
 // choose: round 6 met placements where the gated call took 5 / 6.5 / 14 ms against 3.4 / 4.9 / 4.9 ms for the chunked launches, and others where it
 // takes 3.4 / 3.9 against 3.8 / 4.9 (profiles/r06_s41 ... s47).  So: four calls of either form, in turns (the first of each pays for streams, flags,
 // scratch and is not counted; the best of the other three counts), then the faster one by a running mean of its ns per message, with
-// every 32nd call given to the other form so that the picture can change (a background table upgrade, another tenant on the device).  A new message length or parameter
-// set starts over.  Wall time of the whole call: these entry points return when the digests are in the caller's buffer.
+// every 32nd call given to the other form so that the picture can change (a background table upgrade, another tenant on the device).  Figures
+// are kept per shape (tables of the handle, message length), four shapes per context.  Wall time of the whole call: these entry points return when the digests are in the caller's buffer.
 constexpr u32 TE_TUNE_FIRST = 4;  // calls of either form before the choice: the first is not counted, the best of the other three is its figure
-static bool te_gate_choice(akp_ctx* c, uint64_t key) {
-    if (key != c->gate_tune_key) {
-        c->gate_tune_key = key;
-        c->gate_obs[0] = c->gate_obs[1] = c->gate_calls = 0;
-        c->gate_ema[0] = c->gate_ema[1] = 0.0;
-        c->gate_form_noted = -1;
+static akp_ctx::GateTune* te_gate_shape(akp_ctx* c, uint64_t key) {  // key != 0
+    akp_ctx::GateTune* lru = &c->gate_tune[0];
+    ++c->gate_tune_clock;
+    for (akp_ctx::GateTune& g : c->gate_tune) {
+        if (g.key == key) {
+            g.last_used = c->gate_tune_clock;
+            return &g;
+        }
+        if (g.last_used < lru->last_used) lru = &g;
     }
+    *lru = akp_ctx::GateTune{};
+    lru->key = key;
+    lru->last_used = c->gate_tune_clock;
+    return lru;
+}
+static bool te_gate_choice(akp_ctx::GateTune* g) {
     // AKP_TE_PINNED_FORM=gated | chunked pins the form (include/akp.h; the tests of the gated launch and the tools' A/B arms use it)
     if (const char* form = getenv("AKP_TE_PINNED_FORM")) {
         if (!strcmp(form, "gated")) return true;
         if (!strcmp(form, "chunked")) return false;
     }
-    if (c->gate_obs[1] < TE_TUNE_FIRST && c->gate_obs[1] <= c->gate_obs[0]) return true;  // in turns: both forms see the same moments of the process
-    if (c->gate_obs[0] < TE_TUNE_FIRST) return false;
-    if (c->gate_obs[1] < TE_TUNE_FIRST) return true;
-    const bool gated_faster = c->gate_ema[1] <= c->gate_ema[0];
-    if ((int)gated_faster != c->gate_form_noted) {  // the choice, and every change of it, is visible: a note behind the (successful) call
-        c->gate_form_noted = (int)gated_faster;
+    if (g->obs[1] < TE_TUNE_FIRST && g->obs[1] <= g->obs[0]) return true;  // in turns: both forms see the same moments of the process
+    if (g->obs[0] < TE_TUNE_FIRST) return false;
+    if (g->obs[1] < TE_TUNE_FIRST) return true;
+    const bool gated_faster = g->ema[1] <= g->ema[0];
+    if ((int)gated_faster != g->form_noted) {  // the choice, and every change of it, is visible: a note behind the (successful) call
+        g->form_noted = (int)gated_faster;
         (void)fail(AKP_OK, "note: the pinned curve-hash batches of this context take %s (measured: %.2f ns per message gated, %.2f chunked)",
-                gated_faster ? "the gated launch" : "the chunked launches", c->gate_ema[1], c->gate_ema[0]);
+                gated_faster ? "the gated launch" : "the chunked launches", g->ema[1], g->ema[0]);
     }
-    return (++c->gate_calls & 31u) == 0 ? !gated_faster : gated_faster;
+    return (++g->calls & 31u) == 0 ? !gated_faster : gated_faster;
 }
-static void te_gate_observe(akp_ctx* c, bool gated, double ns_per_msg) {
+static void te_gate_observe(akp_ctx::GateTune* g, bool gated, double ns_per_msg) {
     const int i = gated ? 1 : 0;
-    if (c->gate_obs[i] == 1) c->gate_ema[i] = ns_per_msg;
-    else if (c->gate_obs[i] > 1 && c->gate_obs[i] < TE_TUNE_FIRST) c->gate_ema[i] = std::min(c->gate_ema[i], ns_per_msg);  // what disturbs a call only ever adds
-    else if (c->gate_obs[i] >= TE_TUNE_FIRST)  // later: down at once (one probe after a disturbed start is enough to change over), up slowly
-        c->gate_ema[i] = ns_per_msg < c->gate_ema[i] ? ns_per_msg : 0.75 * c->gate_ema[i] + 0.25 * ns_per_msg;
-    if (c->gate_obs[i] < (1u << 30)) ++c->gate_obs[i];
+    if (g->obs[i] == 1) g->ema[i] = ns_per_msg;
+    else if (g->obs[i] > 1 && g->obs[i] < TE_TUNE_FIRST) g->ema[i] = std::min(g->ema[i], ns_per_msg);  // what disturbs a call only ever adds
+    else if (g->obs[i] >= TE_TUNE_FIRST)  // later: down at once (one probe after a disturbed start is enough to change over), up slowly
+        g->ema[i] = ns_per_msg < g->ema[i] ? ns_per_msg : 0.75 * g->ema[i] + 0.25 * ns_per_msg;
+    if (g->obs[i] < (1u << 30)) ++g->obs[i];
 }
 
 extern "C" int32_t akp_te_crh_batch_dev(akp_te_params* p, const uint8_t* d_msgs, size_t n, size_t msg_len, uint64_t* d_out, void* stream) {
@@ -1408,10 +1417,11 @@ extern "C" int32_t akp_te_crh_batch(akp_te_params* p, const uint8_t* msgs, size_
         // (the handle's tables and the message length: a handle with an HBM-sized table has figures of its own)
         const uint64_t tune_key = ((uint64_t)(uintptr_t)p->t << 16) ^ ((uint64_t)(uintptr_t)p->wide << 20) ^ (uint64_t)msg_len;
         const auto call_t0 = std::chrono::steady_clock::now();
+        akp_ctx::GateTune* const tune = te_gate_shape(c, tune_key | 1u);
         const auto observe = [&](bool was_gated) {
-            te_gate_observe(c, was_gated, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - call_t0).count() / (double)n);
+            te_gate_observe(tune, was_gated, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - call_t0).count() / (double)n);
         };
-        const bool try_gate = te_gate_choice(c, tune_key);
+        const bool try_gate = te_gate_choice(tune);
         if (try_gate)
             if (int32_t rc = te_crh_gated(p, msgs, n, msg_len, out, &gated)) return rc;
 #if defined(AKP_TEST_HOOKS)

@@ -114,7 +114,7 @@ int32_t akp_clock_probe_dev(akp_ctx* ctx, uint32_t chain_len, uint64_t* d_out3, 
  *     cannot work, gets round 4's chunked launches (same digests).  Round 6: which of the two forms is faster depends on where the
  *     runtime happens to put the call's streams (hardware queue, pipe of the command processor: gated 3.4 - 5.1 ms against chunked
  *     3.4 - 5.0 ms per 2^20 Pedersen hashes over the placements measured, profiles/r06_s41 ... s46), so a context MEASURES: four calls
- *     of either form, in turns, per (parameter set, message length), then the faster one, every 32nd call given to the other.  The environment
+ *     of either form, in turns, per (parameter set, message length) -- four such shapes are remembered --, then the faster one, every 32nd call given to the other.  The environment
  *     variable AKP_TE_PINNED_FORM=gated | chunked pins the form (read at every call; anything else: measure).  The choice, and every later
  *     change of it, is announced behind the successful call that made it: akp_last_error() then starts with "note: the pinned curve-hash batches".
  * Pinned buffers gain 20 % for the Poseidon batches (3.5e8 against 2.9e8 permutations/s) and, since round 5, 15 - 35 % for the curve
